@@ -1,0 +1,178 @@
+/*
+ * mcrt.h -- C-ABI of libmcrt_hip.so: the MI355X (gfx950) implementation of the Monte-Carlo
+ * ultrasound ray-tracing hot path of thepochynsons/MCRay-Tracing.
+ *
+ * The reference has no FFI layer; its seam is C++ (paths relative to /root/reference/src):
+ *   scene::scene(json, transducer&)            scene.h:24, scene.cpp:16-48   -> mcrt_upload_scene
+ *   transducer<N>::element(i)                  transducer.h:64-67           -> mcrt_set_transducer
+ *   volume<256,145> texture_volume             main.cpp:52, volume.h:19-35  -> mcrt_upload_texture
+ *   rf_image.clear()                           main.cpp:102, rfimage.h:161  -> (inside mcrt_trace_frame)
+ *   scene.cast_rays<S,E>(transducer)           main.cpp:104, scene.cpp:50   -> mcrt_trace_frame / mcrt_cast_rays
+ *   accumulation loop + rf_image::add_echo     main.cpp:106-144, rfimage.h:33-40 -> (fused in mcrt_trace_frame)
+ *   rf_image.convolve(psf)                     main.cpp:146, rfimage.h:93-123 -> mcrt_convolve
+ *   rf_image.envelope() / postprocess()        main.cpp:147-148, rfimage.h:54-91,125-140 -> mcrt_envelope / mcrt_scan_convert
+ * A maintainer of the reference replaces main.cpp:102-148 with the calls shown in INTEGRATION.md.
+ *
+ * Conventions: every function returns 0 on success or a negative mcrt_status; the message is
+ * available from mcrt_last_error() (thread-local).  No exceptions cross this boundary.  A
+ * context belongs to one GPU and is used from one host thread at a time.  Pointers named
+ * *_dev are device pointers on the context's GPU; everything else is host memory.  Uploads copy.
+ * There is NO CPU fallback: without a usable GPU mcrt_create fails.
+ */
+#ifndef MCRT_H
+#define MCRT_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCRT_VERSION 100
+
+typedef enum {
+    MCRT_OK = 0,
+    MCRT_ERR_INVALID = -1,      /* bad argument / call order               */
+    MCRT_ERR_HIP = -2,          /* HIP runtime error (message has details) */
+    MCRT_ERR_NOMEM = -3,
+    MCRT_ERR_NO_DEVICE = -4,
+    MCRT_ERR_LIMIT = -5         /* a documented capacity was exceeded      */
+} mcrt_status;
+
+typedef struct mcrt_ctx mcrt_ctx;
+
+/* Run-time form of the reference's compile-time constants (main.cpp:23-37, ray.h:23-24,
+ * scene.h:49, scene.cpp:115).  mcrt_default_params() fills the reference values. */
+typedef struct {
+    uint32_t n_elements;         /* E: scan-lines = transducer elements = RF columns (512)   */
+    uint32_t n_samples;          /* S: Monte-Carlo sample paths per scan-line (5)            */
+    uint32_t max_depth;          /* B: ray::max_depth (10), <= 16                            */
+    uint32_t n_rows;             /* R: RF rows (465 = max_rows), <= 2048                     */
+    float    frequency;          /* MHz (4.5)                                                */
+    float    intensity_epsilon;  /* 1e-10                                                    */
+    float    initial_intensity;  /* 1.0                                                      */
+    float    ray_start_offset;   /* 0.1 (scene.cpp:115)                                      */
+    uint32_t speed_of_sound;     /* um/us (1500)                                             */
+    double   depth_cm;           /* 15                                                       */
+    uint32_t seed;               /* RNG key word 0; key word 1 is the frame id               */
+    uint32_t sanitize_tir;       /* 0 = reference behaviour: NaN echo on total internal reflection */
+    uint32_t tex_n;              /* texture edge in voxels (256)                             */
+    float    tex_res;            /* voxel edge, scene units (0.145)                          */
+} mcrt_params;
+
+/* mesh.h:12-20 reduced to what the hot path reads */
+typedef struct { uint32_t mat_inside, mat_outside, vascular, _pad; } mcrt_mesh;
+
+/* 64-byte BVH2 node.  child >= 0: inner node index; child < 0: leaf, v = ~child,
+ * first triangle = v >> 3, count = (v & 7) + 1 (positions in leaf order). */
+typedef struct {
+    float lo0[3]; int32_t c0;
+    float hi0[3]; int32_t c1;
+    float lo1[3]; uint32_t pad0;
+    float hi1[3]; uint32_t pad1;
+} mcrt_bvh_node;
+
+typedef struct {
+    uint32_t n_nodes, n_tri, max_depth;
+    float pad_abs;           /* absolute part of the per-triangle bounds padding (4e-6 * scene scale) */
+    mcrt_bvh_node *nodes;    /* [n_nodes]                                                     */
+    float *tri;              /* [n_tri][12] leaf order: v0.xyz,bits(tri id) | v1.xyz,bits(mesh id) | v2.xyz,0 */
+} mcrt_bvh;
+
+/* ray_physics::segment (ray.h:28-36) as a POD; media is the material INDEX in effect along it */
+typedef struct {
+    float from[3], to[3], dir[3];
+    float reflected_intensity, initial_intensity, attenuation;
+    double distance_traveled;
+    int32_t media;
+    int32_t tri;             /* triangle hit at the end of the segment, -1 = none */
+} mcrt_segment;              /* 64 bytes */
+
+typedef struct {
+    uint64_t queries, nodes_visited, tris_tested, segments, rf_steps, hits;
+} mcrt_stats;
+
+const char *mcrt_last_error(void);
+int mcrt_version(void);
+int mcrt_device_count(void);
+
+int mcrt_create(int device, mcrt_ctx **out);
+int mcrt_destroy(mcrt_ctx *ctx);
+int mcrt_set_stream(mcrt_ctx *ctx, void *hip_stream);           /* NULL = the context's own stream */
+int mcrt_synchronize(mcrt_ctx *ctx);
+
+int mcrt_default_params(mcrt_params *p);
+int mcrt_set_params(mcrt_ctx *ctx, const mcrt_params *p);
+
+/* Geometry in WORLD space (scene.cpp:313-324 already applied: v*scaling + deltas*scaling^2 + origin),
+ * triangles in OBJ face order, meshes in scene order.  Builds the BVH on the host and uploads it.
+ * materials: [n_mat][8] = impedance, attenuation, mu0, mu1, sigma, specularity, shininess, thickness. */
+int mcrt_upload_scene(mcrt_ctx *ctx, const float *tri_xyz /*[T][9]*/, const uint32_t *tri_mesh /*[T]*/, uint32_t n_tri,
+                      const mcrt_mesh *meshes, uint32_t n_mesh, const float *materials, uint32_t n_mat,
+                      uint32_t start_mat, const float spacing[3]);
+/* voxels [n^3][2] = {texture_noise, scattering_probability}; NULL => generate the reference's texture */
+int mcrt_upload_texture(mcrt_ctx *ctx, const float *voxels, uint32_t n);
+int mcrt_set_transducer(mcrt_ctx *ctx, const float *pos /*[E][3]*/, const float *dir /*[E][3]*/, uint32_t n_elements);
+
+/* clear + trace + accumulate for scan-lines [e_begin, e_end).  rf_dev: device float [(e_end-e_begin)][R]
+ * (scan-line-major).  Asynchronous on the context's stream. */
+int mcrt_trace_frame(mcrt_ctx *ctx, uint32_t frame_id, uint32_t e_begin, uint32_t e_end, float *rf_dev);
+/* same, and additionally returns per-path data to HOST buffers (any may be NULL); synchronous.
+ * hits [ne][S][B] int32 (-1 miss, -2 not cast); segs [ne][S][B]; seg_count [ne][S]. */
+int mcrt_trace_frame_debug(mcrt_ctx *ctx, uint32_t frame_id, uint32_t e_begin, uint32_t e_end, float *rf_dev,
+                           int32_t *hits, mcrt_segment *segs, uint32_t *seg_count);
+/* scene::cast_rays (scene.cpp:50-183) alone: segments only, no RF accumulation; synchronous */
+int mcrt_cast_rays(mcrt_ctx *ctx, uint32_t frame_id, uint32_t e_begin, uint32_t e_end,
+                   mcrt_segment *segs, uint32_t *seg_count, int32_t *hits);
+
+/* rf_image::convolve (rfimage.h:93-123) in place on a device image [E][R]; tmp_dev same size or NULL */
+int mcrt_convolve(mcrt_ctx *ctx, float *rf_dev, uint32_t n_elements, uint32_t n_rows,
+                  const float *axial, uint32_t n_ax, const float *lateral, uint32_t n_lat);
+/* rf_image::envelope (rfimage.h:54-91) in place on a device image [E][R] */
+int mcrt_envelope(mcrt_ctx *ctx, float *rf_dev, uint32_t n_elements, uint32_t n_rows);
+/* rf_image::postprocess scan conversion (rfimage.h:125-140,183-215), exact bilinear;
+ * out_dev float [out_rows][out_cols] */
+int mcrt_scan_convert(mcrt_ctx *ctx, const float *rf_dev, uint32_t n_elements, uint32_t n_rows,
+                      double radius_mm, double total_angle_rad, float *out_dev, uint32_t out_rows, uint32_t out_cols);
+
+/* device [E][R]  ->  host [R][E] row-major (the cv::Mat layout of rfimage.h:217); synchronous */
+int mcrt_export_rf(mcrt_ctx *ctx, const float *rf_dev, uint32_t n_elements, uint32_t n_rows, float *host_rows_by_cols);
+
+/* device memory helpers for callers without their own allocator */
+int mcrt_alloc(mcrt_ctx *ctx, size_t bytes, void **dev);
+int mcrt_free(mcrt_ctx *ctx, void *dev);
+int mcrt_memcpy_d2h(mcrt_ctx *ctx, void *host, const void *dev, size_t bytes);
+int mcrt_memcpy_h2d(mcrt_ctx *ctx, void *dev, const void *host, size_t bytes);
+
+/* instrumentation: counted BVH nodes / triangles / RF steps of the next trace calls (slower build
+ * of the kernel); enable=0 returns to the timed kernel */
+int mcrt_enable_stats(mcrt_ctx *ctx, int enable);
+int mcrt_get_stats(mcrt_ctx *ctx, mcrt_stats *out, int reset);
+/* average device time of the trace kernel over the launches since the last reset (HIP events on the
+ * context's stream), in milliseconds; n = launches measured */
+int mcrt_enable_timing(mcrt_ctx *ctx, int enable);
+int mcrt_get_kernel_time(mcrt_ctx *ctx, double *avg_ms, uint32_t *n, int reset);
+
+/* ---- host-side pieces of the path (no GPU needed) ---- */
+int mcrt_build_bvh(const float *tri_xyz, const uint32_t *tri_mesh, uint32_t n_tri, mcrt_bvh *out);
+void mcrt_free_bvh(mcrt_bvh *bvh);
+int mcrt_get_bvh(mcrt_ctx *ctx, mcrt_bvh *out /* borrowed pointers, valid until next upload */);
+/* volume<n,res>::volume() volume.h:19-35 */
+int mcrt_generate_texture(float *voxels, uint32_t n);
+/* psf<>::psf psf.h:34-58 */
+int mcrt_psf_kernels(float freq, float var_x, float var_y, uint32_t res_um, float *axial, uint32_t n_ax, float *lateral, uint32_t n_lat);
+/* transducer<N>::transducer transducer.h:24-62 */
+int mcrt_transducer_elements(uint32_t n_elements, double radius_cm, double separation_mm,
+                             const float position[3], const float angles_deg[3], float *pos, float *dir);
+
+/* contract-math probe used by the parity tests: evaluates op over n inputs ON THE GPU.
+ * op: 0 log_d, 1 exp_d, 2 sin_d, 3 cos_d, 4 sqrt_d, 5 div_d(x,y), 6 logf, 7 expf, 8 powf(x,y),
+ *     9 sqrtf, 10 divf(x,y), 11 pow_d(x,y).  x,y,out are host double arrays (float ops use the
+ * value converted to float). */
+int mcrt_debug_math(mcrt_ctx *ctx, int op, const double *x, const double *y, double *out, uint32_t n);
+int mcrt_debug_philox(mcrt_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,261 @@
+"""Python mirror of the reference's host interface for the hot path, over the C-ABI.
+
+  Transducer  <-> transducer<N>            (transducer.h:24-67)
+  Psf         <-> psf<ax,lat,elev,res>     (psf.h:34-77)
+  Simulator   <-> scene + rf_image + the frame loop body of main.cpp:102-148
+  Context     <-> thin 1:1 wrapper of include/mcrt.h
+"""
+import ctypes as C
+import math
+import numpy as np
+
+from . import _lib
+from ._lib import Params, MeshRec, Stats, Bvh, NODE_DTYPE, SEGMENT_DTYPE, check, ptr, load_library
+
+
+# ------------------------------------------------------------------ host-side pieces (no GPU)
+def host_build_bvh(tri, tri_mesh):
+    """-> (nodes structured array [n_nodes] of 64-B nodes, bvh_tri float32 [T,12], max_depth)"""
+    L = load_library()
+    tri = np.ascontiguousarray(tri, np.float32).reshape(-1, 9)
+    tm = np.ascontiguousarray(tri_mesh, np.uint32)
+    b = Bvh()
+    check(L.mcrt_build_bvh(ptr(tri), ptr(tm), tri.shape[0], C.byref(b)))
+    try:
+        nodes = np.frombuffer(C.string_at(b.nodes, 64 * b.n_nodes), dtype=NODE_DTYPE).copy()
+        btri = np.frombuffer(C.string_at(b.tri, 48 * b.n_tri), dtype=np.float32).reshape(-1, 12).copy()
+        depth = int(b.max_depth)
+    finally:
+        L.mcrt_free_bvh(C.byref(b))
+    return nodes, btri, depth
+
+
+def host_texture(n=256):
+    out = np.empty((n, n, n, 2), np.float32)
+    check(load_library().mcrt_generate_texture(ptr(out), n))
+    return out
+
+
+def host_psf(freq=4.5, var_x=0.05, var_y=0.2, res_um=145, n_ax=7, n_lat=13):
+    ax = np.zeros(n_ax, np.float32); lat = np.zeros(n_lat, np.float32)
+    check(load_library().mcrt_psf_kernels(freq, var_x, var_y, res_um, ptr(ax), n_ax, ptr(lat), n_lat))
+    return ax, lat
+
+
+def host_transducer(n_elements, radius_cm, sep_mm, position, angles_deg):
+    pos = np.zeros((n_elements, 3), np.float32); d = np.zeros((n_elements, 3), np.float32)
+    p = np.asarray(position, np.float32); a = np.asarray(angles_deg, np.float32)
+    check(load_library().mcrt_transducer_elements(n_elements, radius_cm, sep_mm, ptr(p), ptr(a), ptr(pos), ptr(d)))
+    return pos, d
+
+
+class Transducer:
+    """transducer<N>(frequency, radius, element_separation, position, angles) -- transducer.h:24-62.
+    main.cpp:28-29,66: total aperture 60 deg on a 3 cm radius; separation = amplitude * radius / N."""
+
+    def __init__(self, n_elements=512, frequency=4.5, radius_cm=3.0, amplitude_deg=60.0, position=(0, 0, 0), angles_deg=(0, 0, 0), separation_mm=None):
+        self.n_elements = n_elements
+        self.frequency = frequency
+        self.radius_cm = radius_cm
+        self.amplitude_rad = (amplitude_deg * math.pi * 1.0) / 180.0
+        if separation_mm is None:
+            # millimeter_t sep = amplitude.to<float>() * radius / N  (float * centimeter_t -> cm, then -> mm: *10)
+            separation_mm = ((float(np.float32(self.amplitude_rad)) * radius_cm) / n_elements) * 10.0
+        self.separation_mm = separation_mm
+        self.position = tuple(float(x) for x in position)
+        self.angles = tuple(float(x) for x in angles_deg)
+        self.update()
+
+    def update(self):
+        self.pos, self.dir = host_transducer(self.n_elements, self.radius_cm, self.separation_mm, self.position, self.angles)
+
+    def element(self, i):
+        return self.pos[i], self.dir[i]
+
+
+class Psf:
+    """psf<axial,lateral,elevation,resolution_um>{freq, var_x, var_y, var_z} -- psf.h:34-58"""
+
+    def __init__(self, freq=4.5, var_x=0.05, var_y=0.2, var_z=0.1, axial_size=7, lateral_size=13, resolution_um=145):
+        self.axial_kernel, self.lateral_kernel = host_psf(freq, var_x, var_y, resolution_um, axial_size, lateral_size)
+
+
+# ------------------------------------------------------------------ C-ABI context
+class Context:
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        check(self.L.mcrt_create(device, C.byref(h)))
+        self.h = h
+        self.params = Params()
+        check(self.L.mcrt_default_params(C.byref(self.params)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mcrt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.params, k):
+                raise AttributeError(k)
+            setattr(self.params, k, v)
+        check(self.L.mcrt_set_params(self.h, C.byref(self.params)))
+
+    def set_stream(self, stream_ptr):
+        check(self.L.mcrt_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def synchronize(self):
+        check(self.L.mcrt_synchronize(self.h))
+
+    def upload_scene(self, sd):
+        meshes = (MeshRec * len(sd.meshes))(*[MeshRec(a, b, c, 0) for a, b, c in sd.meshes])
+        sp = np.asarray(sd.spacing, np.float32)
+        check(self.L.mcrt_upload_scene(self.h, ptr(sd.tri), ptr(sd.tri_mesh), sd.n_tri, C.cast(meshes, C.c_void_p), len(sd.meshes),
+                                       ptr(sd.materials), sd.materials.shape[0], sd.start_mat, ptr(sp)))
+
+    def upload_texture(self, vox=None, n=256):
+        if vox is not None:
+            vox = np.ascontiguousarray(vox, np.float32)
+        check(self.L.mcrt_upload_texture(self.h, ptr(vox), n))
+
+    def set_transducer(self, pos, d):
+        pos = np.ascontiguousarray(pos, np.float32); d = np.ascontiguousarray(d, np.float32)
+        check(self.L.mcrt_set_transducer(self.h, ptr(pos), ptr(d), pos.shape[0]))
+
+    def get_bvh(self):
+        b = Bvh()
+        check(self.L.mcrt_get_bvh(self.h, C.byref(b)))
+        nodes = np.frombuffer(C.string_at(b.nodes, 64 * b.n_nodes), dtype=NODE_DTYPE).copy()
+        btri = np.frombuffer(C.string_at(b.tri, 48 * b.n_tri), dtype=np.float32).reshape(-1, 12).copy()
+        return nodes, btri, int(b.max_depth)
+
+    # device memory
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        check(self.L.mcrt_alloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, dev):
+        check(self.L.mcrt_free(self.h, C.c_void_p(dev)))
+
+    def d2h(self, dev, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        check(self.L.mcrt_memcpy_d2h(self.h, ptr(out), ptr(dev), out.nbytes))
+        return out
+
+    def h2d(self, dev, arr):
+        arr = np.ascontiguousarray(arr)
+        check(self.L.mcrt_memcpy_h2d(self.h, ptr(dev), ptr(arr), arr.nbytes))
+
+    # frame
+    def trace_frame(self, frame_id, rf_dev, e_begin=0, e_end=None):
+        e_end = self.params.n_elements if e_end is None else e_end
+        check(self.L.mcrt_trace_frame(self.h, frame_id, e_begin, e_end, ptr(rf_dev)))
+
+    def trace_frame_debug(self, frame_id, rf_dev, e_begin=0, e_end=None, want_hits=True, want_segs=False):
+        e_end = self.params.n_elements if e_end is None else e_end
+        ne, S, B = e_end - e_begin, self.params.n_samples, self.params.max_depth
+        hits = np.full((ne, S, B), -3, np.int32) if want_hits else None
+        segs = np.zeros((ne, S, B), SEGMENT_DTYPE) if want_segs else None
+        cnt = np.zeros((ne, S), np.uint32) if want_segs else None
+        check(self.L.mcrt_trace_frame_debug(self.h, frame_id, e_begin, e_end, ptr(rf_dev), ptr(hits), ptr(segs), ptr(cnt)))
+        return hits, segs, cnt
+
+    def cast_rays(self, frame_id, e_begin=0, e_end=None, want_hits=True):
+        e_end = self.params.n_elements if e_end is None else e_end
+        ne, S, B = e_end - e_begin, self.params.n_samples, self.params.max_depth
+        segs = np.zeros((ne, S, B), SEGMENT_DTYPE); cnt = np.zeros((ne, S), np.uint32)
+        hits = np.full((ne, S, B), -3, np.int32) if want_hits else None
+        check(self.L.mcrt_cast_rays(self.h, frame_id, e_begin, e_end, ptr(segs), ptr(cnt), ptr(hits)))
+        return segs, cnt, hits
+
+    def convolve(self, rf_dev, n_elements, n_rows, axial, lateral):
+        ax = np.ascontiguousarray(axial, np.float32); lat = np.ascontiguousarray(lateral, np.float32)
+        check(self.L.mcrt_convolve(self.h, ptr(rf_dev), n_elements, n_rows, ptr(ax), ax.size, ptr(lat), lat.size))
+
+    def envelope(self, rf_dev, n_elements, n_rows):
+        check(self.L.mcrt_envelope(self.h, ptr(rf_dev), n_elements, n_rows))
+
+    def scan_convert(self, rf_dev, n_elements, n_rows, out_dev, radius_mm=30.0, total_angle=1.0471975511965976, out_rows=400, out_cols=500):
+        check(self.L.mcrt_scan_convert(self.h, ptr(rf_dev), n_elements, n_rows, radius_mm, total_angle, ptr(out_dev), out_rows, out_cols))
+
+    def export_rf(self, rf_dev, n_elements, n_rows):
+        out = np.empty((n_rows, n_elements), np.float32)
+        check(self.L.mcrt_export_rf(self.h, ptr(rf_dev), n_elements, n_rows, ptr(out)))
+        return out
+
+    # instrumentation
+    def enable_stats(self, on=True):
+        check(self.L.mcrt_enable_stats(self.h, int(on)))
+
+    def get_stats(self, reset=True):
+        s = Stats()
+        check(self.L.mcrt_get_stats(self.h, C.byref(s), int(reset)))
+        return s.as_dict()
+
+    def enable_timing(self, on=True):
+        check(self.L.mcrt_enable_timing(self.h, int(on)))
+
+    def kernel_time(self, reset=True):
+        ms = C.c_double(); n = C.c_uint32()
+        check(self.L.mcrt_get_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def debug_math(self, op, x, y=None):
+        x = np.ascontiguousarray(x, np.float64); out = np.empty_like(x)
+        if y is not None:
+            y = np.ascontiguousarray(y, np.float64)
+        check(self.L.mcrt_debug_math(self.h, op, ptr(x), ptr(y), ptr(out), x.size))
+        return out
+
+    def debug_philox(self, ctr, key):
+        c = np.asarray(ctr, np.uint32); k = np.asarray(key, np.uint32); o = np.zeros(4, np.uint32)
+        check(self.L.mcrt_debug_philox(self.h, ptr(c), ptr(k), ptr(o)))
+        return o
+
+
+# ------------------------------------------------------------------ frame-level mirror of main.cpp:92-152
+class Simulator:
+    """scene + transducer + rf_image of the reference, driven frame by frame.
+
+        sim = Simulator(scene_data, transducer, n_samples=5)
+        rf = sim.frame(0)                 # clear -> cast_rays -> accumulate -> convolve, returns [R][E] host image
+    """
+
+    def __init__(self, scene_data, transducer, n_samples=5, n_rows=None, device=0, seed=0x5EED, psf=None, texture=None,
+                 max_depth=10, sanitize_tir=0, tex_n=256):
+        self.ctx = Context(device)
+        self.tr = transducer
+        E = transducer.n_elements
+        self.ctx.set_params(n_elements=E, n_samples=n_samples, frequency=transducer.frequency, seed=seed, max_depth=max_depth,
+                            sanitize_tir=sanitize_tir, tex_n=tex_n, **({"n_rows": n_rows} if n_rows else {}))
+        self.E, self.R, self.S = E, self.ctx.params.n_rows, n_samples
+        self.ctx.upload_scene(scene_data)
+        self.ctx.upload_texture(texture, tex_n)
+        self.ctx.set_transducer(transducer.pos, transducer.dir)
+        self.psf = psf or Psf(freq=transducer.frequency)
+        self.rf_dev = self.ctx.alloc(E * self.R * 4)
+
+    def close(self):
+        if self.ctx.h:
+            self.ctx.free(self.rf_dev)
+            self.ctx.close()
+
+    def trace(self, frame_id=0):
+        self.ctx.trace_frame(frame_id, self.rf_dev)
+
+    def convolve(self):
+        self.ctx.convolve(self.rf_dev, self.E, self.R, self.psf.axial_kernel, self.psf.lateral_kernel)
+
+    def frame(self, frame_id=0, convolve=True):
+        self.trace(frame_id)
+        if convolve:
+            self.convolve()
+        return self.ctx.export_rf(self.rf_dev, self.E, self.R)

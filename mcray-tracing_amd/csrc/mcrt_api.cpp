@@ -1,0 +1,524 @@
+// mcrt_api.cpp -- the C-ABI of include/mcrt.h: context, uploads, frame orchestration.
+// Host C++ only; kernels live in mcrt_kernels.hip.  No CPU fallback exists: every compute entry point
+// needs the GPU context.
+#include "../../include/mcrt.h"
+#include "mcrt_internal.h"
+#include "mcrt_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace mcrt {
+static thread_local std::string g_err;
+int set_error(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+}  // namespace mcrt
+using mcrt::set_error;
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return set_error(MCRT_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define CTX_TRY(ctx) do { if (!(ctx)) return set_error(MCRT_ERR_INVALID, "null context"); HIP_TRY(hipSetDevice((ctx)->device)); } while (0)
+
+struct Consts {   // main.cpp:23-37, rfimage.h:48-51,178-180 evaluated at run time
+    float axial_res_f; double axial_res_mm, time_step_us, row_dt_us, max_travel_us; uint32_t axial_res_um, max_rows;
+};
+static Consts derive_consts(const mcrt_params &p)
+{
+    Consts c;
+    c.axial_res_f = 1.45f / p.frequency;                               // main.cpp:25
+    c.axial_res_mm = (double)c.axial_res_f;
+    c.axial_res_um = (uint32_t)(c.axial_res_f * 1000.0f);              // main.cpp:36
+    c.time_step_us = (c.axial_res_mm * 1000.0) / (double)p.speed_of_sound;   // main.cpp:118 (mm -> um is *1000, units.h:1365)
+    c.row_dt_us = (double)c.axial_res_um / (double)p.speed_of_sound;   // rfimage.h:35
+    c.max_travel_us = (p.depth_cm / (double)p.speed_of_sound) * 10000.0;     // main.cpp:31 (cm s/m -> us)
+    c.max_rows = (uint32_t)((p.speed_of_sound * (uint32_t)c.max_travel_us) / c.axial_res_um);   // rfimage.h:180
+    return c;
+}
+
+struct mcrt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    mcrt_params p{};
+    Consts c{};
+    // scene
+    mcrt_bvh bvh{};
+    float4 *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr;
+    uint4 *d_meshes = nullptr;
+    uint32_t n_mesh = 0, n_mat = 0, start_mat = 0;
+    float spacing[3] = { 1, 1, 1 };
+    bool have_scene = false;
+    // texture
+    float2 *d_tex = nullptr; uint32_t tex_n = 0; bool tex_finite = false;
+    // transducer
+    float *d_pos = nullptr, *d_dir = nullptr; uint32_t n_el = 0;
+    // accumulators
+    long long *d_acc = nullptr; uint32_t *d_flags = nullptr; size_t acc_cap = 0, flag_cap = 0;
+    uint32_t acc_clean_ne = 0, acc_clean_rows = 0;   // bins known to be all-zero for this shape (k_finalize leaves them so)
+    float *d_tmp = nullptr; size_t tmp_cap = 0;
+    // scan-conversion maps
+    float *d_map_col = nullptr, *d_map_row = nullptr; uint32_t map_key[6] = { 0, 0, 0, 0, 0, 0 }; double map_keyd[2] = { 0, 0 };
+    // instrumentation
+    unsigned long long *d_stats = nullptr; bool stats_on = false;
+    bool timing_on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0;
+};
+
+extern "C" const char *mcrt_last_error(void) { return mcrt::g_err.c_str(); }
+extern "C" int mcrt_version(void) { return MCRT_VERSION; }
+extern "C" int mcrt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int mcrt_default_params(mcrt_params *p)
+{
+    if (!p) return set_error(MCRT_ERR_INVALID, "null params");
+    memset(p, 0, sizeof *p);
+    p->n_elements = 512; p->n_samples = 5; p->max_depth = 10; p->n_rows = 465;
+    p->frequency = 4.5f; p->intensity_epsilon = 1e-10f; p->initial_intensity = 1.0f; p->ray_start_offset = 0.1f;
+    p->speed_of_sound = 1500; p->depth_cm = 15.0; p->seed = 0x5EED; p->sanitize_tir = 0; p->tex_n = 256; p->tex_res = 0.145f;
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_create(int device, mcrt_ctx **out)
+{
+    if (!out) return set_error(MCRT_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return set_error(MCRT_ERR_NO_DEVICE, "no HIP device visible: libmcrt_hip has no CPU fallback");
+    if (device < 0 || device >= n) return set_error(MCRT_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return set_error(MCRT_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", device, prop.gcnArchName);
+    mcrt_ctx *c = new (std::nothrow) mcrt_ctx();
+    if (!c) return set_error(MCRT_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(MCRT_ERR_HIP, "hipStreamCreate failed"); }
+    c->stream = c->own_stream;
+    mcrt_default_params(&c->p);
+    c->c = derive_consts(c->p);
+    if (hipMalloc(&c->d_stats, 6 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_stats, 0, 6 * sizeof(unsigned long long)) != hipSuccess) {
+        hipStreamDestroy(c->own_stream); delete c; return set_error(MCRT_ERR_HIP, "hipMalloc failed");
+    }
+    *out = c;
+    return MCRT_OK;
+}
+
+static void free_scene(mcrt_ctx *c)
+{
+    hipFree(c->d_nodes); hipFree(c->d_tris); hipFree(c->d_mats); hipFree(c->d_meshes);
+    c->d_nodes = c->d_tris = c->d_mats = nullptr; c->d_meshes = nullptr;
+    mcrt_free_bvh(&c->bvh);
+    c->have_scene = false;
+}
+
+extern "C" int mcrt_destroy(mcrt_ctx *c)
+{
+    if (!c) return MCRT_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    free_scene(c);
+    hipFree(c->d_tex); hipFree(c->d_pos); hipFree(c->d_dir); hipFree(c->d_acc); hipFree(c->d_flags); hipFree(c->d_tmp);
+    hipFree(c->d_map_col); hipFree(c->d_map_row); hipFree(c->d_stats);
+    for (auto &e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    hipStreamDestroy(c->own_stream);
+    delete c;
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_set_stream(mcrt_ctx *c, void *s) { CTX_TRY(c); c->stream = s ? (hipStream_t)s : c->own_stream; return MCRT_OK; }
+extern "C" int mcrt_synchronize(mcrt_ctx *c) { CTX_TRY(c); HIP_TRY(hipStreamSynchronize(c->stream)); return MCRT_OK; }
+
+extern "C" int mcrt_set_params(mcrt_ctx *c, const mcrt_params *p)
+{
+    CTX_TRY(c);
+    if (!p) return set_error(MCRT_ERR_INVALID, "null params");
+    if (p->n_elements == 0 || p->n_samples == 0) return set_error(MCRT_ERR_INVALID, "n_elements and n_samples must be positive");
+    if (p->max_depth == 0 || p->max_depth > MCRT_MAX_BOUNCES) return set_error(MCRT_ERR_LIMIT, "max_depth must be 1..%d", MCRT_MAX_BOUNCES);
+    if (p->n_rows == 0 || p->n_rows > MCRT_MAX_ROWS) return set_error(MCRT_ERR_LIMIT, "n_rows must be 1..%d", MCRT_MAX_ROWS);
+    if (!(p->frequency > 0.f) || p->speed_of_sound == 0 || !(p->depth_cm > 0.0)) return set_error(MCRT_ERR_INVALID, "frequency, speed_of_sound and depth must be positive");
+    if (p->tex_n == 0 || !(p->tex_res > 0.f)) return set_error(MCRT_ERR_INVALID, "texture size/resolution must be positive");
+    Consts k = derive_consts(*p);
+    if (k.axial_res_um == 0) return set_error(MCRT_ERR_INVALID, "axial resolution rounds to 0 um at %g MHz", (double)p->frequency);
+    c->p = *p; c->c = k;
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *tri_mesh, uint32_t n_tri,
+                                 const mcrt_mesh *meshes, uint32_t n_mesh, const float *mats, uint32_t n_mat,
+                                 uint32_t start_mat, const float spacing[3])
+{
+    CTX_TRY(c);
+    if (!meshes || !mats || n_mesh == 0 || n_mat == 0 || !spacing) return set_error(MCRT_ERR_INVALID, "mcrt_upload_scene: missing tables");
+    if (n_tri && (!tri || !tri_mesh)) return set_error(MCRT_ERR_INVALID, "mcrt_upload_scene: missing triangles");
+    if (start_mat >= n_mat) return set_error(MCRT_ERR_INVALID, "startingMaterial index %u out of range", start_mat);
+    for (uint32_t i = 0; i < n_mesh; i++)
+        if (meshes[i].mat_inside >= n_mat || meshes[i].mat_outside >= n_mat) return set_error(MCRT_ERR_INVALID, "mesh %u references a material out of range", i);
+    for (uint32_t i = 0; i < n_tri; i++)
+        if (tri_mesh[i] >= n_mesh) return set_error(MCRT_ERR_INVALID, "triangle %u references mesh %u out of range", i, tri_mesh[i]);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_scene(c);
+    if (n_tri) {
+        int rc = mcrt_build_bvh(tri, tri_mesh, n_tri, &c->bvh);
+        if (rc) return rc;
+        HIP_TRY(hipMalloc(&c->d_nodes, sizeof(mcrt_bvh_node) * (size_t)c->bvh.n_nodes));
+        HIP_TRY(hipMalloc(&c->d_tris, 48 * (size_t)n_tri));
+        HIP_TRY(hipMemcpy(c->d_nodes, c->bvh.nodes, sizeof(mcrt_bvh_node) * (size_t)c->bvh.n_nodes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_tris, c->bvh.tri, 48 * (size_t)n_tri, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(&c->d_mats, 32 * (size_t)n_mat));
+    HIP_TRY(hipMemcpy(c->d_mats, mats, 32 * (size_t)n_mat, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&c->d_meshes, sizeof(mcrt_mesh) * (size_t)n_mesh));
+    HIP_TRY(hipMemcpy(c->d_meshes, meshes, sizeof(mcrt_mesh) * (size_t)n_mesh, hipMemcpyHostToDevice));
+    c->n_mesh = n_mesh; c->n_mat = n_mat; c->start_mat = start_mat;
+    for (int i = 0; i < 3; i++) c->spacing[i] = spacing[i];
+    c->have_scene = true;
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_get_bvh(mcrt_ctx *c, mcrt_bvh *out)
+{
+    if (!c || !out) return set_error(MCRT_ERR_INVALID, "null argument");
+    if (!c->have_scene) return set_error(MCRT_ERR_INVALID, "no scene uploaded");
+    *out = c->bvh;
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_upload_texture(mcrt_ctx *c, const float *vox, uint32_t n)
+{
+    CTX_TRY(c);
+    if (n == 0) return set_error(MCRT_ERR_INVALID, "texture size 0");
+    const size_t total = (size_t)n * n * n;
+    std::vector<float> gen;
+    bool finite = true;
+    if (!vox) {
+        gen.resize(total * 2);
+        int rc = mcrt_generate_texture(gen.data(), n);
+        if (rc) return rc;
+        vox = gen.data();
+    } else {
+        for (size_t i = 0; i < total * 2; i++) if (!std::isfinite(vox[i])) { finite = false; break; }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipFree(c->d_tex); c->d_tex = nullptr;
+    HIP_TRY(hipMalloc(&c->d_tex, total * 8));
+    HIP_TRY(hipMemcpy(c->d_tex, vox, total * 8, hipMemcpyHostToDevice));
+    c->tex_n = n; c->tex_finite = finite;
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_set_transducer(mcrt_ctx *c, const float *pos, const float *dir, uint32_t n)
+{
+    CTX_TRY(c);
+    if (!pos || !dir || n == 0) return set_error(MCRT_ERR_INVALID, "mcrt_set_transducer: bad arguments");
+    if (n != c->n_el) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->d_pos); hipFree(c->d_dir); c->d_pos = c->d_dir = nullptr;
+        HIP_TRY(hipMalloc(&c->d_pos, 12 * (size_t)n));
+        HIP_TRY(hipMalloc(&c->d_dir, 12 * (size_t)n));
+        c->n_el = n;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_pos, pos, 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_dir, dir, 12 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // pos/dir may be pageable host memory owned by the caller
+    return MCRT_OK;
+}
+
+static int ensure_acc(mcrt_ctx *c, uint32_t ne)
+{
+    const size_t need = (size_t)ne * c->p.n_rows, needf = (size_t)ne * ((c->p.n_rows + 31u) >> 5);
+    if (need > c->acc_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->d_acc); c->d_acc = nullptr; c->acc_cap = 0; c->acc_clean_ne = 0;
+        HIP_TRY(hipMalloc(&c->d_acc, need * 8));
+        c->acc_cap = need;
+    }
+    if (needf > c->flag_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->d_flags); c->d_flags = nullptr; c->flag_cap = 0; c->acc_clean_ne = 0;
+        HIP_TRY(hipMalloc(&c->d_flags, needf * 4));
+        c->flag_cap = needf;
+    }
+    // k_finalize leaves the bins zeroed; only a shape change (or a failed frame) needs an explicit clear
+    if (c->acc_clean_ne != ne || c->acc_clean_rows != c->p.n_rows) {
+        HIP_TRY(hipMemsetAsync(c->d_acc, 0, need * 8, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_flags, 0, needf * 4, c->stream));
+    }
+    c->acc_clean_ne = 0; c->acc_clean_rows = 0;   // dirty until the frame's k_finalize has been enqueued
+    return MCRT_OK;
+}
+
+static int check_ready(mcrt_ctx *c, uint32_t e0, uint32_t e1)
+{
+    if (!c->have_scene) return set_error(MCRT_ERR_INVALID, "no scene uploaded");
+    if (!c->d_tex) return set_error(MCRT_ERR_INVALID, "no texture uploaded");
+    if (c->tex_n != c->p.tex_n) return set_error(MCRT_ERR_INVALID, "texture is %u^3 but params say %u^3", c->tex_n, c->p.tex_n);
+    if (!c->d_pos) return set_error(MCRT_ERR_INVALID, "no transducer set");
+    if (c->n_el != c->p.n_elements) return set_error(MCRT_ERR_INVALID, "transducer has %u elements but params say %u", c->n_el, c->p.n_elements);
+    if (e0 >= e1 || e1 > c->p.n_elements) return set_error(MCRT_ERR_INVALID, "scan-line range [%u,%u) invalid for %u elements", e0, e1, c->p.n_elements);
+    return MCRT_OK;
+}
+
+static void fill_args(mcrt_ctx *c, mcrt::TraceArgs &a, uint32_t frame, uint32_t e0, uint32_t e1, int block)
+{
+    memset(&a, 0, sizeof a);
+    a.nodes = c->d_nodes; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
+    a.el_pos = c->d_pos; a.el_dir = c->d_dir; a.acc = c->d_acc; a.flags = c->d_flags;
+    a.stats = c->d_stats;
+    a.n_nodes = c->bvh.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
+    a.e_begin = e0; a.ne = e1 - e0; a.chunks = (c->p.n_samples + block - 1) / block;
+    a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n;
+    a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
+    a.freq = c->p.frequency; a.eps = c->p.intensity_epsilon; a.I0 = c->p.initial_intensity; a.offs = c->p.ray_start_offset;
+    a.sx = c->spacing[0]; a.sy = c->spacing[1]; a.sz = c->spacing[2]; a.tex_res = c->p.tex_res; a.axial_res_f = c->c.axial_res_f; a.pad_abs = c->bvh.pad_abs;
+    a.axial_res_mm = c->c.axial_res_mm; a.time_step = c->c.time_step_us; a.row_dt = c->c.row_dt_us;
+    a.max_travel = c->c.max_travel_us; a.sos_d = (double)c->p.speed_of_sound;
+}
+
+static int pick_block(const mcrt_ctx *c) { return c->p.n_samples <= 64 ? 64 : 256; }
+
+static int timed_launch(mcrt_ctx *c, const mcrt::TraceArgs &a, int block, bool emit, bool accum)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing_on) {
+        if (c->ev_used == c->ev.size()) {
+            if (c->ev.size() >= 8192) return set_error(MCRT_ERR_LIMIT, "timing buffer full: call mcrt_get_kernel_time(reset=1)");
+            hipEvent_t x, y;
+            HIP_TRY(hipEventCreate(&x)); HIP_TRY(hipEventCreate(&y));
+            c->ev.emplace_back(x, y);
+        }
+        e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; c->ev_used++;
+        HIP_TRY(hipEventRecord(e0, c->stream));
+    }
+    HIP_TRY(mcrt::launch_trace(a, block, c->stats_on, emit, accum, c->stream));
+    if (c->timing_on) HIP_TRY(hipEventRecord(e1, c->stream));
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_trace_frame(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32_t e1, float *rf_dev)
+{
+    CTX_TRY(c);
+    int rc = check_ready(c, e0, e1); if (rc) return rc;
+    if (!rf_dev) return set_error(MCRT_ERR_INVALID, "null rf_dev");
+    rc = ensure_acc(c, e1 - e0); if (rc) return rc;
+    const int block = pick_block(c);
+    mcrt::TraceArgs a; fill_args(c, a, frame, e0, e1, block);
+    rc = timed_launch(c, a, block, false, true); if (rc) return rc;
+    HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, e1 - e0, c->p.n_rows, c->stream));
+    c->acc_clean_ne = e1 - e0; c->acc_clean_rows = c->p.n_rows;
+    return MCRT_OK;
+}
+
+static int trace_debug(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32_t e1, float *rf_dev, bool accum,
+                       int32_t *hits, mcrt_segment *segs, uint32_t *seg_count)
+{
+    int rc = check_ready(c, e0, e1); if (rc) return rc;
+    const uint32_t ne = e1 - e0;
+    const size_t np = (size_t)ne * c->p.n_samples, nb = np * c->p.max_depth;
+    int32_t *d_hits = nullptr; mcrt_segment *d_segs = nullptr; uint32_t *d_cnt = nullptr;
+    if (accum) { rc = ensure_acc(c, ne); if (rc) return rc; }
+    if (hits) HIP_TRY(hipMalloc(&d_hits, nb * 4));
+    if (segs) { HIP_TRY(hipMalloc(&d_segs, nb * sizeof(mcrt_segment))); HIP_TRY(hipMemsetAsync(d_segs, 0, nb * sizeof(mcrt_segment), c->stream)); }
+    if (seg_count) HIP_TRY(hipMalloc(&d_cnt, np * 4));
+    const int block = pick_block(c);
+    mcrt::TraceArgs a; fill_args(c, a, frame, e0, e1, block);
+    a.hits = d_hits; a.segs = d_segs; a.seg_count = d_cnt;
+    rc = timed_launch(c, a, block, true, accum);
+    if (!rc && accum) { hipError_t e = mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, ne, c->p.n_rows, c->stream); if (e != hipSuccess) rc = set_error(MCRT_ERR_HIP, "finalize: %s", hipGetErrorString(e)); }
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess && hits) e = hipMemcpy(hits, d_hits, nb * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && segs) e = hipMemcpy(segs, d_segs, nb * sizeof(mcrt_segment), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && seg_count) e = hipMemcpy(seg_count, d_cnt, np * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = set_error(MCRT_ERR_HIP, "trace (debug): %s", hipGetErrorString(e));
+    }
+    hipFree(d_hits); hipFree(d_segs); hipFree(d_cnt);
+    return rc;
+}
+
+extern "C" int mcrt_trace_frame_debug(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32_t e1, float *rf_dev,
+                                      int32_t *hits, mcrt_segment *segs, uint32_t *seg_count)
+{
+    CTX_TRY(c);
+    if (!rf_dev) return set_error(MCRT_ERR_INVALID, "null rf_dev");
+    return trace_debug(c, frame, e0, e1, rf_dev, true, hits, segs, seg_count);
+}
+
+extern "C" int mcrt_cast_rays(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32_t e1, mcrt_segment *segs, uint32_t *seg_count, int32_t *hits)
+{
+    CTX_TRY(c);
+    return trace_debug(c, frame, e0, e1, nullptr, false, hits, segs, seg_count);
+}
+
+static int ensure_tmp(mcrt_ctx *c, size_t n)
+{
+    if (n > c->tmp_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->d_tmp); c->d_tmp = nullptr; c->tmp_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_tmp, n * 4));
+        c->tmp_cap = n;
+    }
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_convolve(mcrt_ctx *c, float *rf_dev, uint32_t E, uint32_t R, const float *ax, uint32_t n_ax, const float *lat, uint32_t n_lat)
+{
+    CTX_TRY(c);
+    if (!rf_dev || !ax || !lat || E == 0 || R == 0) return set_error(MCRT_ERR_INVALID, "mcrt_convolve: bad arguments");
+    if (n_ax == 0 || n_ax > 16 || n_lat == 0 || n_lat > 32) return set_error(MCRT_ERR_LIMIT, "kernel sizes must be 1..16 axial, 1..32 lateral");
+    int rc = ensure_tmp(c, (size_t)E * R); if (rc) return rc;
+    mcrt::ConvTaps t; memset(&t, 0, sizeof t);
+    memcpy(t.ax, ax, 4 * n_ax); memcpy(t.lat, lat, 4 * n_lat); t.n_ax = n_ax; t.n_lat = n_lat;
+    HIP_TRY(mcrt::launch_convolve(rf_dev, c->d_tmp, E, R, t, c->stream));
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_envelope(mcrt_ctx *c, float *rf_dev, uint32_t E, uint32_t R)
+{
+    CTX_TRY(c);
+    if (!rf_dev || E == 0 || R == 0) return set_error(MCRT_ERR_INVALID, "mcrt_envelope: bad arguments");
+    HIP_TRY(mcrt::launch_envelope(rf_dev, E, R, c->stream));
+    return MCRT_OK;
+}
+
+// rfimage.h:183-215 create_mapping, evaluated once per geometry on the host (as the reference does in its constructor)
+static void build_maps(const mcrt_ctx *c, uint32_t E, uint32_t R, double radius_mm, double total_angle, uint32_t orows, uint32_t ocols,
+                       std::vector<float> &map_col, std::vector<float> &map_row)
+{
+    const float radius_f = (float)radius_mm, ta_f = (float)total_angle;
+    const double depth_um = c->c.max_travel_us * (double)c->p.speed_of_sound;
+    const float ratio = (float)((depth_um * 0.001f + radius_f - radius_f * std::cos(ta_f / 2.0)) / (double)orows);
+    const double shift_y = radius_mm * (double)std::cos(ta_f / 2.0f);
+    const float half_width = (float)ocols / 2.0f;
+    map_col.resize((size_t)orows * ocols); map_row.resize((size_t)orows * ocols);
+    for (uint32_t j = 0; j < ocols; j++)
+        for (uint32_t i = 0; i < orows; i++) {
+            const float fi = (float)i + (float)shift_y / ratio;
+            const float fj = (float)j - half_width;
+            const float r = std::sqrt(fi * fi + fj * fj);
+            const double angle = (double)std::atan2(fj, fi);
+            map_row[(size_t)i * ocols + j] = (float)((double)(r * ratio - radius_f) / (depth_um * 0.001f) * (double)(float)R);
+            map_col[(size_t)i * ocols + j] = (float)(((angle - (-total_angle / 2)) / total_angle) * (double)(float)E);
+        }
+}
+
+extern "C" int mcrt_scan_convert(mcrt_ctx *c, const float *rf_dev, uint32_t E, uint32_t R, double radius_mm, double total_angle,
+                                 float *out_dev, uint32_t orows, uint32_t ocols)
+{
+    CTX_TRY(c);
+    if (!rf_dev || !out_dev || E == 0 || R == 0 || orows == 0 || ocols == 0) return set_error(MCRT_ERR_INVALID, "mcrt_scan_convert: bad arguments");
+    const uint32_t key[6] = { E, R, orows, ocols, c->p.speed_of_sound, 1u };
+    const double keyd[2] = { radius_mm * 1e6 + total_angle, c->c.max_travel_us };
+    if (memcmp(key, c->map_key, sizeof key) || memcmp(keyd, c->map_keyd, sizeof keyd)) {
+        std::vector<float> mc, mr;
+        build_maps(c, E, R, radius_mm, total_angle, orows, ocols, mc, mr);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->d_map_col); hipFree(c->d_map_row); c->d_map_col = c->d_map_row = nullptr;
+        HIP_TRY(hipMalloc(&c->d_map_col, mc.size() * 4)); HIP_TRY(hipMalloc(&c->d_map_row, mr.size() * 4));
+        HIP_TRY(hipMemcpy(c->d_map_col, mc.data(), mc.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_map_row, mr.data(), mr.size() * 4, hipMemcpyHostToDevice));
+        memcpy(c->map_key, key, sizeof key); memcpy(c->map_keyd, keyd, sizeof keyd);
+    }
+    HIP_TRY(mcrt::launch_remap(rf_dev, E, R, c->d_map_col, c->d_map_row, out_dev, orows * ocols, c->stream));
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_export_rf(mcrt_ctx *c, const float *rf_dev, uint32_t E, uint32_t R, float *host)
+{
+    CTX_TRY(c);
+    if (!rf_dev || !host || E == 0 || R == 0) return set_error(MCRT_ERR_INVALID, "mcrt_export_rf: bad arguments");
+    int rc = ensure_tmp(c, (size_t)E * R); if (rc) return rc;
+    HIP_TRY(mcrt::launch_transpose(rf_dev, c->d_tmp, E, R, c->stream));
+    HIP_TRY(hipMemcpyAsync(host, c->d_tmp, (size_t)E * R * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_alloc(mcrt_ctx *c, size_t bytes, void **dev)
+{
+    CTX_TRY(c);
+    if (!dev) return set_error(MCRT_ERR_INVALID, "null out pointer");
+    HIP_TRY(hipMalloc(dev, bytes ? bytes : 1));
+    return MCRT_OK;
+}
+extern "C" int mcrt_free(mcrt_ctx *c, void *dev) { CTX_TRY(c); HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(dev)); return MCRT_OK; }
+extern "C" int mcrt_memcpy_d2h(mcrt_ctx *c, void *host, const void *dev, size_t bytes)
+{
+    CTX_TRY(c);
+    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+extern "C" int mcrt_memcpy_h2d(mcrt_ctx *c, void *dev, const void *host, size_t bytes)
+{
+    CTX_TRY(c);
+    HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_enable_stats(mcrt_ctx *c, int on) { CTX_TRY(c); c->stats_on = on != 0; return MCRT_OK; }
+extern "C" int mcrt_get_stats(mcrt_ctx *c, mcrt_stats *out, int reset)
+{
+    CTX_TRY(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned long long v[6];
+    HIP_TRY(hipMemcpy(v, c->d_stats, sizeof v, hipMemcpyDeviceToHost));
+    if (out) { out->queries = v[0]; out->nodes_visited = v[1]; out->tris_tested = v[2]; out->segments = v[3]; out->rf_steps = v[4]; out->hits = v[5]; }
+    if (reset) HIP_TRY(hipMemset(c->d_stats, 0, sizeof v));
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_enable_timing(mcrt_ctx *c, int on) { CTX_TRY(c); c->timing_on = on != 0; return MCRT_OK; }
+extern "C" int mcrt_get_kernel_time(mcrt_ctx *c, double *avg_ms, uint32_t *n, int reset)
+{
+    CTX_TRY(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double sum = 0;
+    for (size_t i = 0; i < c->ev_used; i++) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[i].first, c->ev[i].second)); sum += ms; }
+    if (avg_ms) *avg_ms = c->ev_used ? sum / (double)c->ev_used : 0.0;
+    if (n) *n = (uint32_t)c->ev_used;
+    if (reset) c->ev_used = 0;
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_debug_math(mcrt_ctx *c, int op, const double *x, const double *y, double *out, uint32_t n)
+{
+    CTX_TRY(c);
+    if (!x || !out || n == 0) return set_error(MCRT_ERR_INVALID, "mcrt_debug_math: bad arguments");
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&dx, 8 * (size_t)n)); HIP_TRY(hipMalloc(&dout, 8 * (size_t)n));
+    HIP_TRY(hipMemcpy(dx, x, 8 * (size_t)n, hipMemcpyHostToDevice));
+    if (y) { HIP_TRY(hipMalloc(&dy, 8 * (size_t)n)); HIP_TRY(hipMemcpy(dy, y, 8 * (size_t)n, hipMemcpyHostToDevice)); }
+    HIP_TRY(mcrt::launch_math_probe(op, dx, dy, dout, n, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, dout, 8 * (size_t)n, hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(dy); hipFree(dout);
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_debug_philox(mcrt_ctx *c, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    CTX_TRY(c);
+    uint32_t *d = nullptr;
+    HIP_TRY(hipMalloc(&d, 16));
+    HIP_TRY(mcrt::launch_philox_probe(ctr, key, d, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, d, 16, hipMemcpyDeviceToHost));
+    hipFree(d);
+    return MCRT_OK;
+}

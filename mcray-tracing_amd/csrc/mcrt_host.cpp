@@ -1,0 +1,272 @@
+// mcrt_host.cpp -- host-side pieces of the hot path (no GPU needed):
+//   * BVH2 builder (binned SAH) replacing btBvhTriangleMeshShape construction + the DBVT
+//     broadphase (scene.cpp:255,309): ONE flattened tree over the triangles of all meshes.
+//   * the reference's static tables: tissue texture (volume.h:19-35), PSF taps (psf.h:34-58),
+//     transducer element geometry (transducer.h:24-62).
+#include "../../include/mcrt.h"
+#include "mcrt_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct Prim {
+    float lo[3], hi[3];   // padded bounds
+    float c[3];           // centroid of the unpadded bounds
+    uint32_t id;
+};
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int i = 0; i < 3; i++) { lo[i] = INFINITY; hi[i] = -INFINITY; } }
+    void grow(const float *l, const float *h) { for (int i = 0; i < 3; i++) { lo[i] = std::min(lo[i], l[i]); hi[i] = std::max(hi[i], h[i]); } }
+    void grow_pt(const float *p) { for (int i = 0; i < 3; i++) { lo[i] = std::min(lo[i], p[i]); hi[i] = std::max(hi[i], p[i]); } }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0) || !(dy >= 0) || !(dz >= 0)) return 0.f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+constexpr int kLeafMax = 4;
+constexpr int kBins = 16;
+constexpr int kMaxDepth = MCRT_BVH_MAX_DEPTH;   // deepest leaf; the traversal stack holds this many entries
+constexpr float kCostNode = 1.0f, kCostTri = 1.2f;
+
+struct Builder {
+    std::vector<Prim> prims;
+    std::vector<mcrt_bvh_node> nodes;
+    int deepest = 0;
+
+    static int levels_needed(uint32_t n) { int k = 0; uint64_t cap = kLeafMax; while (cap < n) { cap <<= 1; k++; } return k; }
+
+    static int32_t leaf_ref(uint32_t first, uint32_t cnt) { return ~(int32_t)((first << 3) | (cnt - 1)); }
+
+    // returns child reference, bounds of the subtree in `out`
+    int32_t build(uint32_t lo, uint32_t hi, int depth, Box &out)
+    {
+        const uint32_t n = hi - lo;
+        out.reset();
+        Box cb; cb.reset();
+        for (uint32_t i = lo; i < hi; i++) { out.grow(prims[i].lo, prims[i].hi); cb.grow_pt(prims[i].c); }
+        deepest = std::max(deepest, depth);
+
+        uint32_t mid = 0;
+        bool have_split = false;
+        const bool force_median = depth + levels_needed(n) >= kMaxDepth;
+        float best_cost = INFINITY;
+        if (n > 1 && !force_median) {
+            int best_axis = -1, best_bin = -1;
+            const float parent_area = out.half_area();
+            for (int axis = 0; axis < 3; axis++) {
+                const float cmin = cb.lo[axis], cext = cb.hi[axis] - cb.lo[axis];
+                if (!(cext > 0.f)) continue;
+                const float scale = (float)kBins / cext;
+                Box bb[kBins]; uint32_t cnt[kBins];
+                for (int b = 0; b < kBins; b++) { bb[b].reset(); cnt[b] = 0; }
+                for (uint32_t i = lo; i < hi; i++) {
+                    int b = (int)((prims[i].c[axis] - cmin) * scale);
+                    b = std::min(std::max(b, 0), kBins - 1);
+                    bb[b].grow(prims[i].lo, prims[i].hi); cnt[b]++;
+                }
+                float right_area[kBins]; uint32_t right_cnt[kBins];
+                Box acc; acc.reset(); uint32_t c = 0;
+                for (int b = kBins - 1; b > 0; b--) { acc.grow(bb[b].lo, bb[b].hi); c += cnt[b]; right_area[b] = acc.half_area(); right_cnt[b] = c; }
+                acc.reset(); c = 0;
+                for (int b = 0; b < kBins - 1; b++) {
+                    acc.grow(bb[b].lo, bb[b].hi); c += cnt[b];
+                    if (c == 0 || right_cnt[b + 1] == 0) continue;
+                    float cost = kCostNode + kCostTri * (acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1]) / std::max(parent_area, 1e-30f);
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                const float cmin = cb.lo[best_axis], scale = (float)kBins / (cb.hi[best_axis] - cb.lo[best_axis]);
+                auto it = std::partition(prims.begin() + lo, prims.begin() + hi, [&](const Prim &p) {
+                    int b = (int)((p.c[best_axis] - cmin) * scale);
+                    b = std::min(std::max(b, 0), kBins - 1);
+                    return b <= best_bin;
+                });
+                mid = (uint32_t)(it - prims.begin());
+                have_split = mid > lo && mid < hi;
+            }
+        }
+        if (n <= (uint32_t)kLeafMax && (n == 1 || !have_split || best_cost >= kCostTri * (float)n))
+            return leaf_ref(lo, n);
+        if (!have_split) {   // median split on the widest centroid axis (also the depth-limit fallback)
+            int axis = 0; float ext = -1.f;
+            for (int a = 0; a < 3; a++) { float e = cb.hi[a] - cb.lo[a]; if (e > ext) { ext = e; axis = a; } }
+            mid = lo + n / 2;
+            std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi,
+                             [axis](const Prim &a, const Prim &b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.id < b.id); });
+        }
+        const int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        Box bl, br;
+        int32_t cl = build(lo, mid, depth + 1, bl);
+        int32_t cr = build(mid, hi, depth + 1, br);
+        mcrt_bvh_node &N = nodes[me];
+        for (int i = 0; i < 3; i++) { N.lo0[i] = bl.lo[i]; N.hi0[i] = bl.hi[i]; N.lo1[i] = br.lo[i]; N.hi1[i] = br.hi[i]; }
+        N.c0 = cl; N.c1 = cr; N.pad0 = 0; N.pad1 = 0;
+        return me;
+    }
+};
+
+}  // namespace
+
+extern "C" int mcrt_build_bvh(const float *tri, const uint32_t *tri_mesh, uint32_t n_tri, mcrt_bvh *out)
+{
+    if (!tri || !out || n_tri == 0) return mcrt::set_error(MCRT_ERR_INVALID, "mcrt_build_bvh: no triangles");
+    if (n_tri >= (1u << 28)) return mcrt::set_error(MCRT_ERR_LIMIT, "mcrt_build_bvh: more than 2^28 triangles");
+    Builder b;
+    b.prims.resize(n_tri);
+    // Padding (DESIGN.md "Closest hit"): Bullet's triangle test accepts points up to 1e-4 of the triangle's
+    // height outside an edge, and the slab arithmetic rounds; each triangle's bounds are widened accordingly.
+    // A triangle is eligible only while the ray overlaps ITS padded bounds (as in Bullet's per-triangle BVH
+    // leaves); node boxes are exact unions of those, and the float slab test is monotone under containment,
+    // so node culling can never remove an eligible triangle.
+    float scale = 0.f;
+    for (size_t i = 0; i < (size_t)n_tri * 9; i++) { float a = std::fabs(tri[i]); if (a > scale && std::isfinite(a)) scale = a; }
+    const float abs_pad = 4e-6f * std::max(scale, 1e-3f);
+    for (uint32_t t = 0; t < n_tri; t++) {
+        const float *v = tri + (size_t)t * 9;
+        Prim &p = b.prims[t];
+        // must equal the kernel's tri_bounds() bit for bit: node boxes are unions of exactly these boxes
+        float ext = 0.f;
+        for (int a = 0; a < 3; a++) {
+            float l = fminf(v[a], fminf(v[3 + a], v[6 + a]));
+            float h = fmaxf(v[a], fmaxf(v[3 + a], v[6 + a]));
+            p.lo[a] = l; p.hi[a] = h; p.c[a] = 0.5f * (l + h);
+            ext = fmaxf(ext, h - l);
+        }
+        const float pad = 2e-4f * ext + abs_pad;
+        for (int a = 0; a < 3; a++) { p.lo[a] = p.lo[a] - pad; p.hi[a] = p.hi[a] + pad; }
+        p.id = t;
+    }
+    b.nodes.reserve(n_tri);
+    Box root;
+    int32_t r = b.build(0, n_tri, 0, root);
+    if (r < 0) {   // everything fitted one leaf: wrap it in a root node (both children the same leaf)
+        b.nodes.emplace_back();
+        mcrt_bvh_node &N = b.nodes[0];
+        for (int i = 0; i < 3; i++) { N.lo0[i] = root.lo[i]; N.hi0[i] = root.hi[i]; N.lo1[i] = root.lo[i]; N.hi1[i] = root.hi[i]; }
+        N.c0 = r; N.c1 = r; N.pad0 = N.pad1 = 0;
+    }
+    out->n_nodes = (uint32_t)b.nodes.size();
+    out->n_tri = n_tri;
+    out->max_depth = (uint32_t)b.deepest;
+    out->pad_abs = abs_pad;
+    out->nodes = (mcrt_bvh_node *)malloc(sizeof(mcrt_bvh_node) * b.nodes.size());
+    out->tri = (float *)malloc(sizeof(float) * 12 * (size_t)n_tri);
+    if (!out->nodes || !out->tri) { free(out->nodes); free(out->tri); return mcrt::set_error(MCRT_ERR_NOMEM, "mcrt_build_bvh: out of memory"); }
+    memcpy(out->nodes, b.nodes.data(), sizeof(mcrt_bvh_node) * b.nodes.size());
+    for (uint32_t i = 0; i < n_tri; i++) {
+        const uint32_t id = b.prims[i].id;
+        const float *v = tri + (size_t)id * 9;
+        float *o = out->tri + (size_t)i * 12;
+        uint32_t mesh = tri_mesh ? tri_mesh[id] : 0u, zero = 0u;
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; memcpy(&o[3], &id, 4);
+        o[4] = v[3]; o[5] = v[4]; o[6] = v[5]; memcpy(&o[7], &mesh, 4);
+        o[8] = v[6]; o[9] = v[7]; o[10] = v[8]; memcpy(&o[11], &zero, 4);
+    }
+    return MCRT_OK;
+}
+
+extern "C" void mcrt_free_bvh(mcrt_bvh *bvh)
+{
+    if (!bvh) return;
+    free(bvh->nodes); free(bvh->tri);
+    bvh->nodes = nullptr; bvh->tri = nullptr; bvh->n_nodes = bvh->n_tri = 0;
+}
+
+// ---- volume<n,res>::volume() (volume.h:19-35) ------------------------------------------------
+// libstdc++ semantics: std::default_random_engine is minstd_rand0 (multiplier 16807, modulus 2^31-1,
+// default seed 1); generate_canonical<double,53> consumes two draws; normal_distribution<double> is
+// the Marsaglia polar method, which returns y*m and keeps x*m for the following call.
+extern "C" int mcrt_generate_texture(float *vox, uint32_t n)
+{
+    if (!vox || n == 0) return mcrt::set_error(MCRT_ERR_INVALID, "mcrt_generate_texture: bad arguments");
+    uint64_t state = 1;
+    auto next = [&state]() -> double { state = (state * 16807ull) % 2147483647ull; return (double)(uint32_t)(state - 1); };
+    const double R = 2147483646.0, RR = R * R;
+    auto canonical = [&]() -> double {
+        double sum = next();
+        sum += next() * R;
+        double r = sum / RR;
+        return r >= 1.0 ? std::nextafter(1.0, 0.0) : r;
+    };
+    const size_t total = (size_t)n * n * n;
+    for (size_t i = 0; i < total; i++) {
+        double x, y, r2;
+        do {
+            x = 2.0 * canonical() - 1.0;
+            y = 2.0 * canonical() - 1.0;
+            r2 = x * x + y * y;
+        } while (r2 > 1.0 || r2 == 0.0);
+        const double mult = std::sqrt(-2 * std::log(r2) / r2);
+        vox[2 * i] = (float)(y * mult);        // texture_noise: first variate of the pair
+        vox[2 * i + 1] = (float)(x * mult);    // scattering_probability: the saved one
+    }
+    return MCRT_OK;
+}
+
+// ---- psf<>::psf (psf.h:34-58; psf.h:9 defines M_PI as 3.14159) --------------------------------
+extern "C" int mcrt_psf_kernels(float freq, float var_x, float var_y, uint32_t res_um, float *axial, uint32_t n_ax, float *lateral, uint32_t n_lat)
+{
+    if (!axial || !lateral) return mcrt::set_error(MCRT_ERR_INVALID, "mcrt_psf_kernels: null output");
+    const double pi_psf = 3.14159;
+    const float res = (float)res_um / 1000.0f;
+    const float half_ax = (float)((size_t)n_ax * res_um) / 1000.0f / 2.0f;
+    const float half_lat = (float)((size_t)n_lat * res_um) / 1000.0f / 2.0f;
+    for (uint32_t i = 0; i < n_ax; i++) {
+        const float x = (float)i * res - half_ax;
+        const double x2 = (double)x * (double)x;
+        axial[i] = (float)(std::exp(-0.5f * (x2 / (double)var_x)) * std::cos(2 * pi_psf * (double)freq * (double)x));
+    }
+    for (uint32_t i = 0; i < n_lat; i++) {
+        const float y = (float)i * res - half_lat;
+        const double y2 = (double)y * (double)y;
+        lateral[i] = (float)std::exp(-0.5f * (y2 / (double)var_y));
+    }
+    return MCRT_OK;
+}
+
+// ---- transducer<N>::transducer (transducer.h:24-62) -------------------------------------------
+namespace {
+struct F3 { float x, y, z; };
+inline F3 rot(F3 v, F3 ax, float ang)   // btVector3::rotate
+{
+    const float d = ax.x * v.x + ax.y * v.y + ax.z * v.z;
+    const F3 o{ ax.x * d, ax.y * d, ax.z * d };
+    const F3 xx{ v.x - o.x, v.y - o.y, v.z - o.z };
+    const F3 yy{ ax.y * v.z - ax.z * v.y, ax.z * v.x - ax.x * v.z, ax.x * v.y - ax.y * v.x };
+    const float c = std::cos(ang), s = std::sin(ang);
+    return F3{ o.x + xx.x * c + yy.x * s, o.y + xx.y * c + yy.y * s, o.z + xx.z * c + yy.z * s };
+}
+}  // namespace
+
+extern "C" int mcrt_transducer_elements(uint32_t n, double radius_cm, double sep_mm, const float position[3], const float angles_deg[3], float *pos, float *dir)
+{
+    if (!pos || !dir || !position || !angles_deg || n == 0) return mcrt::set_error(MCRT_ERR_INVALID, "mcrt_transducer_elements: bad arguments");
+    const double pi = 3.14159265358979323846264338327950288419716939937510;   // units.h:360
+    const double xa = (angles_deg[0] * pi * 1.0) / 180.0, ya = (angles_deg[1] * pi * 1.0) / 180.0, za = (angles_deg[2] * pi * 1.0) / 180.0;
+    const float amp = (float)(((sep_mm / radius_cm) * 1.0) / 10.0);   // mm/cm -> scalar
+    const double amplitude = amp;
+    double angle = -(amplitude * (double)n / 2.0) + amplitude / 2.0;
+    const float rf = (float)radius_cm;
+    for (uint32_t t = 0; t < n; t++) {
+        const float a = (float)angle;
+        F3 d{ std::sin(a), std::cos(a), 0.f };
+        d = rot(d, F3{ 0, 0, 1 }, (float)za);
+        d = rot(d, F3{ 1, 0, 0 }, (float)xa);
+        d = rot(d, F3{ 0, 1, 0 }, (float)ya);
+        pos[3 * t] = position[0] + rf * d.x; pos[3 * t + 1] = position[1] + rf * d.y; pos[3 * t + 2] = position[2] + rf * d.z;
+        dir[3 * t] = d.x; dir[3 * t + 1] = d.y; dir[3 * t + 2] = d.z;
+        angle = angle + amplitude;
+    }
+    return MCRT_OK;
+}

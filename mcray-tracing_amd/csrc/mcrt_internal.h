@@ -1,0 +1,11 @@
+// mcrt_internal.h -- shared between the translation units of libmcrt_hip.so
+#pragma once
+#include <stdint.h>
+
+#define MCRT_BVH_MAX_DEPTH 32      // deepest leaf the builder may emit == traversal stack entries per lane
+#define MCRT_MAX_ROWS 2048
+#define MCRT_MAX_BOUNCES 16
+
+namespace mcrt {
+int set_error(int code, const char *fmt, ...);
+}

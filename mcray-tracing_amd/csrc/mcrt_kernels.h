@@ -1,0 +1,43 @@
+// mcrt_kernels.h -- kernel argument blocks and launchers (mcrt_kernels.hip <-> mcrt_api.cpp)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mcrt.h"
+
+namespace mcrt {
+
+struct TraceArgs {
+    // scene (HBM-resident, read-only)
+    const float4 *nodes;       // [n_nodes][4]  64-B BVH2 nodes
+    const float4 *tris;        // [T][3]        48-B triangles, leaf order
+    const uint4 *meshes;       // [n_mesh]      mat_inside, mat_outside, vascular, -
+    const float4 *mats;        // [n_mat][2]    imp, att, mu0, mu1 | sigma, spec, shine, thick
+    const float2 *tex;         // [n^3]         texture_noise, scattering_probability
+    const float *el_pos;       // [E][3]
+    const float *el_dir;       // [E][3]
+    // outputs
+    long long *acc;            // [ne][R] fixed-point RF accumulators (2^-52 units)
+    uint32_t *flags;           // [ne][(R+31)/32] non-finite flags
+    int32_t *hits;             // optional [ne][S][B]
+    mcrt_segment *segs;        // optional [ne][S][B]
+    uint32_t *seg_count;       // optional [ne][S]
+    unsigned long long *stats; // optional [6]
+    // sizes / parameters
+    uint32_t n_nodes, S, B, R, e_begin, ne, chunks, frame, seed, start_mat, tex_n, sanitize, tex_finite;
+    float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs;
+    double axial_res_mm, time_step, row_dt, max_travel, sos_d;
+};
+
+struct ConvTaps { float ax[16]; float lat[32]; uint32_t n_ax, n_lat; };
+
+size_t trace_lds_bytes(uint32_t R, int block);
+hipError_t launch_trace(const TraceArgs &a, int block, bool stats, bool emit, bool accum, hipStream_t st);
+hipError_t launch_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t ne, uint32_t R, hipStream_t st);
+hipError_t launch_convolve(float *img, float *tmp, uint32_t E, uint32_t R, const ConvTaps &taps, hipStream_t st);
+hipError_t launch_envelope(float *img, uint32_t E, uint32_t R, hipStream_t st);
+hipError_t launch_remap(const float *img, uint32_t E, uint32_t R, const float *map_col, const float *map_row, float *out, uint32_t n, hipStream_t st);
+hipError_t launch_transpose(const float *in, float *out, uint32_t E, uint32_t R, hipStream_t st);
+hipError_t launch_math_probe(int op, const double *x, const double *y, double *out, uint32_t n, hipStream_t st);
+hipError_t launch_philox_probe(const uint32_t c[4], const uint32_t k[2], uint32_t *out, hipStream_t st);
+
+}  // namespace mcrt

@@ -1,0 +1,672 @@
+// mcrt_kernels.hip -- gfx950 kernels of the hot path.
+//
+//   k_trace      scene::cast_rays (scene.cpp:50-183) + ray_physics (ray.cpp) + the RF accumulation loop
+//                (main.cpp:106-144, rfimage.h:33-40, volume.h:46-61), fused: one lane = one Monte-Carlo
+//                sample path, one wavefront = 64 samples of ONE scan-line (coherent origin), per-lane BVH
+//                traversal stack and per-scan-line RF bins in LDS.
+//   k_finalize   fixed-point RF bins -> float image (+ clears the bins: rf_image::clear, rfimage.h:161)
+//   k_conv_*     rf_image::convolve (rfimage.h:93-123)
+//   k_envelope   rf_image::envelope (rfimage.h:54-91)
+//   k_remap      rf_image::postprocess scan conversion (rfimage.h:125-140)
+//
+// Everything is scalar fp32/fp64 VALU + integer work; there is no dense contraction, hence no MFMA.
+// Arithmetic follows the parity contract expression by expression (compiled -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mcrt.h"
+#include "mcrt_internal.h"
+#include "mcrt_detmath.h"
+#include "mcrt_kernels.h"
+
+namespace mcrt {
+
+struct f3 { float x, y, z; };
+MCRT_DEV f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+MCRT_DEV f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+MCRT_DEV f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+MCRT_DEV f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
+MCRT_DEV f3 scale(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+MCRT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                 // btVector3::dot, scalar path
+MCRT_DEV f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+MCRT_DEV f3 normalized(f3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return scale(a, inv); }    // btVector3::normalized
+MCRT_DEV f3 xyz(float4 q) { return mk(q.x, q.y, q.z); }
+
+enum { M_IMP = 0, M_ATT, M_MU0, M_MU1, M_SIGMA, M_SPEC, M_SHINE, M_THICK };
+constexpr int OUT_NONE = -1;   // media_outside == nullptr
+constexpr int OUT_SELF = -2;   // media_outside aliases the ray's own media (ray.cpp:38 + scene.cpp:154)
+
+struct Hit { float frac; int tri; int mesh; f3 n; float da; };
+
+// ray parameter interval [tmin,tmax] (clamped to [0,tcap]) in which o + t*d lies inside the box
+MCRT_DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tcap, float &tmin_o, float &tmax_o)
+{
+    float t0x = (lo.x - o.x) * inv.x, t1x = (hi.x - o.x) * inv.x;
+    float t0y = (lo.y - o.y) * inv.y, t1y = (hi.y - o.y) * inv.y;
+    float t0z = (lo.z - o.z) * inv.z, t1z = (hi.z - o.z) * inv.z;
+    float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+    float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tcap));
+    tmin_o = tmin; tmax_o = tmax;
+    return tmin <= tmax;
+}
+
+// btTriangleRaycastCallback::processTriangle (Bullet) behind the triangle's own padded-bounds test; contract
+// rules: the fraction must lie inside the ray's overlap with those bounds; ties -> smaller triangle id.
+MCRT_DEV void tri_test(f3 v0, f3 v1, f3 v2, int id, int mesh, f3 from, f3 to, f3 inv, float pad_abs, Hit &best)
+{
+    f3 v10 = v1 - v0, v20 = v2 - v0;
+    f3 n = cross(v10, v20);
+    float dist = dot(v0, n);
+    float da = dot(n, from) - dist;
+    float db = dot(n, to) - dist;
+    if (da * db >= 0.0f) return;
+    float proj = da - db;
+    float frac = da / proj;
+    if (frac < best.frac || (frac == best.frac && id < best.tri)) {
+        f3 lo = mk(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)));
+        f3 hi = mk(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)));
+        float ext = fmaxf(fmaxf(fmaxf(0.0f, hi.x - lo.x), hi.y - lo.y), hi.z - lo.z);
+        const float pad = 2e-4f * ext + pad_abs;
+        lo = mk(lo.x - pad, lo.y - pad, lo.z - pad);
+        hi = mk(hi.x + pad, hi.y + pad, hi.z + pad);
+        float tmin, tmax;
+        if (!slab(lo, hi, from, inv, 1.0f, tmin, tmax)) return;
+        if (!(frac >= tmin && frac <= tmax)) return;
+        float edge_tol = dot(n, n) * -0.0001f;
+        float s = 1.0f - frac;
+        f3 p = mk(s * from.x + frac * to.x, s * from.y + frac * to.y, s * from.z + frac * to.z);
+        f3 v0p = v0 - p, v1p = v1 - p;
+        f3 cp0 = cross(v0p, v1p);
+        if (dot(cp0, n) >= edge_tol) {
+            f3 v2p = v2 - p;
+            f3 cp1 = cross(v1p, v2p);
+            if (dot(cp1, n) >= edge_tol) {
+                f3 cp2 = cross(v2p, v0p);
+                if (dot(cp2, n) >= edge_tol) { best.frac = frac; best.tri = id; best.mesh = mesh; best.n = n; best.da = da; }
+            }
+        }
+    }
+}
+
+struct Rng { uint32_t k0, k1, element, sample, bounce; };
+MCRT_DEV void rng_block(const Rng &g, uint32_t block, double &a, double &b)
+{
+    uint32_t o[4];
+    philox4x32_10(g.element, g.sample, g.bounce, block, g.k0, g.k1, o);
+    a = u53(o[0], o[1]);
+    b = u53(o[2], o[3]);
+}
+
+// ray.cpp:167-211
+MCRT_DEV f3 random_unit_vector(f3 v, float cos_theta, const Rng &g)
+{
+    bool flag = false;
+    float px, py, p;
+    uint32_t attempt = 0;
+    do {
+        double ua, ur;
+        rng_block(g, 2u + attempt, ua, ur);
+        double a = ua * 2 * PI_D;
+        double r = 0.5 * sqrt(ur);
+        double sa, ca;
+        det_sincos(a, sa, ca);
+        px = (float)(r * ca);
+        py = (float)(r * sa);
+        p = px * px + py * py;
+        attempt++;
+    } while (!(p <= 0.25f) && attempt < 8u);
+    float vx = v.x, vy = v.y, vz = v.z;
+    if (fabsf(vx) > fabsf(vy)) { vx = vy; vy = v.x; flag = true; }
+    float b = 1 - vx * vx;
+    float radicando = 1 - cos_theta * cos_theta;
+    radicando = radicando / (p * b);
+    float c = sqrtf(radicando);
+    px = px * c;
+    py = py * c;
+    float d = cos_theta - vx * px;
+    float wx = vx * cos_theta - b * px;
+    float wy = vy * d + vz * py;
+    float wz = vz * d - vy * py;
+    if (flag) { float aux = wy; wy = wx; wx = aux; }
+    return mk(wx, wy, wz);
+}
+
+MCRT_DEV float std_max(float a, float b) { return (a < b) ? b : a; }
+
+MCRT_DEV uint32_t vox_index(float q, uint32_t n)
+{
+    long long i;
+    if (!(fabsf(q) < 9.2233720368547758e18f)) i = (long long)0x8000000000000000ull;
+    else if (fabsf(q) < 2147483648.0f) i = (long long)(int)q;
+    else i = (long long)q;
+    return ((uint32_t)i) % n;
+}
+
+MCRT_DEV uint32_t steps_from(double q)
+{
+    if (!(fabs(q) < 9.2233720368547758e18)) return 0u;
+    return (uint32_t)(long long)q;
+}
+
+MCRT_DEV long long wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// add one echo per lane (row < 0: nothing) into the scan-line's LDS bins.  Integer addition is
+// associative, so lanes that share a row are summed in registers first; the result is identical.
+MCRT_DEV void rf_add_wave(long long *bins, uint32_t *lflags, int row, float echo, int lane)
+{
+    const bool valid = row >= 0;
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0ull) return;
+    long long v = 0;
+    bool bad = false;
+    if (valid) {
+        if (!(fabsf(echo) < 1024.0f)) bad = true;
+        else v = (long long)rint((double)echo * 4503599627370496.0);
+    }
+    const int leader = __ffsll((long long)vm) - 1;
+    const int row0 = __shfl(row, leader, 64);
+    const bool uniform = __all(!valid || row == row0);
+    if (uniform) {
+        const long long sum = wave_sum_i64(v);
+        const bool anybad = __any(bad);
+        if (lane == leader) {
+            if (sum != 0) atomicAdd((unsigned long long *)&bins[row0], (unsigned long long)sum);
+            if (anybad) atomicOr(&lflags[row0 >> 5], 1u << (row0 & 31));
+        }
+    } else if (valid) {
+        if (bad) atomicOr(&lflags[row >> 5], 1u << (row & 31));
+        else if (v != 0) atomicAdd((unsigned long long *)&bins[row], (unsigned long long)v);
+    }
+}
+
+template <bool STATS, bool EMIT, bool ACCUM>
+__global__ void __launch_bounds__(256) k_trace(TraceArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+    const uint32_t R = a.R;
+    long long *bins = (long long *)smem;
+    uint32_t *lflags = (uint32_t *)(bins + ((R + 1u) & ~1u));
+    int *stack = (int *)(lflags + ((((R + 31u) >> 5) + 3u) & ~3u));
+
+    // XCD-aware block -> (scan-line, chunk) map: workgroups are dealt round-robin over the 8 XCDs, so
+    // the chunks of one scan-line (same BVH path, same texture lines) are steered onto one XCD's L2.
+    uint32_t vb = blockIdx.x;
+    {
+        const uint32_t nb = gridDim.x, per = nb >> 3;
+        if (vb < (per << 3)) vb = (vb & 7u) * per + (vb >> 3);
+    }
+    const uint32_t e_local = vb / a.chunks, chunk = vb % a.chunks;
+    const uint32_t e_abs = a.e_begin + e_local;
+
+    if (ACCUM) {
+        for (uint32_t r = tid; r < R; r += nthr) bins[r] = 0;
+        for (uint32_t r = tid; r < ((R + 31u) >> 5); r += nthr) lflags[r] = 0u;
+        __syncthreads();
+    }
+
+    const uint32_t s = chunk * (uint32_t)nthr + (uint32_t)tid;
+    bool alive = s < a.S;
+    const size_t path = ((size_t)e_local * a.S + s);
+
+    f3 from = mk(a.el_pos[3 * e_abs], a.el_pos[3 * e_abs + 1], a.el_pos[3 * e_abs + 2]);
+    f3 dir = mk(a.el_dir[3 * e_abs], a.el_dir[3 * e_abs + 1], a.el_dir[3 * e_abs + 2]);
+    int media = (int)a.start_mat, outside = OUT_NONE;
+    float intensity = a.I0 / (float)a.S;
+    double dist_mm = 0.0;
+    Rng g; g.k0 = a.seed; g.k1 = a.frame; g.element = e_abs; g.sample = s; g.bounce = 0;
+    uint32_t nseg = 0;
+    unsigned long long st_nodes = 0, st_tris = 0, st_q = 0, st_seg = 0, st_steps = 0, st_hits = 0;
+
+    for (uint32_t b = 0; b < a.B; b++) {
+        if (EMIT && a.hits && s < a.S) a.hits[path * a.B + b] = -2;
+        if (!__any(alive)) { if (EMIT) continue; else break; }
+        g.bounce = b;
+
+        // ---- launch the query: max_ray_length (ray.cpp:110-113), enlarge (scene.cpp:292-298) ----
+        const int mi = alive ? media : (int)a.start_mat;
+        const float4 m0 = a.mats[2 * mi], m1 = a.mats[2 * mi + 1];   // imp, att, mu0, mu1 | sigma, spec, shine, thick
+        const float att = m0.y;
+        const float L = 10.f * det_logf(a.eps / intensity) / -att * a.freq;
+        const float Ls = L / 100.0f;
+        const f3 to = mk(from.x + Ls * (a.sx * dir.x), from.y + Ls * (a.sy * dir.y), from.z + Ls * (a.sz * dir.z));
+        const f3 f2 = mk(from.x + a.offs * dir.x, from.y + a.offs * dir.y, from.z + a.offs * dir.z);
+
+        // ---- closest hit: per-lane BVH2 walk, stack in LDS ([level][lane] => conflict-free) ----
+        Hit best; best.frac = 1.0f; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
+        {
+            const f3 d = to - f2;
+            const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            int sp = 0, cur = 0;
+            bool walking = alive && a.n_nodes != 0u;
+            if (STATS && walking) st_q++;
+            while (__any(walking)) {
+                if (walking) {
+                    if (cur >= 0) {
+                        const float4 *N = a.nodes + 4 * (size_t)cur;
+                        const float4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3];
+                        if (STATS) st_nodes++;
+                        float tn0, tn1, tx0, tx1;
+                        const float tcap = fminf(1.0f, best.frac);
+                        const bool h0 = slab(xyz(q0), xyz(q1), f2, inv, tcap, tn0, tx0);
+                        const bool h1 = slab(xyz(q2), xyz(q3), f2, inv, tcap, tn1, tx1);
+                        const int c0 = __float_as_int(q0.w), c1 = __float_as_int(q1.w);
+                        if (h0 && h1) {
+                            int nearc = c0, farc = c1;
+                            if (tn1 < tn0) { nearc = c1; farc = c0; }
+                            if (sp < MCRT_BVH_MAX_DEPTH) { stack[sp * nthr + tid] = farc; sp++; }
+                            cur = nearc;
+                        } else if (h0) cur = c0;
+                        else if (h1) cur = c1;
+                        else if (sp > 0) { sp--; cur = stack[sp * nthr + tid]; }
+                        else walking = false;
+                    } else {
+                        const uint32_t v = (uint32_t)~cur;
+                        const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+                        for (uint32_t i = 0; i < cnt; i++) {
+                            const float4 *T = a.tris + 3 * (size_t)(first + i);
+                            const float4 t0 = T[0], t1 = T[1], t2 = T[2];
+                            tri_test(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), __float_as_int(t1.w), f2, to, inv, a.pad_abs, best);
+                            if (STATS) st_tris++;
+                        }
+                        if (sp > 0) { sp--; cur = stack[sp * nthr + tid]; }
+                        else walking = false;
+                    }
+                }
+            }
+        }
+
+        // ---- interface interaction (scene.cpp:122-165, ray.cpp:11-97) ----
+        bool seg_valid = alive;
+        f3 seg_from = from, seg_to = to, seg_dir = dir;
+        float seg_refl = 0.0f, seg_init = intensity, seg_att = att;
+        double seg_dist = dist_mm;
+        int seg_media = mi, seg_tri = -1;
+        if (alive) {
+            if (best.tri >= 0) {
+                if (STATS) st_hits++;
+                f3 nn = normalized(best.n);
+                if (best.da <= 0.0f) nn = neg(nn);
+                const float sfr = 1.0f - best.frac;
+                const f3 hp = mk(sfr * f2.x + best.frac * to.x, sfr * f2.y + best.frac * to.y, sfr * f2.z + best.frac * to.z);
+                const uint4 organ = a.meshes[best.mesh];   // mat_inside, mat_outside, vascular
+                // thickness penetration scene.cpp:132-139 (Box-Muller on block 0)
+                const float sigma_t = a.mats[2 * organ.x + 1].w;
+                float q = 0.0f;
+                if (sigma_t != 0.0f) {
+                    double n1, n2, sn, cs;
+                    rng_block(g, 0u, n1, n2);
+                    det_sincos(n2 * 2 * PI_D, sn, cs);
+                    const double z = sqrt(-2.0 * det_log(1.0 - n1)) * cs;
+                    q = (float)fabs(z * (double)sigma_t + 0.0);
+                }
+                const f3 inside = mk(q * dir.x + hp.x, q * dir.y + hp.y, q * dir.z + hp.z);
+                // travel ray.cpp:99-103, distance_in_mm scene.cpp:281-290
+                const float xd = fabsf(from.x - inside.x) * a.sx, yd = fabsf(from.y - inside.y) * a.sy, zd = fabsf(from.z - inside.z) * a.sz;
+                const double mm = sqrt((double)xd * (double)xd + (double)yd * (double)yd + (double)zd * (double)zd) * 10;
+                dist_mm = dist_mm + mm;
+                intensity = intensity * det_expf(-att * ((float)mm * 0.01f) * a.freq);
+
+                // hit_boundary: material transition logic ray.cpp:14-47 (bug-compatible)
+                int after_vasc, mat_after;
+                if (outside != OUT_NONE) {
+                    if (organ.z) { after_vasc = OUT_NONE; mat_after = (outside == OUT_SELF) ? media : outside; }
+                    else { after_vasc = (outside == (int)organ.x) ? (int)organ.y : (int)organ.x; mat_after = media; }
+                } else {
+                    if (organ.z) { after_vasc = OUT_SELF; mat_after = (int)organ.x; }
+                    else { after_vasc = OUT_NONE; mat_after = (int)organ.x; }
+                }
+                const float4 a0 = a.mats[2 * mat_after], a1 = a.mats[2 * mat_after + 1];
+                double u_pc, u_x;
+                rng_block(g, 1u, u_pc, u_x);
+                // power_cosine_variate ray.cpp:213-224
+                const int indice = (int)a1.z + 1;
+                const float exponente = (float)((double)1.0 / indice);
+                const float random_angle = (float)det_pow_pos(u_pc, (double)exponente);
+                const f3 rn = random_unit_vector(nn, random_angle, g);
+
+                float inc = dot(dir, neg(rn));
+                if (inc < 0) inc = dot(dir, rn);
+                const float rr = m0.x / a0.x;
+                float refa = 1 - rr * rr * (1 - inc * inc);
+                const bool tir = refa < 0;
+                refa = sqrtf(refa);
+                const float kk = rr * inc - refa;
+                f3 refr = mk(rr * dir.x + kk * rn.x, rr * dir.y + kk * rn.y, rr * dir.z + kk * rn.z);
+                refr = normalized(refr);
+                const float two_c = 2 * inc;
+                f3 refl = mk(dir.x + two_c * rn.x, dir.y + two_c * rn.y, dir.z + two_c * rn.z);
+                refl = normalized(refl);
+
+                float i_refl;
+                if (tir) i_refl = intensity;
+                else {
+                    const float num = m0.x * inc - a0.x * refa;
+                    const float den = m0.x * inc + a0.x * refa;
+                    const float qq = num / den;
+                    i_refl = (float)((double)intensity * ((double)qq * (double)qq));
+                }
+                const float i_refr = intensity - i_refl;
+
+                const float ra = dot(dir, refr);
+                float refraction_factor = det_powf(ra, a1.y);
+                const float rb = dot(dir, refl);
+                const float reflection_factor = det_powf(rb, a1.y);
+                if (a.sanitize && tir) refraction_factor = 0.0f;
+                seg_refl = (std_max(refraction_factor, 0.0f) + std_max(reflection_factor, 0.0f)) * random_angle;
+                seg_to = inside;
+                seg_tri = best.tri;
+
+                const float x = (float)u_x;
+                const float prob = i_refl / intensity;
+                float i_new;
+                from = hp;
+                if (prob > x) { dir = refl; i_new = i_refl > a.eps ? i_refl : 0.0f; }
+                else { dir = refr; media = mat_after; outside = after_vasc; i_new = i_refr > a.eps ? i_refr : 0.0f; }
+                if (i_new > a.eps) intensity = i_new; else alive = false;
+            } else {
+                alive = false;
+            }
+            if (STATS) st_seg++;
+        }
+
+        if (EMIT && seg_valid) {
+            if (a.hits) a.hits[path * a.B + b] = seg_tri;
+            if (a.segs) {
+                mcrt_segment sg;
+                sg.from[0] = seg_from.x; sg.from[1] = seg_from.y; sg.from[2] = seg_from.z;
+                sg.to[0] = seg_to.x; sg.to[1] = seg_to.y; sg.to[2] = seg_to.z;
+                sg.dir[0] = seg_dir.x; sg.dir[1] = seg_dir.y; sg.dir[2] = seg_dir.z;
+                sg.reflected_intensity = seg_refl; sg.initial_intensity = seg_init; sg.attenuation = seg_att;
+                sg.distance_traveled = seg_dist; sg.media = seg_media; sg.tri = seg_tri;
+                a.segs[path * a.B + nseg] = sg;
+            }
+            nseg++;
+        }
+
+        // ---- RF accumulation of this segment (main.cpp:112-140) ----
+        if (ACCUM) {
+            const float4 s0 = a.mats[2 * seg_media], s1 = a.mats[2 * seg_media + 1];
+            const double t_start = (seg_dist * 1000.0) / a.sos_d;
+            const f3 df = seg_to - seg_from;
+            const float dist_f = sqrtf(dot(df, df)) * 10.0f;
+            const uint32_t steps = seg_valid ? steps_from((double)dist_f / a.axial_res_mm) : 0u;
+            const f3 delta = mk(a.axial_res_f * seg_dir.x, a.axial_res_f * seg_dir.y, a.axial_res_f * seg_dir.z);
+            f3 point = seg_from;
+            double t = t_start;
+            float inten = seg_init;
+            const float k_att = det_expf(-seg_att * a.axial_res_f * 0.01f * a.freq * 1.0f);
+            // scattering is exactly +0 for every voxel when mu0 == sigma == 0 (finite texture): the adds are no-ops
+            const bool silent = a.tex_finite && s0.z == 0.0f && s1.x == 0.0f;
+            uint32_t step = 0;
+            bool more = seg_valid && !silent && steps > 0u && t < a.max_travel;
+            while (__any(more)) {
+                int row = -1;
+                float echo = 0.0f;
+                if (more) {
+                    const uint32_t vx = vox_index(point.x / a.tex_res, a.tex_n), vy = vox_index(point.y / a.tex_res, a.tex_n), vz = vox_index(point.z / a.tex_res, a.tex_n);
+                    const float2 vox = a.tex[((size_t)vx * a.tex_n + vy) * a.tex_n + vz];
+                    const float scattering = vox.y >= s0.w ? vox.x * s1.x + s0.z : 0.0f;
+                    echo = inten * scattering;
+                    const double rowd = t / a.row_dt;
+                    if (rowd < (double)R) row = (int)rowd;
+                    point = point + delta;
+                    t = t + a.time_step;
+                    inten *= k_att;
+                    step++;
+                    if (STATS) st_steps++;
+                    more = step < steps && t < a.max_travel;
+                }
+                rf_add_wave(bins, lflags, row, echo, lane);
+            }
+            // boundary echo main.cpp:139
+            {
+                int row = -1;
+                float echo = 0.0f;
+                if (seg_valid) {
+                    echo = seg_refl / (float)a.S;
+                    const double te = t_start + a.time_step * (double)(uint32_t)(steps - 1u);
+                    const double rowd = te / a.row_dt;
+                    if (rowd < (double)R) row = (int)rowd;
+                }
+                rf_add_wave(bins, lflags, row, echo, lane);
+            }
+        }
+    }
+
+    if (EMIT && a.seg_count && s < a.S) a.seg_count[path] = nseg;
+
+    if (STATS) {
+        unsigned long long v[6] = { st_q, st_nodes, st_tris, st_seg, st_steps, st_hits };
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            long long x = wave_sum_i64((long long)v[i]);
+            if (lane == 0 && x) atomicAdd(&a.stats[i], (unsigned long long)x);
+        }
+    }
+
+    if (ACCUM) {
+        __syncthreads();
+        long long *gacc = a.acc + (size_t)e_local * R;
+        for (uint32_t r = tid; r < R; r += nthr) {
+            const long long v = bins[r];
+            if (v != 0) atomicAdd((unsigned long long *)&gacc[r], (unsigned long long)v);
+        }
+        const uint32_t nf = (R + 31u) >> 5;
+        for (uint32_t r = tid; r < nf; r += nthr) { const uint32_t f = lflags[r]; if (f) atomicOr(&a.flags[(size_t)e_local * nf + r], f); }
+    }
+}
+
+// fixed-point bins -> float RF image [ne][R]; clears the bins for the next frame
+__global__ void k_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t ne, uint32_t R)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ne * R) return;
+    const uint32_t e = (uint32_t)(i / R), r = (uint32_t)(i % R);
+    const uint32_t nf = (R + 31u) >> 5;
+    const bool bad = (flags[(size_t)e * nf + (r >> 5)] >> (r & 31)) & 1u;
+    const long long v = acc[i];
+    rf[i] = bad ? __uint_as_float(0x7fc00000u) : (float)((double)v * 0x1p-52);
+    acc[i] = 0;
+}
+__global__ void k_clear_flags(uint32_t *flags, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = 0u;
+}
+
+// rfimage.h:96-108 on the scan-line-major image: tmp[e][row] = sum_k img[e][row+k]*ax[k], row in [na, R-na)
+__global__ void k_conv_axial(const float *img, float *tmp, uint32_t E, uint32_t R, ConvTaps taps)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)E * R) return;
+    const int row = (int)(i % R), na = (int)taps.n_ax;
+    if (row < na || row >= (int)R - na) return;
+    float conv = 0;
+    for (int k = 0; k < na; k++) conv += img[i + k] * taps.ax[k];
+    tmp[i] = conv;
+}
+// rfimage.h:111-122: img[col][row] = sum_k tmp[col+k][row]*lat[k], row in [na,R-na), col in [nl/2, E-nl)
+__global__ void k_conv_lateral(const float *tmp, float *img, uint32_t E, uint32_t R, ConvTaps taps)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)E * R) return;
+    const int row = (int)(i % R), col = (int)(i / R), na = (int)taps.n_ax, nl = (int)taps.n_lat;
+    if (row < na || row >= (int)R - na) return;
+    if (col < nl / 2 || col >= (int)E - nl) return;
+    float conv = 0;
+    for (int k = 0; k < nl; k++) conv += tmp[i + (size_t)k * R] * taps.lat[k];
+    img[i] = conv;
+}
+
+// rfimage.h:54-91: one lane per scan-line (the scan is sequential along the line)
+__global__ void k_envelope(float *img, uint32_t E, uint32_t R)
+{
+    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= E || R < 2) return;
+    float *c = img + (size_t)col * R;
+    bool ascending = c[0] < c[1];
+    uint32_t last_peak_pos = 0;
+    float last_peak = c[0];
+    for (uint32_t i = 1; i + 1 < R; i++) {
+        if (c[i] < c[i + 1]) ascending = true;
+        else if (ascending) {
+            ascending = false;
+            const float new_peak = fabsf(c[i]);
+            for (uint32_t j = last_peak_pos; j < i; j++) {
+                const float alpha = ((float)j - (float)last_peak_pos) / ((float)i - (float)last_peak_pos);
+                c[j] = last_peak * (1 - alpha) + new_peak * alpha;
+            }
+            last_peak_pos = i;
+            last_peak = new_peak;
+        }
+    }
+}
+
+// cv::remap(src, dst, map_y, map_x, INTER_LINEAR, BORDER_CONSTANT 0) with precomputed maps (rfimage.h:139):
+// mx = column coordinate (scan-line), my = row coordinate.  src is [E][R] scan-line-major.
+__global__ void k_remap(const float *img, uint32_t E, uint32_t R, const float *map_col, const float *map_row, float *out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float mx = map_col[i], my = map_row[i];
+    const float fx = floorf(mx), fy = floorf(my);
+    const float ax = mx - fx, ay = my - fy;
+    const long long x0 = (long long)fx, y0 = (long long)fy;
+    float v[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+        for (int dx = 0; dx < 2; dx++) {
+            const long long xx = x0 + dx, yy = y0 + dy;
+            const bool in = (mx == mx) && (my == my) && xx >= 0 && yy >= 0 && xx < (long long)E && yy < (long long)R;
+            v[dy][dx] = in ? img[(size_t)xx * R + (size_t)yy] : 0.0f;
+        }
+    const float top = v[0][0] * (1.0f - ax) + v[0][1] * ax;
+    const float bot = v[1][0] * (1.0f - ax) + v[1][1] * ax;
+    out[i] = top * (1.0f - ay) + bot * ay;
+}
+
+// [E][R] -> [R][E]
+__global__ void k_transpose(const float *in, float *out, uint32_t E, uint32_t R)
+{
+    __shared__ float tile[32][33];
+    const uint32_t r0 = blockIdx.x * 32, e0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const uint32_t e = e0 + j, r = r0 + threadIdx.x;
+        if (e < E && r < R) tile[j][threadIdx.x] = in[(size_t)e * R + r];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const uint32_t r = r0 + j, e = e0 + threadIdx.x;
+        if (e < E && r < R) out[(size_t)r * E + e] = tile[threadIdx.x][j];
+    }
+}
+
+__global__ void k_math_probe(int op, const double *x, const double *y, double *out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = x[i], b = y ? y[i] : 0.0;
+    double r = 0.0, s, c;
+    switch (op) {
+    case 0: r = det_log(a); break;
+    case 1: r = det_exp(a); break;
+    case 2: det_sincos(a, s, c); r = s; break;
+    case 3: det_sincos(a, s, c); r = c; break;
+    case 4: r = sqrt(a); break;
+    case 5: r = a / b; break;
+    case 6: r = (double)det_logf((float)a); break;
+    case 7: r = (double)det_expf((float)a); break;
+    case 8: r = (double)det_powf((float)a, (float)b); break;
+    case 9: r = (double)sqrtf((float)a); break;
+    case 10: r = (double)((float)a / (float)b); break;
+    case 11: r = det_pow_pos(a, b); break;
+    default: break;
+    }
+    out[i] = r;
+}
+
+__global__ void k_philox_probe(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *out)
+{
+    uint32_t o[4];
+    philox4x32_10(c0, c1, c2, c3, k0, k1, o);
+    for (int i = 0; i < 4; i++) out[i] = o[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers (called from mcrt_api.cpp, which is plain C++)
+// ---------------------------------------------------------------------------------------------
+size_t trace_lds_bytes(uint32_t R, int block)
+{
+    size_t bins = (size_t)((R + 1u) & ~1u) * 8;
+    size_t flg = (size_t)((((R + 31u) >> 5) + 3u) & ~3u) * 4;
+    return bins + flg + (size_t)MCRT_BVH_MAX_DEPTH * block * 4;
+}
+
+hipError_t launch_trace(const TraceArgs &a, int block, bool stats, bool emit, bool accum, hipStream_t st)
+{
+    const dim3 grid(a.ne * a.chunks), blk(block);
+    const size_t lds = trace_lds_bytes(a.R, block);
+#define MCRT_LAUNCH(S_, E_, A_) hipLaunchKernelGGL((k_trace<S_, E_, A_>), grid, blk, lds, st, a)
+    if (stats) { if (emit) { if (accum) MCRT_LAUNCH(true, true, true); else MCRT_LAUNCH(true, true, false); }
+                 else { if (accum) MCRT_LAUNCH(true, false, true); else MCRT_LAUNCH(true, false, false); } }
+    else { if (emit) { if (accum) MCRT_LAUNCH(false, true, true); else MCRT_LAUNCH(false, true, false); }
+           else { if (accum) MCRT_LAUNCH(false, false, true); else MCRT_LAUNCH(false, false, false); } }
+#undef MCRT_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t ne, uint32_t R, hipStream_t st)
+{
+    const size_t n = (size_t)ne * R;
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, acc, flags, rf, ne, R);
+    const size_t nf = (size_t)ne * ((R + 31u) >> 5);
+    hipLaunchKernelGGL(k_clear_flags, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, flags, nf);
+    return hipGetLastError();
+}
+
+hipError_t launch_convolve(float *img, float *tmp, uint32_t E, uint32_t R, const ConvTaps &taps, hipStream_t st)
+{
+    const size_t n = (size_t)E * R;
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(k_conv_axial, grid, blk, 0, st, (const float *)img, tmp, E, R, taps);
+    hipLaunchKernelGGL(k_conv_lateral, grid, blk, 0, st, (const float *)tmp, img, E, R, taps);
+    return hipGetLastError();
+}
+
+hipError_t launch_envelope(float *img, uint32_t E, uint32_t R, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_envelope, dim3((E + 63) / 64), dim3(64), 0, st, img, E, R);
+    return hipGetLastError();
+}
+
+hipError_t launch_remap(const float *img, uint32_t E, uint32_t R, const float *map_col, const float *map_row, float *out, uint32_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_remap, dim3((n + 255) / 256), dim3(256), 0, st, img, E, R, map_col, map_row, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose(const float *in, float *out, uint32_t E, uint32_t R, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_transpose, dim3((R + 31) / 32, (E + 31) / 32), dim3(32, 8), 0, st, in, out, E, R);
+    return hipGetLastError();
+}
+
+hipError_t launch_math_probe(int op, const double *x, const double *y, double *out, uint32_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_math_probe, dim3((n + 255) / 256), dim3(256), 0, st, op, x, y, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_philox_probe(const uint32_t c[4], const uint32_t k[2], uint32_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_philox_probe, dim3(1), dim3(1), 0, st, c[0], c[1], c[2], c[3], k[0], k[1], out);
+    return hipGetLastError();
+}
+
+}  // namespace mcrt

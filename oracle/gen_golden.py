@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/ref_probe.json from the REFERENCE's own headers.
+
+Runs oracle/_ref/ref_probe (built by `make -C oracle ref` from /root/reference/src/psf.h,
+src/volume.h and include/units/units.h, compiled where they lie).  Only works in the
+container that mounts /root/reference; the JSON it writes is the committed fixture that
+pins the oracle (tests/test_oracle_golden.py) everywhere else.
+"""
+import json, os, subprocess, sys
+here = os.path.dirname(os.path.abspath(__file__))
+subprocess.check_call(["make", "-C", here, "ref"])
+probe = os.path.join(here, "_ref", "ref_probe")
+if not os.path.exists(probe):
+    sys.exit("reference not mounted; cannot regenerate goldens")
+data = json.loads(subprocess.check_output([probe]))
+data["_generated_by"] = "oracle/gen_golden.py (oracle/ref_probe.cpp compiled against /root/reference headers)"
+out = os.path.join(here, "..", "tests", "golden", "ref_probe.json")
+with open(out, "w") as f:
+    json.dump(data, f, separators=(",", ":"))
+    f.write("\n")
+print("wrote", os.path.normpath(out), os.path.getsize(out), "bytes")

@@ -1,0 +1,926 @@
+/*
+ * mcrt_oracle.c -- CPU ORACLE (test infrastructure only; see mcrt_oracle.h for the rules
+ * and the parity-pin status).  Plain C99.  Build: see oracle/Makefile
+ *   gcc -O2 -std=gnu99 -ffp-contract=off -mfma -fopenmp -fPIC -shared
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * /root/reference/src unless noted).  Arithmetic types follow the reference expression by
+ * expression (float vs double promotion, operand order); "no contraction" is part of the
+ * contract, fused multiply-adds appear only where written as fma().
+ */
+#include "mcrt_oracle.h"
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ===================================================================================== */
+/*  Deterministic math contract.  The reference calls libm (std::log/exp/pow/sin/cos);     */
+/*  libm results are not reproducible on a GPU, so oracle and HIP kernels share THIS       */
+/*  specification instead: double-precision argument reduction + Taylor/Horner polynomials */
+/*  evaluated with fma(), IEEE +,-,*,/ and sqrt only.  Results are within ~2 ulp (double)  */
+/*  of libm, i.e. identical after the float rounding the reference applies, except in      */
+/*  ~1e-8 of cases (tests/test_oracle_math.py measures this against libm).                 */
+/* ===================================================================================== */
+
+static int g_math_mode = 0;
+void orc_set_math_mode(int mode) { g_math_mode = mode; }
+
+#define LN2_HI   0.6931471803691238      /* 0x3fe62e42fee00000: ln2 with 21 low bits clear */
+#define LN2_LO   1.9082149292705877e-10  /* ln2 - LN2_HI                                  */
+#define INV_LN2  1.4426950408889634
+#define PIO2_HI  1.5707963267948966
+#define PIO2_LO  6.123233995736766e-17
+#define TWO_OVER_PI 0.6366197723675814
+#define SQRT2_D  1.4142135623730951
+#define PI_D     3.141592653589793       /* glibc M_PI, what ray.cpp:178 sees              */
+
+static inline uint64_t d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+static inline double   u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
+static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+static inline float    u2f(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
+
+double orc_log_d(double x)
+{
+    if (g_math_mode) return log(x);
+    if (x != x) return x;
+    if (x < 0.0) return u2d(0x7ff8000000000000ull);
+    if (x == 0.0) return -INFINITY;
+    if (x == INFINITY) return x;
+    int k = 0;
+    uint64_t u = d2u(x);
+    if ((u >> 52) == 0) { x *= 18014398509481984.0 /* 2^54 */; k = -54; u = d2u(x); }
+    k += (int)(u >> 52) - 1023;
+    double m = u2d((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull);   /* [1,2) */
+    if (m > SQRT2_D) { m *= 0.5; k += 1; }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    /* log(m) = 2 atanh(s) = 2s + s * sum_{n>=1} 2/(2n+1) z^n ,  |s| <= 0.1716 */
+    double p = 2.0 / 23.0;
+    p = fma(p, z, 2.0 / 21.0);
+    p = fma(p, z, 2.0 / 19.0);
+    p = fma(p, z, 2.0 / 17.0);
+    p = fma(p, z, 2.0 / 15.0);
+    p = fma(p, z, 2.0 / 13.0);
+    p = fma(p, z, 2.0 / 11.0);
+    p = fma(p, z, 2.0 / 9.0);
+    p = fma(p, z, 2.0 / 7.0);
+    p = fma(p, z, 2.0 / 5.0);
+    p = fma(p, z, 2.0 / 3.0);
+    p = p * z;
+    double r = fma(s, p, 2.0 * s);
+    double kd = (double)k;
+    return fma(kd, LN2_HI, fma(kd, LN2_LO, r));
+}
+
+double orc_exp_d(double x)
+{
+    if (g_math_mode) return exp(x);
+    if (x != x) return x;
+    if (x > 709.782712893384) return INFINITY;
+    if (x < -745.1332191019412) return 0.0;
+    double kd = rint(x * INV_LN2);
+    double r = fma(-kd, LN2_HI, x);
+    r = fma(-kd, LN2_LO, r);
+    /* Taylor, degree 13, |r| <= 0.3466 */
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int k = (int)kd;
+    int k1 = k / 2, k2 = k - k1;
+    double s1 = u2d((uint64_t)(k1 + 1023) << 52);
+    double s2 = u2d((uint64_t)(k2 + 1023) << 52);
+    return (p * s1) * s2;
+}
+
+void orc_sincos_d(double a, double *sn, double *cs)
+{
+    if (g_math_mode) { *sn = sin(a); *cs = cos(a); return; }
+    double kd = rint(a * TWO_OVER_PI);
+    double r = fma(-kd, PIO2_HI, a);
+    r = fma(-kd, PIO2_LO, r);
+    double z = r * r;
+    /* sin r = r + r^3 * S(z), S = -1/3! + z/5! - ... (up to r^17) */
+    double s = 1.0 / 355687428096000.0;              /* 1/17! */
+    s = fma(s, z, -1.0 / 1307674368000.0);           /* 1/15! */
+    s = fma(s, z, 1.0 / 6227020800.0);               /* 1/13! */
+    s = fma(s, z, -1.0 / 39916800.0);                /* 1/11! */
+    s = fma(s, z, 1.0 / 362880.0);                   /* 1/9!  */
+    s = fma(s, z, -1.0 / 5040.0);
+    s = fma(s, z, 1.0 / 120.0);
+    s = fma(s, z, -1.0 / 6.0);
+    double sr = fma(r * z, s, r);
+    /* cos r = 1 + z * C(z), C = -1/2! + z/4! - ... (up to r^18) */
+    double c = -1.0 / 6402373705728000.0;            /* 1/18! */
+    c = fma(c, z, 1.0 / 20922789888000.0);           /* 1/16! */
+    c = fma(c, z, -1.0 / 87178291200.0);             /* 1/14! */
+    c = fma(c, z, 1.0 / 479001600.0);                /* 1/12! */
+    c = fma(c, z, -1.0 / 3628800.0);                 /* 1/10! */
+    c = fma(c, z, 1.0 / 40320.0);
+    c = fma(c, z, -1.0 / 720.0);
+    c = fma(c, z, 1.0 / 24.0);
+    c = fma(c, z, -0.5);
+    double cr = fma(z, c, 1.0);
+    long long q = (long long)kd & 3;
+    switch (q) {
+    case 0:  *sn = sr;  *cs = cr;  break;
+    case 1:  *sn = cr;  *cs = -sr; break;
+    case 2:  *sn = -sr; *cs = -cr; break;
+    default: *sn = -cr; *cs = sr;  break;
+    }
+}
+
+float orc_logf(float x) { return g_math_mode ? logf(x) : (float)orc_log_d((double)x); }
+float orc_expf(float x) { return g_math_mode ? expf(x) : (float)orc_exp_d((double)x); }
+
+/* pow for x >= 0 as used by power_cosine_variate (ray.cpp:297: pow(double, float->double)) */
+double orc_pow_d(double x, double y)
+{
+    if (g_math_mode) return pow(x, y);
+    if (y == 1.0) return x;
+    if (y == 0.0) return 1.0;
+    if (x == 0.0) return y > 0.0 ? 0.0 : INFINITY;
+    return orc_exp_d(y * orc_log_d(x));
+}
+
+/* std::pow(float,float) as used by ray.cpp:232,234 */
+float orc_powf(float x, float y)
+{
+    if (g_math_mode) return powf(x, y);
+    if (y == 1.0f) return x;                 /* every loadable scene has specularity 1.0 */
+    if (y == 0.0f) return 1.0f;
+    if (x != x || y != y) return x + y;
+    double ax = fabs((double)x);
+    int y_is_int = (floorf(y) == y);
+    int y_is_odd = y_is_int && fabsf(y) < 16777216.0f && (((long long)y) & 1);
+    double r;
+    if (ax == 0.0) r = (y > 0.0f) ? 0.0 : INFINITY;
+    else r = orc_exp_d((double)y * orc_log_d(ax));
+    if (x < 0.0f || (x == 0.0f && signbit(x))) {
+        if (!y_is_int) return (x == 0.0f) ? (float)r : u2f(0x7fc00000u);
+        if (y_is_odd) r = -r;
+    }
+    return (float)r;
+}
+
+/* Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11) */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int i = 0; i < 10; i++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+double orc_u53(uint32_t hi, uint32_t lo)
+{
+    uint64_t v = ((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6);
+    return (double)v * 0x1p-53;
+}
+
+/* ===================================================================================== */
+/*  Static pieces                                                                         */
+/* ===================================================================================== */
+
+/* volume.h:19-35.  libstdc++: std::default_random_engine = minstd_rand0 (x <- 16807 x mod
+ * 2^31-1, seed 1); generate_canonical<double,53> draws twice; normal_distribution<double>
+ * is Marsaglia polar, returning y*m first and the saved x*m on the next call. */
+static uint32_t lcg_next(uint32_t *s) { *s = (uint32_t)(((uint64_t)*s * 16807u) % 2147483647u); return *s; }
+static double lcg_canonical(uint32_t *s)
+{
+    const double range = 2147483646.0;   /* max - min + 1 */
+    double sum = (double)(lcg_next(s) - 1u);
+    sum += (double)(lcg_next(s) - 1u) * range;
+    double r = sum / (range * range);
+    if (r >= 1.0) r = nextafter(1.0, 0.0);
+    return r;
+}
+void orc_texture_generate(float *out, uint32_t n)
+{
+    uint32_t st = 1u;
+    size_t total = (size_t)n * n * n;
+    for (size_t i = 0; i < total; i++) {
+        double x, y, r2;
+        do {
+            x = 2.0 * lcg_canonical(&st) - 1.0;
+            y = 2.0 * lcg_canonical(&st) - 1.0;
+            r2 = x * x + y * y;
+        } while (r2 > 1.0 || r2 == 0.0);
+        double mult = sqrt(-2.0 * log(r2) / r2);
+        out[2 * i + 0] = (float)(y * mult * 1.0 + 0.0);   /* texture_noise            */
+        out[2 * i + 1] = (float)(x * mult * 1.0 + 0.0);   /* scattering_probability   */
+    }
+}
+
+/* psf.h:34-58, 80-92 (note psf.h:9 redefines M_PI as 3.14159) */
+void orc_psf(float freq, float var_x, float var_y, uint32_t res_um,
+             float *axial, uint32_t n_ax, float *lateral, uint32_t n_lat)
+{
+    const float half_axial = (float)((size_t)n_ax * res_um) / 1000.0f / 2.0f;
+    const float half_lateral = (float)((size_t)n_lat * res_um) / 1000.0f / 2.0f;
+    const float resolution = (float)res_um / 1000.0f;
+    for (uint32_t i = 0; i < n_ax; i++) {
+        const float x = (float)i * resolution - half_axial;
+        double g = exp(-0.5f * (((double)x * (double)x) / (double)var_x));
+        double c = cos(2 * 3.14159 * (double)freq * (double)x);
+        axial[i] = (float)(g * c);
+    }
+    for (uint32_t i = 0; i < n_lat; i++) {
+        const float y = (float)i * resolution - half_lateral;
+        lateral[i] = (float)exp(-0.5f * (((double)y * (double)y) / (double)var_y));
+    }
+}
+
+typedef struct { float x, y, z; } v3;
+static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
+/* btVector3::dot (scalar path): x*x' + y*y' + z*z', left to right */
+static inline float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* btVector3::cross */
+static inline v3 vcross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+/* btVector3::normalized(): *this / length() == *this * (1/length()) */
+static inline v3 vnormalized(v3 a) { float inv = 1.0f / sqrtf(vdot(a, a)); return vscale(a, inv); }
+
+/* btVector3::rotate(axis, angle): o + (v-o) cos + (axis x v) sin, o = axis (axis.v) */
+static v3 vrotate(v3 v, v3 axis, float angle)
+{
+    v3 o = vscale(axis, vdot(axis, v));
+    v3 xx = vsub(v, o);
+    v3 yy = vcross(axis, v);
+    return vadd(vadd(o, vscale(xx, cosf(angle))), vscale(yy, sinf(angle)));
+}
+
+/* transducer.h:24-62; units conversions per include/units/units.h:1375 (deg->rad = v*pi*1/180) */
+void orc_transducer(uint32_t n_elem, double radius_cm, double sep_mm,
+                    const float position[3], const float angles_deg[3], float *pos, float *dir)
+{
+    const double PI_VAL = 3.14159265358979323846264338327950288419716939937510;
+    double xa = ((double)angles_deg[0] * PI_VAL * 1.0) / 180.0;
+    double ya = ((double)angles_deg[1] * PI_VAL * 1.0) / 180.0;
+    double za = ((double)angles_deg[2] * PI_VAL * 1.0) / 180.0;
+    /* amp = sep/radius is mm/cm; .to<float>() converts to scalar: value*1/10 (units.h:1365,1921) */
+    float amp_f = (float)(((sep_mm / radius_cm) * 1.0) / 10.0);
+    double amplitude = (double)amp_f;
+    double center = amplitude / 2.0;
+    double angle = -(amplitude * (double)n_elem / 2.0) + center;
+    v3 p0 = V(position[0], position[1], position[2]);
+    float rad_f = (float)radius_cm;
+    for (uint32_t t = 0; t < n_elem; t++) {
+        float af = (float)angle;
+        v3 d = V(sinf(af), cosf(af), 0.0f);
+        d = vrotate(d, V(0, 0, 1), (float)za);
+        d = vrotate(d, V(1, 0, 0), (float)xa);
+        d = vrotate(d, V(0, 1, 0), (float)ya);
+        v3 p = vadd(p0, V(rad_f * d.x, rad_f * d.y, rad_f * d.z));
+        pos[3 * t + 0] = p.x; pos[3 * t + 1] = p.y; pos[3 * t + 2] = p.z;
+        dir[3 * t + 0] = d.x; dir[3 * t + 1] = d.y; dir[3 * t + 2] = d.z;
+        angle = angle + amplitude;
+    }
+}
+
+/* scene.cpp:313-324 (+ Bullet applying the mesh's local scaling to each vertex component) */
+void orc_place_vertices(float *v, uint32_t n, float scaling, const float deltas[3], const float origin[3])
+{
+    float pos[3];
+    for (int i = 0; i < 3; i++) pos[i] = deltas[i] * scaling * scaling + origin[i];
+    for (uint32_t k = 0; k < n; k++)
+        for (int i = 0; i < 3; i++) v[3 * k + i] = v[3 * k + i] * scaling + pos[i];
+}
+
+/* absolute part of the bounds padding: 4e-6 * largest finite |coordinate| (>= 1e-3) */
+float orc_pad_abs(const float *tri, uint32_t n_tri)
+{
+    float scale = 0.0f;
+    for (size_t i = 0; i < (size_t)n_tri * 9; i++) { float a = fabsf(tri[i]); if (a > scale && isfinite(a)) scale = a; }
+    return 4e-6f * fmaxf(scale, 1e-3f);
+}
+
+/* main.cpp:23-37, rfimage.h:178-180 */
+void orc_constants(float f_mhz, uint32_t sos, double depth_cm, orc_consts *o)
+{
+    o->axial_res_f = 1.45f / f_mhz;
+    o->axial_res_mm = (double)o->axial_res_f;
+    o->axial_res_um = (uint32_t)(o->axial_res_f * 1000.0f);
+    /* micros_traveled(mm): mm -> um is value*1000/1 (units.h:1365), then / sos */
+    o->time_step_us = ((o->axial_res_mm * 1000.0) / 1.0) / (double)sos;
+    o->row_dt_us = (double)o->axial_res_um / (double)sos;
+    /* microsecond_t(cm / (m/s)): (15/1500) [cm s/m] -> us: *10000/1 */
+    o->max_travel_us = ((depth_cm / (double)sos) * 10000.0) / 1.0;
+    o->max_rows = (uint32_t)((sos * (uint32_t)o->max_travel_us) / o->axial_res_um);
+}
+
+void orc_default_params(orc_params *p)
+{
+    memset(p, 0, sizeof *p);
+    p->n_elements = 512; p->n_samples = 5; p->max_depth = 10; p->n_rows = 465;
+    p->frequency = 4.5f; p->intensity_epsilon = 1e-10f; p->initial_intensity = 1.0f;
+    p->ray_start_offset = 0.1f; p->sos = 1500; p->depth_cm = 15.0; p->seed = 0x5EED;
+    p->sanitize_tir = 0; p->tex_n = 256; p->tex_res = 0.145f;
+}
+
+/* ===================================================================================== */
+/*  Closest hit  (Bullet rayTest + ClosestRayResultCallback, scene.cpp:115-126)            */
+/* ===================================================================================== */
+
+typedef struct { float frac; int32_t tri; v3 n; float da; } hit_t;
+
+/* Per-triangle padded bounds (contract, DESIGN.md "Closest hit"): Bullet only hands a triangle to
+ * processTriangle after the ray has passed that triangle's own (quantised, slightly enlarged) AABB in the BVH
+ * leaf.  The float restatement: lo/hi of the three vertices widened by 2e-4*extent + pad_abs. */
+static inline void tri_bounds(const float *t9, float pad_abs, float lo[3], float hi[3])
+{
+    float ext = 0.0f;
+    for (int a = 0; a < 3; a++) {
+        float l = fminf(t9[a], fminf(t9[3 + a], t9[6 + a]));
+        float h = fmaxf(t9[a], fmaxf(t9[3 + a], t9[6 + a]));
+        lo[a] = l; hi[a] = h;
+        ext = fmaxf(ext, h - l);
+    }
+    const float pad = 2e-4f * ext + pad_abs;
+    for (int a = 0; a < 3; a++) { lo[a] = lo[a] - pad; hi[a] = hi[a] + pad; }
+}
+
+/* ray parameter interval [tmin,tmax] (clamped to [0,tcap]) in which o + t*d lies inside the box */
+static inline int slab(const float lo[3], const float hi[3], v3 o, v3 inv, float tcap, float *tmin_o, float *tmax_o)
+{
+    float t0x = (lo[0] - o.x) * inv.x, t1x = (hi[0] - o.x) * inv.x;
+    float t0y = (lo[1] - o.y) * inv.y, t1y = (hi[1] - o.y) * inv.y;
+    float t0z = (lo[2] - o.z) * inv.z, t1z = (hi[2] - o.z) * inv.z;
+    float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+    float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tcap));
+    *tmin_o = tmin; *tmax_o = tmax;
+    return tmin <= tmax;
+}
+
+/* btTriangleRaycastCallback::processTriangle restated (Bullet, not under /root/reference), preceded by the
+ * triangle's own bounds test.  Rules of the contract that make the answer independent of visiting order:
+ *   - a hit counts only if its fraction lies inside the ray's overlap with the triangle's padded bounds
+ *     (float noise far from the triangle can otherwise pass the three edge tests on a 1e9-long segment);
+ *   - smaller fraction wins; equal fraction -> smaller triangle id. */
+static inline void tri_test(const float *t9, int32_t id, v3 from, v3 to, v3 inv, float pad_abs, hit_t *best)
+{
+    v3 v0 = V(t9[0], t9[1], t9[2]), v1 = V(t9[3], t9[4], t9[5]), v2 = V(t9[6], t9[7], t9[8]);
+    v3 v10 = vsub(v1, v0), v20 = vsub(v2, v0);
+    v3 n = vcross(v10, v20);
+    float dist = vdot(v0, n);
+    float da = vdot(n, from) - dist;
+    float db = vdot(n, to) - dist;
+    if (da * db >= 0.0f) return;
+    float proj = da - db;
+    float frac = da / proj;
+    if (frac < best->frac || (frac == best->frac && id < best->tri)) {
+        float lo[3], hi[3], tmin, tmax;
+        tri_bounds(t9, pad_abs, lo, hi);
+        if (!slab(lo, hi, from, inv, 1.0f, &tmin, &tmax)) return;
+        if (!(frac >= tmin && frac <= tmax)) return;
+        float edge_tol = vdot(n, n) * -0.0001f;
+        float s = 1.0f - frac;
+        v3 p = V(s * from.x + frac * to.x, s * from.y + frac * to.y, s * from.z + frac * to.z);
+        v3 v0p = vsub(v0, p), v1p = vsub(v1, p);
+        v3 cp0 = vcross(v0p, v1p);
+        if (vdot(cp0, n) >= edge_tol) {
+            v3 v2p = vsub(v2, p);
+            v3 cp1 = vcross(v1p, v2p);
+            if (vdot(cp1, n) >= edge_tol) {
+                v3 cp2 = vcross(v2p, v0p);
+                if (vdot(cp2, n) >= edge_tol) {
+                    best->frac = frac; best->tri = id; best->n = n; best->da = da;
+                }
+            }
+        }
+    }
+}
+
+#define ORC_STACK 96
+
+static void walk_bvh(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stats *st)
+{
+    v3 d = vsub(to, from);
+    v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int32_t stack[ORC_STACK];
+    int sp = 0;
+    int32_t cur = 0;
+    uint64_t nn = 0, nt = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const orc_bvh_node *N = &sc->nodes[cur];
+            nn++;
+            float tn0, tn1, tx0, tx1;
+            int h0 = slab(N->lo0, N->hi0, from, inv, fminf(1.0f, best->frac), &tn0, &tx0);
+            int h1 = slab(N->lo1, N->hi1, from, inv, fminf(1.0f, best->frac), &tn1, &tx1);
+            if (h0 && h1) {
+                int32_t nearc = N->c0, farc = N->c1;
+                if (tn1 < tn0) { nearc = N->c1; farc = N->c0; }
+                if (sp < ORC_STACK) stack[sp++] = farc;
+                cur = nearc;
+                continue;
+            } else if (h0) { cur = N->c0; continue; }
+            else if (h1) { cur = N->c1; continue; }
+        } else {
+            uint32_t v = (uint32_t)~cur;
+            uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; i++) {
+                const float *t = sc->bvh_tri + (size_t)(first + i) * 12;
+                float t9[9] = { t[0], t[1], t[2], t[4], t[5], t[6], t[8], t[9], t[10] };
+                tri_test(t9, (int32_t)f2u(t[3]), from, to, inv, sc->pad_abs, best);
+                nt++;
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    if (st) { st->nodes_visited += nn; st->tris_tested += nt; }
+}
+
+int32_t orc_closest_hit(const orc_scene *sc, const float from_[3], const float to_[3], int use_bvh,
+                        float *frac, float normal[3], float point[3], orc_stats *st)
+{
+    v3 from = V(from_[0], from_[1], from_[2]), to = V(to_[0], to_[1], to_[2]);
+    hit_t best; best.frac = 1.0f; best.tri = -1; best.n = V(0, 0, 0); best.da = 0;
+    if (st) st->queries++;
+    if (use_bvh && sc->nodes && sc->n_nodes) {
+        walk_bvh(sc, from, to, &best, st);
+    } else {
+        v3 d = vsub(to, from);
+        v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        for (uint32_t i = 0; i < sc->n_tri; i++) tri_test(sc->tri + (size_t)i * 9, (int32_t)i, from, to, inv, sc->pad_abs, &best);
+        if (st) st->tris_tested += sc->n_tri;
+    }
+    if (best.tri < 0) return -1;
+    /* triangleNormal.normalize(); flipped to face the ray origin when dist_a <= 0 */
+    v3 nn = vnormalized(best.n);
+    if (best.da <= 0.0f) nn = vneg(nn);
+    /* ClosestRayResultCallback: m_hitPointWorld.setInterpolate3(from, to, fraction) */
+    float s = 1.0f - best.frac;
+    if (frac) *frac = best.frac;
+    if (normal) { normal[0] = nn.x; normal[1] = nn.y; normal[2] = nn.z; }
+    if (point) {
+        point[0] = s * from.x + best.frac * to.x;
+        point[1] = s * from.y + best.frac * to.y;
+        point[2] = s * from.z + best.frac * to.z;
+    }
+    if (st) st->hits++;
+    return best.tri;
+}
+
+/* ===================================================================================== */
+/*  Ray physics (ray.cpp)                                                                 */
+/* ===================================================================================== */
+
+enum { M_IMP = 0, M_ATT, M_MU0, M_MU1, M_SIGMA, M_SPEC, M_SHINE, M_THICK };
+#define OUT_NONE (-1)   /* media_outside == nullptr                                         */
+#define OUT_SELF (-2)   /* media_outside aliases the ray's own media (quirk 2, ray.cpp:38)   */
+
+typedef struct {
+    v3 from, dir;
+    int32_t media, outside;
+    float intensity, frequency;
+    double dist_mm;
+    int alive;
+} ray_t;
+
+typedef struct {
+    uint32_t key[2];
+    uint32_t element, sample, bounce;
+} rng_t;
+
+static inline void rng_block(const rng_t *g, uint32_t block, double *a, double *b)
+{
+    uint32_t ctr[4] = { g->element, g->sample, g->bounce, block }, out[4];
+    orc_philox4x32_10(ctr, g->key, out);
+    *a = orc_u53(out[0], out[1]);
+    *b = orc_u53(out[2], out[3]);
+}
+
+/* ray.cpp:213-224 power_cosine_variate(int v) */
+static float power_cosine_variate(int v, double number)
+{
+    int indice = v + 1;
+    float exponente = (float)((double)1.0 / indice);
+    return (float)orc_pow_d(number, (double)exponente);
+}
+
+/* ray.cpp:167-211 random_unit_vector; draws come from blocks 2,3,... (one block per attempt) */
+static v3 random_unit_vector(v3 v, float cos_theta, const rng_t *g)
+{
+    int flag = 0;
+    float px, py, p;
+    uint32_t attempt = 0;
+    do {
+        double ua, ur;
+        rng_block(g, 2u + attempt, &ua, &ur);
+        double a = ua * 2 * PI_D;
+        double r = 0.5 * sqrt(ur);
+        double sa, ca;
+        orc_sincos_d(a, &sa, &ca);
+        px = (float)(r * ca);
+        py = (float)(r * sa);
+        p = px * px + py * py;
+        attempt++;
+    } while (!(p <= 0.25f) && attempt < 8u);
+    float vx = v.x, vy = v.y, vz = v.z;
+    if (fabsf(vx) > fabsf(vy)) { vx = vy; vy = v.x; flag = 1; }
+    float b = 1 - vx * vx;
+    float radicando = 1 - cos_theta * cos_theta;
+    radicando = radicando / (p * b);
+    float c = sqrtf(radicando);
+    px = px * c;
+    py = py * c;
+    float d = cos_theta - vx * px;
+    float wx = vx * cos_theta - b * px;
+    float wy = vy * d + vz * py;
+    float wz = vz * d - vy * py;
+    if (flag) { float aux = wy; wy = wx; wx = aux; }
+    return V(wx, wy, wz);
+}
+
+static inline float std_max(float a, float b) { return (a < b) ? b : a; }   /* std::max operand order */
+
+typedef struct { float reflected_intensity; ray_t returned; } hit_result;
+
+/* ray.cpp:11-97 */
+static hit_result hit_boundary(const ray_t *r, v3 hit_point, v3 surface_normal, const orc_mesh *cm,
+                               const orc_scene *sc, const orc_params *prm, const rng_t *g)
+{
+    int32_t after_vasc, mat_after;
+    if (r->outside != OUT_NONE) {
+        if (cm->vascular) { after_vasc = OUT_NONE; mat_after = (r->outside == OUT_SELF) ? r->media : r->outside; }
+        else {
+            after_vasc = (r->outside == (int32_t)cm->mat_inside) ? (int32_t)cm->mat_outside : (int32_t)cm->mat_inside;
+            mat_after = r->media;
+        }
+    } else {
+        if (cm->vascular) { after_vasc = OUT_SELF; mat_after = (int32_t)cm->mat_inside; }
+        else { after_vasc = OUT_NONE; mat_after = (int32_t)cm->mat_inside; /* quirk 1: &r.media never equals a map element */ }
+    }
+    const float *ma = sc->mat + (size_t)mat_after * 8;
+    const float *mr = sc->mat + (size_t)r->media * 8;
+
+    double u_pc, u_x;
+    rng_block(g, 1u, &u_pc, &u_x);
+    float random_angle = power_cosine_variate((int)ma[M_SHINE], u_pc);
+    v3 random_normal = random_unit_vector(surface_normal, random_angle, g);
+
+    float incidence = vdot(r->dir, vneg(random_normal));
+    if (incidence < 0) incidence = vdot(r->dir, random_normal);
+    const float refr_ratio = mr[M_IMP] / ma[M_IMP];
+    float refraction_angle = 1 - refr_ratio * refr_ratio * (1 - incidence * incidence);
+    const int tir = refraction_angle < 0;
+    refraction_angle = sqrtf(refraction_angle);
+
+    /* snells_law ray.cpp:115-124: r*l + (r*c - c2)*n */
+    float k = refr_ratio * incidence - refraction_angle;
+    v3 refr = V(refr_ratio * r->dir.x + k * random_normal.x,
+                refr_ratio * r->dir.y + k * random_normal.y,
+                refr_ratio * r->dir.z + k * random_normal.z);
+    refr = vnormalized(refr);
+    float two_c = 2 * incidence;
+    v3 refl = V(r->dir.x + two_c * random_normal.x, r->dir.y + two_c * random_normal.y, r->dir.z + two_c * random_normal.z);
+    refl = vnormalized(refl);
+
+    float intensity_refl;
+    if (tir) intensity_refl = r->intensity;
+    else {
+        /* reflection_intensity ray.cpp:126-132: pow(num/denom, 2) promotes to double */
+        float num = mr[M_IMP] * incidence - ma[M_IMP] * refraction_angle;
+        float den = mr[M_IMP] * incidence + ma[M_IMP] * refraction_angle;
+        float q = num / den;
+        intensity_refl = (float)((double)r->intensity * ((double)q * (double)q));
+    }
+    const float intensity_refr = r->intensity - intensity_refl;
+
+    /* Eq. 8, ray.cpp:154-164 */
+    float ra = vdot(r->dir, refr);
+    float refraction_factor = orc_powf(ra, ma[M_SPEC]);
+    float rb = vdot(r->dir, refl);
+    float reflection_factor = orc_powf(rb, ma[M_SPEC]);
+    if (prm->sanitize_tir && tir) refraction_factor = 0.0f;
+    float back = (std_max(refraction_factor, 0.0f) + std_max(reflection_factor, 0.0f)) * random_angle;
+
+    float x = (float)u_x;
+    float prob = intensity_refl / r->intensity;
+    hit_result res;
+    res.reflected_intensity = back;
+    res.returned = *r;
+    res.returned.from = hit_point;
+    if (prob > x) {
+        res.returned.dir = refl;
+        res.returned.intensity = intensity_refl > prm->intensity_epsilon ? intensity_refl : 0.0f;
+    } else {
+        res.returned.dir = refr;
+        res.returned.media = mat_after;
+        res.returned.outside = after_vasc;
+        res.returned.intensity = intensity_refr > prm->intensity_epsilon ? intensity_refr : 0.0f;
+    }
+    return res;
+}
+
+/* scene.cpp:281-290 */
+static double distance_in_mm(const orc_scene *sc, v3 a, v3 b)
+{
+    float xd = fabsf(a.x - b.x) * sc->spacing[0];
+    float yd = fabsf(a.y - b.y) * sc->spacing[1];
+    float zd = fabsf(a.z - b.z) * sc->spacing[2];
+    return sqrt((double)xd * (double)xd + (double)yd * (double)yd + (double)zd * (double)zd) * 10;
+}
+
+/* volume.h:46-61; quirk 4: float -> unsigned of a possibly negative value wraps (x86-64) */
+static inline uint32_t vox_index(float q, uint32_t n)
+{
+    int64_t i;
+    if (!(fabsf(q) < 9.2233720368547758e18f)) i = (int64_t)0x8000000000000000ull; /* cvttss2si indefinite */
+    else i = (int64_t)q;
+    return ((uint32_t)i) % n;
+}
+static inline float get_scattering(const float *tex, uint32_t n, float res, float density, float mu, float sigma, v3 p)
+{
+    uint32_t x = vox_index(p.x / res, n), y = vox_index(p.y / res, n), z = vox_index(p.z / res, n);
+    const float *vx = tex + 2 * (((size_t)x * n + y) * n + z);
+    return vx[1] >= density ? vx[0] * sigma + mu : 0.0f;
+}
+
+static inline uint32_t steps_from(double q)
+{
+    /* (unsigned int)(double): x86-64 cvttsd2si r64 then low 32 bits */
+    if (!(fabs(q) < 9.2233720368547758e18)) return 0u;
+    return (uint32_t)(int64_t)q;
+}
+
+#define FIX_SCALE 4503599627370496.0   /* 2^52 */
+static inline void fix_add(int64_t *acc, uint8_t *flag, float echo)
+{
+    if (!(fabsf(echo) < 1024.0f)) { if (flag) *flag = 1; return; }
+    *acc += (int64_t)rint((double)echo * FIX_SCALE);
+}
+
+typedef struct {
+    float *rf_ref; uint32_t ref_cols, ref_col;       /* [R][cols] */
+    int64_t *rf_fix; uint8_t *rf_flags;               /* [R] of this element */
+} rf_sink;
+
+static inline void add_echo(const rf_sink *k, const orc_consts *c, uint32_t n_rows, float echo, double t_us)
+{
+    /* rfimage.h:33-40 */
+    double row = t_us / c->row_dt_us;
+    if (row < (double)n_rows) {
+        int r = (int)row;
+        if (k->rf_ref) k->rf_ref[(size_t)r * k->ref_cols + k->ref_col] += echo;
+        if (k->rf_fix) fix_add(&k->rf_fix[r], k->rf_flags ? &k->rf_flags[r] : NULL, echo);
+    }
+}
+
+/* main.cpp:106-144 for one segment */
+static void accumulate_segment(const orc_scene *sc, const orc_params *prm, const orc_consts *c, const float *tex,
+                               const orc_segment *sg, const rf_sink *k, orc_stats *st)
+{
+    const float *m = sc->mat + (size_t)sg->media * 8;
+    const double starting_micros = ((sg->distance_traveled * 1000.0) / 1.0) / (double)prm->sos;
+    /* scene::distance scene.cpp:342-346: from.distance(to)*10.0f */
+    v3 from = V(sg->from[0], sg->from[1], sg->from[2]), to = V(sg->to[0], sg->to[1], sg->to[2]);
+    v3 df = vsub(to, from);
+    float dist_f = sqrtf(vdot(df, df)) * 10.0f;
+    uint32_t steps = steps_from((double)dist_f / c->axial_res_mm);
+    v3 dir = V(sg->dir[0], sg->dir[1], sg->dir[2]);
+    v3 delta = V(c->axial_res_f * dir.x, c->axial_res_f * dir.y, c->axial_res_f * dir.z);
+    v3 point = from;
+    double t = starting_micros;
+    float intensity = sg->initial_intensity;
+    const float k_att = orc_expf(-sg->attenuation * c->axial_res_f * 0.01f * prm->frequency * 1.0f);
+    uint64_t n = 0;
+    for (uint32_t step = 0; step < steps && t < c->max_travel_us; step++) {
+        float scattering = get_scattering(tex, prm->tex_n, prm->tex_res, m[M_MU1], m[M_MU0], m[M_SIGMA], point);
+        add_echo(k, c, prm->n_rows, intensity * scattering, t);
+        point = vadd(point, delta);
+        t = t + c->time_step_us;
+        intensity *= k_att;
+        n++;
+    }
+    if (st) st->rf_steps += n;
+    add_echo(k, c, prm->n_rows, sg->reflected_intensity / (float)prm->n_samples,
+             starting_micros + c->time_step_us * (double)(uint32_t)(steps - 1u));
+}
+
+/* scene.cpp:50-183 for one path (element e, sample s) */
+static void trace_path(const orc_scene *sc, const orc_params *prm, const orc_consts *c, const float *tex,
+                       v3 el_pos, v3 el_dir, uint32_t frame_id, uint32_t e_abs, uint32_t s, int use_bvh,
+                       int32_t *hits, orc_segment *segs, uint32_t *seg_count, const rf_sink *k, orc_stats *st)
+{
+    ray_t r;
+    r.from = el_pos; r.dir = el_dir; r.media = (int32_t)sc->start_mat; r.outside = OUT_NONE;
+    r.intensity = prm->initial_intensity / (float)prm->n_samples;
+    r.frequency = prm->frequency; r.dist_mm = 0.0; r.alive = 1;
+    rng_t g; g.key[0] = prm->seed; g.key[1] = frame_id; g.element = e_abs; g.sample = s;
+    uint32_t nseg = 0;
+    for (uint32_t b = 0; b < prm->max_depth; b++) {
+        if (hits) hits[b] = -2;
+        if (!r.alive) continue;
+        g.bounce = b;
+        const float *mr = sc->mat + (size_t)r.media * 8;
+        /* max_ray_length ray.cpp:110-113 */
+        float L = 10.f * orc_logf(prm->intensity_epsilon / r.intensity) / -mr[M_ATT] * r.frequency;
+        /* enlarge scene.cpp:292-298 */
+        float Ls = L / 100.0f;
+        v3 to = V(r.from.x + Ls * (sc->spacing[0] * r.dir.x), r.from.y + Ls * (sc->spacing[1] * r.dir.y), r.from.z + Ls * (sc->spacing[2] * r.dir.z));
+        v3 f2 = V(r.from.x + prm->ray_start_offset * r.dir.x, r.from.y + prm->ray_start_offset * r.dir.y, r.from.z + prm->ray_start_offset * r.dir.z);
+        float ff[3] = { f2.x, f2.y, f2.z }, tt[3] = { to.x, to.y, to.z }, frac, nrm[3], pt[3];
+        int32_t tri = orc_closest_hit(sc, ff, tt, use_bvh, &frac, nrm, pt, st);
+        if (hits) hits[b] = tri;
+        orc_segment sg;
+        if (tri >= 0) {
+            double dist_before = r.dist_mm;
+            float i_before = r.intensity;
+            const orc_mesh *organ = &sc->mesh[sc->tri_mesh[tri]];
+            /* scene.cpp:132-139: q = |N(0, thickness)|, Box-Muller on block 0 */
+            float sigma = sc->mat[(size_t)organ->mat_inside * 8 + M_THICK];
+            float q = 0.0f;
+            if (sigma != 0.0f) {
+                double n1, n2, sn, cs;
+                rng_block(&g, 0u, &n1, &n2);
+                orc_sincos_d(n2 * 2 * PI_D, &sn, &cs);
+                double z = sqrt(-2.0 * orc_log_d(1.0 - n1)) * cs;
+                q = (float)fabs(z * (double)sigma + 0.0);
+            }
+            v3 hp = V(pt[0], pt[1], pt[2]);
+            v3 inside = V(q * r.dir.x + hp.x, q * r.dir.y + hp.y, q * r.dir.z + hp.z);
+            /* travel ray.cpp:99-103 */
+            double mm = distance_in_mm(sc, r.from, inside);
+            r.dist_mm = r.dist_mm + mm;
+            r.intensity = r.intensity * orc_expf(-mr[M_ATT] * ((float)mm * 0.01f) * r.frequency);
+            hit_result hr = hit_boundary(&r, hp, V(nrm[0], nrm[1], nrm[2]), organ, sc, prm, &g);
+            sg.from[0] = r.from.x; sg.from[1] = r.from.y; sg.from[2] = r.from.z;
+            sg.to[0] = inside.x; sg.to[1] = inside.y; sg.to[2] = inside.z;
+            sg.dir[0] = r.dir.x; sg.dir[1] = r.dir.y; sg.dir[2] = r.dir.z;
+            sg.reflected_intensity = hr.reflected_intensity; sg.initial_intensity = i_before;
+            sg.attenuation = mr[M_ATT]; sg.distance_traveled = dist_before; sg.media = r.media; sg.tri = tri;
+            if (hr.returned.intensity > prm->intensity_epsilon) r = hr.returned; else r.alive = 0;
+        } else {
+            sg.from[0] = r.from.x; sg.from[1] = r.from.y; sg.from[2] = r.from.z;
+            sg.to[0] = to.x; sg.to[1] = to.y; sg.to[2] = to.z;
+            sg.dir[0] = r.dir.x; sg.dir[1] = r.dir.y; sg.dir[2] = r.dir.z;
+            sg.reflected_intensity = 0.0f; sg.initial_intensity = r.intensity;
+            sg.attenuation = mr[M_ATT]; sg.distance_traveled = r.dist_mm; sg.media = r.media; sg.tri = -1;
+            r.alive = 0;
+        }
+        if (segs) segs[nseg] = sg;
+        nseg++;
+        if (st) st->segments++;
+        if (k && (k->rf_ref || k->rf_fix)) accumulate_segment(sc, prm, c, tex, &sg, k, st);
+    }
+    if (seg_count) *seg_count = nseg;
+}
+
+void orc_trace_frame(const orc_scene *sc, const orc_params *p,
+                     const float *el_pos, const float *el_dir, const float *texture,
+                     uint32_t frame_id, uint32_t e_begin, uint32_t e_end, int use_bvh, int n_threads,
+                     int32_t *hits, orc_segment *segs, uint32_t *seg_count,
+                     float *rf_ref, int64_t *rf_fix, uint8_t *rf_flags, orc_stats *st_out)
+{
+    orc_consts c;
+    orc_constants(p->frequency, p->sos, p->depth_cm, &c);
+    const uint32_t ne = e_end - e_begin, S = p->n_samples, B = p->max_depth, R = p->n_rows;
+    orc_stats total; memset(&total, 0, sizeof total);
+    if (n_threads < 1) n_threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+#endif
+    for (uint32_t ei = 0; ei < ne; ei++) {
+        orc_stats st; memset(&st, 0, sizeof st);
+        uint32_t e = e_begin + ei;
+        v3 pos = V(el_pos[3 * e], el_pos[3 * e + 1], el_pos[3 * e + 2]);
+        v3 dir = V(el_dir[3 * e], el_dir[3 * e + 1], el_dir[3 * e + 2]);
+        rf_sink k;
+        k.rf_ref = rf_ref; k.ref_cols = ne; k.ref_col = ei;
+        k.rf_fix = rf_fix ? rf_fix + (size_t)ei * R : NULL;
+        k.rf_flags = rf_flags ? rf_flags + (size_t)ei * R : NULL;
+        for (uint32_t s = 0; s < S; s++) {
+            size_t pi = (size_t)ei * S + s;
+            trace_path(sc, p, &c, texture, pos, dir, frame_id, e, s, use_bvh,
+                       hits ? hits + pi * B : NULL, segs ? segs + pi * B : NULL,
+                       seg_count ? seg_count + pi : NULL, &k, &st);
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            total.queries += st.queries; total.nodes_visited += st.nodes_visited; total.tris_tested += st.tris_tested;
+            total.segments += st.segments; total.rf_steps += st.rf_steps; total.hits += st.hits;
+        }
+    }
+    if (st_out) *st_out = total;
+}
+
+void orc_finalize_rf(const int64_t *rf_fix, const uint8_t *rf_flags, uint32_t n_elem, uint32_t n_rows, float *out)
+{
+    for (uint32_t e = 0; e < n_elem; e++)
+        for (uint32_t r = 0; r < n_rows; r++) {
+            size_t i = (size_t)e * n_rows + r;
+            float v = (rf_flags && rf_flags[i]) ? u2f(0x7fc00000u) : (float)((double)rf_fix[i] * 0x1p-52);
+            out[(size_t)r * n_elem + e] = v;
+        }
+}
+
+/* rfimage.h:93-123 */
+void orc_convolve(float *img, float *tmp, uint32_t rows_, uint32_t cols_,
+                  const float *axial, uint32_t n_ax, const float *lateral, uint32_t n_lat)
+{
+    const int rows = (int)rows_, cols = (int)cols_, na = (int)n_ax, nl = (int)n_lat;
+    for (int col = 0; col < cols; col++)
+        for (int row = na; row < rows - na; row++) {
+            float conv = 0;
+            for (int k = 0; k < na; k++) conv += img[(size_t)(row + k) * cols + col] * axial[k];
+            tmp[(size_t)row * cols + col] = conv;
+        }
+    for (int row = na; row < rows - na; row++)
+        for (int col = nl / 2; col < cols - nl; col++) {
+            float conv = 0;
+            for (int k = 0; k < nl; k++) conv += tmp[(size_t)row * cols + col + k] * lateral[k];
+            img[(size_t)row * cols + col] = conv;
+        }
+}
+
+/* rfimage.h:54-91 */
+void orc_envelope(float *img, uint32_t rows, uint32_t cols)
+{
+#define AT(r, c) img[(size_t)(r) * cols + (c)]
+    for (uint32_t column = 0; column < cols; column++) {
+        int ascending = AT(0, column) < AT(1, column);
+        size_t last_peak_pos = 0;
+        float last_peak = AT(last_peak_pos, column);
+        for (size_t i = 1; i + 1 < rows; i++) {
+            if (AT(i, column) < AT(i + 1, column)) ascending = 1;
+            else if (ascending) {
+                ascending = 0;
+                const float new_peak = fabsf(AT(i, column));
+                for (size_t j = last_peak_pos; j < i; j++) {
+                    const float alpha = ((float)j - (float)last_peak_pos) / ((float)i - (float)last_peak_pos);
+                    AT(j, column) = last_peak * (1 - alpha) + new_peak * alpha;
+                }
+                last_peak_pos = i;
+                last_peak = new_peak;
+            }
+        }
+    }
+#undef AT
+}
+
+/* rfimage.h:183-215 (create_mapping) + :139 cv::remap(src,dst,map_y,map_x,LINEAR,BORDER_CONSTANT 0).
+ * OpenCV is absent: the bilinear kernel is restated as EXACT bilinear in float (OpenCV
+ * quantises fractions to 1/32) -- parity unpinned for this function. */
+void orc_scan_convert(const float *img, uint32_t rows, uint32_t cols, double radius_mm, double total_angle,
+                      double max_travel_us, double sos, float *out, uint32_t out_rows, uint32_t out_cols)
+{
+    float radius_f = (float)radius_mm, ta_f = (float)total_angle;
+    /* ratio: (max_travel_time*sos [um] * 0.001f + r - r*cos(a/2.0)) / rows  (mixed double) */
+    double depth_um = max_travel_us * sos;
+    float ratio = (float)((depth_um * 0.001f + radius_f - radius_f * cos(ta_f / 2.0)) / (double)out_rows);
+    double shift_y = radius_mm * (double)cosf(ta_f / 2.0f);
+    float half_width = (float)out_cols / 2.0f;
+    for (uint32_t j = 0; j < out_cols; j++)
+        for (uint32_t i = 0; i < out_rows; i++) {
+            float fi = (float)i + (float)shift_y / ratio;
+            float fj = (float)j - half_width;
+            float r = sqrtf(fi * fi + fj * fj);
+            double angle = (double)atan2f(fj, fi);
+            float my = (float)((double)((r * ratio - radius_f)) / (depth_um * 0.001f) * (double)(float)rows);   /* map_x: row coord */
+            float mx = (float)(((angle - (-total_angle / 2)) / total_angle) * (double)(float)cols);               /* map_y: col coord */
+            /* remap: dst(i,j) = src(y=my, x=mx) bilinear, constant 0 border */
+            float fx = floorf(mx), fy = floorf(my);
+            float ax = mx - fx, ay = my - fy;
+            long x0 = (long)fx, y0 = (long)fy;
+            float v[2][2];
+            for (int dy = 0; dy < 2; dy++)
+                for (int dx = 0; dx < 2; dx++) {
+                    long xx = x0 + dx, yy = y0 + dy;
+                    v[dy][dx] = (mx == mx && my == my && xx >= 0 && yy >= 0 && xx < (long)cols && yy < (long)rows) ? img[(size_t)yy * cols + xx] : 0.0f;
+                }
+            float top = v[0][0] * (1.0f - ax) + v[0][1] * ax;
+            float bot = v[1][0] * (1.0f - ax) + v[1][1] * ax;
+            out[(size_t)i * out_cols + j] = top * (1.0f - ay) + bot * ay;
+        }
+}

@@ -1,0 +1,163 @@
+// ref_probe.cpp -- ORACLE-SIDE TOOL (test infrastructure).
+//
+// Compiles the parts of the REFERENCE that build without Bullet/OpenCV, from the sources
+// where they lie under /root/reference (nothing is copied into this repo), and prints the
+// values the oracle is pinned against as JSON:
+//   src/psf.h            -> PSF taps                         (main.cpp:54 parameters)
+//   src/volume.h         -> tissue texture (hash, sums, samples, get_scattering probes)
+//   include/units/units.h-> the unit arithmetic of main.cpp:23-37,114-139 and rfimage.h:33-51,178-180
+// Built by oracle/Makefile into oracle/_ref/ref_probe (git-ignored); run by oracle/gen_golden.py,
+// which writes tests/golden/ref_probe.json.  Only this container has /root/reference.
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include <vector>
+
+#define private public           // the probe reads volume::matrix directly
+#include "volume.h"
+#undef private
+#include "psf.h"                 // note: redefines M_PI as 3.14159 (psf.h:9)
+#include <units/units.h>
+
+using namespace units::literals;
+using namespace units::velocity;
+using namespace units::length;
+using namespace units::time;
+using namespace units::angle;
+
+// main.cpp:23-33 verbatim semantics (these are declarations of the reference's constants, re-typed
+// here because main.cpp itself cannot be compiled: it includes Bullet and OpenCV headers)
+constexpr meters_per_second_t speed_of_sound = 1500_m / 1_s;
+constexpr float transducer_frequency = 4.5f;
+constexpr millimeter_t axial_resolution = millimeter_t(1.45f / transducer_frequency);
+constexpr size_t transducer_elements = 512;
+constexpr radian_t transducer_amplitude = 60_deg;
+constexpr centimeter_t transducer_radius = 3_cm;
+constexpr centimeter_t ultrasound_depth = 15_cm;
+constexpr microsecond_t max_travel_time = microsecond_t(ultrasound_depth / speed_of_sound);
+
+static uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+// rfimage.h:48-51 / :33-40 / :178-180 restated with the reference's unit types
+template <unsigned int axial_resolution_um, unsigned int sos>
+struct rf_axis {
+    static constexpr meters_per_second_t speed_of_sound_ = meters_per_second_t(sos);
+    static constexpr micrometer_t axial_resolution_ = micrometer_t(axial_resolution_um);
+    static microsecond_t micros_traveled(micrometer_t um) { return um / speed_of_sound_; }
+    static double row(microsecond_t t) { const units::dimensionless::dimensionless_t r = t / (axial_resolution_ / speed_of_sound_); return r; }
+    static double dt() { microsecond_t d = axial_resolution_ / speed_of_sound_; return d(); }
+};
+template <unsigned int a, unsigned int s> constexpr meters_per_second_t rf_axis<a, s>::speed_of_sound_;
+template <unsigned int a, unsigned int s> constexpr micrometer_t rf_axis<a, s>::axial_resolution_;
+
+int main()
+{
+    printf("{\n");
+    // ---- psf (main.cpp:54: psf<7,13,7,145>{4.5f, 0.05f, 0.2f, 0.1f}) ----
+    {
+        const psf<7, 13, 7, 145> p{ transducer_frequency, 0.05f, 0.2f, 0.1f };
+        printf("\"psf_axial_bits\": [");
+        for (size_t i = 0; i < 7; i++) printf("%s%u", i ? "," : "", fbits(p.axial_kernel[i]));
+        printf("],\n\"psf_lateral_bits\": [");
+        for (size_t i = 0; i < 13; i++) printf("%s%u", i ? "," : "", fbits(p.lateral_kernel[i]));
+        printf("],\n");
+        const psf<5, 9, 7, 200> p2{ 3.0f, 0.1f, 0.3f, 0.1f };
+        printf("\"psf2_axial_bits\": [");
+        for (size_t i = 0; i < 5; i++) printf("%s%u", i ? "," : "", fbits(p2.axial_kernel[i]));
+        printf("],\n\"psf2_lateral_bits\": [");
+        for (size_t i = 0; i < 9; i++) printf("%s%u", i ? "," : "", fbits(p2.lateral_kernel[i]));
+        printf("],\n");
+    }
+    // ---- constants ----
+    {
+        const unsigned int ar_um = static_cast<unsigned int>(axial_resolution.to<float>() * 1000.0f);
+        using axis = rf_axis<322, 1500>;
+        printf("\"axial_resolution_mm\": %.17g,\n", axial_resolution());
+        printf("\"axial_resolution_um\": %u,\n", ar_um);
+        printf("\"max_travel_time_us\": %.17g,\n", max_travel_time());
+        printf("\"max_travel_time_uint\": %u,\n", max_travel_time.to<unsigned int>());
+        printf("\"max_rows\": %u,\n", (1500u * max_travel_time.to<unsigned int>()) / ar_um);
+        printf("\"time_step_us\": %.17g,\n", axis::micros_traveled(axial_resolution)());
+        printf("\"row_dt_us\": %.17g,\n", axis::dt());
+        printf("\"amplitude_rad\": %.17g,\n", transducer_amplitude());
+        millimeter_t sep = transducer_amplitude.to<float>() * transducer_radius / transducer_elements;   // main.cpp:66
+        printf("\"element_separation_mm\": %.17g,\n", sep());
+        auto amp = sep / transducer_radius;                                                                // transducer.h:41
+        printf("\"amp_float_bits\": %u,\n", fbits(amp.to<float>()));
+        printf("\"radius_float_bits\": %u,\n", fbits(transducer_radius.to<float>()));
+        // angle walk of transducer.h:42-59 (the float handed to sin/cos for each element)
+        const radian_t amplitude{ amp.to<float>() };
+        const radian_t angle_center{ amplitude / 2.0f };
+        radian_t angle = -(amplitude * transducer_elements / 2) + angle_center;
+        printf("\"element_angle_bits\": [");
+        for (size_t t = 0; t < transducer_elements; t++) { printf("%s%u", t ? "," : "", fbits(angle.to<float>())); angle = angle + amplitude; }
+        printf("],\n");
+        // degree -> radian as transducer.h:37-39 does it
+        const float degs[] = { 0.0f, -90.0f, 120.0f, 45.0f, 90.0f, 33.3f };
+        printf("\"deg2rad\": [");
+        for (int i = 0; i < 6; i++) { degree_t d(degs[i]); radian_t r{ d }; printf("%s[%u,%.17g,%u]", i ? "," : "", fbits(degs[i]), r(), fbits(r.to<float>())); }
+        printf("],\n");
+    }
+    // ---- time axis: main.cpp:114-118,139 + rfimage.h:33-40 on a sweep of inputs ----
+    {
+        using axis = rf_axis<322, 1500>;
+        printf("\"time_axis\": [");
+        const microsecond_t time_step = axis::micros_traveled(axial_resolution);
+        uint64_t s = 88172645463325252ull;
+        for (int i = 0; i < 400; i++) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            double dist_mm = (double)(s >> 11) * (1.0 / 9007199254740992.0) * 160.0;            // distance_traveled
+            float seg_len = (float)((s & 0xffff) * (1.0 / 65536.0) * 20.0);                       // |to-from| in scene units
+            millimeter_t distance_traveled(dist_mm);
+            const auto starting_micros = axis::micros_traveled(distance_traveled);
+            millimeter_t distance(seg_len * 10.0f);
+            unsigned int steps = (unsigned int)(distance / axial_resolution);
+            microsecond_t t = starting_micros;
+            for (unsigned int k = 0; k < (s >> 20) % 50; k++) t = t + time_step;
+            double row = axis::row(t);
+            microsecond_t t_end = starting_micros + time_step * (steps - 1);
+            printf("%s[%.17g,%u,%.17g,%u,%u,%.17g,%.17g,%.17g]", i ? "," : "", dist_mm, fbits(seg_len), starting_micros(), steps,
+                   (unsigned)((s >> 20) % 50), t(), row, t_end());
+        }
+        printf("],\n");
+    }
+    // ---- texture volume (main.cpp:52 volume<256,145>) ----
+    {
+        static const volume<256, 145> vol;
+        const float *m = reinterpret_cast<const float *>(&vol.matrix[0][0][0]);
+        const size_t n = (size_t)256 * 256 * 256 * 2;
+        uint64_t h = 1469598103934665603ull;
+        double sum_noise = 0, sum_prob = 0;
+        for (size_t i = 0; i < n; i++) {
+            uint32_t b = fbits(m[i]);
+            for (int k = 0; k < 4; k++) { h ^= (b >> (8 * k)) & 0xff; h *= 1099511628211ull; }
+            if (i & 1) sum_prob += m[i]; else sum_noise += m[i];
+        }
+        printf("\"texture_fnv1a64\": \"%016llx\",\n", (unsigned long long)h);
+        printf("\"texture_sum_noise\": %.17g,\n\"texture_sum_prob\": %.17g,\n", sum_noise, sum_prob);
+        printf("\"texture_first_bits\": [");
+        for (int i = 0; i < 16; i++) printf("%s%u", i ? "," : "", fbits(m[i]));
+        printf("],\n\"texture_samples\": [");
+        uint64_t s = 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < 64; i++) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            size_t idx = (size_t)(s % (n / 2));
+            printf("%s[%zu,%u,%u]", i ? "," : "", idx, fbits(m[2 * idx]), fbits(m[2 * idx + 1]));
+        }
+        printf("],\n\"scattering_probes\": [");
+        // get_scattering(density, mu, sigma, x, y, z) volume.h:46-61, including negative coordinates
+        for (int i = 0; i < 64; i++) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            float x = (float)((double)(s & 0xfffff) / 1048576.0 * 60.0 - 30.0);
+            float y = (float)((double)((s >> 20) & 0xfffff) / 1048576.0 * 60.0 - 30.0);
+            float z = (float)((double)((s >> 40) & 0xfffff) / 1048576.0 * 60.0 - 30.0);
+            float dens = (i & 1) ? 0.6f : 1.0f, mu = 0.4f, sg = 0.3f;
+            float r = vol.get_scattering(dens, mu, sg, x, y, z);
+            printf("%s[%u,%u,%u,%u,%u,%u,%u]", i ? "," : "", fbits(x), fbits(y), fbits(z), fbits(dens), fbits(mu), fbits(sg), fbits(r));
+        }
+        printf("]\n");
+    }
+    printf("}\n");
+    return 0;
+}
