@@ -89,7 +89,7 @@ def test_c1_sphere_32x64_bruteforce(mcrt, orc, sphere, tex256):
     assert np.array_equal(hits, o["hits"])
     assert np.array_equal(cnt, o["seg_count"])
     for f in o["segs"].dtype.names:
-        a, b = segs[f], o["segs"][f]
+        a, b = np.ascontiguousarray(segs[f]), np.ascontiguousarray(o["segs"][f])
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), "segment field %s" % f
     _assert_rf(rf, o)
     # convolution
@@ -99,7 +99,7 @@ def test_c1_sphere_32x64_bruteforce(mcrt, orc, sphere, tex256):
     assert np.array_equal(rfc.view(np.uint32), oc.view(np.uint32))
     # cast_rays alone returns the same segments
     segs2, cnt2, hits2 = sim.ctx.cast_rays(0)
-    assert np.array_equal(hits2, hits) and np.array_equal(cnt2, cnt) and np.array_equal(segs2.view(np.uint8), segs.view(np.uint8))
+    assert np.array_equal(hits2, hits) and np.array_equal(cnt2, cnt) and segs2.tobytes() == segs.tobytes()
     sim.close()
 
 

