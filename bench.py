@@ -108,9 +108,9 @@ def main():
         ctx.trace_frame(f, rf_local, e0, e1)
     st = ctx.get_stats(reset=True)
     ctx.enable_stats(False)
-    # per closest-hit query nodes*64 B + triangles*48 B; per RF step one 8-B texture gather;
+    # SURVEY 8(d) adapted to the BVH4 layout: per closest-hit query nodes*128 B + triangles*48 B; per RF step one 8-B texture gather;
     # per launch the RF block written once (ne*R*4 B) + its 8-B fixed-point bins
-    alg_bytes = (st["nodes_visited"] * 64 + st["tris_tested"] * 48 + st["rf_steps"] * 8) / args.steps + E_local * R * (4 + 8)
+    alg_bytes = (st["nodes_visited"] * 128 + st["tris_tested"] * 48 + st["rf_steps"] * 8) / args.steps + E_local * R * (4 + 8)
 
     for f in range(args.warmup):
         step(1000 + f)
@@ -162,11 +162,12 @@ def cpu_baseline(m, sd, tr, ctx, S, R):
     cores = os.cpu_count() or 1
     nodes, btri, _ = ctx.get_bvh()
     osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
+    osc.set_bvh4(ctx.get_bvh4()[0])
     tex = orc.texture(256)
     n_el = min(tr.n_elements, max(cores, 8))
     p = orc.default_params(n_elements=tr.n_elements, n_samples=S, n_rows=R)
     t0 = time.perf_counter()
-    osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=0, e_begin=0, e_end=n_el, use_bvh=True, n_threads=cores, want_hits=False)
+    osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=0, e_begin=0, e_end=n_el, use_bvh=2, n_threads=cores, want_hits=False)
     dt = time.perf_counter() - t0
     # keep the sample between ~10 and 30 s of CPU work
     reps = 1
@@ -175,7 +176,7 @@ def cpu_baseline(m, sd, tr, ctx, S, R):
     if reps > 1:
         t0 = time.perf_counter()
         for i in range(reps):
-            osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=i, e_begin=0, e_end=n_el, use_bvh=True, n_threads=cores, want_hits=False)
+            osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=i, e_begin=0, e_end=n_el, use_bvh=2, n_threads=cores, want_hits=False)
         dt = time.perf_counter() - t0
     return {"value": n_el * S * reps / dt, "unit": "rays/s", "cores": cores, "kind": "port",
             "sample": "%d scan-lines x %d rays x %d frame(s) of the same workload, OpenMP over scan-lines (trace + RF accumulation, no PSF)" % (n_el, S, reps),

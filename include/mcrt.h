@@ -79,6 +79,17 @@ typedef struct {
     float *tri;              /* [n_tri][12] leaf order: v0.xyz,bits(tri id) | v1.xyz,bits(mesh id) | v2.xyz,0 */
 } mcrt_bvh;
 
+/* 128-byte BVH4 node read by the GPU walk: four 32-byte child records, so the four lanes that own a ray fetch one
+ * record each and the quad reads one contiguous 128-B line.  ref: >= 0 inner node; < 0 leaf (as in mcrt_bvh_node,
+ * at most 4 triangles); MCRT_BVH4_EMPTY = unused slot.  Built by collapsing the SAH BVH2. */
+#define MCRT_BVH4_EMPTY ((int32_t)0x80000000)
+typedef struct { float lo[3]; float hi_x; float hi_y, hi_z; int32_t ref; uint32_t pad; } mcrt_bvh4_child;
+typedef struct { mcrt_bvh4_child c[4]; } mcrt_bvh4_node;
+typedef struct {
+    uint32_t n_nodes, max_stack;   /* max_stack: worst-case traversal stack entries for this tree */
+    mcrt_bvh4_node *nodes;
+} mcrt_bvh4;
+
 /* ray_physics::segment (ray.h:28-36) as a POD; media is the material INDEX in effect along it */
 typedef struct {
     float from[3], to[3], dir[3];
@@ -157,6 +168,12 @@ int mcrt_get_kernel_time(mcrt_ctx *ctx, double *avg_ms, uint32_t *n, int reset);
 int mcrt_build_bvh(const float *tri_xyz, const uint32_t *tri_mesh, uint32_t n_tri, mcrt_bvh *out);
 void mcrt_free_bvh(mcrt_bvh *bvh);
 int mcrt_get_bvh(mcrt_ctx *ctx, mcrt_bvh *out /* borrowed pointers, valid until next upload */);
+int mcrt_build_bvh4(const mcrt_bvh *bvh2, mcrt_bvh4 *out);
+void mcrt_free_bvh4(mcrt_bvh4 *bvh4);
+int mcrt_get_bvh4(mcrt_ctx *ctx, mcrt_bvh4 *out /* borrowed */);
+/* the exact row look-up table used instead of the per-echo double division (see DESIGN.md "RF rows"):
+ * thr[r] = smallest double t with fl(t / row_dt) >= r, r = 0..n_rows */
+int mcrt_row_thresholds(double row_dt_us, uint32_t n_rows, double *thr);
 /* volume<n,res>::volume() volume.h:19-35 */
 int mcrt_generate_texture(float *voxels, uint32_t n);
 /* psf<>::psf psf.h:34-58 */

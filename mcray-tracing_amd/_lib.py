@@ -5,7 +5,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libmcrt_hip.so")
+_SO = os.environ.get("MCRT_LIB") or os.path.join(_HERE, "libmcrt_hip.so")   # MCRT_LIB: tuning builds only
 _LIB = None
 
 
@@ -36,6 +36,10 @@ class Bvh(C.Structure):
                 ("nodes", C.c_void_p), ("tri", C.c_void_p)]
 
 
+class Bvh4(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("max_stack", C.c_uint32), ("nodes", C.c_void_p)]
+
+
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("queries", "nodes_visited", "tris_tested", "segments", "rf_steps", "hits")]
 
@@ -56,7 +60,7 @@ SYMBOLS = ["mcrt_last_error", "mcrt_version", "mcrt_device_count", "mcrt_create"
            "mcrt_set_transducer", "mcrt_trace_frame", "mcrt_trace_frame_debug", "mcrt_cast_rays", "mcrt_convolve",
            "mcrt_envelope", "mcrt_scan_convert", "mcrt_export_rf", "mcrt_alloc", "mcrt_free", "mcrt_memcpy_d2h",
            "mcrt_memcpy_h2d", "mcrt_enable_stats", "mcrt_get_stats", "mcrt_enable_timing", "mcrt_get_kernel_time",
-           "mcrt_build_bvh", "mcrt_free_bvh", "mcrt_get_bvh", "mcrt_generate_texture", "mcrt_psf_kernels",
+           "mcrt_build_bvh", "mcrt_free_bvh", "mcrt_get_bvh", "mcrt_build_bvh4", "mcrt_free_bvh4", "mcrt_get_bvh4", "mcrt_row_thresholds", "mcrt_generate_texture", "mcrt_psf_kernels",
            "mcrt_transducer_elements", "mcrt_debug_math", "mcrt_debug_philox"]
 
 
@@ -94,6 +98,8 @@ def load_library():
         "mcrt_enable_stats": [vp, i32], "mcrt_get_stats": [vp, C.POINTER(Stats), i32],
         "mcrt_enable_timing": [vp, i32], "mcrt_get_kernel_time": [vp, C.POINTER(C.c_double), C.POINTER(u32), i32],
         "mcrt_build_bvh": [vp, vp, u32, C.POINTER(Bvh)], "mcrt_free_bvh": [C.POINTER(Bvh)], "mcrt_get_bvh": [vp, C.POINTER(Bvh)],
+        "mcrt_build_bvh4": [C.POINTER(Bvh), C.POINTER(Bvh4)], "mcrt_free_bvh4": [C.POINTER(Bvh4)], "mcrt_get_bvh4": [vp, C.POINTER(Bvh4)],
+        "mcrt_row_thresholds": [C.c_double, u32, vp],
         "mcrt_generate_texture": [vp, u32], "mcrt_psf_kernels": [C.c_float, C.c_float, C.c_float, u32, vp, u32, vp, u32],
         "mcrt_transducer_elements": [u32, C.c_double, C.c_double, vp, vp, vp, vp],
         "mcrt_debug_math": [vp, i32, vp, vp, vp, u32], "mcrt_debug_philox": [vp, vp, vp, vp],
@@ -101,7 +107,7 @@ def load_library():
     for name, args in sig.items():
         f = getattr(L, name)
         f.argtypes = args
-        f.restype = None if name == "mcrt_free_bvh" else C.c_int
+        f.restype = None if name in ("mcrt_free_bvh", "mcrt_free_bvh4") else C.c_int
     _LIB = L
     return L
 

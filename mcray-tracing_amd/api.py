@@ -10,7 +10,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import Params, MeshRec, Stats, Bvh, NODE_DTYPE, SEGMENT_DTYPE, check, ptr, load_library
+from ._lib import Params, MeshRec, Stats, Bvh, Bvh4, NODE_DTYPE, SEGMENT_DTYPE, check, ptr, load_library
 
 
 # ------------------------------------------------------------------ host-side pieces (no GPU)
@@ -28,6 +28,30 @@ def host_build_bvh(tri, tri_mesh):
     finally:
         L.mcrt_free_bvh(C.byref(b))
     return nodes, btri, depth
+
+
+def host_build_bvh4(tri, tri_mesh):
+    """-> (BVH2 nodes, leaf-order triangles [T,12], BVH4 nodes uint8 [n4,128], max_stack)"""
+    L = load_library()
+    tri = np.ascontiguousarray(tri, np.float32).reshape(-1, 9)
+    tm = np.ascontiguousarray(tri_mesh, np.uint32)
+    b = Bvh(); b4 = Bvh4()
+    check(L.mcrt_build_bvh(ptr(tri), ptr(tm), tri.shape[0], C.byref(b)))
+    try:
+        check(L.mcrt_build_bvh4(C.byref(b), C.byref(b4)))
+        nodes = np.frombuffer(C.string_at(b.nodes, 64 * b.n_nodes), dtype=NODE_DTYPE).copy()
+        btri = np.frombuffer(C.string_at(b.tri, 48 * b.n_tri), dtype=np.float32).reshape(-1, 12).copy()
+        n4 = np.frombuffer(C.string_at(b4.nodes, 128 * b4.n_nodes), dtype=np.uint8).reshape(-1, 128).copy()
+        ms = int(b4.max_stack)
+    finally:
+        L.mcrt_free_bvh(C.byref(b)); L.mcrt_free_bvh4(C.byref(b4))
+    return nodes, btri, n4, ms
+
+
+def host_row_thresholds(row_dt_us, n_rows):
+    thr = np.zeros(n_rows + 1, np.float64)
+    check(load_library().mcrt_row_thresholds(row_dt_us, n_rows, ptr(thr)))
+    return thr
 
 
 def host_texture(n=256):
@@ -135,6 +159,11 @@ class Context:
         nodes = np.frombuffer(C.string_at(b.nodes, 64 * b.n_nodes), dtype=NODE_DTYPE).copy()
         btri = np.frombuffer(C.string_at(b.tri, 48 * b.n_tri), dtype=np.float32).reshape(-1, 12).copy()
         return nodes, btri, int(b.max_depth)
+
+    def get_bvh4(self):
+        b = Bvh4()
+        check(self.L.mcrt_get_bvh4(self.h, C.byref(b)))
+        return np.frombuffer(C.string_at(b.nodes, 128 * b.n_nodes), dtype=np.uint8).reshape(-1, 128).copy(), int(b.max_stack)
 
     # device memory
     def alloc(self, nbytes):

@@ -52,6 +52,8 @@ struct mcrt_ctx {
     Consts c{};
     // scene
     mcrt_bvh bvh{};
+    mcrt_bvh4 bvh4{};
+    uint32_t *d_error = nullptr;
     float4 *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr;
     uint4 *d_meshes = nullptr;
     uint32_t n_mesh = 0, n_mat = 0, start_mat = 0;
@@ -65,12 +67,42 @@ struct mcrt_ctx {
     long long *d_acc = nullptr; uint32_t *d_flags = nullptr; size_t acc_cap = 0, flag_cap = 0;
     uint32_t acc_clean_ne = 0, acc_clean_rows = 0;   // bins known to be all-zero for this shape (k_finalize leaves them so)
     float *d_tmp = nullptr; size_t tmp_cap = 0;
+    // row thresholds (exact replacement of the per-echo double division) and the verified fast division by tex_res
+    double *d_row_thr = nullptr; uint32_t thr_rows = 0; double thr_dt = 0.0;
+    float verified_res = 0.0f; bool fast_div = false;
     // scan-conversion maps
     float *d_map_col = nullptr, *d_map_row = nullptr; uint32_t map_key[6] = { 0, 0, 0, 0, 0, 0 }; double map_keyd[2] = { 0, 0 };
     // instrumentation
     unsigned long long *d_stats = nullptr; bool stats_on = false;
     bool timing_on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0;
 };
+
+
+static int prepare_tables(mcrt_ctx *c)
+{
+    if (c->thr_rows != c->p.n_rows || c->thr_dt != c->c.row_dt_us || !c->d_row_thr) {
+        std::vector<double> thr((size_t)c->p.n_rows + 1);
+        { int rc = mcrt_row_thresholds(c->c.row_dt_us, c->p.n_rows, thr.data()); if (rc) return rc; }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->d_row_thr); c->d_row_thr = nullptr;
+        HIP_TRY(hipMalloc(&c->d_row_thr, thr.size() * 8));
+        HIP_TRY(hipMemcpy(c->d_row_thr, thr.data(), thr.size() * 8, hipMemcpyHostToDevice));
+        c->thr_rows = c->p.n_rows; c->thr_dt = c->c.row_dt_us;
+    }
+    if (c->verified_res != c->p.tex_res) {
+        // the GPU checks, exhaustively, that its fma-corrected reciprocal multiply IS IEEE division by tex_res
+        unsigned long long *d_bad = nullptr, bad = 1;
+        HIP_TRY(hipMalloc(&d_bad, 8));
+        HIP_TRY(hipMemsetAsync(d_bad, 0, 8, c->stream));
+        HIP_TRY(mcrt::launch_verify_div(c->p.tex_res, 1.0f / c->p.tex_res, d_bad, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
+        hipFree(d_bad);
+        c->fast_div = (bad == 0) && !getenv("MCRT_NO_FAST_DIV");
+        c->verified_res = c->p.tex_res;
+    }
+    return MCRT_OK;
+}
 
 extern "C" const char *mcrt_last_error(void) { return mcrt::g_err.c_str(); }
 extern "C" int mcrt_version(void) { return MCRT_VERSION; }
@@ -111,9 +143,12 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     c->stream = c->own_stream;
     mcrt_default_params(&c->p);
     c->c = derive_consts(c->p);
-    if (hipMalloc(&c->d_stats, 6 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_stats, 0, 6 * sizeof(unsigned long long)) != hipSuccess) {
+    c->stream = c->own_stream;
+    if (hipMalloc(&c->d_stats, 6 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_stats, 0, 6 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&c->d_error, 4) != hipSuccess || hipMemset(c->d_error, 0, 4) != hipSuccess) {
         hipStreamDestroy(c->own_stream); delete c; return set_error(MCRT_ERR_HIP, "hipMalloc failed");
     }
+    { int rc = prepare_tables(c); if (rc) { mcrt_destroy(c); return rc; } }
     *out = c;
     return MCRT_OK;
 }
@@ -123,6 +158,7 @@ static void free_scene(mcrt_ctx *c)
     hipFree(c->d_nodes); hipFree(c->d_tris); hipFree(c->d_mats); hipFree(c->d_meshes);
     c->d_nodes = c->d_tris = c->d_mats = nullptr; c->d_meshes = nullptr;
     mcrt_free_bvh(&c->bvh);
+    mcrt_free_bvh4(&c->bvh4);
     c->have_scene = false;
 }
 
@@ -133,7 +169,7 @@ extern "C" int mcrt_destroy(mcrt_ctx *c)
     hipStreamSynchronize(c->stream);
     free_scene(c);
     hipFree(c->d_tex); hipFree(c->d_pos); hipFree(c->d_dir); hipFree(c->d_acc); hipFree(c->d_flags); hipFree(c->d_tmp);
-    hipFree(c->d_map_col); hipFree(c->d_map_row); hipFree(c->d_stats);
+    hipFree(c->d_map_col); hipFree(c->d_map_row); hipFree(c->d_stats); hipFree(c->d_row_thr); hipFree(c->d_error);
     for (auto &e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     hipStreamDestroy(c->own_stream);
     delete c;
@@ -141,7 +177,14 @@ extern "C" int mcrt_destroy(mcrt_ctx *c)
 }
 
 extern "C" int mcrt_set_stream(mcrt_ctx *c, void *s) { CTX_TRY(c); c->stream = s ? (hipStream_t)s : c->own_stream; return MCRT_OK; }
-extern "C" int mcrt_synchronize(mcrt_ctx *c) { CTX_TRY(c); HIP_TRY(hipStreamSynchronize(c->stream)); return MCRT_OK; }
+static int check_device_error(mcrt_ctx *c)
+{
+    uint32_t e = 0;
+    HIP_TRY(hipMemcpy(&e, c->d_error, 4, hipMemcpyDeviceToHost));
+    if (e) { HIP_TRY(hipMemset(c->d_error, 0, 4)); return set_error(MCRT_ERR_LIMIT, "device error flag 0x%x: BVH traversal stack overflow", e); }
+    return MCRT_OK;
+}
+extern "C" int mcrt_synchronize(mcrt_ctx *c) { CTX_TRY(c); HIP_TRY(hipStreamSynchronize(c->stream)); return check_device_error(c); }
 
 extern "C" int mcrt_set_params(mcrt_ctx *c, const mcrt_params *p)
 {
@@ -155,7 +198,7 @@ extern "C" int mcrt_set_params(mcrt_ctx *c, const mcrt_params *p)
     Consts k = derive_consts(*p);
     if (k.axial_res_um == 0) return set_error(MCRT_ERR_INVALID, "axial resolution rounds to 0 um at %g MHz", (double)p->frequency);
     c->p = *p; c->c = k;
-    return MCRT_OK;
+    return prepare_tables(c);
 }
 
 extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *tri_mesh, uint32_t n_tri,
@@ -175,9 +218,13 @@ extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *
     if (n_tri) {
         int rc = mcrt_build_bvh(tri, tri_mesh, n_tri, &c->bvh);
         if (rc) return rc;
-        HIP_TRY(hipMalloc(&c->d_nodes, sizeof(mcrt_bvh_node) * (size_t)c->bvh.n_nodes));
+        rc = mcrt_build_bvh4(&c->bvh, &c->bvh4);
+        if (rc) return rc;
+        if (c->bvh4.max_stack > MCRT_STACK)
+            return set_error(MCRT_ERR_LIMIT, "BVH4 needs a %u-entry traversal stack, the kernel has %d", c->bvh4.max_stack, MCRT_STACK);
+        HIP_TRY(hipMalloc(&c->d_nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes));
         HIP_TRY(hipMalloc(&c->d_tris, 48 * (size_t)n_tri));
-        HIP_TRY(hipMemcpy(c->d_nodes, c->bvh.nodes, sizeof(mcrt_bvh_node) * (size_t)c->bvh.n_nodes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_nodes, c->bvh4.nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_tris, c->bvh.tri, 48 * (size_t)n_tri, hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMalloc(&c->d_mats, 32 * (size_t)n_mat));
@@ -195,6 +242,14 @@ extern "C" int mcrt_get_bvh(mcrt_ctx *c, mcrt_bvh *out)
     if (!c || !out) return set_error(MCRT_ERR_INVALID, "null argument");
     if (!c->have_scene) return set_error(MCRT_ERR_INVALID, "no scene uploaded");
     *out = c->bvh;
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_get_bvh4(mcrt_ctx *c, mcrt_bvh4 *out)
+{
+    if (!c || !out) return set_error(MCRT_ERR_INVALID, "null argument");
+    if (!c->have_scene) return set_error(MCRT_ERR_INVALID, "no scene uploaded");
+    *out = c->bvh4;
     return MCRT_OK;
 }
 
@@ -277,19 +332,29 @@ static void fill_args(mcrt_ctx *c, mcrt::TraceArgs &a, uint32_t frame, uint32_t 
 {
     memset(&a, 0, sizeof a);
     a.nodes = c->d_nodes; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
-    a.el_pos = c->d_pos; a.el_dir = c->d_dir; a.acc = c->d_acc; a.flags = c->d_flags;
-    a.stats = c->d_stats;
-    a.n_nodes = c->bvh.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
-    a.e_begin = e0; a.ne = e1 - e0; a.chunks = (c->p.n_samples + block - 1) / block;
+    a.el_pos = c->d_pos; a.el_dir = c->d_dir; a.acc = c->d_acc; a.flags = c->d_flags; a.row_thr = c->d_row_thr;
+    a.stats = c->d_stats; a.error_flag = c->d_error;
+    a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
+    a.e_begin = e0; a.ne = e1 - e0;
+    {   // 4 lanes per path; each quad works through ~paths_per_quad paths of its block's queue
+        int ppq = 1;
+        if (const char *e = getenv("MCRT_PPQ")) { int v = atoi(e); if (v >= 1 && v <= 64) ppq = v; }   // tuning knob
+        a.paths_per_block = (uint32_t)(block / 4) * (uint32_t)ppq;
+        a.chunks = (c->p.n_samples + a.paths_per_block - 1) / a.paths_per_block;
+    }
     a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
     a.freq = c->p.frequency; a.eps = c->p.intensity_epsilon; a.I0 = c->p.initial_intensity; a.offs = c->p.ray_start_offset;
-    a.sx = c->spacing[0]; a.sy = c->spacing[1]; a.sz = c->spacing[2]; a.tex_res = c->p.tex_res; a.axial_res_f = c->c.axial_res_f; a.pad_abs = c->bvh.pad_abs;
+    a.sx = c->spacing[0]; a.sy = c->spacing[1]; a.sz = c->spacing[2]; a.tex_res = c->p.tex_res; a.axial_res_f = c->c.axial_res_f; a.pad_abs = c->bvh.pad_abs; a.tex_rcp = 1.0f / c->p.tex_res; a.fast_div = c->fast_div ? 1u : 0u;
     a.axial_res_mm = c->c.axial_res_mm; a.time_step = c->c.time_step_us; a.row_dt = c->c.row_dt_us;
-    a.max_travel = c->c.max_travel_us; a.sos_d = (double)c->p.speed_of_sound;
+    a.max_travel = c->c.max_travel_us; a.sos_d = (double)c->p.speed_of_sound; a.inv_row_dt = 1.0 / c->c.row_dt_us;
 }
 
-static int pick_block(const mcrt_ctx *c) { return c->p.n_samples <= 64 ? 64 : 256; }
+static int pick_block(const mcrt_ctx *c)
+{
+    if (const char *e = getenv("MCRT_BLOCK")) { int b = atoi(e); if (b == 64 || b == 128 || b == 256) return b; }   // tuning knob
+    return c->p.n_samples <= 16 ? 64 : (c->p.n_samples <= 32 ? 128 : 256);   // 4 lanes per sample path
+}
 
 static int timed_launch(mcrt_ctx *c, const mcrt::TraceArgs &a, int block, bool emit, bool accum)
 {
@@ -317,7 +382,7 @@ extern "C" int mcrt_trace_frame(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32
     rc = ensure_acc(c, e1 - e0); if (rc) return rc;
     const int block = pick_block(c);
     mcrt::TraceArgs a; fill_args(c, a, frame, e0, e1, block);
-    rc = timed_launch(c, a, block, false, true); if (rc) return rc;
+    rc = timed_launch(c, a, block, false, getenv("MCRT_DEBUG_NO_ACCUM") == nullptr); if (rc) return rc;   // env: timing split only
     HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, e1 - e0, c->p.n_rows, c->stream));
     c->acc_clean_ne = e1 - e0; c->acc_clean_rows = c->p.n_rows;
     return MCRT_OK;
@@ -345,6 +410,7 @@ static int trace_debug(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32_t e1, fl
         if (e == hipSuccess && segs) e = hipMemcpy(segs, d_segs, nb * sizeof(mcrt_segment), hipMemcpyDeviceToHost);
         if (e == hipSuccess && seg_count) e = hipMemcpy(seg_count, d_cnt, np * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = set_error(MCRT_ERR_HIP, "trace (debug): %s", hipGetErrorString(e));
+        if (!rc) rc = check_device_error(c);
     }
     hipFree(d_hits); hipFree(d_segs); hipFree(d_cnt);
     return rc;

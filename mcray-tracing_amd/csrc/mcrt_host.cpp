@@ -183,6 +183,86 @@ extern "C" void mcrt_free_bvh(mcrt_bvh *bvh)
     bvh->nodes = nullptr; bvh->tri = nullptr; bvh->n_nodes = bvh->n_tri = 0;
 }
 
+// ---- BVH2 -> BVH4 collapse ----------------------------------------------------------------------
+namespace {
+struct Collapser {
+    const mcrt_bvh *b2;
+    std::vector<mcrt_bvh4_node> nodes;
+    struct Slot { int32_t ref; float lo[3], hi[3]; };
+    static float harea(const Slot &s) { float dx = s.hi[0] - s.lo[0], dy = s.hi[1] - s.lo[1], dz = s.hi[2] - s.lo[2]; return dx * dy + dy * dz + dz * dx; }
+    static void kids(const mcrt_bvh_node &n, Slot &a, Slot &b)
+    {
+        a.ref = n.c0; b.ref = n.c1;
+        for (int i = 0; i < 3; i++) { a.lo[i] = n.lo0[i]; a.hi[i] = n.hi0[i]; b.lo[i] = n.lo1[i]; b.hi[i] = n.hi1[i]; }
+    }
+    // returns {node4 index, worst-case stack entries needed below (and including) this node}
+    std::pair<int32_t, uint32_t> build(int32_t n2)
+    {
+        Slot s[4]; int k = 2;
+        kids(b2->nodes[n2], s[0], s[1]);
+        if (s[0].ref == s[1].ref && s[0].ref < 0) k = 1;          // degenerate single-leaf root wrapper
+        while (k < 4) {
+            int pick = -1; float best = -1.f;
+            for (int i = 0; i < k; i++) if (s[i].ref >= 0) { float a = harea(s[i]); if (a > best) { best = a; pick = i; } }
+            if (pick < 0) break;
+            Slot a, b; kids(b2->nodes[s[pick].ref], a, b);
+            s[pick] = a; s[k++] = b;
+        }
+        const int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        uint32_t deepest = 0;
+        for (int i = 0; i < 4; i++) {
+            mcrt_bvh4_child c;
+            if (i < k) {
+                int32_t ref = s[i].ref;
+                if (ref >= 0) { auto r = build(ref); ref = r.first; deepest = std::max(deepest, r.second); }
+                c.lo[0] = s[i].lo[0]; c.lo[1] = s[i].lo[1]; c.lo[2] = s[i].lo[2];
+                c.hi_x = s[i].hi[0]; c.hi_y = s[i].hi[1]; c.hi_z = s[i].hi[2]; c.ref = ref; c.pad = 0;
+            } else {
+                c.lo[0] = c.lo[1] = c.lo[2] = INFINITY; c.hi_x = c.hi_y = c.hi_z = -INFINITY; c.ref = MCRT_BVH4_EMPTY; c.pad = 0;
+            }
+            nodes[me].c[i] = c;
+        }
+        return { me, (uint32_t)(k - 1) + deepest };
+    }
+};
+}  // namespace
+
+extern "C" int mcrt_build_bvh4(const mcrt_bvh *b2, mcrt_bvh4 *out)
+{
+    if (!b2 || !out || !b2->nodes || b2->n_nodes == 0) return mcrt::set_error(MCRT_ERR_INVALID, "mcrt_build_bvh4: no BVH2");
+    Collapser c; c.b2 = b2;
+    c.nodes.reserve(b2->n_nodes / 2 + 4);
+    auto r = c.build(0);
+    out->n_nodes = (uint32_t)c.nodes.size();
+    out->max_stack = r.second;
+    out->nodes = (mcrt_bvh4_node *)malloc(sizeof(mcrt_bvh4_node) * c.nodes.size());
+    if (!out->nodes) return mcrt::set_error(MCRT_ERR_NOMEM, "mcrt_build_bvh4: out of memory");
+    memcpy(out->nodes, c.nodes.data(), sizeof(mcrt_bvh4_node) * c.nodes.size());
+    return MCRT_OK;
+}
+
+extern "C" void mcrt_free_bvh4(mcrt_bvh4 *b)
+{
+    if (!b) return;
+    free(b->nodes); b->nodes = nullptr; b->n_nodes = 0;
+}
+
+// thr[r] = smallest double t with fl(t / dt) >= r (IEEE division is monotone in t), r = 0..R: the kernel's row_of()
+// turns the reference's `row = t / dt; if (row < max_rows)` (rfimage.h:35-36) into table look-ups, exactly.
+extern "C" int mcrt_row_thresholds(double dt, uint32_t R, double *thr)
+{
+    if (!thr || !(dt > 0.0)) return mcrt::set_error(MCRT_ERR_INVALID, "mcrt_row_thresholds: bad arguments");
+    thr[0] = 0.0;
+    for (uint32_t r = 1; r <= R; r++) {
+        double t = (double)r * dt;
+        while (t / dt >= (double)r) t = std::nextafter(t, -INFINITY);
+        while (t / dt < (double)r) t = std::nextafter(t, INFINITY);
+        thr[r] = t;
+    }
+    return MCRT_OK;
+}
+
 // ---- volume<n,res>::volume() (volume.h:19-35) ------------------------------------------------
 // libstdc++ semantics: std::default_random_engine is minstd_rand0 (multiplier 16807, modulus 2^31-1,
 // default seed 1); generate_canonical<double,53> consumes two draws; normal_distribution<double> is

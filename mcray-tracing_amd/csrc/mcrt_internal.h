@@ -3,6 +3,7 @@
 #include <stdint.h>
 
 #define MCRT_BVH_MAX_DEPTH 32      // deepest leaf the builder may emit == traversal stack entries per lane
+#define MCRT_STACK 64              // BVH4 traversal stack entries per path (LDS); trees needing more are rejected at upload
 #define MCRT_MAX_ROWS 2048
 #define MCRT_MAX_BOUNCES 16
 

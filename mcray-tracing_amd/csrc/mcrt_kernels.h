@@ -8,13 +8,14 @@ namespace mcrt {
 
 struct TraceArgs {
     // scene (HBM-resident, read-only)
-    const float4 *nodes;       // [n_nodes][4]  64-B BVH2 nodes
+    const float4 *nodes;       // [n_nodes][8]  128-B BVH4 nodes (4 x 32-B child records)
     const float4 *tris;        // [T][3]        48-B triangles, leaf order
     const uint4 *meshes;       // [n_mesh]      mat_inside, mat_outside, vascular, -
     const float4 *mats;        // [n_mat][2]    imp, att, mu0, mu1 | sigma, spec, shine, thick
     const float2 *tex;         // [n^3]         texture_noise, scattering_probability
     const float *el_pos;       // [E][3]
     const float *el_dir;       // [E][3]
+    const double *row_thr;     // [R+1] row thresholds (see row_of)
     // outputs
     long long *acc;            // [ne][R] fixed-point RF accumulators (2^-52 units)
     uint32_t *flags;           // [ne][(R+31)/32] non-finite flags
@@ -22,10 +23,11 @@ struct TraceArgs {
     mcrt_segment *segs;        // optional [ne][S][B]
     uint32_t *seg_count;       // optional [ne][S]
     unsigned long long *stats; // optional [6]
+    uint32_t *error_flag;      // device word, bit 0: traversal stack overflow
     // sizes / parameters
-    uint32_t n_nodes, S, B, R, e_begin, ne, chunks, frame, seed, start_mat, tex_n, sanitize, tex_finite;
-    float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs;
-    double axial_res_mm, time_step, row_dt, max_travel, sos_d;
+    uint32_t n_nodes, S, B, R, e_begin, ne, chunks, paths_per_block, frame, seed, start_mat, tex_n, sanitize, tex_finite, fast_div;
+    float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs, tex_rcp;
+    double axial_res_mm, time_step, row_dt, max_travel, sos_d, inv_row_dt;
 };
 
 struct ConvTaps { float ax[16]; float lat[32]; uint32_t n_ax, n_lat; };
@@ -38,6 +40,7 @@ hipError_t launch_envelope(float *img, uint32_t E, uint32_t R, hipStream_t st);
 hipError_t launch_remap(const float *img, uint32_t E, uint32_t R, const float *map_col, const float *map_row, float *out, uint32_t n, hipStream_t st);
 hipError_t launch_transpose(const float *in, float *out, uint32_t E, uint32_t R, hipStream_t st);
 hipError_t launch_math_probe(int op, const double *x, const double *y, double *out, uint32_t n, hipStream_t st);
+hipError_t launch_verify_div(float res, float rcp, unsigned long long *bad, hipStream_t st);
 hipError_t launch_philox_probe(const uint32_t c[4], const uint32_t k[2], uint32_t *out, hipStream_t st);
 
 }  // namespace mcrt

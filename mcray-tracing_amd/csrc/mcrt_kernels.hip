@@ -1,9 +1,9 @@
 // mcrt_kernels.hip -- gfx950 kernels of the hot path.
 //
 //   k_trace      scene::cast_rays (scene.cpp:50-183) + ray_physics (ray.cpp) + the RF accumulation loop
-//                (main.cpp:106-144, rfimage.h:33-40, volume.h:46-61), fused: one lane = one Monte-Carlo
-//                sample path, one wavefront = 64 samples of ONE scan-line (coherent origin), per-lane BVH
-//                traversal stack and per-scan-line RF bins in LDS.
+//                (main.cpp:106-144, rfimage.h:33-40, volume.h:46-61), fused: one DPP quad (4 lanes) = one
+//                Monte-Carlo sample path, one wavefront = 16 paths of ONE scan-line, quad-cooperative BVH4 walk
+//                with the traversal stacks and the per-scan-line RF bins in LDS.
 //   k_finalize   fixed-point RF bins -> float image (+ clears the bins: rf_image::clear, rfimage.h:161)
 //   k_conv_*     rf_image::convolve (rfimage.h:93-123)
 //   k_envelope   rf_image::envelope (rfimage.h:54-91)
@@ -17,6 +17,13 @@
 #include "mcrt_internal.h"
 #include "mcrt_detmath.h"
 #include "mcrt_kernels.h"
+
+#ifndef MCRT_MIN_WAVES
+#define MCRT_MIN_WAVES 4           // waves per SIMD the register allocator must leave room for
+#endif
+#ifndef MCRT_LEAF_BATCH
+#define MCRT_LEAF_BATCH 4          // leave the inner-node phase once this many of a wave's 16 paths are parked on a leaf
+#endif
 
 namespace mcrt {
 
@@ -154,44 +161,71 @@ MCRT_DEV long long wave_sum_i64(long long v)
     return v;
 }
 
-// add one echo per lane (row < 0: nothing) into the scan-line's LDS bins.  Integer addition is
-// associative, so lanes that share a row are summed in registers first; the result is identical.
-MCRT_DEV void rf_add_wave(long long *bins, uint32_t *lflags, int row, float echo, int lane)
+// ---- quad (4-lane) exchanges on the DPP path: no LDS, VALU rate.  Control flow around them is quad-uniform (the four
+// lanes of a path hold identical state), so the source lanes are always active.
+template <int CTRL> MCRT_DEV int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+template <int CTRL> MCRT_DEV float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+constexpr int QP_XOR1 = 0xB1;   // quad_perm [1,0,3,2]
+constexpr int QP_XOR2 = 0x4E;   // quad_perm [2,3,0,1]
+#define QP_BCAST(k) ((k) * 0x55)
+
+// row = (int)(t / row_dt) if that quotient is < R, else -1 (rfimage.h:33-40), WITHOUT the double division:
+// thr[r] (host-computed, mcrt_row_thresholds) is the smallest double t whose IEEE quotient fl(t/row_dt) is >= r, so the
+// row is the largest r with thr[r] <= t.  Exactly equivalent to the division for every double t >= 0.
+MCRT_DEV int row_of(double t, const double *thr, uint32_t R, double inv_dt)
 {
-    const bool valid = row >= 0;
-    const unsigned long long vm = __ballot(valid);
-    if (vm == 0ull) return;
-    long long v = 0;
-    bool bad = false;
-    if (valid) {
-        if (!(fabsf(echo) < 1024.0f)) bad = true;
-        else v = (long long)rint((double)echo * 4503599627370496.0);
-    }
-    const int leader = __ffsll((long long)vm) - 1;
-    const int row0 = __shfl(row, leader, 64);
-    const bool uniform = __all(!valid || row == row0);
-    if (uniform) {
-        const long long sum = wave_sum_i64(v);
-        const bool anybad = __any(bad);
-        if (lane == leader) {
-            if (sum != 0) atomicAdd((unsigned long long *)&bins[row0], (unsigned long long)sum);
-            if (anybad) atomicOr(&lflags[row0 >> 5], 1u << (row0 & 31));
-        }
-    } else if (valid) {
-        if (bad) atomicOr(&lflags[row >> 5], 1u << (row & 31));
-        else if (v != 0) atomicAdd((unsigned long long *)&bins[row], (unsigned long long)v);
-    }
+    if (!(t < thr[R]) || !(t >= 0.0)) return -1;
+    int r = (int)(t * inv_dt);
+    r = r < 0 ? 0 : (r > (int)R - 1 ? (int)R - 1 : r);
+    while (t < thr[r]) r--;
+    while (t >= thr[r + 1]) r++;
+    return r;
 }
 
+// x / tex_res, correctly rounded, as two fmas around a multiply by the rounded reciprocal (Markstein's correction).
+// Used only when the GPU itself has verified (k_verify_div, exhaustive over the gated range) that the sequence
+// equals IEEE division for this tex_res; otherwise, and outside the gate, the division instruction sequence is used.
+MCRT_DEV float div_res(float x, const TraceArgs &a)
+{
+    const float ax = fabsf(x);
+    if (a.fast_div && ((ax > 1e-18f && ax < 1e18f) || x == 0.0f)) {
+        const float q0 = x * a.tex_rcp;
+        const float r = fmaf(-q0, a.tex_res, x);
+        return fmaf(r, a.tex_rcp, q0);
+    }
+    return x / a.tex_res;
+}
+
+// one echo into the scan-line's fixed-point LDS bins (2^-52 units; integer adds commute, so the image does not depend
+// on the order lanes, waves or workgroups arrive in)
+MCRT_DEV void rf_add(long long *bins, uint32_t *lflags, int row, float echo)
+{
+    if (row < 0) return;
+    if (!(fabsf(echo) < 1024.0f)) { atomicOr(&lflags[row >> 5], 1u << (row & 31)); return; }
+    const long long v = (long long)rint((double)echo * 4503599627370496.0);
+    if (v != 0) atomicAdd((unsigned long long *)&bins[row], (unsigned long long)v);
+}
+
+// =============================================================================================================
+// k_trace: FOUR lanes (one DPP quad) own one Monte-Carlo sample path; a wavefront holds 16 paths of one scan-line.
+//   * BVH4 walk: each lane fetches ONE 32-byte child record (the quad reads the node's 128 contiguous bytes), tests
+//     its box, and the quad ranks the hit children with DPP exchanges; leaves hold <= 4 triangles, one per lane.
+//   * interface physics and RNG are evaluated redundantly by the four lanes (identical inputs, identical results).
+//   * RF march: four consecutive steps per iteration, lane j owns step j -- four independent texture gathers in flight.
+// Path state is therefore quad-uniform; only box / triangle / march-step data differs between the lanes of a quad.
+// =============================================================================================================
 template <bool STATS, bool EMIT, bool ACCUM>
-__global__ void __launch_bounds__(256) k_trace(TraceArgs a)
+__global__ void __launch_bounds__(256, MCRT_MIN_WAVES) k_trace(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+    const int j = tid & 3, q = tid >> 2, Q = nthr >> 2;
     const uint32_t R = a.R;
     long long *bins = (long long *)smem;
     uint32_t *lflags = (uint32_t *)(bins + ((R + 1u) & ~1u));
-    int *stack = (int *)(lflags + ((((R + 31u) >> 5) + 3u) & ~3u));
+    double *thr = (double *)(lflags + ((((R + 31u) >> 5) + 3u) & ~3u));
+    int *stack = (int *)(thr + ((R + 2u) & ~1u));          // [MCRT_STACK][Q]: entry sp of quad q at sp*Q + q -> conflict-free
+    int *next_path = stack + MCRT_STACK * Q;               // the block's path queue head (path regeneration)
 
     // XCD-aware block -> (scan-line, chunk) map: workgroups are dealt round-robin over the 8 XCDs, so
     // the chunks of one scan-line (same BVH path, same texture lines) are steered onto one XCD's L2.
@@ -206,81 +240,118 @@ __global__ void __launch_bounds__(256) k_trace(TraceArgs a)
     if (ACCUM) {
         for (uint32_t r = tid; r < R; r += nthr) bins[r] = 0;
         for (uint32_t r = tid; r < ((R + 31u) >> 5); r += nthr) lflags[r] = 0u;
-        __syncthreads();
+        for (uint32_t r = tid; r <= R; r += nthr) thr[r] = a.row_thr[r];
     }
+    if (tid == 0) *next_path = Q;
+    __syncthreads();
 
-    const uint32_t s = chunk * (uint32_t)nthr + (uint32_t)tid;
-    bool alive = s < a.S;
-    const size_t path = ((size_t)e_local * a.S + s);
+    // The block owns sample paths [s_begin, s_end) of its scan-line.  Quad q starts on path s_begin + q; whenever a path
+    // terminates (intensity below epsilon, a miss, or max_depth) the quad pulls the next unclaimed one from the LDS counter
+    // ("path regeneration"), so lanes do not idle behind the longest path of the wavefront.  Every path draws its random
+    // numbers from its own (scan-line, sample, bounce) counter and RF bins are integer sums, so the result does not depend
+    // on which quad traced which path or when.
+    const uint32_t s_begin = chunk * a.paths_per_block;
+    const uint32_t s_end = min(a.S, s_begin + a.paths_per_block);
+    const f3 el_from = mk(a.el_pos[3 * e_abs], a.el_pos[3 * e_abs + 1], a.el_pos[3 * e_abs + 2]);
+    const f3 el_dir = mk(a.el_dir[3 * e_abs], a.el_dir[3 * e_abs + 1], a.el_dir[3 * e_abs + 2]);
 
-    f3 from = mk(a.el_pos[3 * e_abs], a.el_pos[3 * e_abs + 1], a.el_pos[3 * e_abs + 2]);
-    f3 dir = mk(a.el_dir[3 * e_abs], a.el_dir[3 * e_abs + 1], a.el_dir[3 * e_abs + 2]);
+    uint32_t s = s_begin + (uint32_t)q;
+    bool alive = s < s_end;                 // the quad holds a live path
+    size_t path = ((size_t)e_local * a.S + s);
+    f3 from = el_from, dir = el_dir;
     int media = (int)a.start_mat, outside = OUT_NONE;
     float intensity = a.I0 / (float)a.S;
     double dist_mm = 0.0;
     Rng g; g.k0 = a.seed; g.k1 = a.frame; g.element = e_abs; g.sample = s; g.bounce = 0;
-    uint32_t nseg = 0;
+    uint32_t nseg = 0, b = 0;
     unsigned long long st_nodes = 0, st_tris = 0, st_q = 0, st_seg = 0, st_steps = 0, st_hits = 0;
+    if (EMIT && a.hits && alive && j == 0)
+        for (uint32_t k = 0; k < a.B; k++) a.hits[path * a.B + k] = -2;
 
-    for (uint32_t b = 0; b < a.B; b++) {
-        if (EMIT && a.hits && s < a.S) a.hits[path * a.B + b] = -2;
-        if (!__any(alive)) { if (EMIT) continue; else break; }
+    while (__any(alive)) {
         g.bounce = b;
 
         // ---- launch the query: max_ray_length (ray.cpp:110-113), enlarge (scene.cpp:292-298) ----
         const int mi = alive ? media : (int)a.start_mat;
-        const float4 m0 = a.mats[2 * mi], m1 = a.mats[2 * mi + 1];   // imp, att, mu0, mu1 | sigma, spec, shine, thick
+        const float4 m0 = a.mats[2 * mi];   // imp, att, mu0, mu1  (second half: sigma, spec, shine, thick)
         const float att = m0.y;
         const float L = 10.f * det_logf(a.eps / intensity) / -att * a.freq;
         const float Ls = L / 100.0f;
         const f3 to = mk(from.x + Ls * (a.sx * dir.x), from.y + Ls * (a.sy * dir.y), from.z + Ls * (a.sz * dir.z));
         const f3 f2 = mk(from.x + a.offs * dir.x, from.y + a.offs * dir.y, from.z + a.offs * dir.z);
 
-        // ---- closest hit: per-lane BVH2 walk, stack in LDS ([level][lane] => conflict-free) ----
+        // ---- closest hit: quad-cooperative BVH4 walk ----
         Hit best; best.frac = 1.0f; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
         {
             const f3 d = to - f2;
             const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
             int sp = 0, cur = 0;
             bool walking = alive && a.n_nodes != 0u;
-            if (STATS && walking) st_q++;
+            if (STATS && walking && j == 0) st_q++;
             while (__any(walking)) {
-                if (walking) {
-                    if (cur >= 0) {
-                        const float4 *N = a.nodes + 4 * (size_t)cur;
-                        const float4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3];
-                        if (STATS) st_nodes++;
-                        float tn0, tn1, tx0, tx1;
+                // phase 1: inner nodes, until enough quads are parked on a leaf (their triangle code then runs once for all)
+                for (;;) {
+                    const unsigned long long inner = __ballot(walking && cur >= 0);
+                    if (inner == 0ull) break;
+                    if (__popcll(__ballot(walking && cur < 0)) >= 4 * MCRT_LEAF_BATCH) break;
+                    if (walking && cur >= 0) {
+                        const float4 *N = a.nodes + 8 * (size_t)cur + 2 * j;
+                        const float4 A = N[0], B = N[1];               // lo.xyz hi.x | hi.y hi.z ref pad
+                        if (STATS && j == 0) st_nodes++;
+                        const int ref = __float_as_int(B.z);
+                        float tn, tx;
                         const float tcap = fminf(1.0f, best.frac);
-                        const bool h0 = slab(xyz(q0), xyz(q1), f2, inv, tcap, tn0, tx0);
-                        const bool h1 = slab(xyz(q2), xyz(q3), f2, inv, tcap, tn1, tx1);
-                        const int c0 = __float_as_int(q0.w), c1 = __float_as_int(q1.w);
-                        if (h0 && h1) {
-                            int nearc = c0, farc = c1;
-                            if (tn1 < tn0) { nearc = c1; farc = c0; }
-                            if (sp < MCRT_BVH_MAX_DEPTH) { stack[sp * nthr + tid] = farc; sp++; }
-                            cur = nearc;
-                        } else if (h0) cur = c0;
-                        else if (h1) cur = c1;
-                        else if (sp > 0) { sp--; cur = stack[sp * nthr + tid]; }
-                        else walking = false;
-                    } else {
-                        const uint32_t v = (uint32_t)~cur;
-                        const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-                        for (uint32_t i = 0; i < cnt; i++) {
-                            const float4 *T = a.tris + 3 * (size_t)(first + i);
-                            const float4 t0 = T[0], t1 = T[1], t2 = T[2];
-                            tri_test(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), __float_as_int(t1.w), f2, to, inv, a.pad_abs, best);
-                            if (STATS) st_tris++;
+                        const bool hit = slab(mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), f2, inv, tcap, tn, tx) && ref != MCRT_BVH4_EMPTY;
+                        const float key = hit ? tn : __int_as_float(0x7f800000);
+                        const float k0 = dpp_f<QP_BCAST(0)>(key), k1 = dpp_f<QP_BCAST(1)>(key), k2 = dpp_f<QP_BCAST(2)>(key), k3 = dpp_f<QP_BCAST(3)>(key);
+                        const float inf = __int_as_float(0x7f800000);
+                        const int nh = (k0 < inf) + (k1 < inf) + (k2 < inf) + (k3 < inf);
+                        const int rank = ((k0 < key) || (k0 == key && 0 < j)) + ((k1 < key) || (k1 == key && 1 < j)) +
+                                         ((k2 < key) || (k2 == key && 2 < j)) + ((k3 < key) || (k3 == key && 3 < j));
+                        int cand = (hit && rank == 0) ? ref : 0;
+                        cand |= dpp_i<QP_XOR1>(cand);
+                        cand |= dpp_i<QP_XOR2>(cand);
+                        if (nh == 0) {
+                            if (sp > 0) { sp--; cur = stack[sp * Q + q]; }
+                            else walking = false;
+                        } else if (sp + nh - 1 > MCRT_STACK) {
+                            if (j == 0) atomicOr(a.error_flag, 1u);      // cannot happen for a tree the builder accepted
+                            walking = false;
+                        } else {
+                            if (hit && rank > 0) stack[(sp + nh - 1 - rank) * Q + q] = ref;
+                            sp += nh - 1;
+                            cur = cand;
                         }
-                        if (sp > 0) { sp--; cur = stack[sp * nthr + tid]; }
-                        else walking = false;
                     }
+                }
+                // phase 2: leaves -- lane j tests triangle j
+                if (walking && cur < 0) {
+                    const uint32_t v = (uint32_t)~cur;
+                    const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+                    Hit mine = best;
+                    for (uint32_t i = (uint32_t)j; i < cnt; i += 4u) {
+                        const float4 *T = a.tris + 3 * (size_t)(first + i);
+                        const float4 t0 = T[0], t1 = T[1], t2 = T[2];
+                        tri_test(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), __float_as_int(t1.w), f2, to, inv, a.pad_abs, mine);
+                    }
+                    if (STATS && j == 0) st_tris += cnt;
+#define MCRT_QUAD_MIN(CTRL)                                                                                             \
+                    {                                                                                                   \
+                        const float of = dpp_f<CTRL>(mine.frac); const int ot = dpp_i<CTRL>(mine.tri), om = dpp_i<CTRL>(mine.mesh); \
+                        const float onx = dpp_f<CTRL>(mine.n.x), ony = dpp_f<CTRL>(mine.n.y), onz = dpp_f<CTRL>(mine.n.z), oda = dpp_f<CTRL>(mine.da); \
+                        if (of < mine.frac || (of == mine.frac && ot < mine.tri)) { mine.frac = of; mine.tri = ot; mine.mesh = om; mine.n = mk(onx, ony, onz); mine.da = oda; } \
+                    }
+                    MCRT_QUAD_MIN(QP_XOR1)
+                    MCRT_QUAD_MIN(QP_XOR2)
+#undef MCRT_QUAD_MIN
+                    best = mine;
+                    if (sp > 0) { sp--; cur = stack[sp * Q + q]; }
+                    else walking = false;
                 }
             }
         }
 
-        // ---- interface interaction (scene.cpp:122-165, ray.cpp:11-97) ----
+        // ---- interface interaction (scene.cpp:122-165, ray.cpp:11-97), evaluated by all four lanes ----
         bool seg_valid = alive;
         f3 seg_from = from, seg_to = to, seg_dir = dir;
         float seg_refl = 0.0f, seg_init = intensity, seg_att = att;
@@ -288,7 +359,7 @@ __global__ void __launch_bounds__(256) k_trace(TraceArgs a)
         int seg_media = mi, seg_tri = -1;
         if (alive) {
             if (best.tri >= 0) {
-                if (STATS) st_hits++;
+                if (STATS && j == 0) st_hits++;
                 f3 nn = normalized(best.n);
                 if (best.da <= 0.0f) nn = neg(nn);
                 const float sfr = 1.0f - best.frac;
@@ -296,15 +367,15 @@ __global__ void __launch_bounds__(256) k_trace(TraceArgs a)
                 const uint4 organ = a.meshes[best.mesh];   // mat_inside, mat_outside, vascular
                 // thickness penetration scene.cpp:132-139 (Box-Muller on block 0)
                 const float sigma_t = a.mats[2 * organ.x + 1].w;
-                float q = 0.0f;
+                float qpen = 0.0f;
                 if (sigma_t != 0.0f) {
                     double n1, n2, sn, cs;
                     rng_block(g, 0u, n1, n2);
                     det_sincos(n2 * 2 * PI_D, sn, cs);
                     const double z = sqrt(-2.0 * det_log(1.0 - n1)) * cs;
-                    q = (float)fabs(z * (double)sigma_t + 0.0);
+                    qpen = (float)fabs(z * (double)sigma_t + 0.0);
                 }
-                const f3 inside = mk(q * dir.x + hp.x, q * dir.y + hp.y, q * dir.z + hp.z);
+                const f3 inside = mk(qpen * dir.x + hp.x, qpen * dir.y + hp.y, qpen * dir.z + hp.z);
                 // travel ray.cpp:99-103, distance_in_mm scene.cpp:281-290
                 const float xd = fabsf(from.x - inside.x) * a.sx, yd = fabsf(from.y - inside.y) * a.sy, zd = fabsf(from.z - inside.z) * a.sz;
                 const double mm = sqrt((double)xd * (double)xd + (double)yd * (double)yd + (double)zd * (double)zd) * 10;
@@ -371,24 +442,26 @@ __global__ void __launch_bounds__(256) k_trace(TraceArgs a)
             } else {
                 alive = false;
             }
-            if (STATS) st_seg++;
+            if (STATS && j == 0) st_seg++;
         }
 
         if (EMIT && seg_valid) {
-            if (a.hits) a.hits[path * a.B + b] = seg_tri;
-            if (a.segs) {
-                mcrt_segment sg;
-                sg.from[0] = seg_from.x; sg.from[1] = seg_from.y; sg.from[2] = seg_from.z;
-                sg.to[0] = seg_to.x; sg.to[1] = seg_to.y; sg.to[2] = seg_to.z;
-                sg.dir[0] = seg_dir.x; sg.dir[1] = seg_dir.y; sg.dir[2] = seg_dir.z;
-                sg.reflected_intensity = seg_refl; sg.initial_intensity = seg_init; sg.attenuation = seg_att;
-                sg.distance_traveled = seg_dist; sg.media = seg_media; sg.tri = seg_tri;
-                a.segs[path * a.B + nseg] = sg;
+            if (j == 0) {
+                if (a.hits) a.hits[path * a.B + b] = seg_tri;
+                if (a.segs) {
+                    mcrt_segment sg;
+                    sg.from[0] = seg_from.x; sg.from[1] = seg_from.y; sg.from[2] = seg_from.z;
+                    sg.to[0] = seg_to.x; sg.to[1] = seg_to.y; sg.to[2] = seg_to.z;
+                    sg.dir[0] = seg_dir.x; sg.dir[1] = seg_dir.y; sg.dir[2] = seg_dir.z;
+                    sg.reflected_intensity = seg_refl; sg.initial_intensity = seg_init; sg.attenuation = seg_att;
+                    sg.distance_traveled = seg_dist; sg.media = seg_media; sg.tri = seg_tri;
+                    a.segs[path * a.B + nseg] = sg;
+                }
             }
             nseg++;
         }
 
-        // ---- RF accumulation of this segment (main.cpp:112-140) ----
+        // ---- RF accumulation of this segment (main.cpp:112-140): 4 steps per iteration, lane j owns step j ----
         if (ACCUM) {
             const float4 s0 = a.mats[2 * seg_media], s1 = a.mats[2 * seg_media + 1];
             const double t_start = (seg_dist * 1000.0) / a.sos_d;
@@ -405,40 +478,52 @@ __global__ void __launch_bounds__(256) k_trace(TraceArgs a)
             uint32_t step = 0;
             bool more = seg_valid && !silent && steps > 0u && t < a.max_travel;
             while (__any(more)) {
-                int row = -1;
-                float echo = 0.0f;
-                if (more) {
-                    const uint32_t vx = vox_index(point.x / a.tex_res, a.tex_n), vy = vox_index(point.y / a.tex_res, a.tex_n), vz = vox_index(point.z / a.tex_res, a.tex_n);
-                    const float2 vox = a.tex[((size_t)vx * a.tex_n + vy) * a.tex_n + vz];
-                    const float scattering = vox.y >= s0.w ? vox.x * s1.x + s0.z : 0.0f;
-                    echo = inten * scattering;
-                    const double rowd = t / a.row_dt;
-                    if (rowd < (double)R) row = (int)rowd;
-                    point = point + delta;
+                f3 myp = point; double myt = t; float myin = inten; bool myv = false;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool vu = more && (step + (uint32_t)u < steps) && (t < a.max_travel);   // the reference's loop test
+                    if (u == j) { myp = point; myt = t; myin = inten; myv = vu; }
+                    point = point + delta;                                                       // ... and its loop tail
                     t = t + a.time_step;
                     inten *= k_att;
-                    step++;
-                    if (STATS) st_steps++;
-                    more = step < steps && t < a.max_travel;
                 }
-                rf_add_wave(bins, lflags, row, echo, lane);
+                step += 4u;
+                more = more && step < steps && t < a.max_travel;
+                if (myv) {
+                    const uint32_t vx = vox_index(div_res(myp.x, a), a.tex_n), vy = vox_index(div_res(myp.y, a), a.tex_n), vz = vox_index(div_res(myp.z, a), a.tex_n);
+                    const float2 vox = a.tex[((size_t)vx * a.tex_n + vy) * a.tex_n + vz];
+                    const float scattering = vox.y >= s0.w ? vox.x * s1.x + s0.z : 0.0f;
+                    rf_add(bins, lflags, row_of(myt, thr, R, a.inv_row_dt), myin * scattering);
+                    if (STATS) st_steps++;
+                }
             }
             // boundary echo main.cpp:139
-            {
-                int row = -1;
-                float echo = 0.0f;
-                if (seg_valid) {
-                    echo = seg_refl / (float)a.S;
-                    const double te = t_start + a.time_step * (double)(uint32_t)(steps - 1u);
-                    const double rowd = te / a.row_dt;
-                    if (rowd < (double)R) row = (int)rowd;
+            if (seg_valid && j == 0) {
+                const double te = t_start + a.time_step * (double)(uint32_t)(steps - 1u);
+                rf_add(bins, lflags, row_of(te, thr, R, a.inv_row_dt), seg_refl / (float)a.S);
+            }
+        }
+
+        // ---- next bounce, or path regeneration ----
+        if (seg_valid) {
+            b++;
+            if (!alive || b >= a.B) {
+                if (EMIT && a.seg_count && j == 0) a.seg_count[path] = nseg;
+                int nxt = 0;
+                if (j == 0) nxt = atomicAdd(next_path, 1);
+                nxt = dpp_i<QP_BCAST(0)>(nxt);
+                s = s_begin + (uint32_t)nxt;
+                alive = s < s_end;
+                if (alive) {
+                    path = ((size_t)e_local * a.S + s);
+                    from = el_from; dir = el_dir; media = (int)a.start_mat; outside = OUT_NONE;
+                    intensity = a.I0 / (float)a.S; dist_mm = 0.0; g.sample = s; nseg = 0; b = 0;
+                    if (EMIT && a.hits && j == 0)
+                        for (uint32_t k = 0; k < a.B; k++) a.hits[path * a.B + k] = -2;
                 }
-                rf_add_wave(bins, lflags, row, echo, lane);
             }
         }
     }
-
-    if (EMIT && a.seg_count && s < a.S) a.seg_count[path] = nseg;
 
     if (STATS) {
         unsigned long long v[6] = { st_q, st_nodes, st_tris, st_seg, st_steps, st_hits };
@@ -591,6 +676,24 @@ __global__ void k_math_probe(int op, const double *x, const double *y, double *o
     out[i] = r;
 }
 
+// exhaustive check that the fmaf-corrected reciprocal multiply equals IEEE division by `res` for every float in
+// the gate of div_res(); mismatches are counted
+__global__ void k_verify_div(float res, float rcp, unsigned long long *bad)
+{
+    const uint64_t n = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long local = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32); b += n) {
+        const float x = __uint_as_float((uint32_t)b);
+        const float ax = fabsf(x);
+        if (!((ax > 1e-18f && ax < 1e18f) || x == 0.0f)) continue;
+        const float q0 = x * rcp;
+        const float r = fmaf(-q0, res, x);
+        const float q = fmaf(r, rcp, q0);
+        if (__float_as_uint(q) != __float_as_uint(x / res)) local++;
+    }
+    if (local) atomicAdd(bad, local);
+}
+
 __global__ void k_philox_probe(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *out)
 {
     uint32_t o[4];
@@ -605,7 +708,8 @@ size_t trace_lds_bytes(uint32_t R, int block)
 {
     size_t bins = (size_t)((R + 1u) & ~1u) * 8;
     size_t flg = (size_t)((((R + 31u) >> 5) + 3u) & ~3u) * 4;
-    return bins + flg + (size_t)MCRT_BVH_MAX_DEPTH * block * 4;
+    size_t thr = (size_t)((R + 2u) & ~1u) * 8;
+    return bins + flg + thr + (size_t)MCRT_STACK * (block / 4) * 4 + 16;
 }
 
 hipError_t launch_trace(const TraceArgs &a, int block, bool stats, bool emit, bool accum, hipStream_t st)
@@ -660,6 +764,12 @@ hipError_t launch_transpose(const float *in, float *out, uint32_t E, uint32_t R,
 hipError_t launch_math_probe(int op, const double *x, const double *y, double *out, uint32_t n, hipStream_t st)
 {
     hipLaunchKernelGGL(k_math_probe, dim3((n + 255) / 256), dim3(256), 0, st, op, x, y, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_verify_div(float res, float rcp, unsigned long long *bad, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_verify_div, dim3(256 * 16), dim3(256), 0, st, res, rcp, bad);
     return hipGetLastError();
 }
 

@@ -458,13 +458,68 @@ static void walk_bvh(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stats
     if (st) { st->nodes_visited += nn; st->tris_tested += nt; }
 }
 
+/* BVH4 walk in the GPU kernel's order: children hit are visited nearest-first (ties: lower slot), the others
+ * are stacked so that they pop in ascending order; a leaf's triangles are all tested. */
+typedef struct { float lo[3]; float hix, hiy, hiz; int32_t ref; uint32_t pad; } orc_bvh4_child;
+#define ORC_BVH4_EMPTY ((int32_t)0x80000000)
+static void walk_bvh4(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stats *st)
+{
+    const orc_bvh4_child *nodes = (const orc_bvh4_child *)sc->nodes4;
+    v3 d = vsub(to, from);
+    v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int32_t stack[ORC_STACK];
+    int sp = 0;
+    int32_t cur = 0;
+    uint64_t nn = 0, nt = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const orc_bvh4_child *N = nodes + 4 * (size_t)cur;
+            nn++;
+            float key[4]; int32_t ref[4]; int nh = 0;
+            float tcap = fminf(1.0f, best->frac);
+            for (int k = 0; k < 4; k++) {
+                float hi[3] = { N[k].hix, N[k].hiy, N[k].hiz }, tn, tx;
+                int h = slab(N[k].lo, hi, from, inv, tcap, &tn, &tx) && N[k].ref != ORC_BVH4_EMPTY;
+                key[k] = h ? tn : INFINITY; ref[k] = N[k].ref; nh += h;
+            }
+            if (nh > 0) {
+                int32_t next = 0;
+                for (int k = 0; k < 4; k++) {
+                    if (!(key[k] < INFINITY)) continue;
+                    int rank = 0;
+                    for (int m = 0; m < 4; m++) rank += (key[m] < key[k]) || (key[m] == key[k] && m < k);
+                    if (rank == 0) next = ref[k];
+                    else if (sp + nh - 1 - rank < ORC_STACK) stack[sp + nh - 1 - rank] = ref[k];
+                }
+                sp += nh - 1;
+                cur = next;
+                continue;
+            }
+        } else {
+            uint32_t v = (uint32_t)~cur;
+            uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; i++) {
+                const float *t = sc->bvh_tri + (size_t)(first + i) * 12;
+                float t9[9] = { t[0], t[1], t[2], t[4], t[5], t[6], t[8], t[9], t[10] };
+                tri_test(t9, (int32_t)f2u(t[3]), from, to, inv, sc->pad_abs, best);
+                nt++;
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    if (st) { st->nodes_visited += nn; st->tris_tested += nt; }
+}
+
 int32_t orc_closest_hit(const orc_scene *sc, const float from_[3], const float to_[3], int use_bvh,
                         float *frac, float normal[3], float point[3], orc_stats *st)
 {
     v3 from = V(from_[0], from_[1], from_[2]), to = V(to_[0], to_[1], to_[2]);
     hit_t best; best.frac = 1.0f; best.tri = -1; best.n = V(0, 0, 0); best.da = 0;
     if (st) st->queries++;
-    if (use_bvh && sc->nodes && sc->n_nodes) {
+    if (use_bvh == 2 && sc->nodes4 && sc->n_nodes4) {
+        walk_bvh4(sc, from, to, &best, st);
+    } else if (use_bvh && sc->nodes && sc->n_nodes) {
         walk_bvh(sc, from, to, &best, st);
     } else {
         v3 d = vsub(to, from);

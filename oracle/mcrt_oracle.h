@@ -97,6 +97,9 @@ typedef struct {
     const orc_bvh_node *nodes;
     const float *bvh_tri;      /* [T][12]: v0.xyz,id | v1.xyz,mesh | v2.xyz,0   (leaf order) */
     float pad_abs;             /* orc_pad_abs(tri, n_tri): absolute part of the per-triangle bounds padding */
+    /* optional BVH4 built by the product (include/mcrt.h mcrt_bvh4_node: 4 x {lo[3],hi[3],ref,pad}); walked with use_bvh = 2 */
+    uint32_t n_nodes4;
+    const void *nodes4;
 } orc_scene;
 float orc_pad_abs(const float *tri, uint32_t n_tri);
 
@@ -127,7 +130,8 @@ typedef struct {
     uint64_t queries, nodes_visited, tris_tested, segments, rf_steps, hits;
 } orc_stats;
 
-/* closest hit on the segment [from,to]; returns tri id or -1.  use_bvh selects the walk. */
+/* closest hit on the segment [from,to]; returns tri id or -1.  use_bvh: 0 brute force, 1 BVH2 walk, 2 BVH4 walk
+ * (the GPU's visiting order, so node/triangle counts can be compared). */
 int32_t orc_closest_hit(const orc_scene *sc, const float from[3], const float to[3], int use_bvh,
                         float *frac, float normal[3], float point[3], orc_stats *st);
 

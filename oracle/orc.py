@@ -27,7 +27,7 @@ class Scene(C.Structure):
                 ("n_mesh", C.c_uint32), ("mesh", C.c_void_p),
                 ("n_mat", C.c_uint32), ("mat", C.c_void_p),
                 ("start_mat", C.c_uint32), ("spacing", C.c_float * 3),
-                ("n_nodes", C.c_uint32), ("nodes", C.c_void_p), ("bvh_tri", C.c_void_p), ("pad_abs", C.c_float)]
+                ("n_nodes", C.c_uint32), ("nodes", C.c_void_p), ("bvh_tri", C.c_void_p), ("pad_abs", C.c_float), ("n_nodes4", C.c_uint32), ("nodes4", C.c_void_p)]
 
 
 class Params(C.Structure):
@@ -156,14 +156,14 @@ class OracleScene:
         self.tri_mesh = np.ascontiguousarray(tri_mesh, np.uint32)
         self.mesh = (Mesh * len(meshes))(*[Mesh(int(a), int(b), int(c), 0) for a, b, c in meshes])
         self.mat = np.ascontiguousarray(materials, np.float32).reshape(-1, 8)
-        self.bvh_nodes = self.bvh_tri = None
+        self.bvh_nodes = self.bvh_tri = self.bvh4_nodes = None
         s = Scene()
         s.n_tri = self.tri.shape[0]; s.tri = self.tri.ctypes.data; s.tri_mesh = self.tri_mesh.ctypes.data
         s.n_mesh = len(meshes); s.mesh = C.cast(self.mesh, C.c_void_p)
         s.n_mat = self.mat.shape[0]; s.mat = self.mat.ctypes.data
         s.start_mat = int(start_mat)
         s.spacing = (C.c_float * 3)(*[float(x) for x in spacing])
-        s.n_nodes = 0; s.nodes = None; s.bvh_tri = None
+        s.n_nodes = 0; s.nodes = None; s.bvh_tri = None; s.n_nodes4 = 0; s.nodes4 = None
         lib().orc_pad_abs.restype = C.c_float
         s.pad_abs = lib().orc_pad_abs(_p(self.tri), C.c_uint32(self.tri.shape[0]))
         self.c = s
@@ -178,6 +178,16 @@ class OracleScene:
         self.c.n_nodes = self.bvh_nodes.nbytes // 64
         self.c.nodes = self.bvh_nodes.ctypes.data
         self.c.bvh_tri = self.bvh_tri.ctypes.data
+
+    def set_bvh4(self, nodes4, bvh_tri=None):
+        """nodes4: array of 128-byte BVH4 nodes built by the PRODUCT (use_bvh=2); triangles are shared with the BVH2"""
+        self.bvh4_nodes = np.ascontiguousarray(nodes4)
+        assert self.bvh4_nodes.nbytes % 128 == 0
+        if bvh_tri is not None:
+            self.bvh_tri = np.ascontiguousarray(bvh_tri, np.float32)
+            self.c.bvh_tri = self.bvh_tri.ctypes.data
+        self.c.n_nodes4 = self.bvh4_nodes.nbytes // 128
+        self.c.nodes4 = self.bvh4_nodes.ctypes.data
 
     def closest_hit(self, frm, to, use_bvh=False):
         f = np.asarray(frm, np.float32); t = np.asarray(to, np.float32)

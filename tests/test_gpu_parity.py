@@ -105,16 +105,19 @@ def test_c1_sphere_32x64_bruteforce(mcrt, orc, sphere, tex256):
 
 def test_c2_sphere_128x1024_depth512(mcrt, orc, sphere, tex256):
     """BASELINE config 2: 128 scan-lines x 1024 rays, 512 RF rows, GPU BVH vs CPU parity (oracle walks the product's BVH,
-    itself validated against brute force in tests/test_bvh_cpu.py)"""
+    itself validated against brute force in tests/test_host_pieces.py)"""
     cfg, sd = sphere
     E, S = 128, 1024
     tr, sim = _sim(mcrt, cfg, sd, E, S, n_rows=512, texture=tex256)
     hits, _, _ = sim.ctx.trace_frame_debug(3, sim.rf_dev)
     rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
     nodes, btri, _ = sim.ctx.get_bvh()
+    nodes4, max_stack = sim.ctx.get_bvh4()
+    assert max_stack <= 64
     osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
+    osc.set_bvh4(nodes4)
     p = orc.default_params(n_elements=E, n_samples=S, n_rows=512)
-    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=3, use_bvh=True, n_threads=8)
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=3, use_bvh=2, n_threads=16)
     assert np.array_equal(hits, o["hits"])
     _assert_rf(rf, o)
     # node / triangle visit counts are part of the contract (same walk on both sides)

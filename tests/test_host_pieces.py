@@ -74,6 +74,58 @@ def test_bvh_structure_and_walk_equals_bruteforce(mcrt, orc):
         assert nhit > 25
 
 
+def test_bvh4_collapse_and_row_thresholds(mcrt, orc):
+    """the BVH4 the GPU walks: every BVH2 leaf reachable exactly once, child boxes equal the BVH2 boxes, stack bound
+    honoured; walk equals brute force.  Row thresholds reproduce (int)(t / dt) for every t."""
+    rng = np.random.default_rng(5)
+    for cfg, meshes in [mcrt.synth.sphere_scene(3), mcrt.synth.random_scene(30000, 8, seed=3)]:
+        sd = mcrt.scene_io.build_scene(cfg, meshes)
+        nodes, btri, n4, max_stack = mcrt.host_build_bvh4(sd.tri, sd.tri_mesh)
+        assert max_stack <= 64
+        rec = n4.view(np.dtype([("lo", "<f4", 3), ("hi", "<f4", 3), ("ref", "<i4"), ("pad", "<u4")])).reshape(-1, 4)
+        leaves = []
+        stack = [0]
+        seen_nodes = 0
+        while stack:
+            n = stack.pop(); seen_nodes += 1
+            for c in rec[n]:
+                if c["ref"] == -2 ** 31:
+                    continue
+                if c["ref"] >= 0:
+                    stack.append(int(c["ref"]))
+                else:
+                    v = (~int(c["ref"])) & 0xFFFFFFFF
+                    leaves.append((v >> 3, (v & 7) + 1))
+                    for k in range(v >> 3, (v >> 3) + (v & 7) + 1):
+                        V = np.stack([btri[k][0:3], btri[k][4:7], btri[k][8:11]])
+                        assert np.all(V.min(0) >= c["lo"]) and np.all(V.max(0) <= c["hi"])
+        assert seen_nodes == len(rec)
+        cover = np.zeros(sd.n_tri, int)
+        for f, c in leaves:
+            assert c <= 4
+            cover[f:f + c] += 1
+        assert np.all(cover == 1)
+        osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
+        osc.set_bvh4(n4)
+        for i in range(300):
+            o = rng.uniform(-9, 9, 3).astype(np.float32)
+            d = sd.tri[rng.integers(sd.n_tri)][:3] + rng.normal(size=3) * 0.3 - o
+            d /= np.linalg.norm(d)
+            if i % 5 == 0:
+                d[rng.integers(3)] = 0.0
+            to = (o + d * rng.choice([4.0, 40.0, 1e9])).astype(np.float32)
+            a = osc.closest_hit(o, to, 0); c = osc.closest_hit(o, to, 2)
+            assert a[0] == c[0] and a[1] == c[1]
+    for dt, R in [(322 / 1500.0, 465), (322 / 1500.0, 512), (0.1234567, 100)]:
+        thr = mcrt.host_row_thresholds(dt, R)
+        t = np.concatenate([rng.uniform(0, (R + 2) * dt, 400000), thr, np.nextafter(thr, -1), np.nextafter(thr, 1e9), np.arange(R + 2) * dt])
+        t = t[t >= 0]
+        ref = np.where(t / dt < R, np.floor(t / dt), -1).astype(np.int64)
+        got = np.searchsorted(thr, t, side="right") - 1
+        got = np.where(t < thr[R], got, -1)
+        assert np.array_equal(ref, got)
+
+
 def test_bvh_degenerate_inputs(mcrt, orc):
     # one triangle; identical triangles; a zero-area triangle
     one = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32)

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output dirs (kernel stats + PMC passes) of tools/pmc.sh into one JSON + text table."""
+import csv, glob, json, os, sys, collections
+out = sys.argv[1]
+res = {"kernel_stats": [], "pmc": {}}
+for f in glob.glob(out + "/stats/*/*kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        if float(r["Percentage"]) > 0.05:
+            res["kernel_stats"].append({k: r[k] for k in ("Name", "Calls", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+for d in sorted(glob.glob(out + "/*/")):
+    for f in glob.glob(d + "*/*counter_collection.csv"):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            if "k_trace<false, false, true>" in k:
+                for c, x in v.items():
+                    res["pmc"][c] = {"avg_per_launch": sum(x) / len(x), "launches": len(x), "pass": os.path.basename(d.rstrip("/"))}
+json.dump(res, open(out + "/summary.json", "w"), indent=1)
+for k in res["kernel_stats"]:
+    print("%-90s calls %5s avg %10.1f us  %5s%%" % (k["Name"][:90], k["Calls"], float(k["AverageNs"]) / 1e3, k["Percentage"]))
+for c, v in sorted(res["pmc"].items()):
+    print("%-34s %16.1f  (%s, n=%d)" % (c, v["avg_per_launch"], v["pass"], v["launches"]))

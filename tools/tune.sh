@@ -1,0 +1,25 @@
+#!/bin/bash
+# tuning sweep on the GPU box: parity first, then bench.py per spec.  spec = name[:VAR=VAL[,VAR=VAL...]]
+# (VAR LIB=<variant> selects mcray-tracing_amd/build/libmcrt_hip_<variant>.so)
+mkdir -p gpurun_out/tune
+if [ -z "$SKIP_TESTS" ]; then
+(timeout 600 python -m pytest tests -m gpu -x -q --timeout 240 > gpurun_out/tune/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/tune/pytest.log); tail -4 gpurun_out/tune/pytest.log
+fi
+for spec in "$@"; do
+  name=${spec%%:*}; vars=""
+  if [[ "$spec" == *:* ]]; then vars=$(echo "${spec#*:}" | tr ',' ' '); fi
+  envs=""
+  for v in $vars; do
+    if [[ "$v" == LIB=* ]]; then envs="$envs MCRT_LIB=$PWD/mcray-tracing_amd/build/libmcrt_hip_${v#LIB=}.so"; else envs="$envs $v"; fi
+  done
+  env $envs timeout 90 python bench.py --steps 10 --warmup 2 --no-cpu-baseline ${BENCH_ARGS} > gpurun_out/tune/$name.log 2>&1
+  python3 - "$name" <<'PY'
+import json,sys
+name=sys.argv[1]
+try:
+    l=[x for x in open('gpurun_out/tune/%s.log'%name) if x.startswith('{')][-1]; d=json.loads(l)
+    print("%-16s value %.3e rays/s  ms/step %.3f  kernel_ms %.3f  achieved %.0f GB/s" % (name, d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['achieved']))
+except Exception as e:
+    print(name, 'FAILED', e)
+PY
+done
