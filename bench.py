@@ -108,9 +108,13 @@ def main():
         ctx.trace_frame(f, rf_local, e0, e1)
     st = ctx.get_stats(reset=True)
     ctx.enable_stats(False)
-    # SURVEY 8(d) adapted to the BVH4 layout: per closest-hit query nodes*128 B + triangles*48 B; per RF step one 8-B texture gather;
-    # per launch the RF block written once (ne*R*4 B) + its 8-B fixed-point bins
-    alg_bytes = (st["nodes_visited"] * 128 + st["tris_tested"] * 48 + st["rf_steps"] * 8) / args.steps + E_local * R * (4 + 8)
+    # Algorithmic bytes (adapted to the 128-B BVH4 nodes).  The dominant kernel is k_trace, launched once per
+    # bounce: per closest-hit query nodes*128 B + triangles*48 B + the 32-B ray read and 32-B hit record written.
+    launches_per_frame = int(ctx.params.max_depth)
+    trace_bytes_frame = (st["nodes_visited"] * 128 + st["tris_tested"] * 48 + st["queries"] * 64) / args.steps
+    alg_bytes = trace_bytes_frame / launches_per_frame
+    # the rest of the frame, for the record: 64-B segment written + read, 8-B texture gather per RF step, RF block + bins
+    other_bytes_frame = (st["segments"] * 128 + st["rf_steps"] * 8) / args.steps + E_local * R * (4 + 8)
 
     for f in range(args.warmup):
         step(1000 + f)
@@ -143,6 +147,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms, "launches": k_n,
+                         "launches_per_frame": launches_per_frame, "trace_bytes_per_frame": trace_bytes_frame,
+                         "other_stage_bytes_per_frame": other_bytes_frame,
                          "per_launch": {k: v / args.steps for k, v in st.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:

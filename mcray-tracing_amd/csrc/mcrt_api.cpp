@@ -48,6 +48,8 @@ static Consts derive_consts(const mcrt_params &p)
 struct mcrt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t side_stream = nullptr;                    // RF accumulation of bounce b overlaps the walk of bounce b+1
+    hipEvent_t ev_bounce[MCRT_MAX_BOUNCES] = {}, ev_join = nullptr;
     mcrt_params p{};
     Consts c{};
     // scene
@@ -63,6 +65,10 @@ struct mcrt_ctx {
     float2 *d_tex = nullptr; uint32_t tex_n = 0; bool tex_finite = false;
     // transducer
     float *d_pos = nullptr, *d_dir = nullptr; uint32_t n_el = 0;
+    // per-frame work buffers of the wavefront pipeline (sized for work_paths paths)
+    float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr, *d_hit = nullptr;
+    uint32_t *d_q0 = nullptr, *d_q1 = nullptr, *d_counts = nullptr, *d_seg_count = nullptr;
+    mcrt_segment *d_segs = nullptr; size_t work_paths = 0; uint32_t work_depth = 0;
     // accumulators
     long long *d_acc = nullptr; uint32_t *d_flags = nullptr; size_t acc_cap = 0, flag_cap = 0;
     uint32_t acc_clean_ne = 0, acc_clean_rows = 0;   // bins known to be all-zero for this shape (k_finalize leaves them so)
@@ -141,6 +147,9 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(MCRT_ERR_HIP, "hipStreamCreate failed"); }
     c->stream = c->own_stream;
+    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(c->own_stream); delete c; return set_error(MCRT_ERR_HIP, "hipStreamCreate failed"); }
+    for (int i = 0; i < MCRT_MAX_BOUNCES; i++) hipEventCreateWithFlags(&c->ev_bounce[i], hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     mcrt_default_params(&c->p);
     c->c = derive_consts(c->p);
     c->stream = c->own_stream;
@@ -151,6 +160,14 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     { int rc = prepare_tables(c); if (rc) { mcrt_destroy(c); return rc; } }
     *out = c;
     return MCRT_OK;
+}
+
+static void free_work(mcrt_ctx *c)
+{
+    hipFree(c->d_st0); hipFree(c->d_st1); hipFree(c->d_st2); hipFree(c->d_ray0); hipFree(c->d_ray1); hipFree(c->d_hit);
+    hipFree(c->d_q0); hipFree(c->d_q1); hipFree(c->d_counts); hipFree(c->d_seg_count); hipFree(c->d_segs);
+    c->d_st0 = c->d_st1 = c->d_st2 = c->d_ray0 = c->d_ray1 = c->d_hit = nullptr; c->d_q0 = c->d_q1 = c->d_counts = c->d_seg_count = nullptr;
+    c->d_segs = nullptr; c->work_paths = 0; c->work_depth = 0;
 }
 
 static void free_scene(mcrt_ctx *c)
@@ -168,9 +185,14 @@ extern "C" int mcrt_destroy(mcrt_ctx *c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     free_scene(c);
+    free_work(c);
     hipFree(c->d_tex); hipFree(c->d_pos); hipFree(c->d_dir); hipFree(c->d_acc); hipFree(c->d_flags); hipFree(c->d_tmp);
     hipFree(c->d_map_col); hipFree(c->d_map_row); hipFree(c->d_stats); hipFree(c->d_row_thr); hipFree(c->d_error);
     for (auto &e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    hipStreamSynchronize(c->side_stream);
+    for (int i = 0; i < MCRT_MAX_BOUNCES; i++) if (c->ev_bounce[i]) hipEventDestroy(c->ev_bounce[i]);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    hipStreamDestroy(c->side_stream);
     hipStreamDestroy(c->own_stream);
     delete c;
     return MCRT_OK;
@@ -328,20 +350,32 @@ static int check_ready(mcrt_ctx *c, uint32_t e0, uint32_t e1)
     return MCRT_OK;
 }
 
-static void fill_args(mcrt_ctx *c, mcrt::TraceArgs &a, uint32_t frame, uint32_t e0, uint32_t e1, int block)
+static int ensure_work(mcrt_ctx *c, uint32_t ne)
+{
+    const size_t np = (size_t)ne * c->p.n_samples;
+    if (np <= c->work_paths && c->p.max_depth <= c->work_depth) return MCRT_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_work(c);
+    const uint32_t B = c->p.max_depth;
+    HIP_TRY(hipMalloc(&c->d_st0, 16 * np)); HIP_TRY(hipMalloc(&c->d_st1, 16 * np)); HIP_TRY(hipMalloc(&c->d_st2, 16 * np));
+    HIP_TRY(hipMalloc(&c->d_ray0, 32 * np)); HIP_TRY(hipMalloc(&c->d_ray1, 32 * np)); HIP_TRY(hipMalloc(&c->d_hit, 32 * np));
+    HIP_TRY(hipMalloc(&c->d_q0, 4 * np)); HIP_TRY(hipMalloc(&c->d_q1, 4 * np)); HIP_TRY(hipMalloc(&c->d_seg_count, 4 * np));
+    HIP_TRY(hipMalloc(&c->d_counts, 4 * (MCRT_MAX_BOUNCES + 1)));
+    HIP_TRY(hipMalloc(&c->d_segs, sizeof(mcrt_segment) * np * B));
+    c->work_paths = np; c->work_depth = B;
+    return MCRT_OK;
+}
+
+static void fill_args(mcrt_ctx *c, mcrt::FrameArgs &a, uint32_t frame, uint32_t e0, uint32_t e1)
 {
     memset(&a, 0, sizeof a);
     a.nodes = c->d_nodes; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
     a.el_pos = c->d_pos; a.el_dir = c->d_dir; a.acc = c->d_acc; a.flags = c->d_flags; a.row_thr = c->d_row_thr;
+    a.st0 = c->d_st0; a.st1 = c->d_st1; a.st2 = c->d_st2; a.queue0 = c->d_q0; a.queue1 = c->d_q1;
+    a.ray0 = c->d_ray0; a.ray1 = c->d_ray1; a.hit = c->d_hit; a.counts = c->d_counts; a.segs = c->d_segs; a.seg_count = c->d_seg_count;
     a.stats = c->d_stats; a.error_flag = c->d_error;
     a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
     a.e_begin = e0; a.ne = e1 - e0;
-    {   // 4 lanes per path; each quad works through ~paths_per_quad paths of its block's queue
-        int ppq = 1;
-        if (const char *e = getenv("MCRT_PPQ")) { int v = atoi(e); if (v >= 1 && v <= 64) ppq = v; }   // tuning knob
-        a.paths_per_block = (uint32_t)(block / 4) * (uint32_t)ppq;
-        a.chunks = (c->p.n_samples + a.paths_per_block - 1) / a.paths_per_block;
-    }
     a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
     a.freq = c->p.frequency; a.eps = c->p.intensity_epsilon; a.I0 = c->p.initial_intensity; a.offs = c->p.ray_start_offset;
@@ -350,27 +384,39 @@ static void fill_args(mcrt_ctx *c, mcrt::TraceArgs &a, uint32_t frame, uint32_t 
     a.max_travel = c->c.max_travel_us; a.sos_d = (double)c->p.speed_of_sound; a.inv_row_dt = 1.0 / c->c.row_dt_us;
 }
 
-static int pick_block(const mcrt_ctx *c)
+// scene::cast_rays (scene.cpp:50-183): k_init, then k_trace + k_shade per bounce.  With timing enabled every k_trace launch
+// (the dominant kernel) is bracketed by HIP events on the context's stream.
+static int run_cast(mcrt_ctx *c, const mcrt::FrameArgs &a, bool accumulate)
 {
-    if (const char *e = getenv("MCRT_BLOCK")) { int b = atoi(e); if (b == 64 || b == 128 || b == 256) return b; }   // tuning knob
-    return c->p.n_samples <= 16 ? 64 : (c->p.n_samples <= 32 ? 128 : 256);   // 4 lanes per sample path
-}
-
-static int timed_launch(mcrt_ctx *c, const mcrt::TraceArgs &a, int block, bool emit, bool accum)
-{
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->timing_on) {
-        if (c->ev_used == c->ev.size()) {
-            if (c->ev.size() >= 8192) return set_error(MCRT_ERR_LIMIT, "timing buffer full: call mcrt_get_kernel_time(reset=1)");
-            hipEvent_t x, y;
-            HIP_TRY(hipEventCreate(&x)); HIP_TRY(hipEventCreate(&y));
-            c->ev.emplace_back(x, y);
+    const bool overlap = accumulate && !getenv("MCRT_NO_OVERLAP");
+    HIP_TRY(mcrt::launch_init(a, c->stream));
+    for (uint32_t b = 0; b < a.B; b++) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->timing_on) {
+            if (c->ev_used == c->ev.size()) {
+                if (c->ev.size() >= 65536) return set_error(MCRT_ERR_LIMIT, "timing buffer full: call mcrt_get_kernel_time(reset=1)");
+                hipEvent_t x, y;
+                HIP_TRY(hipEventCreate(&x)); HIP_TRY(hipEventCreate(&y));
+                c->ev.emplace_back(x, y);
+            }
+            e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; c->ev_used++;
+            HIP_TRY(hipEventRecord(e0, c->stream));
         }
-        e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; c->ev_used++;
-        HIP_TRY(hipEventRecord(e0, c->stream));
+        HIP_TRY(mcrt::launch_trace(a, b, c->stats_on, c->stream));
+        if (c->timing_on) HIP_TRY(hipEventRecord(e1, c->stream));
+        HIP_TRY(mcrt::launch_shade(a, b, c->stats_on, c->stream));
+        if (overlap) {   // the segments of bounce b are final: accumulate them beside the next bounce's walk
+            HIP_TRY(hipEventRecord(c->ev_bounce[b], c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_bounce[b], 0));
+            HIP_TRY(mcrt::launch_march(a, b, 1, c->stats_on, c->side_stream));
+        }
     }
-    HIP_TRY(mcrt::launch_trace(a, block, c->stats_on, emit, accum, c->stream));
-    if (c->timing_on) HIP_TRY(hipEventRecord(e1, c->stream));
+    if (overlap) {
+        HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    } else if (accumulate) {
+        HIP_TRY(mcrt::launch_march(a, 0, a.B, c->stats_on, c->stream));
+    }
     return MCRT_OK;
 }
 
@@ -380,54 +426,52 @@ extern "C" int mcrt_trace_frame(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32
     int rc = check_ready(c, e0, e1); if (rc) return rc;
     if (!rf_dev) return set_error(MCRT_ERR_INVALID, "null rf_dev");
     rc = ensure_acc(c, e1 - e0); if (rc) return rc;
-    const int block = pick_block(c);
-    mcrt::TraceArgs a; fill_args(c, a, frame, e0, e1, block);
-    rc = timed_launch(c, a, block, false, getenv("MCRT_DEBUG_NO_ACCUM") == nullptr); if (rc) return rc;   // env: timing split only
+    rc = ensure_work(c, e1 - e0); if (rc) return rc;
+    mcrt::FrameArgs a; fill_args(c, a, frame, e0, e1);
+    rc = run_cast(c, a, true); if (rc) return rc;
     HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, e1 - e0, c->p.n_rows, c->stream));
     c->acc_clean_ne = e1 - e0; c->acc_clean_rows = c->p.n_rows;
     return MCRT_OK;
 }
 
-static int trace_debug(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32_t e1, float *rf_dev, bool accum,
-                       int32_t *hits, mcrt_segment *segs, uint32_t *seg_count)
+// copies the segment table to the host: segs [ne][S][B], seg_count [ne][S], hits [ne][S][B] (= segment.tri, -2 beyond the path's end)
+static int copy_out(mcrt_ctx *c, uint32_t ne, int32_t *hits, mcrt_segment *segs, uint32_t *seg_count)
 {
-    int rc = check_ready(c, e0, e1); if (rc) return rc;
-    const uint32_t ne = e1 - e0;
-    const size_t np = (size_t)ne * c->p.n_samples, nb = np * c->p.max_depth;
-    int32_t *d_hits = nullptr; mcrt_segment *d_segs = nullptr; uint32_t *d_cnt = nullptr;
-    if (accum) { rc = ensure_acc(c, ne); if (rc) return rc; }
-    if (hits) HIP_TRY(hipMalloc(&d_hits, nb * 4));
-    if (segs) { HIP_TRY(hipMalloc(&d_segs, nb * sizeof(mcrt_segment))); HIP_TRY(hipMemsetAsync(d_segs, 0, nb * sizeof(mcrt_segment), c->stream)); }
-    if (seg_count) HIP_TRY(hipMalloc(&d_cnt, np * 4));
-    const int block = pick_block(c);
-    mcrt::TraceArgs a; fill_args(c, a, frame, e0, e1, block);
-    a.hits = d_hits; a.segs = d_segs; a.seg_count = d_cnt;
-    rc = timed_launch(c, a, block, true, accum);
-    if (!rc && accum) { hipError_t e = mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, ne, c->p.n_rows, c->stream); if (e != hipSuccess) rc = set_error(MCRT_ERR_HIP, "finalize: %s", hipGetErrorString(e)); }
-    if (!rc) {
-        hipError_t e = hipStreamSynchronize(c->stream);
-        if (e == hipSuccess && hits) e = hipMemcpy(hits, d_hits, nb * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && segs) e = hipMemcpy(segs, d_segs, nb * sizeof(mcrt_segment), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && seg_count) e = hipMemcpy(seg_count, d_cnt, np * 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = set_error(MCRT_ERR_HIP, "trace (debug): %s", hipGetErrorString(e));
-        if (!rc) rc = check_device_error(c);
+    const size_t np = (size_t)ne * c->p.n_samples, B = c->p.max_depth;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = check_device_error(c); if (rc) return rc;
+    std::vector<mcrt_segment> tmp;
+    std::vector<uint32_t> cnt;
+    if (!segs && hits) { tmp.resize(np * B); segs = tmp.data(); }
+    if (!seg_count && hits) { cnt.resize(np); seg_count = cnt.data(); }
+    if (seg_count) HIP_TRY(hipMemcpy(seg_count, c->d_seg_count, np * 4, hipMemcpyDeviceToHost));
+    if (segs) {
+        HIP_TRY(hipMemcpy(segs, c->d_segs, np * B * sizeof(mcrt_segment), hipMemcpyDeviceToHost));
+        for (size_t p = 0; p < np; p++)                         // slots beyond a path's end are unspecified on the device
+            for (size_t b = seg_count[p]; b < B; b++) memset(&segs[p * B + b], 0, sizeof(mcrt_segment));
     }
-    hipFree(d_hits); hipFree(d_segs); hipFree(d_cnt);
-    return rc;
+    if (hits)
+        for (size_t p = 0; p < np; p++)
+            for (size_t b = 0; b < B; b++) hits[p * B + b] = b < seg_count[p] ? segs[p * B + b].tri : -2;
+    return MCRT_OK;
 }
 
 extern "C" int mcrt_trace_frame_debug(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32_t e1, float *rf_dev,
                                       int32_t *hits, mcrt_segment *segs, uint32_t *seg_count)
 {
     CTX_TRY(c);
-    if (!rf_dev) return set_error(MCRT_ERR_INVALID, "null rf_dev");
-    return trace_debug(c, frame, e0, e1, rf_dev, true, hits, segs, seg_count);
+    int rc = mcrt_trace_frame(c, frame, e0, e1, rf_dev); if (rc) return rc;
+    return copy_out(c, e1 - e0, hits, segs, seg_count);
 }
 
 extern "C" int mcrt_cast_rays(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32_t e1, mcrt_segment *segs, uint32_t *seg_count, int32_t *hits)
 {
     CTX_TRY(c);
-    return trace_debug(c, frame, e0, e1, nullptr, false, hits, segs, seg_count);
+    int rc = check_ready(c, e0, e1); if (rc) return rc;
+    rc = ensure_work(c, e1 - e0); if (rc) return rc;
+    mcrt::FrameArgs a; fill_args(c, a, frame, e0, e1);
+    rc = run_cast(c, a, false); if (rc) return rc;
+    return copy_out(c, e1 - e0, hits, segs, seg_count);
 }
 
 static int ensure_tmp(mcrt_ctx *c, size_t n)

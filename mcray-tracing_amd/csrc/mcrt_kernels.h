@@ -6,7 +6,7 @@
 
 namespace mcrt {
 
-struct TraceArgs {
+struct FrameArgs {
     // scene (HBM-resident, read-only)
     const float4 *nodes;       // [n_nodes][8]  128-B BVH4 nodes (4 x 32-B child records)
     const float4 *tris;        // [T][3]        48-B triangles, leaf order
@@ -16,24 +16,31 @@ struct TraceArgs {
     const float *el_pos;       // [E][3]
     const float *el_dir;       // [E][3]
     const double *row_thr;     // [R+1] row thresholds (see row_of)
-    // outputs
+    // per-frame work buffers; np = ne * S paths
+    float4 *st0, *st1, *st2;   // [np] path state: from,intensity | dir,media | distance_traveled(f64),outside,-
+    uint32_t *queue0, *queue1; // [np] live path ids, ping-pong by bounce parity
+    float4 *ray0, *ray1;       // [np][2] f2.xyz,to.x | to.yz,-,-   (indexed by queue position), ping-pong
+    float4 *hit;               // [np][2] frac,tri,da,mesh | n.xyz,-  (indexed by queue position)
+    uint32_t *counts;          // [B+1] live rays per bounce
+    mcrt_segment *segs;        // [np][B]
+    uint32_t *seg_count;       // [np]
     long long *acc;            // [ne][R] fixed-point RF accumulators (2^-52 units)
     uint32_t *flags;           // [ne][(R+31)/32] non-finite flags
-    int32_t *hits;             // optional [ne][S][B]
-    mcrt_segment *segs;        // optional [ne][S][B]
-    uint32_t *seg_count;       // optional [ne][S]
-    unsigned long long *stats; // optional [6]
+    unsigned long long *stats; // [6]
     uint32_t *error_flag;      // device word, bit 0: traversal stack overflow
     // sizes / parameters
-    uint32_t n_nodes, S, B, R, e_begin, ne, chunks, paths_per_block, frame, seed, start_mat, tex_n, sanitize, tex_finite, fast_div;
+    uint32_t n_nodes, S, B, R, e_begin, ne, frame, seed, start_mat, tex_n, sanitize, tex_finite, fast_div;
     float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs, tex_rcp;
     double axial_res_mm, time_step, row_dt, max_travel, sos_d, inv_row_dt;
 };
 
 struct ConvTaps { float ax[16]; float lat[32]; uint32_t n_ax, n_lat; };
 
-size_t trace_lds_bytes(uint32_t R, int block);
-hipError_t launch_trace(const TraceArgs &a, int block, bool stats, bool emit, bool accum, hipStream_t st);
+void march_shape(uint32_t S, uint32_t B, uint32_t ne, uint32_t &slots, uint32_t &chunks);
+hipError_t launch_init(const FrameArgs &a, hipStream_t st);
+hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
+hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
+hipError_t launch_march(const FrameArgs &a, uint32_t b_begin, uint32_t n_bounces, bool stats, hipStream_t st);
 hipError_t launch_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t ne, uint32_t R, hipStream_t st);
 hipError_t launch_convolve(float *img, float *tmp, uint32_t E, uint32_t R, const ConvTaps &taps, hipStream_t st);
 hipError_t launch_envelope(float *img, uint32_t E, uint32_t R, hipStream_t st);

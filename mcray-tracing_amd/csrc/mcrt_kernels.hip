@@ -1,9 +1,8 @@
 // mcrt_kernels.hip -- gfx950 kernels of the hot path.
 //
-//   k_trace      scene::cast_rays (scene.cpp:50-183) + ray_physics (ray.cpp) + the RF accumulation loop
-//                (main.cpp:106-144, rfimage.h:33-40, volume.h:46-61), fused: one DPP quad (4 lanes) = one
-//                Monte-Carlo sample path, one wavefront = 16 paths of ONE scan-line, quad-cooperative BVH4 walk
-//                with the traversal stacks and the per-scan-line RF bins in LDS.
+//   k_init/k_trace/k_shade   scene::cast_rays (scene.cpp:50-183) + ray_physics (ray.cpp) as a wavefront pipeline:
+//                quad-cooperative BVH4 closest hit, then the interface physics, one launch each per bounce
+//   k_march      the RF accumulation loop (main.cpp:106-144, rfimage.h:33-40, volume.h:46-61), one quad per segment
 //   k_finalize   fixed-point RF bins -> float image (+ clears the bins: rf_image::clear, rfimage.h:161)
 //   k_conv_*     rf_image::convolve (rfimage.h:93-123)
 //   k_envelope   rf_image::envelope (rfimage.h:54-91)
@@ -18,8 +17,8 @@
 #include "mcrt_detmath.h"
 #include "mcrt_kernels.h"
 
-#ifndef MCRT_MIN_WAVES
-#define MCRT_MIN_WAVES 4           // waves per SIMD the register allocator must leave room for
+#ifndef MCRT_TRACE_WAVES
+#define MCRT_TRACE_WAVES 8          // waves per SIMD k_trace's register allocation must allow
 #endif
 #ifndef MCRT_LEAF_BATCH
 #define MCRT_LEAF_BATCH 4          // leave the inner-node phase once this many of a wave's 16 paths are parked on a leaf
@@ -185,7 +184,7 @@ MCRT_DEV int row_of(double t, const double *thr, uint32_t R, double inv_dt)
 // x / tex_res, correctly rounded, as two fmas around a multiply by the rounded reciprocal (Markstein's correction).
 // Used only when the GPU itself has verified (k_verify_div, exhaustive over the gated range) that the sequence
 // equals IEEE division for this tex_res; otherwise, and outside the gate, the division instruction sequence is used.
-MCRT_DEV float div_res(float x, const TraceArgs &a)
+MCRT_DEV float div_res(float x, const FrameArgs &a)
 {
     const float ax = fabsf(x);
     if (a.fast_div && ((ax > 1e-18f && ax < 1e18f) || x == 0.0f)) {
@@ -207,343 +206,399 @@ MCRT_DEV void rf_add(long long *bins, uint32_t *lflags, int row, float echo)
 }
 
 // =============================================================================================================
-// k_trace: FOUR lanes (one DPP quad) own one Monte-Carlo sample path; a wavefront holds 16 paths of one scan-line.
-//   * BVH4 walk: each lane fetches ONE 32-byte child record (the quad reads the node's 128 contiguous bytes), tests
-//     its box, and the quad ranks the hit children with DPP exchanges; leaves hold <= 4 triangles, one per lane.
-//   * interface physics and RNG are evaluated redundantly by the four lanes (identical inputs, identical results).
-//   * RF march: four consecutive steps per iteration, lane j owns step j -- four independent texture gathers in flight.
-// Path state is therefore quad-uniform; only box / triangle / march-step data differs between the lanes of a quad.
+// The frame is a WAVEFRONT pipeline that mirrors the reference's own structure (scene::cast_rays produces segments,
+// main.cpp:106-144 consumes them), one launch per stage and bounce, queues of live paths in HBM between stages:
+//
+//   k_init            first_ray of every (scan-line, sample) path, scene.cpp:83-101            1 lane  / path
+//   for bounce b:
+//     k_trace         closest hit of every live ray: quad-cooperative BVH4 walk                 4 lanes / ray
+//     k_shade         thickness draw, travel, hit_boundary, segment record, next ray;           1 lane  / ray
+//                     survivors are compacted into the next bounce's queue (wave ballot + prefix)
+//   k_march           RF accumulation of every segment (main.cpp:112-140)                       4 lanes / segment
+//
+// Every stage therefore runs with full wavefronts of lanes doing the same thing: dead paths cost nothing after the
+// bounce they die in, the fp64-heavy interface physics is not replicated, and the lean walk kernel keeps 8 waves/SIMD.
+// Paths draw random numbers from their own (scan-line, sample, bounce) counter and RF bins are integer sums, so the
+// image does not depend on queue order.
 // =============================================================================================================
-template <bool STATS, bool EMIT, bool ACCUM>
-__global__ void __launch_bounds__(256, MCRT_MIN_WAVES) k_trace(TraceArgs a)
+
+struct Ray { f3 f2, to; };
+
+// max_ray_length (ray.cpp:110-113) + enlarge (scene.cpp:292-298) + the 0.1 start offset (scene.cpp:115)
+MCRT_DEV Ray make_ray(f3 from, f3 dir, float intensity, float att, const FrameArgs &a)
+{
+    const float L = 10.f * det_logf(a.eps / intensity) / -att * a.freq;
+    const float Ls = L / 100.0f;
+    Ray r;
+    r.to = mk(from.x + Ls * (a.sx * dir.x), from.y + Ls * (a.sy * dir.y), from.z + Ls * (a.sz * dir.z));
+    r.f2 = mk(from.x + a.offs * dir.x, from.y + a.offs * dir.y, from.z + a.offs * dir.z);
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_init(FrameArgs a)
+{
+    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t np = a.ne * a.S;
+    if (pid == 0) { a.counts[0] = np; for (uint32_t b = 1; b <= a.B; b++) a.counts[b] = 0u; }
+    if (pid >= np) return;
+    const uint32_t e_abs = a.e_begin + pid / a.S;
+    const f3 from = mk(a.el_pos[3 * e_abs], a.el_pos[3 * e_abs + 1], a.el_pos[3 * e_abs + 2]);
+    const f3 dir = mk(a.el_dir[3 * e_abs], a.el_dir[3 * e_abs + 1], a.el_dir[3 * e_abs + 2]);
+    const float intensity = a.I0 / (float)a.S;
+    a.st0[pid] = make_float4(from.x, from.y, from.z, intensity);
+    a.st1[pid] = make_float4(dir.x, dir.y, dir.z, __int_as_float((int)a.start_mat));
+    a.st2[pid] = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), 0.0f);      // distance_traveled (double) | outside | -
+    a.queue0[pid] = pid;
+    a.seg_count[pid] = 0u;
+    const Ray r = make_ray(from, dir, intensity, a.mats[2 * a.start_mat].y, a);
+    a.ray0[2 * pid] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
+    a.ray0[2 * pid + 1] = make_float4(r.to.y, r.to.z, 0.0f, 0.0f);
+}
+
+// ---- closest hit: FOUR lanes (one DPP quad) own one ray; a wavefront holds 16 rays.  Each lane fetches ONE 32-byte
+// child record of the BVH4 node (the quad reads the node's 128 contiguous bytes), tests its box, and the quad ranks the
+// hit children with DPP exchanges; leaves hold <= 4 triangles, one per lane.  Traversal stacks live in LDS.
+template <bool STATS>
+__global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, uint32_t b)
+{
+    __shared__ int stack[MCRT_STACK * 64];          // [MCRT_STACK][64 quads]: entry sp of quad q at sp*64 + q -> conflict-free
+    const int tid = threadIdx.x, lane = tid & 63, j = tid & 3, q = tid >> 2;
+    const uint32_t n = a.counts[b];
+    const uint32_t i = blockIdx.x * 64u + (uint32_t)q;
+    if (blockIdx.x * 64u >= n) return;
+    const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
+    bool walking = i < n && a.n_nodes != 0u;
+    f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1);
+    if (i < n) {
+        const float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
+        f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
+    }
+    unsigned long long st_nodes = 0, st_tris = 0, st_q = 0;
+    Hit best; best.frac = 1.0f; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
+    const f3 d = to - f2;
+    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int sp = 0, cur = 0;
+    if (STATS && walking && j == 0) st_q++;
+    while (__any(walking)) {
+        // phase 1: inner nodes, until enough rays are parked on a leaf (their triangle code then runs once for all)
+        for (;;) {
+            const unsigned long long inner = __ballot(walking && cur >= 0);
+            if (inner == 0ull) break;
+            if (__popcll(__ballot(walking && cur < 0)) >= 4 * MCRT_LEAF_BATCH) break;
+            if (walking && cur >= 0) {
+                const float4 *N = a.nodes + 8 * (size_t)cur + 2 * j;
+                const float4 A = N[0], B = N[1];               // lo.xyz hi.x | hi.y hi.z ref pad
+                if (STATS && j == 0) st_nodes++;
+                const int ref = __float_as_int(B.z);
+                float tn, tx;
+                const float tcap = fminf(1.0f, best.frac);
+                const bool hit = slab(mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), f2, inv, tcap, tn, tx) && ref != MCRT_BVH4_EMPTY;
+                const float inf = __int_as_float(0x7f800000);
+                const float key = hit ? tn : inf;
+                const float k0 = dpp_f<QP_BCAST(0)>(key), k1 = dpp_f<QP_BCAST(1)>(key), k2 = dpp_f<QP_BCAST(2)>(key), k3 = dpp_f<QP_BCAST(3)>(key);
+                const int nh = (k0 < inf) + (k1 < inf) + (k2 < inf) + (k3 < inf);
+                const int rank = ((k0 < key) || (k0 == key && 0 < j)) + ((k1 < key) || (k1 == key && 1 < j)) +
+                                 ((k2 < key) || (k2 == key && 2 < j)) + ((k3 < key) || (k3 == key && 3 < j));
+                int cand = (hit && rank == 0) ? ref : 0;
+                cand |= dpp_i<QP_XOR1>(cand);
+                cand |= dpp_i<QP_XOR2>(cand);
+                if (nh == 0) {
+                    if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
+                    else walking = false;
+                } else if (sp + nh - 1 > MCRT_STACK) {
+                    if (j == 0) atomicOr(a.error_flag, 1u);      // cannot happen for a tree the builder accepted
+                    walking = false;
+                } else {
+                    if (hit && rank > 0) stack[(sp + nh - 1 - rank) * 64 + q] = ref;
+                    sp += nh - 1;
+                    cur = cand;
+                }
+            }
+        }
+        // phase 2: leaves -- lane j tests triangle j
+        if (walking && cur < 0) {
+            const uint32_t v = (uint32_t)~cur;
+            const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+            Hit mine = best;
+            for (uint32_t k = (uint32_t)j; k < cnt; k += 4u) {
+                const float4 *T = a.tris + 3 * (size_t)(first + k);
+                const float4 t0 = T[0], t1 = T[1], t2 = T[2];
+                tri_test(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), __float_as_int(t1.w), f2, to, inv, a.pad_abs, mine);
+            }
+            if (STATS && j == 0) st_tris += cnt;
+#define MCRT_QUAD_MIN(CTRL)                                                                                             \
+            {                                                                                                           \
+                const float of = dpp_f<CTRL>(mine.frac); const int ot = dpp_i<CTRL>(mine.tri), om = dpp_i<CTRL>(mine.mesh); \
+                const float onx = dpp_f<CTRL>(mine.n.x), ony = dpp_f<CTRL>(mine.n.y), onz = dpp_f<CTRL>(mine.n.z), oda = dpp_f<CTRL>(mine.da); \
+                if (of < mine.frac || (of == mine.frac && ot < mine.tri)) { mine.frac = of; mine.tri = ot; mine.mesh = om; mine.n = mk(onx, ony, onz); mine.da = oda; } \
+            }
+            MCRT_QUAD_MIN(QP_XOR1)
+            MCRT_QUAD_MIN(QP_XOR2)
+#undef MCRT_QUAD_MIN
+            best = mine;
+            if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
+            else walking = false;
+        }
+    }
+    if (i < n && j == 0) {
+        a.hit[2 * (size_t)i] = make_float4(best.frac, __int_as_float(best.tri), best.da, __int_as_float(best.mesh));
+        a.hit[2 * (size_t)i + 1] = make_float4(best.n.x, best.n.y, best.n.z, 0.0f);
+    }
+    if (STATS) {
+        unsigned long long v[3] = { st_q, st_nodes, st_tris };
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            long long x = wave_sum_i64((long long)v[k]);
+            if (lane == 0 && x) atomicAdd(&a.stats[k], (unsigned long long)x);
+        }
+    }
+}
+
+// ---- interface interaction (scene.cpp:122-165, ray.cpp:11-97): one lane per live ray ----
+template <bool STATS>
+__global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
+{
+    const uint32_t n = a.counts[b];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= n) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t *q_in = (b & 1u) ? a.queue1 : a.queue0;
+    uint32_t *q_out = (b & 1u) ? a.queue0 : a.queue1;
+    const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
+    float4 *rays_out = (b & 1u) ? a.ray0 : a.ray1;
+    const bool valid = i < n;
+    bool alive = false;
+    uint32_t pid = 0;
+    f3 from = mk(0, 0, 0), dir = mk(0, 0, 1);
+    float intensity = 0.0f; int media = 0, outside = OUT_NONE; double dist_mm = 0.0;
+    unsigned long long st_seg = 0, st_hits = 0;
+    if (valid) {
+        pid = q_in[i];
+        const float4 s0 = a.st0[pid], s1 = a.st1[pid], s2 = a.st2[pid];
+        from = mk(s0.x, s0.y, s0.z); intensity = s0.w;
+        dir = mk(s1.x, s1.y, s1.z); media = __float_as_int(s1.w);
+        dist_mm = __hiloint2double(__float_as_int(s2.y), __float_as_int(s2.x));
+        outside = __float_as_int(s2.z);
+        const float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
+        const f3 f2 = mk(r0.x, r0.y, r0.z), to = mk(r0.w, r1.x, r1.y);
+        const float4 h0 = a.hit[2 * (size_t)i], h1 = a.hit[2 * (size_t)i + 1];
+        Hit best; best.frac = h0.x; best.tri = __float_as_int(h0.y); best.da = h0.z; best.mesh = __float_as_int(h0.w); best.n = mk(h1.x, h1.y, h1.z);
+        const uint32_t e_abs = a.e_begin + pid / a.S;
+        Rng g; g.k0 = a.seed; g.k1 = a.frame; g.element = e_abs; g.sample = pid % a.S; g.bounce = b;
+        const float4 m0 = a.mats[2 * media];   // imp, att, mu0, mu1  (second half: sigma, spec, shine, thick)
+        const float att = m0.y;
+
+        f3 seg_to = to;
+        float seg_refl = 0.0f; const float seg_init = intensity; const double seg_dist = dist_mm;
+        const f3 seg_from = from, seg_dir = dir; const int seg_media = media; int seg_tri = -1;
+        if (best.tri >= 0) {
+            if (STATS) st_hits++;
+            f3 nn = normalized(best.n);
+            if (best.da <= 0.0f) nn = neg(nn);
+            const float sfr = 1.0f - best.frac;
+            const f3 hp = mk(sfr * f2.x + best.frac * to.x, sfr * f2.y + best.frac * to.y, sfr * f2.z + best.frac * to.z);
+            const uint4 organ = a.meshes[best.mesh];   // mat_inside, mat_outside, vascular
+            // thickness penetration scene.cpp:132-139 (Box-Muller on block 0)
+            const float sigma_t = a.mats[2 * organ.x + 1].w;
+            float qpen = 0.0f;
+            if (sigma_t != 0.0f) {
+                double n1, n2, sn, cs;
+                rng_block(g, 0u, n1, n2);
+                det_sincos(n2 * 2 * PI_D, sn, cs);
+                const double z = sqrt(-2.0 * det_log(1.0 - n1)) * cs;
+                qpen = (float)fabs(z * (double)sigma_t + 0.0);
+            }
+            const f3 inside = mk(qpen * dir.x + hp.x, qpen * dir.y + hp.y, qpen * dir.z + hp.z);
+            // travel ray.cpp:99-103, distance_in_mm scene.cpp:281-290
+            const float xd = fabsf(from.x - inside.x) * a.sx, yd = fabsf(from.y - inside.y) * a.sy, zd = fabsf(from.z - inside.z) * a.sz;
+            const double mm = sqrt((double)xd * (double)xd + (double)yd * (double)yd + (double)zd * (double)zd) * 10;
+            dist_mm = dist_mm + mm;
+            intensity = intensity * det_expf(-att * ((float)mm * 0.01f) * a.freq);
+
+            // hit_boundary: material transition logic ray.cpp:14-47 (bug-compatible)
+            int after_vasc, mat_after;
+            if (outside != OUT_NONE) {
+                if (organ.z) { after_vasc = OUT_NONE; mat_after = (outside == OUT_SELF) ? media : outside; }
+                else { after_vasc = (outside == (int)organ.x) ? (int)organ.y : (int)organ.x; mat_after = media; }
+            } else {
+                if (organ.z) { after_vasc = OUT_SELF; mat_after = (int)organ.x; }
+                else { after_vasc = OUT_NONE; mat_after = (int)organ.x; }
+            }
+            const float4 a0 = a.mats[2 * mat_after], a1 = a.mats[2 * mat_after + 1];
+            double u_pc, u_x;
+            rng_block(g, 1u, u_pc, u_x);
+            // power_cosine_variate ray.cpp:213-224
+            const int indice = (int)a1.z + 1;
+            const float exponente = (float)((double)1.0 / indice);
+            const float random_angle = (float)det_pow_pos(u_pc, (double)exponente);
+            const f3 rn = random_unit_vector(nn, random_angle, g);
+
+            float inc = dot(dir, neg(rn));
+            if (inc < 0) inc = dot(dir, rn);
+            const float rr = m0.x / a0.x;
+            float refa = 1 - rr * rr * (1 - inc * inc);
+            const bool tir = refa < 0;
+            refa = sqrtf(refa);
+            const float kk = rr * inc - refa;
+            f3 refr = mk(rr * dir.x + kk * rn.x, rr * dir.y + kk * rn.y, rr * dir.z + kk * rn.z);
+            refr = normalized(refr);
+            const float two_c = 2 * inc;
+            f3 refl = mk(dir.x + two_c * rn.x, dir.y + two_c * rn.y, dir.z + two_c * rn.z);
+            refl = normalized(refl);
+
+            float i_refl;
+            if (tir) i_refl = intensity;
+            else {
+                const float num = m0.x * inc - a0.x * refa;
+                const float den = m0.x * inc + a0.x * refa;
+                const float qq = num / den;
+                i_refl = (float)((double)intensity * ((double)qq * (double)qq));
+            }
+            const float i_refr = intensity - i_refl;
+
+            const float ra = dot(dir, refr);
+            float refraction_factor = det_powf(ra, a1.y);
+            const float rb = dot(dir, refl);
+            const float reflection_factor = det_powf(rb, a1.y);
+            if (a.sanitize && tir) refraction_factor = 0.0f;
+            seg_refl = (std_max(refraction_factor, 0.0f) + std_max(reflection_factor, 0.0f)) * random_angle;
+            seg_to = inside;
+            seg_tri = best.tri;
+
+            const float x = (float)u_x;
+            const float prob = i_refl / intensity;
+            float i_new;
+            from = hp;
+            if (prob > x) { dir = refl; i_new = i_refl > a.eps ? i_refl : 0.0f; }
+            else { dir = refr; media = mat_after; outside = after_vasc; i_new = i_refr > a.eps ? i_refr : 0.0f; }
+            if (i_new > a.eps) { intensity = i_new; alive = true; }
+        }
+        if (STATS) st_seg++;
+
+        // ray_physics::segment (ray.h:28-36) -> slot [path][bounce]
+        mcrt_segment sg;
+        sg.from[0] = seg_from.x; sg.from[1] = seg_from.y; sg.from[2] = seg_from.z;
+        sg.to[0] = seg_to.x; sg.to[1] = seg_to.y; sg.to[2] = seg_to.z;
+        sg.dir[0] = seg_dir.x; sg.dir[1] = seg_dir.y; sg.dir[2] = seg_dir.z;
+        sg.reflected_intensity = seg_refl; sg.initial_intensity = seg_init; sg.attenuation = att;
+        sg.distance_traveled = seg_dist; sg.media = seg_media; sg.tri = seg_tri;
+        a.segs[(size_t)pid * a.B + b] = sg;
+        a.seg_count[pid] = b + 1u;
+        alive = alive && (b + 1u < a.B);
+    }
+
+    // survivors -> next bounce's queue, order-preserving inside the wavefront (ballot + prefix), one atomic per wave
+    const unsigned long long live = __ballot(alive);
+    if (live) {
+        const int leader = __ffsll((long long)live) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&a.counts[b + 1u], (uint32_t)__popcll(live));
+        base = __shfl(base, leader, 64);
+        if (alive) {
+            const uint32_t pos = base + (uint32_t)__popcll(live & ((1ull << lane) - 1ull));
+            q_out[pos] = pid;
+            a.st0[pid] = make_float4(from.x, from.y, from.z, intensity);
+            a.st1[pid] = make_float4(dir.x, dir.y, dir.z, __int_as_float(media));
+            a.st2[pid] = make_float4(__int_as_float(__double2loint(dist_mm)), __int_as_float(__double2hiint(dist_mm)), __int_as_float(outside), 0.0f);
+            const Ray r = make_ray(from, dir, intensity, a.mats[2 * media].y, a);
+            rays_out[2 * (size_t)pos] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
+            rays_out[2 * (size_t)pos + 1] = make_float4(r.to.y, r.to.z, 0.0f, 0.0f);
+        }
+    }
+    if (STATS) {
+        long long x = wave_sum_i64((long long)st_seg), y = wave_sum_i64((long long)st_hits);
+        if (lane == 0) { if (x) atomicAdd(&a.stats[3], (unsigned long long)x); if (y) atomicAdd(&a.stats[5], (unsigned long long)y); }
+    }
+}
+
+// ---- RF accumulation (main.cpp:112-140): one DPP quad per segment, four consecutive steps per iteration (lane j owns
+// step j: four independent texture gathers in flight), per-scan-line fixed-point bins in LDS ----
+template <bool STATS>
+__global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b_begin, uint32_t n_bounces, uint32_t march_slots, uint32_t march_chunks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
-    const int j = tid & 3, q = tid >> 2, Q = nthr >> 2;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, j = tid & 3, q = tid >> 2;
     const uint32_t R = a.R;
     long long *bins = (long long *)smem;
     uint32_t *lflags = (uint32_t *)(bins + ((R + 1u) & ~1u));
     double *thr = (double *)(lflags + ((((R + 31u) >> 5) + 3u) & ~3u));
-    int *stack = (int *)(thr + ((R + 2u) & ~1u));          // [MCRT_STACK][Q]: entry sp of quad q at sp*Q + q -> conflict-free
-    int *next_path = stack + MCRT_STACK * Q;               // the block's path queue head (path regeneration)
-
-    // XCD-aware block -> (scan-line, chunk) map: workgroups are dealt round-robin over the 8 XCDs, so
-    // the chunks of one scan-line (same BVH path, same texture lines) are steered onto one XCD's L2.
-    uint32_t vb = blockIdx.x;
-    {
-        const uint32_t nb = gridDim.x, per = nb >> 3;
-        if (vb < (per << 3)) vb = (vb & 7u) * per + (vb >> 3);
-    }
-    const uint32_t e_local = vb / a.chunks, chunk = vb % a.chunks;
-    const uint32_t e_abs = a.e_begin + e_local;
-
-    if (ACCUM) {
-        for (uint32_t r = tid; r < R; r += nthr) bins[r] = 0;
-        for (uint32_t r = tid; r < ((R + 31u) >> 5); r += nthr) lflags[r] = 0u;
-        for (uint32_t r = tid; r <= R; r += nthr) thr[r] = a.row_thr[r];
-    }
-    if (tid == 0) *next_path = Q;
+    for (uint32_t r = tid; r < R; r += nthr) bins[r] = 0;
+    for (uint32_t r = tid; r < ((R + 31u) >> 5); r += nthr) lflags[r] = 0u;
+    for (uint32_t r = tid; r <= R; r += nthr) thr[r] = a.row_thr[r];
     __syncthreads();
 
-    // The block owns sample paths [s_begin, s_end) of its scan-line.  Quad q starts on path s_begin + q; whenever a path
-    // terminates (intensity below epsilon, a miss, or max_depth) the quad pulls the next unclaimed one from the LDS counter
-    // ("path regeneration"), so lanes do not idle behind the longest path of the wavefront.  Every path draws its random
-    // numbers from its own (scan-line, sample, bounce) counter and RF bins are integer sums, so the result does not depend
-    // on which quad traced which path or when.
-    const uint32_t s_begin = chunk * a.paths_per_block;
-    const uint32_t s_end = min(a.S, s_begin + a.paths_per_block);
-    const f3 el_from = mk(a.el_pos[3 * e_abs], a.el_pos[3 * e_abs + 1], a.el_pos[3 * e_abs + 2]);
-    const f3 el_dir = mk(a.el_dir[3 * e_abs], a.el_dir[3 * e_abs + 1], a.el_dir[3 * e_abs + 2]);
-
-    uint32_t s = s_begin + (uint32_t)q;
-    bool alive = s < s_end;                 // the quad holds a live path
-    size_t path = ((size_t)e_local * a.S + s);
-    f3 from = el_from, dir = el_dir;
-    int media = (int)a.start_mat, outside = OUT_NONE;
-    float intensity = a.I0 / (float)a.S;
-    double dist_mm = 0.0;
-    Rng g; g.k0 = a.seed; g.k1 = a.frame; g.element = e_abs; g.sample = s; g.bounce = 0;
-    uint32_t nseg = 0, b = 0;
-    unsigned long long st_nodes = 0, st_tris = 0, st_q = 0, st_seg = 0, st_steps = 0, st_hits = 0;
-    if (EMIT && a.hits && alive && j == 0)
-        for (uint32_t k = 0; k < a.B; k++) a.hits[path * a.B + k] = -2;
-
-    while (__any(alive)) {
-        g.bounce = b;
-
-        // ---- launch the query: max_ray_length (ray.cpp:110-113), enlarge (scene.cpp:292-298) ----
-        const int mi = alive ? media : (int)a.start_mat;
-        const float4 m0 = a.mats[2 * mi];   // imp, att, mu0, mu1  (second half: sigma, spec, shine, thick)
-        const float att = m0.y;
-        const float L = 10.f * det_logf(a.eps / intensity) / -att * a.freq;
-        const float Ls = L / 100.0f;
-        const f3 to = mk(from.x + Ls * (a.sx * dir.x), from.y + Ls * (a.sy * dir.y), from.z + Ls * (a.sz * dir.z));
-        const f3 f2 = mk(from.x + a.offs * dir.x, from.y + a.offs * dir.y, from.z + a.offs * dir.z);
-
-        // ---- closest hit: quad-cooperative BVH4 walk ----
-        Hit best; best.frac = 1.0f; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
-        {
-            const f3 d = to - f2;
-            const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-            int sp = 0, cur = 0;
-            bool walking = alive && a.n_nodes != 0u;
-            if (STATS && walking && j == 0) st_q++;
-            while (__any(walking)) {
-                // phase 1: inner nodes, until enough quads are parked on a leaf (their triangle code then runs once for all)
-                for (;;) {
-                    const unsigned long long inner = __ballot(walking && cur >= 0);
-                    if (inner == 0ull) break;
-                    if (__popcll(__ballot(walking && cur < 0)) >= 4 * MCRT_LEAF_BATCH) break;
-                    if (walking && cur >= 0) {
-                        const float4 *N = a.nodes + 8 * (size_t)cur + 2 * j;
-                        const float4 A = N[0], B = N[1];               // lo.xyz hi.x | hi.y hi.z ref pad
-                        if (STATS && j == 0) st_nodes++;
-                        const int ref = __float_as_int(B.z);
-                        float tn, tx;
-                        const float tcap = fminf(1.0f, best.frac);
-                        const bool hit = slab(mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), f2, inv, tcap, tn, tx) && ref != MCRT_BVH4_EMPTY;
-                        const float key = hit ? tn : __int_as_float(0x7f800000);
-                        const float k0 = dpp_f<QP_BCAST(0)>(key), k1 = dpp_f<QP_BCAST(1)>(key), k2 = dpp_f<QP_BCAST(2)>(key), k3 = dpp_f<QP_BCAST(3)>(key);
-                        const float inf = __int_as_float(0x7f800000);
-                        const int nh = (k0 < inf) + (k1 < inf) + (k2 < inf) + (k3 < inf);
-                        const int rank = ((k0 < key) || (k0 == key && 0 < j)) + ((k1 < key) || (k1 == key && 1 < j)) +
-                                         ((k2 < key) || (k2 == key && 2 < j)) + ((k3 < key) || (k3 == key && 3 < j));
-                        int cand = (hit && rank == 0) ? ref : 0;
-                        cand |= dpp_i<QP_XOR1>(cand);
-                        cand |= dpp_i<QP_XOR2>(cand);
-                        if (nh == 0) {
-                            if (sp > 0) { sp--; cur = stack[sp * Q + q]; }
-                            else walking = false;
-                        } else if (sp + nh - 1 > MCRT_STACK) {
-                            if (j == 0) atomicOr(a.error_flag, 1u);      // cannot happen for a tree the builder accepted
-                            walking = false;
-                        } else {
-                            if (hit && rank > 0) stack[(sp + nh - 1 - rank) * Q + q] = ref;
-                            sp += nh - 1;
-                            cur = cand;
-                        }
-                    }
-                }
-                // phase 2: leaves -- lane j tests triangle j
-                if (walking && cur < 0) {
-                    const uint32_t v = (uint32_t)~cur;
-                    const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-                    Hit mine = best;
-                    for (uint32_t i = (uint32_t)j; i < cnt; i += 4u) {
-                        const float4 *T = a.tris + 3 * (size_t)(first + i);
-                        const float4 t0 = T[0], t1 = T[1], t2 = T[2];
-                        tri_test(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), __float_as_int(t1.w), f2, to, inv, a.pad_abs, mine);
-                    }
-                    if (STATS && j == 0) st_tris += cnt;
-#define MCRT_QUAD_MIN(CTRL)                                                                                             \
-                    {                                                                                                   \
-                        const float of = dpp_f<CTRL>(mine.frac); const int ot = dpp_i<CTRL>(mine.tri), om = dpp_i<CTRL>(mine.mesh); \
-                        const float onx = dpp_f<CTRL>(mine.n.x), ony = dpp_f<CTRL>(mine.n.y), onz = dpp_f<CTRL>(mine.n.z), oda = dpp_f<CTRL>(mine.da); \
-                        if (of < mine.frac || (of == mine.frac && ot < mine.tri)) { mine.frac = of; mine.tri = ot; mine.mesh = om; mine.n = mk(onx, ony, onz); mine.da = oda; } \
-                    }
-                    MCRT_QUAD_MIN(QP_XOR1)
-                    MCRT_QUAD_MIN(QP_XOR2)
-#undef MCRT_QUAD_MIN
-                    best = mine;
-                    if (sp > 0) { sp--; cur = stack[sp * Q + q]; }
-                    else walking = false;
-                }
-            }
-        }
-
-        // ---- interface interaction (scene.cpp:122-165, ray.cpp:11-97), evaluated by all four lanes ----
-        bool seg_valid = alive;
-        f3 seg_from = from, seg_to = to, seg_dir = dir;
-        float seg_refl = 0.0f, seg_init = intensity, seg_att = att;
-        double seg_dist = dist_mm;
-        int seg_media = mi, seg_tri = -1;
-        if (alive) {
-            if (best.tri >= 0) {
-                if (STATS && j == 0) st_hits++;
-                f3 nn = normalized(best.n);
-                if (best.da <= 0.0f) nn = neg(nn);
-                const float sfr = 1.0f - best.frac;
-                const f3 hp = mk(sfr * f2.x + best.frac * to.x, sfr * f2.y + best.frac * to.y, sfr * f2.z + best.frac * to.z);
-                const uint4 organ = a.meshes[best.mesh];   // mat_inside, mat_outside, vascular
-                // thickness penetration scene.cpp:132-139 (Box-Muller on block 0)
-                const float sigma_t = a.mats[2 * organ.x + 1].w;
-                float qpen = 0.0f;
-                if (sigma_t != 0.0f) {
-                    double n1, n2, sn, cs;
-                    rng_block(g, 0u, n1, n2);
-                    det_sincos(n2 * 2 * PI_D, sn, cs);
-                    const double z = sqrt(-2.0 * det_log(1.0 - n1)) * cs;
-                    qpen = (float)fabs(z * (double)sigma_t + 0.0);
-                }
-                const f3 inside = mk(qpen * dir.x + hp.x, qpen * dir.y + hp.y, qpen * dir.z + hp.z);
-                // travel ray.cpp:99-103, distance_in_mm scene.cpp:281-290
-                const float xd = fabsf(from.x - inside.x) * a.sx, yd = fabsf(from.y - inside.y) * a.sy, zd = fabsf(from.z - inside.z) * a.sz;
-                const double mm = sqrt((double)xd * (double)xd + (double)yd * (double)yd + (double)zd * (double)zd) * 10;
-                dist_mm = dist_mm + mm;
-                intensity = intensity * det_expf(-att * ((float)mm * 0.01f) * a.freq);
-
-                // hit_boundary: material transition logic ray.cpp:14-47 (bug-compatible)
-                int after_vasc, mat_after;
-                if (outside != OUT_NONE) {
-                    if (organ.z) { after_vasc = OUT_NONE; mat_after = (outside == OUT_SELF) ? media : outside; }
-                    else { after_vasc = (outside == (int)organ.x) ? (int)organ.y : (int)organ.x; mat_after = media; }
-                } else {
-                    if (organ.z) { after_vasc = OUT_SELF; mat_after = (int)organ.x; }
-                    else { after_vasc = OUT_NONE; mat_after = (int)organ.x; }
-                }
-                const float4 a0 = a.mats[2 * mat_after], a1 = a.mats[2 * mat_after + 1];
-                double u_pc, u_x;
-                rng_block(g, 1u, u_pc, u_x);
-                // power_cosine_variate ray.cpp:213-224
-                const int indice = (int)a1.z + 1;
-                const float exponente = (float)((double)1.0 / indice);
-                const float random_angle = (float)det_pow_pos(u_pc, (double)exponente);
-                const f3 rn = random_unit_vector(nn, random_angle, g);
-
-                float inc = dot(dir, neg(rn));
-                if (inc < 0) inc = dot(dir, rn);
-                const float rr = m0.x / a0.x;
-                float refa = 1 - rr * rr * (1 - inc * inc);
-                const bool tir = refa < 0;
-                refa = sqrtf(refa);
-                const float kk = rr * inc - refa;
-                f3 refr = mk(rr * dir.x + kk * rn.x, rr * dir.y + kk * rn.y, rr * dir.z + kk * rn.z);
-                refr = normalized(refr);
-                const float two_c = 2 * inc;
-                f3 refl = mk(dir.x + two_c * rn.x, dir.y + two_c * rn.y, dir.z + two_c * rn.z);
-                refl = normalized(refl);
-
-                float i_refl;
-                if (tir) i_refl = intensity;
-                else {
-                    const float num = m0.x * inc - a0.x * refa;
-                    const float den = m0.x * inc + a0.x * refa;
-                    const float qq = num / den;
-                    i_refl = (float)((double)intensity * ((double)qq * (double)qq));
-                }
-                const float i_refr = intensity - i_refl;
-
-                const float ra = dot(dir, refr);
-                float refraction_factor = det_powf(ra, a1.y);
-                const float rb = dot(dir, refl);
-                const float reflection_factor = det_powf(rb, a1.y);
-                if (a.sanitize && tir) refraction_factor = 0.0f;
-                seg_refl = (std_max(refraction_factor, 0.0f) + std_max(reflection_factor, 0.0f)) * random_angle;
-                seg_to = inside;
-                seg_tri = best.tri;
-
-                const float x = (float)u_x;
-                const float prob = i_refl / intensity;
-                float i_new;
-                from = hp;
-                if (prob > x) { dir = refl; i_new = i_refl > a.eps ? i_refl : 0.0f; }
-                else { dir = refr; media = mat_after; outside = after_vasc; i_new = i_refr > a.eps ? i_refr : 0.0f; }
-                if (i_new > a.eps) intensity = i_new; else alive = false;
-            } else {
-                alive = false;
-            }
-            if (STATS && j == 0) st_seg++;
-        }
-
-        if (EMIT && seg_valid) {
-            if (j == 0) {
-                if (a.hits) a.hits[path * a.B + b] = seg_tri;
-                if (a.segs) {
-                    mcrt_segment sg;
-                    sg.from[0] = seg_from.x; sg.from[1] = seg_from.y; sg.from[2] = seg_from.z;
-                    sg.to[0] = seg_to.x; sg.to[1] = seg_to.y; sg.to[2] = seg_to.z;
-                    sg.dir[0] = seg_dir.x; sg.dir[1] = seg_dir.y; sg.dir[2] = seg_dir.z;
-                    sg.reflected_intensity = seg_refl; sg.initial_intensity = seg_init; sg.attenuation = seg_att;
-                    sg.distance_traveled = seg_dist; sg.media = seg_media; sg.tri = seg_tri;
-                    a.segs[path * a.B + nseg] = sg;
-                }
-            }
-            nseg++;
-        }
-
-        // ---- RF accumulation of this segment (main.cpp:112-140): 4 steps per iteration, lane j owns step j ----
-        if (ACCUM) {
-            const float4 s0 = a.mats[2 * seg_media], s1 = a.mats[2 * seg_media + 1];
-            const double t_start = (seg_dist * 1000.0) / a.sos_d;
-            const f3 df = seg_to - seg_from;
-            const float dist_f = sqrtf(dot(df, df)) * 10.0f;
-            const uint32_t steps = seg_valid ? steps_from((double)dist_f / a.axial_res_mm) : 0u;
-            const f3 delta = mk(a.axial_res_f * seg_dir.x, a.axial_res_f * seg_dir.y, a.axial_res_f * seg_dir.z);
-            f3 point = seg_from;
-            double t = t_start;
-            float inten = seg_init;
-            const float k_att = det_expf(-seg_att * a.axial_res_f * 0.01f * a.freq * 1.0f);
-            // scattering is exactly +0 for every voxel when mu0 == sigma == 0 (finite texture): the adds are no-ops
-            const bool silent = a.tex_finite && s0.z == 0.0f && s1.x == 0.0f;
-            uint32_t step = 0;
-            bool more = seg_valid && !silent && steps > 0u && t < a.max_travel;
-            while (__any(more)) {
-                f3 myp = point; double myt = t; float myin = inten; bool myv = false;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const bool vu = more && (step + (uint32_t)u < steps) && (t < a.max_travel);   // the reference's loop test
-                    if (u == j) { myp = point; myt = t; myin = inten; myv = vu; }
-                    point = point + delta;                                                       // ... and its loop tail
-                    t = t + a.time_step;
-                    inten *= k_att;
-                }
-                step += 4u;
-                more = more && step < steps && t < a.max_travel;
-                if (myv) {
-                    const uint32_t vx = vox_index(div_res(myp.x, a), a.tex_n), vy = vox_index(div_res(myp.y, a), a.tex_n), vz = vox_index(div_res(myp.z, a), a.tex_n);
-                    const float2 vox = a.tex[((size_t)vx * a.tex_n + vy) * a.tex_n + vz];
-                    const float scattering = vox.y >= s0.w ? vox.x * s1.x + s0.z : 0.0f;
-                    rf_add(bins, lflags, row_of(myt, thr, R, a.inv_row_dt), myin * scattering);
-                    if (STATS) st_steps++;
-                }
-            }
-            // boundary echo main.cpp:139
-            if (seg_valid && j == 0) {
-                const double te = t_start + a.time_step * (double)(uint32_t)(steps - 1u);
-                rf_add(bins, lflags, row_of(te, thr, R, a.inv_row_dt), seg_refl / (float)a.S);
-            }
-        }
-
-        // ---- next bounce, or path regeneration ----
+    const uint32_t e_local = blockIdx.x / march_chunks, chunk = blockIdx.x % march_chunks;
+    const uint32_t n_slots = a.S * n_bounces;                  // slot k -> bounce k / S, sample k % S: a wavefront's 16 segments share
+    unsigned long long st_steps = 0;                     // the bounce index, hence similar length and coherent texture lines
+    for (uint32_t it = 0; it < march_slots; it++) {
+        const uint32_t k = (chunk * march_slots + it) * 64u + (uint32_t)q;
+        const uint32_t bnc = b_begin + k / a.S, smp = k % a.S;
+        const size_t pid = (size_t)e_local * a.S + smp;
+        bool seg_valid = k < n_slots && bnc < a.seg_count[pid];
+        if (!__any(seg_valid)) continue;
+        float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0;
         if (seg_valid) {
-            b++;
-            if (!alive || b >= a.B) {
-                if (EMIT && a.seg_count && j == 0) a.seg_count[path] = nseg;
-                int nxt = 0;
-                if (j == 0) nxt = atomicAdd(next_path, 1);
-                nxt = dpp_i<QP_BCAST(0)>(nxt);
-                s = s_begin + (uint32_t)nxt;
-                alive = s < s_end;
-                if (alive) {
-                    path = ((size_t)e_local * a.S + s);
-                    from = el_from; dir = el_dir; media = (int)a.start_mat; outside = OUT_NONE;
-                    intensity = a.I0 / (float)a.S; dist_mm = 0.0; g.sample = s; nseg = 0; b = 0;
-                    if (EMIT && a.hits && j == 0)
-                        for (uint32_t k = 0; k < a.B; k++) a.hits[path * a.B + k] = -2;
-                }
+            const float4 *sp = (const float4 *)(a.segs + pid * a.B + bnc);
+            g0 = sp[0]; g1 = sp[1]; g2 = sp[2]; g3 = sp[3];
+        }
+        // mcrt_segment: from[3] to[3] dir[3] refl init att | double dist | media tri
+        const f3 seg_from = mk(g0.x, g0.y, g0.z), seg_to = mk(g0.w, g1.x, g1.y), seg_dir = mk(g1.z, g1.w, g2.x);
+        const float seg_refl = g2.y, seg_init = g2.z, seg_att = g2.w;
+        const double seg_dist = __hiloint2double(__float_as_int(g3.y), __float_as_int(g3.x));
+        const int seg_media = seg_valid ? __float_as_int(g3.z) : 0;
+
+        const float4 s0 = a.mats[2 * seg_media], s1 = a.mats[2 * seg_media + 1];
+        const double t_start = (seg_dist * 1000.0) / a.sos_d;
+        const f3 df = seg_to - seg_from;
+        const float dist_f = sqrtf(dot(df, df)) * 10.0f;
+        const uint32_t steps = seg_valid ? steps_from((double)dist_f / a.axial_res_mm) : 0u;
+        const f3 delta = mk(a.axial_res_f * seg_dir.x, a.axial_res_f * seg_dir.y, a.axial_res_f * seg_dir.z);
+        f3 point = seg_from;
+        double t = t_start;
+        float inten = seg_init;
+        const float k_att = det_expf(-seg_att * a.axial_res_f * 0.01f * a.freq * 1.0f);
+        // scattering is exactly +0 for every voxel when mu0 == sigma == 0 (finite texture): the adds are no-ops
+        const bool silent = a.tex_finite && s0.z == 0.0f && s1.x == 0.0f;
+        uint32_t step = 0;
+        bool more = seg_valid && !silent && steps > 0u && t < a.max_travel;
+        while (__any(more)) {
+            f3 myp = point; double myt = t; float myin = inten; bool myv = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool vu = more && (step + (uint32_t)u < steps) && (t < a.max_travel);   // the reference's loop test
+                if (u == j) { myp = point; myt = t; myin = inten; myv = vu; }
+                point = point + delta;                                                       // ... and its loop tail
+                t = t + a.time_step;
+                inten *= k_att;
+            }
+            step += 4u;
+            more = more && step < steps && t < a.max_travel;
+            if (myv) {
+                const uint32_t vx = vox_index(div_res(myp.x, a), a.tex_n), vy = vox_index(div_res(myp.y, a), a.tex_n), vz = vox_index(div_res(myp.z, a), a.tex_n);
+                const float2 vox = a.tex[((size_t)vx * a.tex_n + vy) * a.tex_n + vz];
+                const float scattering = vox.y >= s0.w ? vox.x * s1.x + s0.z : 0.0f;
+                rf_add(bins, lflags, row_of(myt, thr, R, a.inv_row_dt), myin * scattering);
+                if (STATS) st_steps++;
             }
         }
+        // boundary echo main.cpp:139
+        if (seg_valid && j == 0) {
+            const double te = t_start + a.time_step * (double)(uint32_t)(steps - 1u);
+            rf_add(bins, lflags, row_of(te, thr, R, a.inv_row_dt), seg_refl / (float)a.S);
+        }
     }
-
     if (STATS) {
-        unsigned long long v[6] = { st_q, st_nodes, st_tris, st_seg, st_steps, st_hits };
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            long long x = wave_sum_i64((long long)v[i]);
-            if (lane == 0 && x) atomicAdd(&a.stats[i], (unsigned long long)x);
-        }
+        long long x = wave_sum_i64((long long)st_steps);
+        if (lane == 0 && x) atomicAdd(&a.stats[4], (unsigned long long)x);
     }
-
-    if (ACCUM) {
-        __syncthreads();
-        long long *gacc = a.acc + (size_t)e_local * R;
-        for (uint32_t r = tid; r < R; r += nthr) {
-            const long long v = bins[r];
-            if (v != 0) atomicAdd((unsigned long long *)&gacc[r], (unsigned long long)v);
-        }
-        const uint32_t nf = (R + 31u) >> 5;
-        for (uint32_t r = tid; r < nf; r += nthr) { const uint32_t f = lflags[r]; if (f) atomicOr(&a.flags[(size_t)e_local * nf + r], f); }
+    __syncthreads();
+    long long *gacc = a.acc + (size_t)e_local * R;
+    for (uint32_t r = tid; r < R; r += nthr) {
+        const long long v = bins[r];
+        if (v != 0) atomicAdd((unsigned long long *)&gacc[r], (unsigned long long)v);
     }
+    const uint32_t nf = (R + 31u) >> 5;
+    for (uint32_t r = tid; r < nf; r += nthr) { const uint32_t f = lflags[r]; if (f) atomicOr(&a.flags[(size_t)e_local * nf + r], f); }
 }
 
 // fixed-point bins -> float RF image [ne][R]; clears the bins for the next frame
@@ -704,24 +759,57 @@ __global__ void k_philox_probe(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c
 // ---------------------------------------------------------------------------------------------
 // launchers (called from mcrt_api.cpp, which is plain C++)
 // ---------------------------------------------------------------------------------------------
-size_t trace_lds_bytes(uint32_t R, int block)
+size_t march_lds_bytes(uint32_t R)
 {
     size_t bins = (size_t)((R + 1u) & ~1u) * 8;
     size_t flg = (size_t)((((R + 31u) >> 5) + 3u) & ~3u) * 4;
     size_t thr = (size_t)((R + 2u) & ~1u) * 8;
-    return bins + flg + thr + (size_t)MCRT_STACK * (block / 4) * 4 + 16;
+    return bins + flg + thr;
 }
 
-hipError_t launch_trace(const TraceArgs &a, int block, bool stats, bool emit, bool accum, hipStream_t st)
+// each k_march block works through march_slots rounds of 64 segment slots; aim at ~4096 blocks per launch
+void march_shape(uint32_t S, uint32_t B, uint32_t ne, uint32_t &slots, uint32_t &chunks)
 {
-    const dim3 grid(a.ne * a.chunks), blk(block);
-    const size_t lds = trace_lds_bytes(a.R, block);
-#define MCRT_LAUNCH(S_, E_, A_) hipLaunchKernelGGL((k_trace<S_, E_, A_>), grid, blk, lds, st, a)
-    if (stats) { if (emit) { if (accum) MCRT_LAUNCH(true, true, true); else MCRT_LAUNCH(true, true, false); }
-                 else { if (accum) MCRT_LAUNCH(true, false, true); else MCRT_LAUNCH(true, false, false); } }
-    else { if (emit) { if (accum) MCRT_LAUNCH(false, true, true); else MCRT_LAUNCH(false, true, false); }
-           else { if (accum) MCRT_LAUNCH(false, false, true); else MCRT_LAUNCH(false, false, false); } }
-#undef MCRT_LAUNCH
+    const uint32_t rounds = (S * B + 63u) / 64u;                       // 64-slot rounds per scan-line
+    const uint32_t want = ne >= 4096u ? 1u : (4096u + ne - 1u) / ne;   // blocks per scan-line
+    slots = (rounds + want - 1u) / want; if (slots == 0u) slots = 1u;
+    chunks = (rounds + slots - 1u) / slots;
+}
+
+hipError_t launch_init(const FrameArgs &a, hipStream_t st)
+{
+    const uint32_t np = a.ne * a.S;
+    hipLaunchKernelGGL(k_init, dim3((np + 255u) / 256u), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st)
+{
+    const uint32_t np = a.ne * a.S;                       // upper bound of live rays; surplus blocks read counts[b] and leave
+    const dim3 grid((np + 63u) / 64u), blk(256);
+    if (stats) hipLaunchKernelGGL((k_trace<true>), grid, blk, 0, st, a, b);
+    else hipLaunchKernelGGL((k_trace<false>), grid, blk, 0, st, a, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st)
+{
+    const uint32_t np = a.ne * a.S;
+    const dim3 grid((np + 255u) / 256u), blk(256);
+    if (stats) hipLaunchKernelGGL((k_shade<true>), grid, blk, 0, st, a, b);
+    else hipLaunchKernelGGL((k_shade<false>), grid, blk, 0, st, a, b);
+    return hipGetLastError();
+}
+
+// RF accumulation of the segments of bounces [b_begin, b_begin + n_bounces)
+hipError_t launch_march(const FrameArgs &a, uint32_t b_begin, uint32_t n_bounces, bool stats, hipStream_t st)
+{
+    uint32_t slots, chunks;
+    march_shape(a.S, n_bounces, a.ne, slots, chunks);
+    const dim3 grid(a.ne * chunks), blk(256);
+    const size_t lds = march_lds_bytes(a.R);
+    if (stats) hipLaunchKernelGGL((k_march<true>), grid, blk, lds, st, a, b_begin, n_bounces, slots, chunks);
+    else hipLaunchKernelGGL((k_march<false>), grid, blk, lds, st, a, b_begin, n_bounces, slots, chunks);
     return hipGetLastError();
 }
 

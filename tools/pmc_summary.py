@@ -13,7 +13,7 @@ for d in sorted(glob.glob(out + "/*/")):
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
-            if "k_trace<false, false, true>" in k:
+            if "k_trace<false>" in k:
                 for c, x in v.items():
                     res["pmc"][c] = {"avg_per_launch": sum(x) / len(x), "launches": len(x), "pass": os.path.basename(d.rstrip("/"))}
 json.dump(res, open(out + "/summary.json", "w"), indent=1)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# per-launch kernel durations of the last benchmark frame (rocprofv3 kernel trace)
+out=gpurun_out/timeline_$1; mkdir -p $out; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $out/kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > $out/bench.log 2>&1
+python3 - $out <<'PY'
+import csv, glob, sys
+out=sys.argv[1]
+f=glob.glob(out+'/kt/*/*kernel_trace.csv')[0]
+rows=list(csv.DictReader(open(f)))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+# last frame = from last k_init on
+idx=[i for i,r in enumerate(rows) if 'k_init' in r['Kernel_Name']]
+last=rows[idx[-1]:]
+t0=int(last[0]['Start_Timestamp'])
+for r in last:
+    n=r['Kernel_Name'].split('(')[0].replace('void mcrt::','').replace('mcrt::','')
+    print("%-28s start %9.1f us  dur %8.1f us  grid %s wg %s vgpr %s lds %s" % (n, (int(r['Start_Timestamp'])-t0)/1e3, (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3, r.get('Grid_Size_X',r.get('Grid_Size','')), r.get('Workgroup_Size_X',r.get('Workgroup_Size','')), r.get('VGPR_Count',''), r.get('LDS_Block_Size','')))
+PY
