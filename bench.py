@@ -85,14 +85,13 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
 
-    e0, e1 = rank * E_local, (rank + 1) * E_local
+    from mcray_tracing_amd.dist import shard_range, gather_rf
+    e0, e1 = shard_range(rank, world, E)
     rf_local = torch.zeros((E_local, R), dtype=torch.float32, device="cuda")
-    rf_full = torch.zeros((E, R), dtype=torch.float32, device="cuda") if world > 1 else rf_local
 
     def step(frame):
         ctx.trace_frame(frame, rf_local, e0, e1)
-        if world > 1:
-            dist.all_gather_into_tensor(rf_full, rf_local)      # RCCL over xGMI: E/N x R floats per rank
+        rf_full = gather_rf(rf_local, E, R, dist)               # RCCL all-gather over xGMI: E/N x R floats per rank
         if rank == 0:
             ctx.convolve(rf_full, E, R, psf.axial_kernel, psf.lateral_kernel)
 

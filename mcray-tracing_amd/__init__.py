@@ -8,5 +8,12 @@ from ._lib import load_library, build_library, McrtError, Params, MeshRec, BvhNo
 from .api import Context, Simulator, Transducer, Psf, host_build_bvh, host_build_bvh4, host_row_thresholds, host_texture, host_psf, host_transducer  # noqa: F401
 from . import synth, scene_io  # noqa: F401
 
+
+def __getattr__(name):          # torch is only needed by the multi-GPU helper
+    if name == "dist":
+        import importlib
+        return importlib.import_module("mcray_tracing_amd.dist")
+    raise AttributeError(name)
+
 __all__ = ["load_library", "build_library", "McrtError", "Params", "Context", "Simulator", "Transducer", "Psf",
            "synth", "scene_io", "host_build_bvh", "host_texture", "host_psf", "host_transducer"]

@@ -163,3 +163,129 @@ def test_reference_shape_512x5_and_tir_flag(mcrt, orc, tex256):
         assert np.array_equal(hits, o["hits"])
         _assert_rf(rf, o)
         sim.close()
+
+
+def test_liver_like_scene_vessels_and_thickness(mcrt, orc, tex256):
+    """the ircad11-like scene: vascular meshes (BLOOD), BONE thickness 0.3 (Box-Muller draw, scene.cpp:132-139), scaling 0.1,
+    rotated probe -- exercises every branch of the material-transition logic (ray.cpp:14-47)"""
+    cfg, meshes = mcrt.synth.liver_scene(3)
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    E, S = 48, 256
+    tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256)
+    hits, segs, cnt = sim.ctx.trace_frame_debug(5, sim.rf_dev, want_segs=True)
+    rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    nodes, btri, _ = sim.ctx.get_bvh()
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
+    osc.set_bvh4(sim.ctx.get_bvh4()[0])
+    p = orc.default_params(n_elements=E, n_samples=S)
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=5, use_bvh=2, n_threads=16, want_segs=True)
+    assert np.array_equal(hits, o["hits"]) and np.array_equal(cnt, o["seg_count"])
+    assert segs.tobytes() == o["segs"].tobytes()
+    assert (hits >= 0).sum() > E * S            # the scene is actually hit, several bounces deep
+    assert len(np.unique(o["segs"]["media"][o["segs"]["initial_intensity"] > 0])) >= 4
+    _assert_rf(rf, o)
+    sim.close()
+
+
+def test_random_triangle_soup_100k(mcrt, orc, tex256):
+    """BASELINE config 4's geometry at 100k triangles: incoherent secondary rays, deep BVH"""
+    cfg, meshes = mcrt.synth.random_scene(100000, 8, seed=99)
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    E, S = 32, 512
+    tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256)
+    hits, _, cnt = sim.ctx.trace_frame_debug(1, sim.rf_dev, want_segs=True)
+    rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    nodes, btri, _ = sim.ctx.get_bvh()
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
+    osc.set_bvh4(sim.ctx.get_bvh4()[0])
+    p = orc.default_params(n_elements=E, n_samples=S)
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=1, use_bvh=2, n_threads=16)
+    assert np.array_equal(hits, o["hits"])
+    _assert_rf(rf, o)
+    sim.close()
+
+
+def test_envelope_and_scan_conversion(mcrt, orc, sphere, tex256):
+    """the rest of a B-mode frame (SURVEY 8(f).1): rf_image::envelope (rfimage.h:54-91) and the polar->Cartesian remap
+    (rfimage.h:125-140,183-215; exact bilinear, maps computed on the host as the reference's constructor does)"""
+    cfg, sd = sphere
+    E, S = 128, 64
+    tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256, sanitize_tir=1)
+    sim.trace(0); sim.convolve()
+    img = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    sim.ctx.envelope(sim.rf_dev, E, sim.R)
+    env = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    ref_env = orc.envelope(img)
+    assert np.array_equal(env.view(np.uint32), ref_env.view(np.uint32))
+    out_dev = sim.ctx.alloc(400 * 500 * 4)
+    sim.ctx.scan_convert(sim.rf_dev, E, sim.R, out_dev)
+    sc = sim.ctx.d2h(out_dev, (400, 500))
+    ref_sc = orc.scan_convert(ref_env)
+    assert np.array_equal(sc.view(np.uint32), ref_sc.view(np.uint32))
+    assert np.count_nonzero(sc) > 10000
+    sim.ctx.free(out_dev)
+    sim.close()
+
+
+def test_user_texture_and_small_shapes(mcrt, orc):
+    """caller-supplied texture (non-finite voxels disable the silent-medium shortcut), odd sizes: E=3, S=7, R=100, B=3"""
+    cfg, meshes = mcrt.synth.sphere_scene(2)
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    rng = np.random.default_rng(3)
+    tex = rng.normal(size=(8, 8, 8, 2)).astype(np.float32)
+    tex[1, 2, 3, 0] = np.inf
+    E, S = 3, 7
+    tr = mcrt.Transducer(E, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
+    sim = mcrt.Simulator(sd, tr, n_samples=S, n_rows=100, texture=tex, tex_n=8, max_depth=3)
+    hits, _, _ = sim.ctx.trace_frame_debug(9, sim.rf_dev)
+    rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
+    p = orc.default_params(n_elements=E, n_samples=S, n_rows=100, max_depth=3, tex_n=8)
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=9)
+    assert hits.shape == (3, 7, 3) and np.array_equal(hits, o["hits"])
+    assert np.array_equal(rf.view(np.uint32), o["rf"].view(np.uint32))
+    sim.close()
+
+
+def test_error_paths(mcrt):
+    ctx = mcrt.Context(0)
+    with pytest.raises(mcrt.McrtError):
+        ctx.set_params(max_depth=99)
+    with pytest.raises(mcrt.McrtError):
+        ctx.set_params(n_rows=0)
+    dev = ctx.alloc(1024)
+    with pytest.raises(mcrt.McrtError) as e:
+        ctx.trace_frame(0, dev)
+    assert "no scene uploaded" in str(e.value)
+    ctx.free(dev)
+    ctx.close()
+
+
+def test_cpp_host_cli_matches_oracle(mcrt, orc, tex256, tmp_path):
+    """the C++ host mirror (host/mcrt_host.hpp: JSON scene file, OBJ meshes, transducer<512>, psf, rf_image) driven by the
+    mattausch_hip CLI with the reference's launch shape (512 x 5) against the oracle: trace + convolve + envelope"""
+    import json, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "mcray-tracing_amd", "mattausch_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "mcray-tracing_amd"), "mattausch_hip"])
+    cfg, meshes = mcrt.synth.sphere_scene(3)
+    cfg["workingDirectory"] = str(tmp_path) + "/"
+    for f, (V, F) in meshes.items():
+        mcrt.scene_io.save_obj(str(tmp_path / f), V, F)
+    (tmp_path / "sphere.scene").write_text(json.dumps(cfg))
+    r = subprocess.run([exe, str(tmp_path / "sphere.scene"), "3", "5", str(tmp_path / "bmode.pgm"), str(tmp_path / "rf.bin")],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rays/s" in r.stdout and (tmp_path / "bmode.pgm").stat().st_size == 15 + 400 * 500
+    got = np.fromfile(str(tmp_path / "rf.bin"), np.float32).reshape(465, 512)
+    sd = mcrt.scene_io.load_scene_file(str(tmp_path / "sphere.scene"))         # OBJ round trip, like the CLI
+    tr = mcrt.Transducer(512, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
+    p = orc.default_params()
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=2, n_threads=8)       # the CLI's last frame id
+    ax, lat = orc.psf()
+    ref = orc.envelope(orc.convolve(o["rf"], ax, lat))
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    bad = subprocess.run([exe, str(tmp_path / "missing.scene")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "The program found an error" in bad.stdout
