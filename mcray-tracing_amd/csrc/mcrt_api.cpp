@@ -360,7 +360,7 @@ static int ensure_work(mcrt_ctx *c, uint32_t ne)
     HIP_TRY(hipMalloc(&c->d_st0, 16 * np)); HIP_TRY(hipMalloc(&c->d_st1, 16 * np)); HIP_TRY(hipMalloc(&c->d_st2, 16 * np));
     HIP_TRY(hipMalloc(&c->d_ray0, 32 * np)); HIP_TRY(hipMalloc(&c->d_ray1, 32 * np)); HIP_TRY(hipMalloc(&c->d_hit, 32 * np));
     HIP_TRY(hipMalloc(&c->d_q0, 4 * np)); HIP_TRY(hipMalloc(&c->d_q1, 4 * np)); HIP_TRY(hipMalloc(&c->d_seg_count, 4 * np));
-    HIP_TRY(hipMalloc(&c->d_counts, 4 * (MCRT_MAX_BOUNCES + 1)));
+    HIP_TRY(hipMalloc(&c->d_counts, 4 * (2 * MCRT_MAX_BOUNCES + 1)));
     HIP_TRY(hipMalloc(&c->d_segs, sizeof(mcrt_segment) * np * B));
     c->work_paths = np; c->work_depth = B;
     return MCRT_OK;
@@ -376,6 +376,8 @@ static void fill_args(mcrt_ctx *c, mcrt::FrameArgs &a, uint32_t frame, uint32_t 
     a.stats = c->d_stats; a.error_flag = c->d_error;
     a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
     a.e_begin = e0; a.ne = e1 - e0;
+    a.trace_blocks = 1280;   // persistent k_trace: 5 waves/SIMD on 256 CUs; quads fetch further rays dynamically
+    if (const char *e = getenv("MCRT_TRACE_BLOCKS")) { int v = atoi(e); if (v >= 1) a.trace_blocks = (uint32_t)v; }   // tuning knob
     a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
     a.freq = c->p.frequency; a.eps = c->p.intensity_epsilon; a.I0 = c->p.initial_intensity; a.offs = c->p.ray_start_offset;

@@ -21,7 +21,7 @@ struct FrameArgs {
     uint32_t *queue0, *queue1; // [np] live path ids, ping-pong by bounce parity
     float4 *ray0, *ray1;       // [np][2] f2.xyz,to.x | to.yz,-,-   (indexed by queue position), ping-pong
     float4 *hit;               // [np][2] frac,tri,da,mesh | n.xyz,-  (indexed by queue position)
-    uint32_t *counts;          // [B+1] live rays per bounce
+    uint32_t *counts;          // [MAX_BOUNCES+1] live rays per bounce, then [MAX_BOUNCES] queue cursors of the persistent walk
     mcrt_segment *segs;        // [np][B]
     uint32_t *seg_count;       // [np]
     long long *acc;            // [ne][R] fixed-point RF accumulators (2^-52 units)
@@ -29,7 +29,7 @@ struct FrameArgs {
     unsigned long long *stats; // [6]
     uint32_t *error_flag;      // device word, bit 0: traversal stack overflow
     // sizes / parameters
-    uint32_t n_nodes, S, B, R, e_begin, ne, frame, seed, start_mat, tex_n, sanitize, tex_finite, fast_div;
+    uint32_t n_nodes, S, B, R, e_begin, ne, trace_blocks, frame, seed, start_mat, tex_n, sanitize, tex_finite, fast_div;
     float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs, tex_rcp;
     double axial_res_mm, time_step, row_dt, max_travel, sos_d, inv_row_dt;
 };

@@ -17,8 +17,11 @@
 #include "mcrt_detmath.h"
 #include "mcrt_kernels.h"
 
+#ifndef MCRT_FETCH_BATCH
+#define MCRT_FETCH_BATCH 16         // queue positions a wavefront of k_trace claims per atomic
+#endif
 #ifndef MCRT_TRACE_WAVES
-#define MCRT_TRACE_WAVES 8          // waves per SIMD k_trace's register allocation must allow
+#define MCRT_TRACE_WAVES 5          // waves per SIMD k_trace's register allocation must allow
 #endif
 #ifndef MCRT_LEAF_BATCH
 #define MCRT_LEAF_BATCH 4          // leave the inner-node phase once this many of a wave's 16 paths are parked on a leaf
@@ -240,6 +243,12 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
     const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t np = a.ne * a.S;
     if (pid == 0) { a.counts[0] = np; for (uint32_t b = 1; b <= a.B; b++) a.counts[b] = 0u; }
+    // queue cursors of the persistent k_trace launches live behind the counts: they start past the statically assigned rays
+    if (pid < MCRT_MAX_BOUNCES) {
+        const uint32_t upper = (pid == 0u) ? a.ne : np;                    // launch_trace()'s grid for bounce pid
+        const uint32_t blocks = (upper + 63u) / 64u;
+        a.counts[MCRT_MAX_BOUNCES + 1 + pid] = (blocks < a.trace_blocks ? blocks : a.trace_blocks) * 64u;
+    }
     if (pid >= np) return;
     const uint32_t e_abs = a.e_begin + pid / a.S;
     const f3 from = mk(a.el_pos[3 * e_abs], a.el_pos[3 * e_abs + 1], a.el_pos[3 * e_abs + 2]);
@@ -258,29 +267,69 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 // ---- closest hit: FOUR lanes (one DPP quad) own one ray; a wavefront holds 16 rays.  Each lane fetches ONE 32-byte
 // child record of the BVH4 node (the quad reads the node's 128 contiguous bytes), tests its box, and the quad ranks the
 // hit children with DPP exchanges; leaves hold <= 4 triangles, one per lane.  Traversal stacks live in LDS.
+// The kernel is PERSISTENT over the bounce's ray queue: a quad whose ray is finished writes its hit record and takes the
+// next unclaimed ray (wave-aggregated atomic on the queue cursor), so a wavefront's lanes do not idle behind its longest
+// walk.  Bounce 0 is special: every sample path of a scan-line starts as a copy of the same first_ray (scene.cpp:83-101),
+// so only ONE ray per scan-line is walked and k_shade hands the hit to all S samples.
 template <bool STATS>
 __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, uint32_t b)
 {
     __shared__ int stack[MCRT_STACK * 64];          // [MCRT_STACK][64 quads]: entry sp of quad q at sp*64 + q -> conflict-free
     const int tid = threadIdx.x, lane = tid & 63, j = tid & 3, q = tid >> 2;
-    const uint32_t n = a.counts[b];
-    const uint32_t i = blockIdx.x * 64u + (uint32_t)q;
+    const uint32_t n = (b == 0u) ? a.ne : a.counts[b];          // rays to walk in this launch
     if (blockIdx.x * 64u >= n) return;
     const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
-    bool walking = i < n && a.n_nodes != 0u;
-    f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1);
-    if (i < n) {
-        const float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
-        f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
-    }
+    const uint32_t ray_stride = (b == 0u) ? a.S : 1u;           // bounce 0: the first path of each scan-line stands for all
+    uint32_t *cursor = a.counts + MCRT_MAX_BOUNCES + 1 + b;      // next unclaimed queue position
     unsigned long long st_nodes = 0, st_tris = 0, st_q = 0;
+
+    uint32_t i = blockIdx.x * 64u + (uint32_t)q;                 // the first ray of each quad is assigned statically
+    bool walking = false, exhausted = false;
+    f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1), inv = mk(1, 1, 1);
     Hit best; best.frac = 1.0f; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
-    const f3 d = to - f2;
-    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     int sp = 0, cur = 0;
-    if (STATS && walking && j == 0) st_q++;
-    while (__any(walking)) {
-        // phase 1: inner nodes, until enough rays are parked on a leaf (their triangle code then runs once for all)
+    bool fresh = true;                                           // this quad needs a ray
+    uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
+    for (;;) {
+        // ---- (re)fill: quads without a ray take the next queue positions ----
+        const bool need = fresh && !exhausted;
+        const unsigned long long dynm = __ballot(need && i == 0xffffffffu && j == 0);
+        if (dynm) {
+            // dynamic fetch (after the static first assignment) from a wave-private pool of queue positions that is refilled
+            // MCRT_FETCH_BATCH at a time: one returning atomic per batch instead of one per finished ray
+            if (pool_next >= pool_end && !queue_empty) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, (uint32_t)MCRT_FETCH_BATCH);
+                base = __shfl(base, 0, 64);
+                pool_next = base; pool_end = base + MCRT_FETCH_BATCH;
+                if (base >= n) queue_empty = true;
+            }
+            if (need && i == 0xffffffffu) {
+                const uint32_t mine = pool_next + (uint32_t)__popcll(dynm & ((1ull << (lane & ~3)) - 1ull));
+                if (queue_empty) i = n;                                  // nothing left: this quad retires
+                else if (mine < pool_end) i = mine;                      // else: wait for the next batch (stay fresh)
+            }
+            const uint32_t taken = (uint32_t)__popcll(dynm);
+            pool_next = (pool_next + taken < pool_end) ? pool_next + taken : pool_end;
+        }
+        if (need && i != 0xffffffffu) {
+            if (i < n) {
+                const float4 r0 = rays[2 * (size_t)i * ray_stride], r1 = rays[2 * (size_t)i * ray_stride + 1];
+                f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
+                const f3 d = to - f2;
+                inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                best.frac = 1.0f; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
+                sp = 0; cur = 0; walking = a.n_nodes != 0u; fresh = false;
+                if (STATS && j == 0) st_q++;
+                if (!walking) {                                  // empty scene: every ray misses
+                    if (j == 0) { a.hit[2 * (size_t)i] = make_float4(1.0f, __int_as_float(-1), 0.0f, 0.0f); a.hit[2 * (size_t)i + 1] = make_float4(0, 0, 0, 0); }
+                    fresh = true; i = 0xffffffffu;
+                }
+            } else exhausted = true;
+        }
+        if (!__any(walking)) { if (!__any(fresh && !exhausted)) break; else continue; }
+
+        // ---- phase 1: inner nodes, until enough rays are parked on a leaf (their triangle code then runs once for all) ----
         for (;;) {
             const unsigned long long inner = __ballot(walking && cur >= 0);
             if (inner == 0ull) break;
@@ -293,29 +342,27 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                 float tn, tx;
                 const float tcap = fminf(1.0f, best.frac);
                 const bool hit = slab(mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), f2, inv, tcap, tn, tx) && ref != MCRT_BVH4_EMPTY;
-                const float inf = __int_as_float(0x7f800000);
-                const float key = hit ? tn : inf;
-                const float k0 = dpp_f<QP_BCAST(0)>(key), k1 = dpp_f<QP_BCAST(1)>(key), k2 = dpp_f<QP_BCAST(2)>(key), k3 = dpp_f<QP_BCAST(3)>(key);
-                const int nh = (k0 < inf) + (k1 < inf) + (k2 < inf) + (k3 < inf);
-                const int rank = ((k0 < key) || (k0 == key && 0 < j)) + ((k1 < key) || (k1 == key && 1 < j)) +
-                                 ((k2 < key) || (k2 == key && 2 < j)) + ((k3 < key) || (k3 == key && 3 < j));
+                // ordering key: t_near >= 0, so its bit pattern orders like the value; the two low bits carry the slot
+                // number, which makes the four keys distinct (visiting order only affects the work done, never the hit)
+                const uint32_t key = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)j) : 0xffffffffu;
+                const uint32_t k0 = (uint32_t)dpp_i<QP_BCAST(0)>((int)key), k1 = (uint32_t)dpp_i<QP_BCAST(1)>((int)key),
+                               k2 = (uint32_t)dpp_i<QP_BCAST(2)>((int)key), k3 = (uint32_t)dpp_i<QP_BCAST(3)>((int)key);
+                const int nh = (k0 != 0xffffffffu) + (k1 != 0xffffffffu) + (k2 != 0xffffffffu) + (k3 != 0xffffffffu);
+                const int rank = (k0 < key) + (k1 < key) + (k2 < key) + (k3 < key);
                 int cand = (hit && rank == 0) ? ref : 0;
                 cand |= dpp_i<QP_XOR1>(cand);
                 cand |= dpp_i<QP_XOR2>(cand);
                 if (nh == 0) {
                     if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
                     else walking = false;
-                } else if (sp + nh - 1 > MCRT_STACK) {
-                    if (j == 0) atomicOr(a.error_flag, 1u);      // cannot happen for a tree the builder accepted
-                    walking = false;
-                } else {
+                } else {                                       // mcrt_upload_scene rejected trees that need more than MCRT_STACK entries
                     if (hit && rank > 0) stack[(sp + nh - 1 - rank) * 64 + q] = ref;
                     sp += nh - 1;
                     cur = cand;
                 }
             }
         }
-        // phase 2: leaves -- lane j tests triangle j
+        // ---- phase 2: leaves -- lane j tests triangle j ----
         if (walking && cur < 0) {
             const uint32_t v = (uint32_t)~cur;
             const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
@@ -339,10 +386,14 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
             if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
             else walking = false;
         }
-    }
-    if (i < n && j == 0) {
-        a.hit[2 * (size_t)i] = make_float4(best.frac, __int_as_float(best.tri), best.da, __int_as_float(best.mesh));
-        a.hit[2 * (size_t)i + 1] = make_float4(best.n.x, best.n.y, best.n.z, 0.0f);
+        // ---- finished rays: write the hit record, ask for the next ray ----
+        if (!walking && !fresh && !exhausted) {
+            if (j == 0) {
+                a.hit[2 * (size_t)i] = make_float4(best.frac, __int_as_float(best.tri), best.da, __int_as_float(best.mesh));
+                a.hit[2 * (size_t)i + 1] = make_float4(best.n.x, best.n.y, best.n.z, 0.0f);
+            }
+            fresh = true; i = 0xffffffffu;
+        }
     }
     if (STATS) {
         unsigned long long v[3] = { st_q, st_nodes, st_tris };
@@ -381,7 +432,8 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
         outside = __float_as_int(s2.z);
         const float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
         const f3 f2 = mk(r0.x, r0.y, r0.z), to = mk(r0.w, r1.x, r1.y);
-        const float4 h0 = a.hit[2 * (size_t)i], h1 = a.hit[2 * (size_t)i + 1];
+        const size_t hi = (b == 0u) ? (size_t)(pid / a.S) : (size_t)i;          // bounce 0: one walk per scan-line (see k_trace)
+        const float4 h0 = a.hit[2 * hi], h1 = a.hit[2 * hi + 1];
         Hit best; best.frac = h0.x; best.tri = __float_as_int(h0.y); best.da = h0.z; best.mesh = __float_as_int(h0.w); best.n = mk(h1.x, h1.y, h1.z);
         const uint32_t e_abs = a.e_begin + pid / a.S;
         Rng g; g.k0 = a.seed; g.k1 = a.frame; g.element = e_abs; g.sample = pid % a.S; g.bounce = b;
@@ -785,8 +837,11 @@ hipError_t launch_init(const FrameArgs &a, hipStream_t st)
 
 hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st)
 {
-    const uint32_t np = a.ne * a.S;                       // upper bound of live rays; surplus blocks read counts[b] and leave
-    const dim3 grid((np + 63u) / 64u), blk(256);
+    // persistent over the bounce's queue: at most trace_blocks workgroups (the rest of the queue is fetched dynamically);
+    // the live-ray count is only known on the device, surplus blocks read it and leave
+    const uint32_t np = (b == 0u) ? a.ne : a.ne * a.S;
+    const uint32_t blocks = (np + 63u) / 64u;
+    const dim3 grid(blocks < a.trace_blocks ? blocks : a.trace_blocks), blk(256);
     if (stats) hipLaunchKernelGGL((k_trace<true>), grid, blk, 0, st, a, b);
     else hipLaunchKernelGGL((k_trace<false>), grid, blk, 0, st, a, b);
     return hipGetLastError();

@@ -475,19 +475,20 @@ static void walk_bvh4(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stat
         if (cur >= 0) {
             const orc_bvh4_child *N = nodes + 4 * (size_t)cur;
             nn++;
-            float key[4]; int32_t ref[4]; int nh = 0;
+            uint32_t key[4]; int32_t ref[4]; int nh = 0;
             float tcap = fminf(1.0f, best->frac);
             for (int k = 0; k < 4; k++) {
                 float hi[3] = { N[k].hix, N[k].hiy, N[k].hiz }, tn, tx;
                 int h = slab(N[k].lo, hi, from, inv, tcap, &tn, &tx) && N[k].ref != ORC_BVH4_EMPTY;
-                key[k] = h ? tn : INFINITY; ref[k] = N[k].ref; nh += h;
+                /* the kernel's ordering key: bits of t_near (>= 0) with the slot number in the two low bits */
+                key[k] = h ? ((f2u(tn) & ~3u) | (uint32_t)k) : 0xffffffffu; ref[k] = N[k].ref; nh += h;
             }
             if (nh > 0) {
                 int32_t next = 0;
                 for (int k = 0; k < 4; k++) {
-                    if (!(key[k] < INFINITY)) continue;
+                    if (key[k] == 0xffffffffu) continue;
                     int rank = 0;
-                    for (int m = 0; m < 4; m++) rank += (key[m] < key[k]) || (key[m] == key[k] && m < k);
+                    for (int m = 0; m < 4; m++) rank += key[m] < key[k];
                     if (rank == 0) next = ref[k];
                     else if (sp + nh - 1 - rank < ORC_STACK) stack[sp + nh - 1 - rank] = ref[k];
                 }

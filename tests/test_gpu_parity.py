@@ -124,8 +124,15 @@ def test_c2_sphere_128x1024_depth512(mcrt, orc, sphere, tex256):
     sim.ctx.enable_stats(True); sim.ctx.get_stats(reset=True)
     sim.trace(3); st = sim.ctx.get_stats()
     sim.ctx.enable_stats(False)
-    for k in ("queries", "nodes_visited", "tris_tested", "segments", "hits"):
+    # bounce 0 is walked once per scan-line on the GPU (all S samples start as copies of first_ray, scene.cpp:83-101)
+    p0 = orc.default_params(n_elements=E, n_samples=S, n_rows=512, max_depth=1)
+    o0 = osc.trace_frame(p0, tr.pos, tr.dir, tex256, frame_id=3, use_bvh=2, n_threads=16, want_ref=False, want_fix=False)["stats"]
+    for k in ("queries", "nodes_visited", "tris_tested"):
+        assert o0[k] % S == 0
+        assert st[k] == o["stats"][k] - o0[k] + o0[k] // S, k
+    for k in ("segments", "hits"):
         assert st[k] == o["stats"][k], k
+    assert 0 < st["rf_steps"] <= o["stats"]["rf_steps"]      # the GPU skips the steps of silent media (mu0 = sigma = 0): exact no-ops
     sim.close()
 
 
