@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 namespace mcrt {
 static thread_local std::string g_err;
@@ -59,6 +60,7 @@ struct mcrt_ctx {
     float4 *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr;
     uint4 *d_meshes = nullptr;
     uint32_t n_mesh = 0, n_mat = 0, start_mat = 0;
+    float scene_lo[3] = { 0, 0, 0 }, scene_hi[3] = { 0, 0, 0 };
     float spacing[3] = { 1, 1, 1 };
     bool have_scene = false;
     // texture
@@ -242,6 +244,13 @@ extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *
         if (rc) return rc;
         rc = mcrt_build_bvh4(&c->bvh, &c->bvh4);
         if (rc) return rc;
+        for (int i = 0; i < 3; i++) { c->scene_lo[i] = INFINITY; c->scene_hi[i] = -INFINITY; }
+        for (int k = 0; k < 4; k++) {
+            const mcrt_bvh4_child &ch = c->bvh4.nodes[0].c[k];
+            if (ch.ref == MCRT_BVH4_EMPTY) continue;
+            const float hi[3] = { ch.hi_x, ch.hi_y, ch.hi_z };
+            for (int i = 0; i < 3; i++) { c->scene_lo[i] = std::min(c->scene_lo[i], ch.lo[i]); c->scene_hi[i] = std::max(c->scene_hi[i], hi[i]); }
+        }
         if (c->bvh4.max_stack > MCRT_STACK)
             return set_error(MCRT_ERR_LIMIT, "BVH4 needs a %u-entry traversal stack, the kernel has %d", c->bvh4.max_stack, MCRT_STACK);
         HIP_TRY(hipMalloc(&c->d_nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes));
@@ -358,7 +367,7 @@ static int ensure_work(mcrt_ctx *c, uint32_t ne)
     free_work(c);
     const uint32_t B = c->p.max_depth;
     HIP_TRY(hipMalloc(&c->d_st0, 16 * np)); HIP_TRY(hipMalloc(&c->d_st1, 16 * np)); HIP_TRY(hipMalloc(&c->d_st2, 16 * np));
-    HIP_TRY(hipMalloc(&c->d_ray0, 32 * np)); HIP_TRY(hipMalloc(&c->d_ray1, 32 * np)); HIP_TRY(hipMalloc(&c->d_hit, 32 * np));
+    HIP_TRY(hipMalloc(&c->d_ray0, 32 * np)); HIP_TRY(hipMalloc(&c->d_ray1, 32 * np)); HIP_TRY(hipMalloc(&c->d_hit, 32 * std::max(np, (size_t)MCRT_KSPLIT_MAX)));
     HIP_TRY(hipMalloc(&c->d_q0, 4 * np)); HIP_TRY(hipMalloc(&c->d_q1, 4 * np)); HIP_TRY(hipMalloc(&c->d_seg_count, 4 * np));
     HIP_TRY(hipMalloc(&c->d_counts, 4 * (2 * MCRT_MAX_BOUNCES + 1)));
     HIP_TRY(hipMalloc(&c->d_segs, sizeof(mcrt_segment) * np * B));
@@ -376,6 +385,9 @@ static void fill_args(mcrt_ctx *c, mcrt::FrameArgs &a, uint32_t frame, uint32_t 
     a.stats = c->d_stats; a.error_flag = c->d_error;
     a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
     a.e_begin = e0; a.ne = e1 - e0;
+    a.ksplit_limit = MCRT_KSPLIT_DEFAULT;   // bounces with fewer rays than this are cut into pieces (see k_trace)
+    if (const char *e = getenv("MCRT_KSPLIT_LIMIT")) { long v = atol(e); if (v >= 0 && v <= MCRT_KSPLIT_MAX) a.ksplit_limit = (uint32_t)v; }   // tuning knob; 0 = off
+    for (int i = 0; i < 3; i++) { a.scene_lo[i] = c->scene_lo[i]; a.scene_hi[i] = c->scene_hi[i]; }
     a.trace_blocks = 1280;   // persistent k_trace: 5 waves/SIMD on 256 CUs; quads fetch further rays dynamically
     if (const char *e = getenv("MCRT_TRACE_BLOCKS")) { int v = atoi(e); if (v >= 1) a.trace_blocks = (uint32_t)v; }   // tuning knob
     a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n;

@@ -4,6 +4,8 @@
 
 #define MCRT_BVH_MAX_DEPTH 32      // deepest leaf the builder may emit == traversal stack entries per lane
 #define MCRT_STACK 64              // BVH4 traversal stack entries per path (LDS); trees needing more are rejected at upload
+#define MCRT_KSPLIT_DEFAULT 131072 // work items a small bounce of k_trace is cut into (pieces x rays)
+#define MCRT_KSPLIT_MAX 1048576
 #define MCRT_MAX_ROWS 2048
 #define MCRT_MAX_BOUNCES 16
 

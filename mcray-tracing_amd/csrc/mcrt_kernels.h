@@ -20,7 +20,7 @@ struct FrameArgs {
     float4 *st0, *st1, *st2;   // [np] path state: from,intensity | dir,media | distance_traveled(f64),outside,-
     uint32_t *queue0, *queue1; // [np] live path ids, ping-pong by bounce parity
     float4 *ray0, *ray1;       // [np][2] f2.xyz,to.x | to.yz,-,-   (indexed by queue position), ping-pong
-    float4 *hit;               // [np][2] frac,tri,da,mesh | n.xyz,-  (indexed by queue position)
+    float4 *hit;               // [max(np, ksplit_limit)][2] frac,tri,da,mesh | n.xyz,-  (indexed by work item = piece * n_rays + queue position)
     uint32_t *counts;          // [MAX_BOUNCES+1] live rays per bounce, then [MAX_BOUNCES] queue cursors of the persistent walk
     mcrt_segment *segs;        // [np][B]
     uint32_t *seg_count;       // [np]
@@ -29,7 +29,8 @@ struct FrameArgs {
     unsigned long long *stats; // [6]
     uint32_t *error_flag;      // device word, bit 0: traversal stack overflow
     // sizes / parameters
-    uint32_t n_nodes, S, B, R, e_begin, ne, trace_blocks, frame, seed, start_mat, tex_n, sanitize, tex_finite, fast_div;
+    uint32_t n_nodes, S, B, R, e_begin, ne, trace_blocks, ksplit_limit, frame, seed, start_mat, tex_n, sanitize, tex_finite, fast_div;
+    float scene_lo[3], scene_hi[3];   // bounds of the whole BVH
     float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs, tex_rcp;
     double axial_res_mm, time_step, row_dt, max_travel, sos_d, inv_row_dt;
 };

@@ -46,13 +46,13 @@ constexpr int OUT_SELF = -2;   // media_outside aliases the ray's own media (ray
 
 struct Hit { float frac; int tri; int mesh; f3 n; float da; };
 
-// ray parameter interval [tmin,tmax] (clamped to [0,tcap]) in which o + t*d lies inside the box
-MCRT_DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tcap, float &tmin_o, float &tmax_o)
+// ray parameter interval [tmin,tmax] (clamped to [tlow,tcap]) in which o + t*d lies inside the box
+MCRT_DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tlow, float tcap, float &tmin_o, float &tmax_o)
 {
     float t0x = (lo.x - o.x) * inv.x, t1x = (hi.x - o.x) * inv.x;
     float t0y = (lo.y - o.y) * inv.y, t1y = (hi.y - o.y) * inv.y;
     float t0z = (lo.z - o.z) * inv.z, t1z = (hi.z - o.z) * inv.z;
-    float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+    float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tlow));
     float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tcap));
     tmin_o = tmin; tmax_o = tmax;
     return tmin <= tmax;
@@ -60,7 +60,7 @@ MCRT_DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tcap, float &tmin_o, float 
 
 // btTriangleRaycastCallback::processTriangle (Bullet) behind the triangle's own padded-bounds test; contract
 // rules: the fraction must lie inside the ray's overlap with those bounds; ties -> smaller triangle id.
-MCRT_DEV void tri_test(f3 v0, f3 v1, f3 v2, int id, int mesh, f3 from, f3 to, f3 inv, float pad_abs, Hit &best)
+MCRT_DEV void tri_test(f3 v0, f3 v1, f3 v2, int id, int mesh, f3 from, f3 to, f3 inv, float pad_abs, float t_lo, Hit &best)
 {
     f3 v10 = v1 - v0, v20 = v2 - v0;
     f3 n = cross(v10, v20);
@@ -78,8 +78,8 @@ MCRT_DEV void tri_test(f3 v0, f3 v1, f3 v2, int id, int mesh, f3 from, f3 to, f3
         lo = mk(lo.x - pad, lo.y - pad, lo.z - pad);
         hi = mk(hi.x + pad, hi.y + pad, hi.z + pad);
         float tmin, tmax;
-        if (!slab(lo, hi, from, inv, 1.0f, tmin, tmax)) return;
-        if (!(frac >= tmin && frac <= tmax)) return;
+        if (!slab(lo, hi, from, inv, 0.0f, 1.0f, tmin, tmax)) return;
+        if (!(frac >= tmin && frac <= tmax && frac >= t_lo)) return;
         float edge_tol = dot(n, n) * -0.0001f;
         float s = 1.0f - frac;
         f3 p = mk(s * from.x + frac * to.x, s * from.y + frac * to.y, s * from.z + frac * to.z);
@@ -227,6 +227,14 @@ MCRT_DEV void rf_add(long long *bins, uint32_t *lflags, int row, float echo)
 
 struct Ray { f3 f2, to; };
 
+// pieces per ray for a bounce with n rays: the largest power of two <= limit / n, at most 16 (1 when the bounce is large)
+MCRT_DEV uint32_t ksplit(uint32_t n, uint32_t limit)
+{
+    uint32_t k = 1u;
+    while (k < 16u && n * (k * 2u) <= limit) k *= 2u;
+    return k;
+}
+
 // max_ray_length (ray.cpp:110-113) + enlarge (scene.cpp:292-298) + the 0.1 start offset (scene.cpp:115)
 MCRT_DEV Ray make_ray(f3 from, f3 dir, float intensity, float att, const FrameArgs &a)
 {
@@ -245,7 +253,8 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
     if (pid == 0) { a.counts[0] = np; for (uint32_t b = 1; b <= a.B; b++) a.counts[b] = 0u; }
     // queue cursors of the persistent k_trace launches live behind the counts: they start past the statically assigned rays
     if (pid < MCRT_MAX_BOUNCES) {
-        const uint32_t upper = (pid == 0u) ? a.ne : np;                    // launch_trace()'s grid for bounce pid
+        uint32_t upper = (pid == 0u) ? a.ne : np;                          // launch_trace()'s grid for bounce pid
+        if (upper < a.ksplit_limit) upper = a.ksplit_limit;
         const uint32_t blocks = (upper + 63u) / 64u;
         a.counts[MCRT_MAX_BOUNCES + 1 + pid] = (blocks < a.trace_blocks ? blocks : a.trace_blocks) * 64u;
     }
@@ -276,7 +285,13 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 {
     __shared__ int stack[MCRT_STACK * 64];          // [MCRT_STACK][64 quads]: entry sp of quad q at sp*64 + q -> conflict-free
     const int tid = threadIdx.x, lane = tid & 63, j = tid & 3, q = tid >> 2;
-    const uint32_t n = (b == 0u) ? a.ne : a.counts[b];          // rays to walk in this launch
+    const uint32_t n_rays = (b == 0u) ? a.ne : a.counts[b];     // rays to walk in this launch
+    // When a bounce has far fewer rays than the GPU has lanes, each ray is cut into K sub-ranges of its parameter interval
+    // inside the scene bounds and the K pieces are walked by K different quads: the launch then lasts as long as the longest
+    // PIECE instead of the longest ray.  Sub-ranges are half-open and partition [0,1), so the minimum (fraction, id) over
+    // the pieces (taken in k_shade) is exactly the single-walk answer.
+    const uint32_t K = ksplit(n_rays, a.ksplit_limit);
+    const uint32_t n = n_rays * K;                              // work items
     if (blockIdx.x * 64u >= n) return;
     const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
     const uint32_t ray_stride = (b == 0u) ? a.S : 1u;           // bounce 0: the first path of each scan-line stands for all
@@ -286,6 +301,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
     uint32_t i = blockIdx.x * 64u + (uint32_t)q;                 // the first ray of each quad is assigned statically
     bool walking = false, exhausted = false;
     f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1), inv = mk(1, 1, 1);
+    float t_lo = 0.0f;
     Hit best; best.frac = 1.0f; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
     int sp = 0, cur = 0;
     bool fresh = true;                                           // this quad needs a ray
@@ -314,14 +330,25 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
         }
         if (need && i != 0xffffffffu) {
             if (i < n) {
-                const float4 r0 = rays[2 * (size_t)i * ray_stride], r1 = rays[2 * (size_t)i * ray_stride + 1];
+                const uint32_t ray = i % n_rays, piece = i / n_rays;     // the pieces of one ray land in different wavefronts
+                const float4 r0 = rays[2 * (size_t)ray * ray_stride], r1 = rays[2 * (size_t)ray * ray_stride + 1];
                 f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
                 const f3 d = to - f2;
                 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                best.frac = 1.0f; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
-                sp = 0; cur = 0; walking = a.n_nodes != 0u; fresh = false;
-                if (STATS && j == 0) st_q++;
-                if (!walking) {                                  // empty scene: every ray misses
+                t_lo = 0.0f;
+                float t_hi = 1.0f;
+                if (K > 1u) {
+                    float tin, tout;
+                    if (slab(mk(a.scene_lo[0], a.scene_lo[1], a.scene_lo[2]), mk(a.scene_hi[0], a.scene_hi[1], a.scene_hi[2]), f2, inv, 0.0f, 1.0f, tin, tout)) {
+                        const float w = tout - tin;
+                        if (piece > 0u) t_lo = tin + w * ((float)piece / (float)K);
+                        if (piece + 1u < K) t_hi = tin + w * ((float)(piece + 1u) / (float)K);
+                    } else if (piece > 0u) t_hi = 0.0f;                  // the ray misses the scene: piece 0 reports the miss
+                }
+                best.frac = t_hi; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
+                sp = 0; cur = 0; walking = a.n_nodes != 0u && t_lo < t_hi; fresh = false;
+                if (STATS && j == 0 && piece == 0u) st_q++;
+                if (!walking) {                                  // empty scene or empty piece: a miss
                     if (j == 0) { a.hit[2 * (size_t)i] = make_float4(1.0f, __int_as_float(-1), 0.0f, 0.0f); a.hit[2 * (size_t)i + 1] = make_float4(0, 0, 0, 0); }
                     fresh = true; i = 0xffffffffu;
                 }
@@ -341,7 +368,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                 const int ref = __float_as_int(B.z);
                 float tn, tx;
                 const float tcap = fminf(1.0f, best.frac);
-                const bool hit = slab(mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), f2, inv, tcap, tn, tx) && ref != MCRT_BVH4_EMPTY;
+                const bool hit = slab(mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), f2, inv, t_lo, tcap, tn, tx) && ref != MCRT_BVH4_EMPTY;
                 // ordering key: t_near >= 0, so its bit pattern orders like the value; the two low bits carry the slot
                 // number, which makes the four keys distinct (visiting order only affects the work done, never the hit)
                 const uint32_t key = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)j) : 0xffffffffu;
@@ -370,7 +397,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
             for (uint32_t k = (uint32_t)j; k < cnt; k += 4u) {
                 const float4 *T = a.tris + 3 * (size_t)(first + k);
                 const float4 t0 = T[0], t1 = T[1], t2 = T[2];
-                tri_test(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), __float_as_int(t1.w), f2, to, inv, a.pad_abs, mine);
+                tri_test(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), __float_as_int(t1.w), f2, to, inv, a.pad_abs, t_lo, mine);
             }
             if (STATS && j == 0) st_tris += cnt;
 #define MCRT_QUAD_MIN(CTRL)                                                                                             \
@@ -432,9 +459,17 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
         outside = __float_as_int(s2.z);
         const float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
         const f3 f2 = mk(r0.x, r0.y, r0.z), to = mk(r0.w, r1.x, r1.y);
+        const uint32_t n_rays = (b == 0u) ? a.ne : n;
+        const uint32_t K = ksplit(n_rays, a.ksplit_limit);
         const size_t hi = (b == 0u) ? (size_t)(pid / a.S) : (size_t)i;          // bounce 0: one walk per scan-line (see k_trace)
-        const float4 h0 = a.hit[2 * hi], h1 = a.hit[2 * hi + 1];
-        Hit best; best.frac = h0.x; best.tri = __float_as_int(h0.y); best.da = h0.z; best.mesh = __float_as_int(h0.w); best.n = mk(h1.x, h1.y, h1.z);
+        Hit best; best.frac = 1.0f; best.tri = -1; best.da = 0.0f; best.mesh = 0; best.n = mk(0, 0, 0);
+        for (uint32_t k = 0; k < K; k++) {                                       // closest over the ray's pieces
+            const float4 h0 = a.hit[2 * (hi + (size_t)k * n_rays)], h1 = a.hit[2 * (hi + (size_t)k * n_rays) + 1];
+            const int tri = __float_as_int(h0.y);
+            if (tri >= 0 && (h0.x < best.frac || (h0.x == best.frac && tri < best.tri) || best.tri < 0)) {
+                best.frac = h0.x; best.tri = tri; best.da = h0.z; best.mesh = __float_as_int(h0.w); best.n = mk(h1.x, h1.y, h1.z);
+            }
+        }
         const uint32_t e_abs = a.e_begin + pid / a.S;
         Rng g; g.k0 = a.seed; g.k1 = a.frame; g.element = e_abs; g.sample = pid % a.S; g.bounce = b;
         const float4 m0 = a.mats[2 * media];   // imp, att, mu0, mu1  (second half: sigma, spec, shine, thick)
@@ -614,23 +649,39 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b_begin, ui
         uint32_t step = 0;
         bool more = seg_valid && !silent && steps > 0u && t < a.max_travel;
         while (__any(more)) {
-            f3 myp = point; double myt = t; float myin = inten; bool myv = false;
+            // eight consecutive steps per iteration: lane j owns steps j and j+4, so two independent texture gathers per
+            // lane (eight per segment) are in flight; every lane replays the cheap sequential recurrence (point, t, intensity)
+            f3 myp[2]; double myt[2]; float myin[2]; bool myv[2];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const bool vu = more && (step + (uint32_t)u < steps) && (t < a.max_travel);   // the reference's loop test
-                if (u == j) { myp = point; myt = t; myin = inten; myv = vu; }
-                point = point + delta;                                                       // ... and its loop tail
-                t = t + a.time_step;
-                inten *= k_att;
+            for (int h = 0; h < 2; h++) {
+                myp[h] = point; myt[h] = t; myin[h] = inten; myv[h] = false;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool vu = more && (step + (uint32_t)(4 * h + u) < steps) && (t < a.max_travel);   // the reference's loop test
+                    if (u == j) { myp[h] = point; myt[h] = t; myin[h] = inten; myv[h] = vu; }
+                    point = point + delta;                                                                 // ... and its loop tail
+                    t = t + a.time_step;
+                    inten *= k_att;
+                }
             }
-            step += 4u;
+            step += 8u;
             more = more && step < steps && t < a.max_travel;
-            if (myv) {
-                const uint32_t vx = vox_index(div_res(myp.x, a), a.tex_n), vy = vox_index(div_res(myp.y, a), a.tex_n), vz = vox_index(div_res(myp.z, a), a.tex_n);
-                const float2 vox = a.tex[((size_t)vx * a.tex_n + vy) * a.tex_n + vz];
-                const float scattering = vox.y >= s0.w ? vox.x * s1.x + s0.z : 0.0f;
-                rf_add(bins, lflags, row_of(myt, thr, R, a.inv_row_dt), myin * scattering);
-                if (STATS) st_steps++;
+            float2 vox[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                vox[h] = make_float2(0.0f, 0.0f);
+                if (myv[h]) {
+                    const uint32_t vx = vox_index(div_res(myp[h].x, a), a.tex_n), vy = vox_index(div_res(myp[h].y, a), a.tex_n), vz = vox_index(div_res(myp[h].z, a), a.tex_n);
+                    vox[h] = a.tex[((size_t)vx * a.tex_n + vy) * a.tex_n + vz];
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (myv[h]) {
+                    const float scattering = vox[h].y >= s0.w ? vox[h].x * s1.x + s0.z : 0.0f;
+                    rf_add(bins, lflags, row_of(myt[h], thr, R, a.inv_row_dt), myin[h] * scattering);
+                    if (STATS) st_steps++;
+                }
             }
         }
         // boundary echo main.cpp:139
@@ -839,7 +890,8 @@ hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
 {
     // persistent over the bounce's queue: at most trace_blocks workgroups (the rest of the queue is fetched dynamically);
     // the live-ray count is only known on the device, surplus blocks read it and leave
-    const uint32_t np = (b == 0u) ? a.ne : a.ne * a.S;
+    uint32_t np = (b == 0u) ? a.ne : a.ne * a.S;
+    if (np < a.ksplit_limit) np = a.ksplit_limit;          // small bounces are cut into up to ksplit_limit pieces
     const uint32_t blocks = (np + 63u) / 64u;
     const dim3 grid(blocks < a.trace_blocks ? blocks : a.trace_blocks), blk(256);
     if (stats) hipLaunchKernelGGL((k_trace<true>), grid, blk, 0, st, a, b);
