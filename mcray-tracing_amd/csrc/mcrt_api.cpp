@@ -155,7 +155,7 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     mcrt_default_params(&c->p);
     c->c = derive_consts(c->p);
     c->stream = c->own_stream;
-    if (hipMalloc(&c->d_stats, 6 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_stats, 0, 6 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc(&c->d_stats, 32 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_stats, 0, 32 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_error, 4) != hipSuccess || hipMemset(c->d_error, 0, 4) != hipSuccess) {
         hipStreamDestroy(c->own_stream); delete c; return set_error(MCRT_ERR_HIP, "hipMalloc failed");
     }
@@ -382,7 +382,7 @@ static void fill_args(mcrt_ctx *c, mcrt::FrameArgs &a, uint32_t frame, uint32_t 
     a.el_pos = c->d_pos; a.el_dir = c->d_dir; a.acc = c->d_acc; a.flags = c->d_flags; a.row_thr = c->d_row_thr;
     a.st0 = c->d_st0; a.st1 = c->d_st1; a.st2 = c->d_st2; a.queue0 = c->d_q0; a.queue1 = c->d_q1;
     a.ray0 = c->d_ray0; a.ray1 = c->d_ray1; a.hit = c->d_hit; a.counts = c->d_counts; a.segs = c->d_segs; a.seg_count = c->d_seg_count;
-    a.stats = c->d_stats; a.error_flag = c->d_error;
+    a.stats = c->d_stats; a.error_flag = c->d_error; a.stamps = c->d_stats + 8;
     a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
     a.e_begin = e0; a.ne = e1 - e0;
     a.ksplit_limit = MCRT_KSPLIT_DEFAULT;   // bounces with fewer rays than this are cut into pieces (see k_trace)
@@ -604,6 +604,16 @@ extern "C" int mcrt_get_stats(mcrt_ctx *c, mcrt_stats *out, int reset)
     HIP_TRY(hipMemcpy(v, c->d_stats, sizeof v, hipMemcpyDeviceToHost));
     if (out) { out->queries = v[0]; out->nodes_visited = v[1]; out->tris_tested = v[2]; out->segments = v[3]; out->rf_steps = v[4]; out->hits = v[5]; }
     if (reset) HIP_TRY(hipMemset(c->d_stats, 0, sizeof v));
+    return MCRT_OK;
+}
+
+// diagnostic builds (-DMCRT_STAMP): per-phase cycle sums of k_trace; zeros otherwise
+extern "C" int mcrt_debug_stamps(mcrt_ctx *c, uint64_t out[16], int reset)
+{
+    CTX_TRY(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->d_stats + 8, 16 * 8, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(c->d_stats + 8, 0, 16 * 8));
     return MCRT_OK;
 }
 

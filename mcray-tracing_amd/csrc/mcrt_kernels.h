@@ -28,6 +28,7 @@ struct FrameArgs {
     uint32_t *flags;           // [ne][(R+31)/32] non-finite flags
     unsigned long long *stats; // [6]
     uint32_t *error_flag;      // device word, bit 0: traversal stack overflow
+    unsigned long long *stamps; // [16] diagnostic build (-DMCRT_STAMP) only
     // sizes / parameters
     uint32_t n_nodes, S, B, R, e_begin, ne, trace_blocks, ksplit_limit, frame, seed, start_mat, tex_n, sanitize, tex_finite, fast_div;
     float scene_lo[3], scene_hi[3];   // bounds of the whole BVH

@@ -17,6 +17,9 @@
 #include "mcrt_detmath.h"
 #include "mcrt_kernels.h"
 
+#ifndef MCRT_REFILL_MIN
+#define MCRT_REFILL_MIN 2           // hand out new rays as soon as this many of a wave's 16 quads have none
+#endif
 #ifndef MCRT_FETCH_BATCH
 #define MCRT_FETCH_BATCH 16         // queue positions a wavefront of k_trace claims per atomic
 #endif
@@ -305,62 +308,81 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
     Hit best; best.frac = 1.0f; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
     int sp = 0, cur = 0;
     bool fresh = true;                                           // this quad needs a ray
+#ifdef MCRT_STAMP
+    unsigned long long sc_refill = 0, sc_p1 = 0, sc_p2 = 0, sc_n1 = 0, sc_n2 = 0, sc_outer = 0, sc_t0 = __builtin_readcyclecounter(), sc_act1 = 0, sc_act2 = 0;
+#define STAMP(var) { const unsigned long long t_ = __builtin_readcyclecounter(); var += t_ - sc_t0; sc_t0 = t_; }
+#else
+#define STAMP(var)
+#endif
     uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
+    // One wave-uniform decision per iteration: (1) hand rays to quads that have none, (2) test the parked leaves once enough
+    // rays wait on one (or nothing else can run), (3) otherwise one inner-node step for every ray that is on an inner node.
     for (;;) {
-        // ---- (re)fill: quads without a ray take the next queue positions ----
-        const bool need = fresh && !exhausted;
-        const unsigned long long dynm = __ballot(need && i == 0xffffffffu && j == 0);
-        if (dynm) {
-            // dynamic fetch (after the static first assignment) from a wave-private pool of queue positions that is refilled
-            // MCRT_FETCH_BATCH at a time: one returning atomic per batch instead of one per finished ray
-            if (pool_next >= pool_end && !queue_empty) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, (uint32_t)MCRT_FETCH_BATCH);
-                base = __shfl(base, 0, 64);
-                pool_next = base; pool_end = base + MCRT_FETCH_BATCH;
-                if (base >= n) queue_empty = true;
+        // finished rays: write the hit record, ask for the next ray
+        if (!walking && !fresh && !exhausted) {
+            if (j == 0) {
+                a.hit[2 * (size_t)i] = make_float4(best.frac, __int_as_float(best.tri), best.da, __int_as_float(best.mesh));
+                a.hit[2 * (size_t)i + 1] = make_float4(best.n.x, best.n.y, best.n.z, 0.0f);
             }
-            if (need && i == 0xffffffffu) {
-                const uint32_t mine = pool_next + (uint32_t)__popcll(dynm & ((1ull << (lane & ~3)) - 1ull));
-                if (queue_empty) i = n;                                  // nothing left: this quad retires
-                else if (mine < pool_end) i = mine;                      // else: wait for the next batch (stay fresh)
+            fresh = true; i = 0xffffffffu;
+        }
+        const unsigned long long m_inner = __ballot(walking && cur >= 0);
+        const unsigned long long m_leaf = __ballot(walking && cur < 0);
+        const unsigned long long m_need = __ballot(fresh && !exhausted);
+        if (m_need && (__popcll(m_need) >= 4 * MCRT_REFILL_MIN || (m_inner | m_leaf) == 0ull)) {
+            // ---- (re)fill: quads without a ray take the next queue positions ----
+            const bool need = fresh && !exhausted;
+            const unsigned long long dynm = __ballot(need && i == 0xffffffffu && j == 0);
+            if (dynm) {
+                // dynamic fetch (after the static first assignment) from a wave-private pool of queue positions that is refilled
+                // MCRT_FETCH_BATCH at a time: one returning atomic per batch instead of one per finished ray
+                if (pool_next >= pool_end && !queue_empty) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(cursor, (uint32_t)MCRT_FETCH_BATCH);
+                    base = __shfl(base, 0, 64);
+                    pool_next = base; pool_end = base + MCRT_FETCH_BATCH;
+                    if (base >= n) queue_empty = true;
+                }
+                if (need && i == 0xffffffffu) {
+                    const uint32_t mine = pool_next + (uint32_t)__popcll(dynm & ((1ull << (lane & ~3)) - 1ull));
+                    if (queue_empty) i = n;                                  // nothing left: this quad retires
+                    else if (mine < pool_end) i = mine;                      // else: wait for the next batch (stay fresh)
+                }
+                const uint32_t taken = (uint32_t)__popcll(dynm);
+                pool_next = (pool_next + taken < pool_end) ? pool_next + taken : pool_end;
             }
-            const uint32_t taken = (uint32_t)__popcll(dynm);
-            pool_next = (pool_next + taken < pool_end) ? pool_next + taken : pool_end;
+            if (need && i != 0xffffffffu) {
+                if (i < n) {
+                    const uint32_t ray = i % n_rays, piece = i / n_rays;     // the pieces of one ray land in different wavefronts
+                    const float4 r0 = rays[2 * (size_t)ray * ray_stride], r1 = rays[2 * (size_t)ray * ray_stride + 1];
+                    f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
+                    const f3 d = to - f2;
+                    inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    t_lo = 0.0f;
+                    float t_hi = 1.0f;
+                    if (K > 1u) {
+                        float tin, tout;
+                        if (slab(mk(a.scene_lo[0], a.scene_lo[1], a.scene_lo[2]), mk(a.scene_hi[0], a.scene_hi[1], a.scene_hi[2]), f2, inv, 0.0f, 1.0f, tin, tout)) {
+                            const float w = tout - tin;
+                            if (piece > 0u) t_lo = tin + w * ((float)piece / (float)K);
+                            if (piece + 1u < K) t_hi = tin + w * ((float)(piece + 1u) / (float)K);
+                        } else if (piece > 0u) t_hi = 0.0f;                  // the ray misses the scene: piece 0 reports the miss
+                    }
+                    best.frac = t_hi; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
+                    sp = 0; cur = 0; walking = a.n_nodes != 0u && t_lo < t_hi; fresh = false;   // (not walking: an immediate miss, written at the loop top)
+                    if (STATS && j == 0 && piece == 0u) st_q++;
+                } else exhausted = true;
+            }
+            STAMP(sc_refill)
+            continue;
         }
-        if (need && i != 0xffffffffu) {
-            if (i < n) {
-                const uint32_t ray = i % n_rays, piece = i / n_rays;     // the pieces of one ray land in different wavefronts
-                const float4 r0 = rays[2 * (size_t)ray * ray_stride], r1 = rays[2 * (size_t)ray * ray_stride + 1];
-                f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
-                const f3 d = to - f2;
-                inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                t_lo = 0.0f;
-                float t_hi = 1.0f;
-                if (K > 1u) {
-                    float tin, tout;
-                    if (slab(mk(a.scene_lo[0], a.scene_lo[1], a.scene_lo[2]), mk(a.scene_hi[0], a.scene_hi[1], a.scene_hi[2]), f2, inv, 0.0f, 1.0f, tin, tout)) {
-                        const float w = tout - tin;
-                        if (piece > 0u) t_lo = tin + w * ((float)piece / (float)K);
-                        if (piece + 1u < K) t_hi = tin + w * ((float)(piece + 1u) / (float)K);
-                    } else if (piece > 0u) t_hi = 0.0f;                  // the ray misses the scene: piece 0 reports the miss
-                }
-                best.frac = t_hi; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
-                sp = 0; cur = 0; walking = a.n_nodes != 0u && t_lo < t_hi; fresh = false;
-                if (STATS && j == 0 && piece == 0u) st_q++;
-                if (!walking) {                                  // empty scene or empty piece: a miss
-                    if (j == 0) { a.hit[2 * (size_t)i] = make_float4(1.0f, __int_as_float(-1), 0.0f, 0.0f); a.hit[2 * (size_t)i + 1] = make_float4(0, 0, 0, 0); }
-                    fresh = true; i = 0xffffffffu;
-                }
-            } else exhausted = true;
-        }
-        if (!__any(walking)) { if (!__any(fresh && !exhausted)) break; else continue; }
+        if ((m_inner | m_leaf) == 0ull) break;                               // nothing walking, nobody can get a ray
 
-        // ---- phase 1: inner nodes, until enough rays are parked on a leaf (their triangle code then runs once for all) ----
-        for (;;) {
-            const unsigned long long inner = __ballot(walking && cur >= 0);
-            if (inner == 0ull) break;
-            if (__popcll(__ballot(walking && cur < 0)) >= 4 * MCRT_LEAF_BATCH) break;
+        if (m_inner != 0ull && __popcll(m_leaf) < 4 * MCRT_LEAF_BATCH) {
+            // ---- one inner-node step ----
+#ifdef MCRT_STAMP
+            sc_n1++; sc_act1 += __popcll(m_inner);
+#endif
             if (walking && cur >= 0) {
                 const float4 *N = a.nodes + 8 * (size_t)cur + 2 * j;
                 const float4 A = N[0], B = N[1];               // lo.xyz hi.x | hi.y hi.z ref pad
@@ -369,59 +391,70 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                 float tn, tx;
                 const float tcap = fminf(1.0f, best.frac);
                 const bool hit = slab(mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), f2, inv, t_lo, tcap, tn, tx) && ref != MCRT_BVH4_EMPTY;
-                // ordering key: t_near >= 0, so its bit pattern orders like the value; the two low bits carry the slot
-                // number, which makes the four keys distinct (visiting order only affects the work done, never the hit)
-                const uint32_t key = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)j) : 0xffffffffu;
-                const uint32_t k0 = (uint32_t)dpp_i<QP_BCAST(0)>((int)key), k1 = (uint32_t)dpp_i<QP_BCAST(1)>((int)key),
-                               k2 = (uint32_t)dpp_i<QP_BCAST(2)>((int)key), k3 = (uint32_t)dpp_i<QP_BCAST(3)>((int)key);
-                const int nh = (k0 != 0xffffffffu) + (k1 != 0xffffffffu) + (k2 != 0xffffffffu) + (k3 != 0xffffffffu);
-                const int rank = (k0 < key) + (k1 < key) + (k2 < key) + (k3 < key);
-                int cand = (hit && rank == 0) ? ref : 0;
+                // Next node = the NEAREST hit child (t_near >= 0, so its bit pattern orders like the value; ties -> lowest slot);
+                // the other hit children are stacked in slot order.  Visiting order only affects the work done, never the hit.
+                const uint32_t key = hit ? __float_as_uint(tn) : 0xffffffffu;
+                uint32_t kmin = min(key, (uint32_t)dpp_i<QP_XOR1>((int)key));
+                kmin = min(kmin, (uint32_t)dpp_i<QP_XOR2>((int)kmin));
+                const int qsh = lane & ~3;
+                const uint32_t hit4 = (uint32_t)(__ballot(hit) >> qsh) & 15u;                 // the quad's four hit bits
+                const uint32_t eq4 = (uint32_t)(__ballot(hit && key == kmin) >> qsh) & 15u;
+                const int nh = __popc(hit4);
+                const int jn = __ffs((int)eq4) - 1;                                            // slot of the nearest child
+                int cand = (j == jn) ? ref : 0;
                 cand |= dpp_i<QP_XOR1>(cand);
                 cand |= dpp_i<QP_XOR2>(cand);
                 if (nh == 0) {
                     if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
                     else walking = false;
                 } else {                                       // mcrt_upload_scene rejected trees that need more than MCRT_STACK entries
-                    if (hit && rank > 0) stack[(sp + nh - 1 - rank) * 64 + q] = ref;
+                    const uint32_t others = hit4 & ~(1u << jn);
+                    if (hit && j != jn) stack[(sp + __popc(others & ((1u << j) - 1u))) * 64 + q] = ref;
                     sp += nh - 1;
                     cur = cand;
                 }
             }
-        }
-        // ---- phase 2: leaves -- lane j tests triangle j ----
-        if (walking && cur < 0) {
-            const uint32_t v = (uint32_t)~cur;
-            const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-            Hit mine = best;
-            for (uint32_t k = (uint32_t)j; k < cnt; k += 4u) {
-                const float4 *T = a.tris + 3 * (size_t)(first + k);
-                const float4 t0 = T[0], t1 = T[1], t2 = T[2];
-                tri_test(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), __float_as_int(t1.w), f2, to, inv, a.pad_abs, t_lo, mine);
-            }
-            if (STATS && j == 0) st_tris += cnt;
+            STAMP(sc_p1)
+        } else {
+            // ---- the parked leaves: lane j tests triangle j ----
+#ifdef MCRT_STAMP
+            sc_n2++; sc_act2 += __popcll(m_leaf);
+#endif
+            if (walking && cur < 0) {
+                const uint32_t v = (uint32_t)~cur;
+                const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+                Hit mine = best;
+                for (uint32_t k = (uint32_t)j; k < cnt; k += 4u) {
+                    const float4 *T = a.tris + 3 * (size_t)(first + k);
+                    const float4 t0 = T[0], t1 = T[1], t2 = T[2];
+                    tri_test(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), __float_as_int(t1.w), f2, to, inv, a.pad_abs, t_lo, mine);
+                }
+                if (STATS && j == 0) st_tris += cnt;
 #define MCRT_QUAD_MIN(CTRL)                                                                                             \
-            {                                                                                                           \
-                const float of = dpp_f<CTRL>(mine.frac); const int ot = dpp_i<CTRL>(mine.tri), om = dpp_i<CTRL>(mine.mesh); \
-                const float onx = dpp_f<CTRL>(mine.n.x), ony = dpp_f<CTRL>(mine.n.y), onz = dpp_f<CTRL>(mine.n.z), oda = dpp_f<CTRL>(mine.da); \
-                if (of < mine.frac || (of == mine.frac && ot < mine.tri)) { mine.frac = of; mine.tri = ot; mine.mesh = om; mine.n = mk(onx, ony, onz); mine.da = oda; } \
-            }
-            MCRT_QUAD_MIN(QP_XOR1)
-            MCRT_QUAD_MIN(QP_XOR2)
+                {                                                                                                       \
+                    const float of = dpp_f<CTRL>(mine.frac); const int ot = dpp_i<CTRL>(mine.tri), om = dpp_i<CTRL>(mine.mesh); \
+                    const float onx = dpp_f<CTRL>(mine.n.x), ony = dpp_f<CTRL>(mine.n.y), onz = dpp_f<CTRL>(mine.n.z), oda = dpp_f<CTRL>(mine.da); \
+                    if (of < mine.frac || (of == mine.frac && ot < mine.tri)) { mine.frac = of; mine.tri = ot; mine.mesh = om; mine.n = mk(onx, ony, onz); mine.da = oda; } \
+                }
+                MCRT_QUAD_MIN(QP_XOR1)
+                MCRT_QUAD_MIN(QP_XOR2)
 #undef MCRT_QUAD_MIN
-            best = mine;
-            if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
-            else walking = false;
-        }
-        // ---- finished rays: write the hit record, ask for the next ray ----
-        if (!walking && !fresh && !exhausted) {
-            if (j == 0) {
-                a.hit[2 * (size_t)i] = make_float4(best.frac, __int_as_float(best.tri), best.da, __int_as_float(best.mesh));
-                a.hit[2 * (size_t)i + 1] = make_float4(best.n.x, best.n.y, best.n.z, 0.0f);
+                best = mine;
+                if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
+                else walking = false;
             }
-            fresh = true; i = 0xffffffffu;
+            STAMP(sc_p2)
         }
+#ifdef MCRT_STAMP
+        sc_outer++;
+#endif
     }
+#ifdef MCRT_STAMP
+    if (lane == 0) {   // diagnostic build only: per-phase cycles and iteration counts, summed over wavefronts
+        atomicAdd(&a.stamps[0], sc_refill); atomicAdd(&a.stamps[1], sc_p1); atomicAdd(&a.stamps[2], sc_p2); atomicAdd(&a.stamps[3], sc_n1);
+        atomicAdd(&a.stamps[4], sc_n2); atomicAdd(&a.stamps[5], sc_outer); atomicAdd(&a.stamps[6], sc_act1); atomicAdd(&a.stamps[7], sc_act2); atomicAdd(&a.stamps[8], 1ull);
+    }
+#endif
     if (STATS) {
         unsigned long long v[3] = { st_q, st_nodes, st_tris };
 #pragma unroll

@@ -480,17 +480,18 @@ static void walk_bvh4(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stat
             for (int k = 0; k < 4; k++) {
                 float hi[3] = { N[k].hix, N[k].hiy, N[k].hiz }, tn, tx;
                 int h = slab(N[k].lo, hi, from, inv, tcap, &tn, &tx) && N[k].ref != ORC_BVH4_EMPTY;
-                /* the kernel's ordering key: bits of t_near (>= 0) with the slot number in the two low bits */
-                key[k] = h ? ((f2u(tn) & ~3u) | (uint32_t)k) : 0xffffffffu; ref[k] = N[k].ref; nh += h;
+                key[k] = h ? f2u(tn) : 0xffffffffu; ref[k] = N[k].ref; nh += h;   /* t_near >= 0: bits order like the value */
             }
             if (nh > 0) {
-                int32_t next = 0;
+                /* the kernel's order: nearest hit child next (ties: lowest slot), the others stacked in slot order */
+                int jn = -1;
+                for (int k = 0; k < 4; k++) if (key[k] != 0xffffffffu && (jn < 0 || key[k] < key[jn])) jn = k;
+                int32_t next = ref[jn];
+                int pos = 0;
                 for (int k = 0; k < 4; k++) {
-                    if (key[k] == 0xffffffffu) continue;
-                    int rank = 0;
-                    for (int m = 0; m < 4; m++) rank += key[m] < key[k];
-                    if (rank == 0) next = ref[k];
-                    else if (sp + nh - 1 - rank < ORC_STACK) stack[sp + nh - 1 - rank] = ref[k];
+                    if (key[k] == 0xffffffffu || k == jn) continue;
+                    if (sp + pos < ORC_STACK) stack[sp + pos] = ref[k];
+                    pos++;
                 }
                 sp += nh - 1;
                 cur = next;
