@@ -102,15 +102,13 @@ def main():
         torch.cuda.synchronize()
 
     # ---- counted algorithmic bytes of the timed frames (instrumented build of the same kernel, untimed) ----
-    # (counted with one walk per ray -- MCRT_KSPLIT_LIMIT=0 -- i.e. exactly the oracle's node/triangle visits: the timed kernel
-    #  may cut the rays of a small bounce into pieces, whose extra visits are overhead, not algorithmic bytes)
-    os.environ["MCRT_KSPLIT_LIMIT"] = "0"
+    # (the counting build walks every ray once, i.e. exactly the oracle's node/triangle visits: the timed kernel may cut the
+    #  rays of a small bounce into pieces, whose extra visits are overhead, not algorithmic bytes)
     ctx.enable_stats(True); ctx.get_stats(reset=True)
     for f in range(args.steps):
         ctx.trace_frame(f, rf_local, e0, e1)
     st = ctx.get_stats(reset=True)
     ctx.enable_stats(False)
-    del os.environ["MCRT_KSPLIT_LIMIT"]
     # Algorithmic bytes (adapted to the 128-B BVH4 nodes).  The dominant kernel is k_trace, launched once per
     # bounce: per closest-hit query nodes*128 B + triangles*48 B + the 32-B ray read and 32-B hit record written.
     launches_per_frame = int(ctx.params.max_depth)

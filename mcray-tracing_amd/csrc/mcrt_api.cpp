@@ -68,7 +68,9 @@ struct mcrt_ctx {
     // transducer
     float *d_pos = nullptr, *d_dir = nullptr; uint32_t n_el = 0;
     // per-frame work buffers of the wavefront pipeline (sized for work_paths paths)
-    float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr, *d_hit = nullptr;
+    float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr;
+    unsigned long long *d_key0 = nullptr, *d_key1 = nullptr;
+    uint32_t *d_tri_slot = nullptr;
     uint32_t *d_q0 = nullptr, *d_q1 = nullptr, *d_counts = nullptr, *d_seg_count = nullptr;
     mcrt_segment *d_segs = nullptr; size_t work_paths = 0; uint32_t work_depth = 0;
     // accumulators
@@ -166,15 +168,15 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
 
 static void free_work(mcrt_ctx *c)
 {
-    hipFree(c->d_st0); hipFree(c->d_st1); hipFree(c->d_st2); hipFree(c->d_ray0); hipFree(c->d_ray1); hipFree(c->d_hit);
+    hipFree(c->d_st0); hipFree(c->d_st1); hipFree(c->d_st2); hipFree(c->d_ray0); hipFree(c->d_ray1); hipFree(c->d_key0); hipFree(c->d_key1);
     hipFree(c->d_q0); hipFree(c->d_q1); hipFree(c->d_counts); hipFree(c->d_seg_count); hipFree(c->d_segs);
-    c->d_st0 = c->d_st1 = c->d_st2 = c->d_ray0 = c->d_ray1 = c->d_hit = nullptr; c->d_q0 = c->d_q1 = c->d_counts = c->d_seg_count = nullptr;
+    c->d_st0 = c->d_st1 = c->d_st2 = c->d_ray0 = c->d_ray1 = nullptr; c->d_key0 = c->d_key1 = nullptr; c->d_q0 = c->d_q1 = c->d_counts = c->d_seg_count = nullptr;
     c->d_segs = nullptr; c->work_paths = 0; c->work_depth = 0;
 }
 
 static void free_scene(mcrt_ctx *c)
 {
-    hipFree(c->d_nodes); hipFree(c->d_tris); hipFree(c->d_mats); hipFree(c->d_meshes);
+    hipFree(c->d_nodes); hipFree(c->d_tris); hipFree(c->d_mats); hipFree(c->d_meshes); hipFree(c->d_tri_slot); c->d_tri_slot = nullptr;
     c->d_nodes = c->d_tris = c->d_mats = nullptr; c->d_meshes = nullptr;
     mcrt_free_bvh(&c->bvh);
     mcrt_free_bvh4(&c->bvh4);
@@ -257,6 +259,12 @@ extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *
         HIP_TRY(hipMalloc(&c->d_tris, 48 * (size_t)n_tri));
         HIP_TRY(hipMemcpy(c->d_nodes, c->bvh4.nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_tris, c->bvh.tri, 48 * (size_t)n_tri, hipMemcpyHostToDevice));
+        {   // triangle id -> leaf-order slot (k_shade re-derives the winning triangle's normal from its vertices)
+            std::vector<uint32_t> slot(n_tri);
+            for (uint32_t k = 0; k < n_tri; k++) { uint32_t id; memcpy(&id, &c->bvh.tri[(size_t)k * 12 + 3], 4); slot[id] = k; }
+            HIP_TRY(hipMalloc(&c->d_tri_slot, 4 * (size_t)n_tri));
+            HIP_TRY(hipMemcpy(c->d_tri_slot, slot.data(), 4 * (size_t)n_tri, hipMemcpyHostToDevice));
+        }
     }
     HIP_TRY(hipMalloc(&c->d_mats, 32 * (size_t)n_mat));
     HIP_TRY(hipMemcpy(c->d_mats, mats, 32 * (size_t)n_mat, hipMemcpyHostToDevice));
@@ -367,7 +375,7 @@ static int ensure_work(mcrt_ctx *c, uint32_t ne)
     free_work(c);
     const uint32_t B = c->p.max_depth;
     HIP_TRY(hipMalloc(&c->d_st0, 16 * np)); HIP_TRY(hipMalloc(&c->d_st1, 16 * np)); HIP_TRY(hipMalloc(&c->d_st2, 16 * np));
-    HIP_TRY(hipMalloc(&c->d_ray0, 32 * np)); HIP_TRY(hipMalloc(&c->d_ray1, 32 * np)); HIP_TRY(hipMalloc(&c->d_hit, 32 * std::max(np, (size_t)MCRT_KSPLIT_MAX)));
+    HIP_TRY(hipMalloc(&c->d_ray0, 32 * np)); HIP_TRY(hipMalloc(&c->d_ray1, 32 * np)); HIP_TRY(hipMalloc(&c->d_key0, 8 * np)); HIP_TRY(hipMalloc(&c->d_key1, 8 * np));
     HIP_TRY(hipMalloc(&c->d_q0, 4 * np)); HIP_TRY(hipMalloc(&c->d_q1, 4 * np)); HIP_TRY(hipMalloc(&c->d_seg_count, 4 * np));
     HIP_TRY(hipMalloc(&c->d_counts, 4 * (2 * MCRT_MAX_BOUNCES + 1)));
     HIP_TRY(hipMalloc(&c->d_segs, sizeof(mcrt_segment) * np * B));
@@ -381,12 +389,13 @@ static void fill_args(mcrt_ctx *c, mcrt::FrameArgs &a, uint32_t frame, uint32_t 
     a.nodes = c->d_nodes; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
     a.el_pos = c->d_pos; a.el_dir = c->d_dir; a.acc = c->d_acc; a.flags = c->d_flags; a.row_thr = c->d_row_thr;
     a.st0 = c->d_st0; a.st1 = c->d_st1; a.st2 = c->d_st2; a.queue0 = c->d_q0; a.queue1 = c->d_q1;
-    a.ray0 = c->d_ray0; a.ray1 = c->d_ray1; a.hit = c->d_hit; a.counts = c->d_counts; a.segs = c->d_segs; a.seg_count = c->d_seg_count;
+    a.ray0 = c->d_ray0; a.ray1 = c->d_ray1; a.key0 = c->d_key0; a.key1 = c->d_key1; a.tri_slot = c->d_tri_slot; a.counts = c->d_counts; a.segs = c->d_segs; a.seg_count = c->d_seg_count;
     a.stats = c->d_stats; a.error_flag = c->d_error; a.stamps = c->d_stats + 8;
     a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
     a.e_begin = e0; a.ne = e1 - e0;
     a.ksplit_limit = MCRT_KSPLIT_DEFAULT;   // bounces with fewer rays than this are cut into pieces (see k_trace)
     if (const char *e = getenv("MCRT_KSPLIT_LIMIT")) { long v = atol(e); if (v >= 0 && v <= MCRT_KSPLIT_MAX) a.ksplit_limit = (uint32_t)v; }   // tuning knob; 0 = off
+    if (c->stats_on) a.ksplit_limit = 0;   // counting mode = one walk per ray, so the counts are the oracle's
     for (int i = 0; i < 3; i++) { a.scene_lo[i] = c->scene_lo[i]; a.scene_hi[i] = c->scene_hi[i]; }
     a.trace_blocks = 1280;   // persistent k_trace: 5 waves/SIMD on 256 CUs; quads fetch further rays dynamically
     if (const char *e = getenv("MCRT_TRACE_BLOCKS")) { int v = atoi(e); if (v >= 1) a.trace_blocks = (uint32_t)v; }   // tuning knob

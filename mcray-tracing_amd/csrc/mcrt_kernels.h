@@ -20,7 +20,8 @@ struct FrameArgs {
     float4 *st0, *st1, *st2;   // [np] path state: from,intensity | dir,media | distance_traveled(f64),outside,-
     uint32_t *queue0, *queue1; // [np] live path ids, ping-pong by bounce parity
     float4 *ray0, *ray1;       // [np][2] f2.xyz,to.x | to.yz,-,-   (indexed by queue position), ping-pong
-    float4 *hit;               // [max(np, ksplit_limit)][2] frac,tri,da,mesh | n.xyz,-  (indexed by work item = piece * n_rays + queue position)
+    unsigned long long *key0, *key1;   // [np] closest hit per ray: fraction bits << 32 | triangle id (atomicMin), ping-pong by bounce parity
+    const uint32_t *tri_slot;  // [T] triangle id -> position in the leaf-order triangle array
     uint32_t *counts;          // [MAX_BOUNCES+1] live rays per bounce, then [MAX_BOUNCES] queue cursors of the persistent walk
     mcrt_segment *segs;        // [np][B]
     uint32_t *seg_count;       // [np]

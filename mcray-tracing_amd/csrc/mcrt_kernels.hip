@@ -17,9 +17,6 @@
 #include "mcrt_detmath.h"
 #include "mcrt_kernels.h"
 
-#ifndef MCRT_REFILL_MIN
-#define MCRT_REFILL_MIN 2           // hand out new rays as soon as this many of a wave's 16 quads have none
-#endif
 #ifndef MCRT_FETCH_BATCH
 #define MCRT_FETCH_BATCH 16         // queue positions a wavefront of k_trace claims per atomic
 #endif
@@ -230,6 +227,8 @@ MCRT_DEV void rf_add(long long *bins, uint32_t *lflags, int row, float echo)
 
 struct Ray { f3 f2, to; };
 
+#define MCRT_KEY_MISS ((0x3f800000ull << 32) | 0xffffffffull)   // fraction 1.0, no triangle
+
 // pieces per ray for a bounce with n rays: the largest power of two <= limit / n, at most 16 (1 when the bounce is large)
 MCRT_DEV uint32_t ksplit(uint32_t n, uint32_t limit)
 {
@@ -271,6 +270,7 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
     a.st2[pid] = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), 0.0f);      // distance_traveled (double) | outside | -
     a.queue0[pid] = pid;
     a.seg_count[pid] = 0u;
+    if (pid < a.ne) a.key0[pid] = MCRT_KEY_MISS;          // bounce 0: one closest-hit word per scan-line
     const Ray r = make_ray(from, dir, intensity, a.mats[2 * a.start_mat].y, a);
     a.ray0[2 * pid] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
     a.ray0[2 * pid + 1] = make_float4(r.to.y, r.to.z, 0.0f, 0.0f);
@@ -299,6 +299,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
     const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
     const uint32_t ray_stride = (b == 0u) ? a.S : 1u;           // bounce 0: the first path of each scan-line stands for all
     uint32_t *cursor = a.counts + MCRT_MAX_BOUNCES + 1 + b;      // next unclaimed queue position
+    unsigned long long *keys = (b & 1u) ? a.key1 : a.key0;     // per-ray closest-hit words of this bounce
     unsigned long long st_nodes = 0, st_tris = 0, st_q = 0;
 
     uint32_t i = blockIdx.x * 64u + (uint32_t)q;                 // the first ray of each quad is assigned statically
@@ -315,73 +316,69 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 #define STAMP(var)
 #endif
     uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
-    // One wave-uniform decision per iteration: (1) hand rays to quads that have none, (2) test the parked leaves once enough
-    // rays wait on one (or nothing else can run), (3) otherwise one inner-node step for every ray that is on an inner node.
     for (;;) {
-        // finished rays: write the hit record, ask for the next ray
+        // ---- finished rays: report, then ask for the next ray ----
+        // The closest hit of a ray is ONE 64-bit word, (fraction bits << 32 | triangle id): fractions are in [0,1), so their bit
+        // patterns order like the values and an integer atomicMin IS the contract's rule (smaller fraction, then smaller id).
+        // The K pieces of a ray therefore just race their finds into the ray's word.
         if (!walking && !fresh && !exhausted) {
-            if (j == 0) {
-                a.hit[2 * (size_t)i] = make_float4(best.frac, __int_as_float(best.tri), best.da, __int_as_float(best.mesh));
-                a.hit[2 * (size_t)i + 1] = make_float4(best.n.x, best.n.y, best.n.z, 0.0f);
-            }
+            if (j == 0 && best.tri >= 0)
+                atomicMin(&keys[i % n_rays], ((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri);
             fresh = true; i = 0xffffffffu;
         }
-        const unsigned long long m_inner = __ballot(walking && cur >= 0);
-        const unsigned long long m_leaf = __ballot(walking && cur < 0);
-        const unsigned long long m_need = __ballot(fresh && !exhausted);
-        if (m_need && (__popcll(m_need) >= 4 * MCRT_REFILL_MIN || (m_inner | m_leaf) == 0ull)) {
-            // ---- (re)fill: quads without a ray take the next queue positions ----
-            const bool need = fresh && !exhausted;
-            const unsigned long long dynm = __ballot(need && i == 0xffffffffu && j == 0);
-            if (dynm) {
-                // dynamic fetch (after the static first assignment) from a wave-private pool of queue positions that is refilled
-                // MCRT_FETCH_BATCH at a time: one returning atomic per batch instead of one per finished ray
-                if (pool_next >= pool_end && !queue_empty) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(cursor, (uint32_t)MCRT_FETCH_BATCH);
-                    base = __shfl(base, 0, 64);
-                    pool_next = base; pool_end = base + MCRT_FETCH_BATCH;
-                    if (base >= n) queue_empty = true;
-                }
-                if (need && i == 0xffffffffu) {
-                    const uint32_t mine = pool_next + (uint32_t)__popcll(dynm & ((1ull << (lane & ~3)) - 1ull));
-                    if (queue_empty) i = n;                                  // nothing left: this quad retires
-                    else if (mine < pool_end) i = mine;                      // else: wait for the next batch (stay fresh)
-                }
-                const uint32_t taken = (uint32_t)__popcll(dynm);
-                pool_next = (pool_next + taken < pool_end) ? pool_next + taken : pool_end;
+        // ---- (re)fill: quads without a ray take the next queue positions ----
+        const bool need = fresh && !exhausted;
+        const unsigned long long dynm = __ballot(need && i == 0xffffffffu && j == 0);
+        if (dynm) {
+            // dynamic fetch (after the static first assignment) from a wave-private pool of queue positions that is refilled
+            // MCRT_FETCH_BATCH at a time: one returning atomic per batch instead of one per finished ray
+            if (pool_next >= pool_end && !queue_empty) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, (uint32_t)MCRT_FETCH_BATCH);
+                base = __shfl(base, 0, 64);
+                pool_next = base; pool_end = base + MCRT_FETCH_BATCH;
+                if (base >= n) queue_empty = true;
             }
-            if (need && i != 0xffffffffu) {
-                if (i < n) {
-                    const uint32_t ray = i % n_rays, piece = i / n_rays;     // the pieces of one ray land in different wavefronts
-                    const float4 r0 = rays[2 * (size_t)ray * ray_stride], r1 = rays[2 * (size_t)ray * ray_stride + 1];
-                    f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
-                    const f3 d = to - f2;
-                    inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    t_lo = 0.0f;
-                    float t_hi = 1.0f;
-                    if (K > 1u) {
-                        float tin, tout;
-                        if (slab(mk(a.scene_lo[0], a.scene_lo[1], a.scene_lo[2]), mk(a.scene_hi[0], a.scene_hi[1], a.scene_hi[2]), f2, inv, 0.0f, 1.0f, tin, tout)) {
-                            const float w = tout - tin;
-                            if (piece > 0u) t_lo = tin + w * ((float)piece / (float)K);
-                            if (piece + 1u < K) t_hi = tin + w * ((float)(piece + 1u) / (float)K);
-                        } else if (piece > 0u) t_hi = 0.0f;                  // the ray misses the scene: piece 0 reports the miss
-                    }
-                    best.frac = t_hi; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
-                    sp = 0; cur = 0; walking = a.n_nodes != 0u && t_lo < t_hi; fresh = false;   // (not walking: an immediate miss, written at the loop top)
-                    if (STATS && j == 0 && piece == 0u) st_q++;
-                } else exhausted = true;
+            if (need && i == 0xffffffffu) {
+                const uint32_t mine = pool_next + (uint32_t)__popcll(dynm & ((1ull << (lane & ~3)) - 1ull));
+                if (queue_empty) i = n;                                  // nothing left: this quad retires
+                else if (mine < pool_end) i = mine;                      // else: wait for the next batch (stay fresh)
             }
-            STAMP(sc_refill)
-            continue;
+            const uint32_t taken = (uint32_t)__popcll(dynm);
+            pool_next = (pool_next + taken < pool_end) ? pool_next + taken : pool_end;
         }
-        if ((m_inner | m_leaf) == 0ull) break;                               // nothing walking, nobody can get a ray
+        if (need && i != 0xffffffffu) {
+            if (i < n) {
+                const uint32_t ray = i % n_rays, piece = i / n_rays;     // the pieces of one ray land in different wavefronts
+                const float4 r0 = rays[2 * (size_t)ray * ray_stride], r1 = rays[2 * (size_t)ray * ray_stride + 1];
+                f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
+                const f3 d = to - f2;
+                inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                t_lo = 0.0f;
+                float t_hi = 1.0f;
+                if (K > 1u) {
+                    float tin, tout;
+                    if (slab(mk(a.scene_lo[0], a.scene_lo[1], a.scene_lo[2]), mk(a.scene_hi[0], a.scene_hi[1], a.scene_hi[2]), f2, inv, 0.0f, 1.0f, tin, tout)) {
+                        const float w = tout - tin;
+                        if (piece > 0u) t_lo = tin + w * ((float)piece / (float)K);
+                        if (piece + 1u < K) t_hi = tin + w * ((float)(piece + 1u) / (float)K);
+                    } else if (piece > 0u) t_hi = 0.0f;                  // the ray misses the scene: piece 0 reports the miss
+                }
+                best.frac = t_hi; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
+                sp = 0; cur = 0; walking = a.n_nodes != 0u && t_lo < t_hi; fresh = false;   // (not walking: an immediate miss)
+                if (STATS && j == 0 && piece == 0u) st_q++;
+            } else exhausted = true;
+        }
+        STAMP(sc_refill)
+        if (!__any(walking)) { if (!__any(!exhausted)) break; else continue; }
 
-        if (m_inner != 0ull && __popcll(m_leaf) < 4 * MCRT_LEAF_BATCH) {
-            // ---- one inner-node step ----
+        // ---- phase 1: inner nodes, until enough rays are parked on a leaf (their triangle code then runs once for all) ----
+        for (;;) {
+            const unsigned long long inner = __ballot(walking && cur >= 0);
+            if (inner == 0ull) break;
+            if (__popcll(__ballot(walking && cur < 0)) >= 4 * MCRT_LEAF_BATCH) break;
 #ifdef MCRT_STAMP
-            sc_n1++; sc_act1 += __popcll(m_inner);
+            sc_n1++; sc_act1 += __popcll(inner);
 #endif
             if (walking && cur >= 0) {
                 const float4 *N = a.nodes + 8 * (size_t)cur + 2 * j;
@@ -414,37 +411,36 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                     cur = cand;
                 }
             }
-            STAMP(sc_p1)
-        } else {
-            // ---- the parked leaves: lane j tests triangle j ----
-#ifdef MCRT_STAMP
-            sc_n2++; sc_act2 += __popcll(m_leaf);
-#endif
-            if (walking && cur < 0) {
-                const uint32_t v = (uint32_t)~cur;
-                const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-                Hit mine = best;
-                for (uint32_t k = (uint32_t)j; k < cnt; k += 4u) {
-                    const float4 *T = a.tris + 3 * (size_t)(first + k);
-                    const float4 t0 = T[0], t1 = T[1], t2 = T[2];
-                    tri_test(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), __float_as_int(t1.w), f2, to, inv, a.pad_abs, t_lo, mine);
-                }
-                if (STATS && j == 0) st_tris += cnt;
-#define MCRT_QUAD_MIN(CTRL)                                                                                             \
-                {                                                                                                       \
-                    const float of = dpp_f<CTRL>(mine.frac); const int ot = dpp_i<CTRL>(mine.tri), om = dpp_i<CTRL>(mine.mesh); \
-                    const float onx = dpp_f<CTRL>(mine.n.x), ony = dpp_f<CTRL>(mine.n.y), onz = dpp_f<CTRL>(mine.n.z), oda = dpp_f<CTRL>(mine.da); \
-                    if (of < mine.frac || (of == mine.frac && ot < mine.tri)) { mine.frac = of; mine.tri = ot; mine.mesh = om; mine.n = mk(onx, ony, onz); mine.da = oda; } \
-                }
-                MCRT_QUAD_MIN(QP_XOR1)
-                MCRT_QUAD_MIN(QP_XOR2)
-#undef MCRT_QUAD_MIN
-                best = mine;
-                if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
-                else walking = false;
-            }
-            STAMP(sc_p2)
         }
+        STAMP(sc_p1)
+#ifdef MCRT_STAMP
+        { const unsigned long long lm = __ballot(walking && cur < 0); if (lm) { sc_n2++; sc_act2 += __popcll(lm); } }
+#endif
+        // ---- phase 2: the parked leaves -- lane j tests triangle j ----
+        if (walking && cur < 0) {
+            const uint32_t v = (uint32_t)~cur;
+            const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+            Hit mine = best;
+            for (uint32_t k = (uint32_t)j; k < cnt; k += 4u) {
+                const float4 *T = a.tris + 3 * (size_t)(first + k);
+                const float4 t0 = T[0], t1 = T[1], t2 = T[2];
+                tri_test(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), __float_as_int(t1.w), f2, to, inv, a.pad_abs, t_lo, mine);
+            }
+            if (STATS && j == 0) st_tris += cnt;
+#define MCRT_QUAD_MIN(CTRL)                                                                                             \
+            {                                                                                                           \
+                const float of = dpp_f<CTRL>(mine.frac); const int ot = dpp_i<CTRL>(mine.tri), om = dpp_i<CTRL>(mine.mesh); \
+                const float onx = dpp_f<CTRL>(mine.n.x), ony = dpp_f<CTRL>(mine.n.y), onz = dpp_f<CTRL>(mine.n.z), oda = dpp_f<CTRL>(mine.da); \
+                if (of < mine.frac || (of == mine.frac && ot < mine.tri)) { mine.frac = of; mine.tri = ot; mine.mesh = om; mine.n = mk(onx, ony, onz); mine.da = oda; } \
+            }
+            MCRT_QUAD_MIN(QP_XOR1)
+            MCRT_QUAD_MIN(QP_XOR2)
+#undef MCRT_QUAD_MIN
+            best = mine;
+            if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
+            else walking = false;
+        }
+        STAMP(sc_p2)
 #ifdef MCRT_STAMP
         sc_outer++;
 #endif
@@ -492,16 +488,17 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
         outside = __float_as_int(s2.z);
         const float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
         const f3 f2 = mk(r0.x, r0.y, r0.z), to = mk(r0.w, r1.x, r1.y);
-        const uint32_t n_rays = (b == 0u) ? a.ne : n;
-        const uint32_t K = ksplit(n_rays, a.ksplit_limit);
         const size_t hi = (b == 0u) ? (size_t)(pid / a.S) : (size_t)i;          // bounce 0: one walk per scan-line (see k_trace)
-        Hit best; best.frac = 1.0f; best.tri = -1; best.da = 0.0f; best.mesh = 0; best.n = mk(0, 0, 0);
-        for (uint32_t k = 0; k < K; k++) {                                       // closest over the ray's pieces
-            const float4 h0 = a.hit[2 * (hi + (size_t)k * n_rays)], h1 = a.hit[2 * (hi + (size_t)k * n_rays) + 1];
-            const int tri = __float_as_int(h0.y);
-            if (tri >= 0 && (h0.x < best.frac || (h0.x == best.frac && tri < best.tri) || best.tri < 0)) {
-                best.frac = h0.x; best.tri = tri; best.da = h0.z; best.mesh = __float_as_int(h0.w); best.n = mk(h1.x, h1.y, h1.z);
-            }
+        const unsigned long long key = ((b & 1u) ? a.key1 : a.key0)[hi];
+        Hit best; best.frac = __uint_as_float((uint32_t)(key >> 32)); best.tri = (int)(uint32_t)key; best.da = 0.0f; best.mesh = 0; best.n = mk(0, 0, 0);
+        if (best.tri >= 0) {
+            // plane normal, mesh and the origin-side value of the winning triangle, recomputed exactly as tri_test() does
+            const float4 *T = a.tris + 3 * (size_t)a.tri_slot[best.tri];
+            const float4 t0 = T[0], t1 = T[1], t2 = T[2];
+            const f3 v0 = xyz(t0), v10 = xyz(t1) - v0, v20 = xyz(t2) - v0;
+            best.n = cross(v10, v20);
+            best.da = dot(best.n, f2) - dot(v0, best.n);
+            best.mesh = __float_as_int(t1.w);
         }
         const uint32_t e_abs = a.e_begin + pid / a.S;
         Rng g; g.k0 = a.seed; g.k1 = a.frame; g.element = e_abs; g.sample = pid % a.S; g.bounce = b;
@@ -617,6 +614,7 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
         if (alive) {
             const uint32_t pos = base + (uint32_t)__popcll(live & ((1ull << lane) - 1ull));
             q_out[pos] = pid;
+            ((b & 1u) ? a.key0 : a.key1)[pos] = MCRT_KEY_MISS;            // the next bounce's closest-hit word of this ray
             a.st0[pid] = make_float4(from.x, from.y, from.z, intensity);
             a.st1[pid] = make_float4(dir.x, dir.y, dir.z, __int_as_float(media));
             a.st2[pid] = make_float4(__int_as_float(__double2loint(dist_mm)), __int_as_float(__double2hiint(dist_mm)), __int_as_float(outside), 0.0f);

@@ -121,12 +121,10 @@ def test_c2_sphere_128x1024_depth512(mcrt, orc, sphere, tex256):
     assert np.array_equal(hits, o["hits"])
     _assert_rf(rf, o)
     # node / triangle visit counts are part of the contract (same walk on both sides)
-    import os
-    os.environ["MCRT_KSPLIT_LIMIT"] = "0"                      # one walk per ray, like the oracle (no sub-range pieces)
+    # (with statistics enabled the library walks every ray once -- no sub-range pieces -- so the counts are comparable)
     sim.ctx.enable_stats(True); sim.ctx.get_stats(reset=True)
     sim.trace(3); st = sim.ctx.get_stats()
     sim.ctx.enable_stats(False)
-    del os.environ["MCRT_KSPLIT_LIMIT"]
     # bounce 0 is walked once per scan-line on the GPU (all S samples start as copies of first_ray, scene.cpp:83-101)
     p0 = orc.default_params(n_elements=E, n_samples=S, n_rows=512, max_depth=1)
     o0 = osc.trace_frame(p0, tr.pos, tr.dir, tex256, frame_id=3, use_bvh=2, n_threads=16, want_ref=False, want_fix=False)["stats"]
