@@ -397,7 +397,7 @@ static void fill_args(mcrt_ctx *c, mcrt::FrameArgs &a, uint32_t frame, uint32_t 
     if (const char *e = getenv("MCRT_KSPLIT_LIMIT")) { long v = atol(e); if (v >= 0 && v <= MCRT_KSPLIT_MAX) a.ksplit_limit = (uint32_t)v; }   // tuning knob; 0 = off
     if (c->stats_on) a.ksplit_limit = 0;   // counting mode = one walk per ray, so the counts are the oracle's
     for (int i = 0; i < 3; i++) { a.scene_lo[i] = c->scene_lo[i]; a.scene_hi[i] = c->scene_hi[i]; }
-    a.trace_blocks = 1280;   // persistent k_trace: 5 waves/SIMD on 256 CUs; quads fetch further rays dynamically
+    a.trace_blocks = 1024;   // persistent k_trace: 4 waves/SIMD on 256 CUs; quads fetch further rays dynamically
     if (const char *e = getenv("MCRT_TRACE_BLOCKS")) { int v = atoi(e); if (v >= 1) a.trace_blocks = (uint32_t)v; }   // tuning knob
     a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;

@@ -21,7 +21,7 @@
 #define MCRT_FETCH_BATCH 16         // queue positions a wavefront of k_trace claims per atomic
 #endif
 #ifndef MCRT_TRACE_WAVES
-#define MCRT_TRACE_WAVES 5          // waves per SIMD k_trace's register allocation must allow
+#define MCRT_TRACE_WAVES 4          // waves per SIMD k_trace's register allocation must allow
 #endif
 #ifndef MCRT_LEAF_BATCH
 #define MCRT_LEAF_BATCH 4          // leave the inner-node phase once this many of a wave's 16 paths are parked on a leaf
