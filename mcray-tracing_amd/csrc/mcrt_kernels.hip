@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
     const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
     float4 *rays_out = (b & 1u) ? a.ray0 : a.ray1;
     const bool valid = i < n;
-    bool alive = false;
+    bool alive = false, reflected = false;
     uint32_t pid = 0;
     f3 from = mk(0, 0, 0), dir = mk(0, 0, 1);
     float intensity = 0.0f; int media = 0, outside = OUT_NONE; double dist_mm = 0.0;
@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
             const float prob = i_refl / intensity;
             float i_new;
             from = hp;
-            if (prob > x) { dir = refl; i_new = i_refl > a.eps ? i_refl : 0.0f; }
+            if (prob > x) { dir = refl; i_new = i_refl > a.eps ? i_refl : 0.0f; reflected = true; }
             else { dir = refr; media = mat_after; outside = after_vasc; i_new = i_refr > a.eps ? i_refr : 0.0f; }
             if (i_new > a.eps) { intensity = i_new; alive = true; }
         }
@@ -604,15 +604,20 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
         alive = alive && (b + 1u < a.B);
     }
 
-    // survivors -> next bounce's queue, order-preserving inside the wavefront (ballot + prefix), one atomic per wave
+    // survivors -> next bounce's queue (ballot + prefix, one atomic per wave).  Inside the wavefront's block the reflected rays
+    // come first, then the refracted ones, each in queue order: the samples of a scan-line that took the same decisions stay
+    // adjacent, so the 16 rays of a k_trace wavefront mostly belong to one tight bundle (same nodes, similar walk length).
     const unsigned long long live = __ballot(alive);
+    const unsigned long long live_refl = __ballot(alive && reflected);
     if (live) {
         const int leader = __ffsll((long long)live) - 1;
         uint32_t base = 0;
         if (lane == leader) base = atomicAdd(&a.counts[b + 1u], (uint32_t)__popcll(live));
         base = __shfl(base, leader, 64);
         if (alive) {
-            const uint32_t pos = base + (uint32_t)__popcll(live & ((1ull << lane) - 1ull));
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint32_t pos = base + (reflected ? (uint32_t)__popcll(live_refl & below)
+                                                   : (uint32_t)__popcll(live_refl) + (uint32_t)__popcll(live & ~live_refl & below));
             q_out[pos] = pid;
             ((b & 1u) ? a.key0 : a.key1)[pos] = MCRT_KEY_MISS;            // the next bounce's closest-hit word of this ray
             a.st0[pid] = make_float4(from.x, from.y, from.z, intensity);

@@ -17,6 +17,8 @@ def gather_rf(rf_local, n_elements, n_rows, dist=None, group=None):
     if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return rf_local
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo" and rf_local.is_cuda:      # plumbing checks only: stage through the host
+        return gather_rf(rf_local.cpu(), n_elements, n_rows, dist, group).to(rf_local.device)
     sizes = [shard_range(r, world, n_elements) for r in range(world)]
     full = torch.empty((n_elements, n_rows), dtype=rf_local.dtype, device=rf_local.device)
     if n_elements % world == 0:
