@@ -153,7 +153,7 @@ def main():
                        "scan_lines_total": E, "rays_per_scan_line": S, "triangles": int(sd.n_tri), "parallelism": "scanline-shard x%d" % world,
                        "bvh_build_s": round(t_bvh, 3)},
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms, "launches": k_n,
                          "launches_per_frame": launches_per_frame, "trace_bytes_per_frame": trace_bytes_frame,
                          "other_stage_bytes_per_frame": other_bytes_frame,
@@ -166,6 +166,18 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(args):
+    """HBM-side bytes per k_trace launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/round1/pmc_k_trace.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction applied); null for other workloads."""
+    if (args.workload, args.scanlines, args.rays, args.rows, args.gpus) != ("random1m", 128, 1024, 465, 1):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1", "pmc_k_trace.json")) as f:
+            return json.load(f)["derived"]["traffic_bytes_per_k_trace_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(m, sd, tr, ctx, S, R):
