@@ -7,7 +7,10 @@
 A "step" is one frame of the hot path over synthetic input already resident in HBM:
 clear -> trace (BVH closest-hit + interface sampling) -> RF accumulation -> [RCCL all-gather of the
 scan-line blocks when N > 1] -> PSF convolution.  Each rank traces 128 scan-lines x 1024 sample paths
-(weak scaling: the frame has 128*N scan-lines).  The JSON line carries the live roofline figure of the
+(weak scaling: the frame has 128*N scan-lines).  By default 8 consecutive frames are in flight per
+pass (mcrt_trace_frames: every launch carries 8 frames' rays; images are bit-identical to
+one-at-a-time tracing); `--frames-in-flight 1` is the strict latency mode, also reported in the
+JSON as `one_frame_at_a_time`.  The JSON line carries the live roofline figure of the
 dominant kernel (k_trace: counted algorithmic bytes / HIP-event kernel time) and a CPU baseline (the
 oracle = port of the reference algorithm, timed on this box's host cores on a bounded sample).
 """
@@ -47,6 +50,9 @@ def main():
     ap.add_argument("--scanlines", type=int, default=128, help="scan-lines per GPU")
     ap.add_argument("--rays", type=int, default=1024, help="sample paths per scan-line")
     ap.add_argument("--rows", type=int, default=465)
+    ap.add_argument("--frames-in-flight", type=int, default=8,
+                    help="frames traced per pass (mcrt_trace_frames): a step is still ONE frame, but every kernel launch then carries the "
+                         "rays of this many consecutive frames (1 = strict one-frame-at-a-time latency mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for plumbing checks")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing check on a 1-GPU box: every rank uses GPU 0")
@@ -92,15 +98,38 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
 
-    from mcray_tracing_amd.dist import shard_range, gather_rf
+    from mcray_tracing_amd.dist import shard_range
+    assert E % world == 0
     e0, e1 = shard_range(rank, world, E)
-    rf_local = torch.zeros((E_local, R), dtype=torch.float32, device="cuda")
+    F = max(1, args.frames_in_flight)
+    rf_local = torch.zeros((F, E_local, R), dtype=torch.float32, device="cuda")
 
-    def step(frame):
-        ctx.trace_frame(frame, rf_local, e0, e1)
-        rf_full = gather_rf(rf_local, E, R, dist)               # RCCL all-gather over xGMI: E/N x R floats per rank
+    def step_batch(frame, nf):
+        """nf consecutive frames (nf = 1 unless --frames-in-flight): trace -> gather -> PSF convolution of each frame"""
+        ctx.trace_frames(frame, nf, rf_local, e0, e1)
+        if world > 1:
+            # ONE RCCL all-gather over xGMI per pass: every rank contributes its [nf][E/N][R] block; frame f of the result is the
+            # concatenation of the ranks' scan-line blocks, made contiguous for the convolution
+            gathered = torch.empty((world, nf, E_local, R), dtype=torch.float32, device="cuda")
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, rf_local[:nf].contiguous())
+            else:
+                parts = [torch.empty((nf, E_local, R)) for _ in range(world)]
+                dist.all_gather(parts, rf_local[:nf].cpu())
+                gathered = torch.stack(parts).cuda()
+            frames = gathered.permute(1, 0, 2, 3).reshape(nf, E, R).contiguous()
+        else:
+            frames = rf_local
         if rank == 0:
-            ctx.convolve(rf_full, E, R, psf.axial_kernel, psf.lateral_kernel)
+            for f in range(nf):
+                ctx.convolve(frames[f], E, R, psf.axial_kernel, psf.lateral_kernel)
+
+    def run_steps(first, count):
+        f = first
+        while f < first + count:
+            nf = min(F, first + count - f)
+            step_batch(f, nf)
+            f += nf
 
     def sync():
         torch.cuda.synchronize()
@@ -112,29 +141,30 @@ def main():
     # (the counting build walks every ray once, i.e. exactly the oracle's node/triangle visits: the timed kernel may cut the
     #  rays of a small bounce into pieces, whose extra visits are overhead, not algorithmic bytes)
     ctx.enable_stats(True); ctx.get_stats(reset=True)
-    for f in range(args.steps):
-        ctx.trace_frame(f, rf_local, e0, e1)
+    f = 0
+    while f < args.steps:
+        nf = min(F, args.steps - f)
+        ctx.trace_frames(f, nf, rf_local, e0, e1)
+        f += nf
     st = ctx.get_stats(reset=True)
     ctx.enable_stats(False)
     # Algorithmic bytes (adapted to the 128-B BVH4 nodes).  The dominant kernel is k_trace, launched once per
     # bounce: per closest-hit query nodes*128 B + triangles*48 B + the 32-B ray read and 32-B hit record written.
-    launches_per_frame = int(ctx.params.max_depth)
     trace_bytes_frame = (st["nodes_visited"] * 128 + st["tris_tested"] * 48 + st["queries"] * 64) / args.steps
-    alg_bytes = trace_bytes_frame / launches_per_frame
     # the rest of the frame, for the record: 64-B segment written + read, 8-B texture gather per RF step, RF block + bins
     other_bytes_frame = (st["segments"] * 128 + st["rf_steps"] * 8) / args.steps + E_local * R * (4 + 8)
 
-    for f in range(args.warmup):
-        step(1000 + f)
+    run_steps(1000, args.warmup)
     ctx.enable_timing(True); ctx.kernel_time(reset=True)
     sync()
     t0 = time.perf_counter()
-    for f in range(args.steps):
-        step(f)
+    run_steps(0, args.steps)
     sync()
     dt = time.perf_counter() - t0
     k_ms, k_n = ctx.kernel_time(reset=True)
     ctx.enable_timing(False)
+    launches_per_frame = k_n / args.steps                   # max_depth bounces (x groups) / frames per pass
+    alg_bytes = trace_bytes_frame / launches_per_frame
 
     dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
@@ -150,7 +180,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "frames_per_sec": args.steps / dt, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s; %d scan-lines x %d rays per GPU, %d RF rows, max depth 10" % (label, E_local, S, R),
-                       "scan_lines_total": E, "rays_per_scan_line": S, "triangles": int(sd.n_tri), "parallelism": "scanline-shard x%d" % world,
+                       "scan_lines_total": E, "rays_per_scan_line": S, "triangles": int(sd.n_tri), "parallelism": "scanline-shard x%d" % world, "frames_in_flight": F,
                        "bvh_build_s": round(t_bvh, 3)},
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
@@ -159,6 +189,16 @@ def main():
                          "other_stage_bytes_per_frame": other_bytes_frame,
                          "per_launch": {k: v / args.steps for k, v in st.items()}},
         }
+        if world == 1 and F > 1:
+            # the same workload strictly one frame at a time (each launch carries one frame's rays), for the record
+            for f in range(args.warmup):
+                step_batch(2000 + f, 1)
+            sync(); t1 = time.perf_counter()
+            for f in range(args.steps):
+                step_batch(f, 1)
+            sync(); dt1 = time.perf_counter() - t1
+            out["one_frame_at_a_time"] = {"value": E * S * args.steps / dt1, "unit": "rays/s", "ms_per_step": dt1 / args.steps * 1e3,
+                                          "frames_per_sec": args.steps / dt1}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, sd, tr, ctx, S, R)
         print(json.dumps(out), flush=True)
@@ -171,7 +211,7 @@ def main():
 def pmc_traffic(args):
     """HBM-side bytes per k_trace launch from the committed rocprofv3 PMC passes of this same command
     (profiles/round1/pmc_k_trace.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction applied); null for other workloads."""
-    if (args.workload, args.scanlines, args.rays, args.rows, args.gpus) != ("random1m", 128, 1024, 465, 1):
+    if (args.workload, args.scanlines, args.rays, args.rows, args.gpus, args.frames_in_flight) != ("random1m", 128, 1024, 465, 1, 8):
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "round1", "pmc_k_trace.json")) as f:

@@ -57,7 +57,7 @@ assert NODE_DTYPE.itemsize == 64 and SEGMENT_DTYPE.itemsize == 64 and C.sizeof(B
 # every symbol include/mcrt.h declares (tests/test_abi.py checks the .so exports each one)
 SYMBOLS = ["mcrt_last_error", "mcrt_version", "mcrt_device_count", "mcrt_create", "mcrt_destroy", "mcrt_set_stream",
            "mcrt_synchronize", "mcrt_default_params", "mcrt_set_params", "mcrt_upload_scene", "mcrt_upload_texture",
-           "mcrt_set_transducer", "mcrt_trace_frame", "mcrt_trace_frame_debug", "mcrt_cast_rays", "mcrt_convolve",
+           "mcrt_set_transducer", "mcrt_trace_frame", "mcrt_trace_frames", "mcrt_trace_frame_debug", "mcrt_cast_rays", "mcrt_convolve",
            "mcrt_envelope", "mcrt_scan_convert", "mcrt_export_rf", "mcrt_alloc", "mcrt_free", "mcrt_memcpy_d2h",
            "mcrt_memcpy_h2d", "mcrt_enable_stats", "mcrt_get_stats", "mcrt_enable_timing", "mcrt_get_kernel_time",
            "mcrt_build_bvh", "mcrt_free_bvh", "mcrt_get_bvh", "mcrt_build_bvh4", "mcrt_free_bvh4", "mcrt_get_bvh4", "mcrt_row_thresholds", "mcrt_generate_texture", "mcrt_psf_kernels",
@@ -89,7 +89,7 @@ def load_library():
         "mcrt_default_params": [C.POINTER(Params)], "mcrt_set_params": [vp, C.POINTER(Params)],
         "mcrt_upload_scene": [vp, vp, vp, u32, vp, u32, vp, u32, u32, vp],
         "mcrt_upload_texture": [vp, vp, u32], "mcrt_set_transducer": [vp, vp, vp, u32],
-        "mcrt_trace_frame": [vp, u32, u32, u32, vp], "mcrt_trace_frame_debug": [vp, u32, u32, u32, vp, vp, vp, vp],
+        "mcrt_trace_frame": [vp, u32, u32, u32, vp], "mcrt_trace_frames": [vp, u32, u32, u32, u32, vp], "mcrt_trace_frame_debug": [vp, u32, u32, u32, vp, vp, vp, vp],
         "mcrt_cast_rays": [vp, u32, u32, u32, vp, vp, vp],
         "mcrt_convolve": [vp, vp, u32, u32, vp, u32, vp, u32], "mcrt_envelope": [vp, vp, u32, u32],
         "mcrt_scan_convert": [vp, vp, u32, u32, C.c_double, C.c_double, vp, u32, u32],

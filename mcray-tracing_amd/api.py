@@ -188,6 +188,11 @@ class Context:
         e_end = self.params.n_elements if e_end is None else e_end
         check(self.L.mcrt_trace_frame(self.h, frame_id, e_begin, e_end, ptr(rf_dev)))
 
+    def trace_frames(self, frame_id, n_frames, rf_dev, e_begin=0, e_end=None):
+        """n_frames consecutive frames in one pass; rf_dev holds [n_frames][e_end-e_begin][R] floats"""
+        e_end = self.params.n_elements if e_end is None else e_end
+        check(self.L.mcrt_trace_frames(self.h, frame_id, n_frames, e_begin, e_end, ptr(rf_dev)))
+
     def trace_frame_debug(self, frame_id, rf_dev, e_begin=0, e_end=None, want_hits=True, want_segs=False):
         e_end = self.params.n_elements if e_end is None else e_end
         ne, S, B = e_end - e_begin, self.params.n_samples, self.params.max_depth

@@ -46,11 +46,24 @@ static Consts derive_consts(const mcrt_params &p)
     return c;
 }
 
+// Per-frame work set of ONE wavefront pipeline: path state, queues, rays, closest-hit words, segments, and the two streams it
+// runs on (k_march of bounce b runs on `side` beside k_trace of bounce b+1).  A context owns several so that the scan-lines of
+// a frame can be traced as independent groups whose kernels overlap (the long walks that end one group's bounce run beside the
+// bulk of another's).
+struct Work {
+    hipStream_t stream = nullptr, side = nullptr;
+    hipEvent_t ev_bounce[MCRT_MAX_BOUNCES] = {}, ev_join = nullptr, ev_done = nullptr;
+    float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr;
+    unsigned long long *d_key0 = nullptr, *d_key1 = nullptr;
+    uint32_t *d_q0 = nullptr, *d_q1 = nullptr, *d_counts = nullptr, *d_seg_count = nullptr;
+    mcrt_segment *d_segs = nullptr; size_t paths = 0; uint32_t depth = 0;
+};
+
 struct mcrt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t side_stream = nullptr;                    // RF accumulation of bounce b overlaps the walk of bounce b+1
-    hipEvent_t ev_bounce[MCRT_MAX_BOUNCES] = {}, ev_join = nullptr;
+    std::vector<Work> work;                               // one per concurrent scan-line group (see mcrt_trace_frame)
+    hipEvent_t ev_start = nullptr;
     mcrt_params p{};
     Consts c{};
     // scene
@@ -59,6 +72,7 @@ struct mcrt_ctx {
     uint32_t *d_error = nullptr;
     float4 *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr;
     uint4 *d_meshes = nullptr;
+    uint32_t *d_tri_slot = nullptr;
     uint32_t n_mesh = 0, n_mat = 0, start_mat = 0;
     float scene_lo[3] = { 0, 0, 0 }, scene_hi[3] = { 0, 0, 0 };
     float spacing[3] = { 1, 1, 1 };
@@ -67,12 +81,6 @@ struct mcrt_ctx {
     float2 *d_tex = nullptr; uint32_t tex_n = 0; bool tex_finite = false;
     // transducer
     float *d_pos = nullptr, *d_dir = nullptr; uint32_t n_el = 0;
-    // per-frame work buffers of the wavefront pipeline (sized for work_paths paths)
-    float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr;
-    unsigned long long *d_key0 = nullptr, *d_key1 = nullptr;
-    uint32_t *d_tri_slot = nullptr;
-    uint32_t *d_q0 = nullptr, *d_q1 = nullptr, *d_counts = nullptr, *d_seg_count = nullptr;
-    mcrt_segment *d_segs = nullptr; size_t work_paths = 0; uint32_t work_depth = 0;
     // accumulators
     long long *d_acc = nullptr; uint32_t *d_flags = nullptr; size_t acc_cap = 0, flag_cap = 0;
     uint32_t acc_clean_ne = 0, acc_clean_rows = 0;   // bins known to be all-zero for this shape (k_finalize leaves them so)
@@ -151,9 +159,8 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(MCRT_ERR_HIP, "hipStreamCreate failed"); }
     c->stream = c->own_stream;
-    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) { hipStreamDestroy(c->own_stream); delete c; return set_error(MCRT_ERR_HIP, "hipStreamCreate failed"); }
-    for (int i = 0; i < MCRT_MAX_BOUNCES; i++) hipEventCreateWithFlags(&c->ev_bounce[i], hipEventDisableTiming);
-    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming);
+    c->work.reserve(16);   // pointers into this vector are held across get_work() calls; never more than 16 groups
     mcrt_default_params(&c->p);
     c->c = derive_consts(c->p);
     c->stream = c->own_stream;
@@ -166,12 +173,41 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     return MCRT_OK;
 }
 
+static void free_work_buffers(Work &w)
+{
+    hipFree(w.d_st0); hipFree(w.d_st1); hipFree(w.d_st2); hipFree(w.d_ray0); hipFree(w.d_ray1); hipFree(w.d_key0); hipFree(w.d_key1);
+    hipFree(w.d_q0); hipFree(w.d_q1); hipFree(w.d_counts); hipFree(w.d_seg_count); hipFree(w.d_segs);
+    w.d_st0 = w.d_st1 = w.d_st2 = w.d_ray0 = w.d_ray1 = nullptr; w.d_key0 = w.d_key1 = nullptr; w.d_q0 = w.d_q1 = w.d_counts = w.d_seg_count = nullptr;
+    w.d_segs = nullptr; w.paths = 0; w.depth = 0;
+}
+
 static void free_work(mcrt_ctx *c)
 {
-    hipFree(c->d_st0); hipFree(c->d_st1); hipFree(c->d_st2); hipFree(c->d_ray0); hipFree(c->d_ray1); hipFree(c->d_key0); hipFree(c->d_key1);
-    hipFree(c->d_q0); hipFree(c->d_q1); hipFree(c->d_counts); hipFree(c->d_seg_count); hipFree(c->d_segs);
-    c->d_st0 = c->d_st1 = c->d_st2 = c->d_ray0 = c->d_ray1 = nullptr; c->d_key0 = c->d_key1 = nullptr; c->d_q0 = c->d_q1 = c->d_counts = c->d_seg_count = nullptr;
-    c->d_segs = nullptr; c->work_paths = 0; c->work_depth = 0;
+    for (Work &w : c->work) {
+        free_work_buffers(w);
+        for (int i = 0; i < MCRT_MAX_BOUNCES; i++) if (w.ev_bounce[i]) hipEventDestroy(w.ev_bounce[i]);
+        if (w.ev_join) hipEventDestroy(w.ev_join);
+        if (w.ev_done) hipEventDestroy(w.ev_done);
+        if (w.side) hipStreamDestroy(w.side);
+        if (w.stream) hipStreamDestroy(w.stream);
+    }
+    c->work.clear();
+}
+
+// work set g (created on first use); set 0 runs on the context's stream, the others on streams of their own
+static int get_work(mcrt_ctx *c, size_t g, Work **out)
+{
+    while (c->work.size() <= g) {
+        Work w;
+        if (!c->work.empty()) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
+        for (int i = 0; i < MCRT_MAX_BOUNCES; i++) HIP_TRY(hipEventCreateWithFlags(&w.ev_bounce[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
+        c->work.push_back(w);
+    }
+    *out = &c->work[g];
+    return MCRT_OK;
 }
 
 static void free_scene(mcrt_ctx *c)
@@ -187,16 +223,13 @@ extern "C" int mcrt_destroy(mcrt_ctx *c)
 {
     if (!c) return MCRT_OK;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    hipDeviceSynchronize();
     free_scene(c);
     free_work(c);
     hipFree(c->d_tex); hipFree(c->d_pos); hipFree(c->d_dir); hipFree(c->d_acc); hipFree(c->d_flags); hipFree(c->d_tmp);
     hipFree(c->d_map_col); hipFree(c->d_map_row); hipFree(c->d_stats); hipFree(c->d_row_thr); hipFree(c->d_error);
     for (auto &e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    hipStreamSynchronize(c->side_stream);
-    for (int i = 0; i < MCRT_MAX_BOUNCES; i++) if (c->ev_bounce[i]) hipEventDestroy(c->ev_bounce[i]);
-    if (c->ev_join) hipEventDestroy(c->ev_join);
-    hipStreamDestroy(c->side_stream);
+    if (c->ev_start) hipEventDestroy(c->ev_start);
     hipStreamDestroy(c->own_stream);
     delete c;
     return MCRT_OK;
@@ -367,32 +400,35 @@ static int check_ready(mcrt_ctx *c, uint32_t e0, uint32_t e1)
     return MCRT_OK;
 }
 
-static int ensure_work(mcrt_ctx *c, uint32_t ne)
+static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne)
 {
     const size_t np = (size_t)ne * c->p.n_samples;
-    if (np <= c->work_paths && c->p.max_depth <= c->work_depth) return MCRT_OK;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    free_work(c);
+    if (np <= w.paths && c->p.max_depth <= w.depth) return MCRT_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    free_work_buffers(w);
     const uint32_t B = c->p.max_depth;
-    HIP_TRY(hipMalloc(&c->d_st0, 16 * np)); HIP_TRY(hipMalloc(&c->d_st1, 16 * np)); HIP_TRY(hipMalloc(&c->d_st2, 16 * np));
-    HIP_TRY(hipMalloc(&c->d_ray0, 32 * np)); HIP_TRY(hipMalloc(&c->d_ray1, 32 * np)); HIP_TRY(hipMalloc(&c->d_key0, 8 * np)); HIP_TRY(hipMalloc(&c->d_key1, 8 * np));
-    HIP_TRY(hipMalloc(&c->d_q0, 4 * np)); HIP_TRY(hipMalloc(&c->d_q1, 4 * np)); HIP_TRY(hipMalloc(&c->d_seg_count, 4 * np));
-    HIP_TRY(hipMalloc(&c->d_counts, 4 * (2 * MCRT_MAX_BOUNCES + 1)));
-    HIP_TRY(hipMalloc(&c->d_segs, sizeof(mcrt_segment) * np * B));
-    c->work_paths = np; c->work_depth = B;
+    HIP_TRY(hipMalloc(&w.d_st0, 16 * np)); HIP_TRY(hipMalloc(&w.d_st1, 16 * np)); HIP_TRY(hipMalloc(&w.d_st2, 16 * np));
+    HIP_TRY(hipMalloc(&w.d_ray0, 32 * np)); HIP_TRY(hipMalloc(&w.d_ray1, 32 * np)); HIP_TRY(hipMalloc(&w.d_key0, 8 * np)); HIP_TRY(hipMalloc(&w.d_key1, 8 * np));
+    HIP_TRY(hipMalloc(&w.d_q0, 4 * np)); HIP_TRY(hipMalloc(&w.d_q1, 4 * np)); HIP_TRY(hipMalloc(&w.d_seg_count, 4 * np));
+    HIP_TRY(hipMalloc(&w.d_counts, 4 * (2 * MCRT_MAX_BOUNCES + 1)));
+    HIP_TRY(hipMalloc(&w.d_segs, sizeof(mcrt_segment) * np * B));
+    w.paths = np; w.depth = B;
     return MCRT_OK;
 }
 
-static void fill_args(mcrt_ctx *c, mcrt::FrameArgs &a, uint32_t frame, uint32_t e0, uint32_t e1)
+// kernel arguments for scan-lines [e0,e1) traced with work set w; acc_e0 = first scan-line of the frame's RF block
+static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, uint32_t acc_e0)
 {
     memset(&a, 0, sizeof a);
     a.nodes = c->d_nodes; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
-    a.el_pos = c->d_pos; a.el_dir = c->d_dir; a.acc = c->d_acc; a.flags = c->d_flags; a.row_thr = c->d_row_thr;
-    a.st0 = c->d_st0; a.st1 = c->d_st1; a.st2 = c->d_st2; a.queue0 = c->d_q0; a.queue1 = c->d_q1;
-    a.ray0 = c->d_ray0; a.ray1 = c->d_ray1; a.key0 = c->d_key0; a.key1 = c->d_key1; a.tri_slot = c->d_tri_slot; a.counts = c->d_counts; a.segs = c->d_segs; a.seg_count = c->d_seg_count;
+    a.el_pos = c->d_pos; a.el_dir = c->d_dir; a.row_thr = c->d_row_thr;
+    a.acc = c->d_acc ? c->d_acc + (size_t)(e0 - acc_e0) * c->p.n_rows : nullptr;
+    a.flags = c->d_flags ? c->d_flags + (size_t)(e0 - acc_e0) * ((c->p.n_rows + 31u) >> 5) : nullptr;
+    a.st0 = w.d_st0; a.st1 = w.d_st1; a.st2 = w.d_st2; a.queue0 = w.d_q0; a.queue1 = w.d_q1;
+    a.ray0 = w.d_ray0; a.ray1 = w.d_ray1; a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.segs = w.d_segs; a.seg_count = w.d_seg_count;
     a.stats = c->d_stats; a.error_flag = c->d_error; a.stamps = c->d_stats + 8;
     a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
-    a.e_begin = e0; a.ne = e1 - e0;
+    a.e_begin = e0; a.ne_frame = e1 - e0; a.ne = (e1 - e0) * n_frames;   // n_frames consecutive frame ids traced as one pass
     a.ksplit_limit = MCRT_KSPLIT_DEFAULT;   // bounces with fewer rays than this are cut into pieces (see k_trace)
     if (const char *e = getenv("MCRT_KSPLIT_LIMIT")) { long v = atol(e); if (v >= 0 && v <= MCRT_KSPLIT_MAX) a.ksplit_limit = (uint32_t)v; }   // tuning knob; 0 = off
     if (c->stats_on) a.ksplit_limit = 0;   // counting mode = one walk per ray, so the counts are the oracle's
@@ -407,69 +443,117 @@ static void fill_args(mcrt_ctx *c, mcrt::FrameArgs &a, uint32_t frame, uint32_t 
     a.max_travel = c->c.max_travel_us; a.sos_d = (double)c->p.speed_of_sound; a.inv_row_dt = 1.0 / c->c.row_dt_us;
 }
 
-// scene::cast_rays (scene.cpp:50-183): k_init, then k_trace + k_shade per bounce.  With timing enabled every k_trace launch
-// (the dominant kernel) is bracketed by HIP events on the context's stream.
-static int run_cast(mcrt_ctx *c, const mcrt::FrameArgs &a, bool accumulate)
+// one bounce of one group: k_trace + k_shade on the group's stream, k_march of the finished segments on its side stream.
+// With timing enabled every k_trace launch (the dominant kernel) is bracketed by HIP events on the stream it is launched on.
+static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArgs &a, uint32_t b, bool accumulate, bool overlap)
 {
-    const bool overlap = accumulate && !getenv("MCRT_NO_OVERLAP");
-    HIP_TRY(mcrt::launch_init(a, c->stream));
-    for (uint32_t b = 0; b < a.B; b++) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (c->timing_on) {
-            if (c->ev_used == c->ev.size()) {
-                if (c->ev.size() >= 65536) return set_error(MCRT_ERR_LIMIT, "timing buffer full: call mcrt_get_kernel_time(reset=1)");
-                hipEvent_t x, y;
-                HIP_TRY(hipEventCreate(&x)); HIP_TRY(hipEventCreate(&y));
-                c->ev.emplace_back(x, y);
-            }
-            e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; c->ev_used++;
-            HIP_TRY(hipEventRecord(e0, c->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing_on) {
+        if (c->ev_used == c->ev.size()) {
+            if (c->ev.size() >= 65536) return set_error(MCRT_ERR_LIMIT, "timing buffer full: call mcrt_get_kernel_time(reset=1)");
+            hipEvent_t x, y;
+            HIP_TRY(hipEventCreate(&x)); HIP_TRY(hipEventCreate(&y));
+            c->ev.emplace_back(x, y);
         }
-        HIP_TRY(mcrt::launch_trace(a, b, c->stats_on, c->stream));
-        if (c->timing_on) HIP_TRY(hipEventRecord(e1, c->stream));
-        HIP_TRY(mcrt::launch_shade(a, b, c->stats_on, c->stream));
-        if (overlap) {   // the segments of bounce b are final: accumulate them beside the next bounce's walk
-            HIP_TRY(hipEventRecord(c->ev_bounce[b], c->stream));
-            HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_bounce[b], 0));
-            HIP_TRY(mcrt::launch_march(a, b, 1, c->stats_on, c->side_stream));
+        e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; c->ev_used++;
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    HIP_TRY(mcrt::launch_trace(a, b, c->stats_on, st));
+    if (c->timing_on) HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(mcrt::launch_shade(a, b, c->stats_on, st));
+    if (accumulate && overlap) {   // the segments of bounce b are final: accumulate them beside the next bounce's walk
+        HIP_TRY(hipEventRecord(w.ev_bounce[b], st));
+        HIP_TRY(hipStreamWaitEvent(w.side, w.ev_bounce[b], 0));
+        HIP_TRY(mcrt::launch_march(a, b, 1, c->stats_on, w.side));
+    }
+    return MCRT_OK;
+}
+
+// scene::cast_rays (scene.cpp:50-183) [+ the accumulation loop] for scan-lines [e0,e1), split into `groups` independent
+// pipelines whose kernels run concurrently.  Everything is ordered after what is already queued on the context's stream, and
+// the context's stream waits for all of it.
+static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, bool accumulate, uint32_t groups)
+{
+    const uint32_t ne = e1 - e0;
+    if (n_frames > 1) groups = 1;
+    if (groups > ne) groups = ne;
+    if (groups < 1) groups = 1;
+    if (groups > 16) groups = 16;
+    const bool overlap = !getenv("MCRT_NO_OVERLAP");
+    std::vector<mcrt::FrameArgs> args(groups);
+    std::vector<Work *> ws(groups);
+    for (uint32_t g = 0; g < groups; g++) {
+        int rc = get_work(c, g, &ws[g]); if (rc) return rc;
+        const uint32_t b0 = e0 + (uint32_t)(((uint64_t)ne * g) / groups), b1 = e0 + (uint32_t)(((uint64_t)ne * (g + 1)) / groups);
+        rc = ensure_work(c, *ws[g], (b1 - b0) * n_frames); if (rc) return rc;
+        fill_args(c, *ws[g], args[g], frame, n_frames, b0, b1, e0);
+    }
+    HIP_TRY(hipEventRecord(c->ev_start, c->stream));
+    for (uint32_t g = 0; g < groups; g++) {
+        hipStream_t st = g == 0 ? c->stream : ws[g]->stream;
+        if (g) HIP_TRY(hipStreamWaitEvent(st, c->ev_start, 0));
+        HIP_TRY(mcrt::launch_init(args[g], st));
+    }
+    for (uint32_t b = 0; b < c->p.max_depth; b++)
+        for (uint32_t g = 0; g < groups; g++) {
+            int rc = run_bounce(c, *ws[g], g == 0 ? c->stream : ws[g]->stream, args[g], b, accumulate, overlap); if (rc) return rc;
+        }
+    for (uint32_t g = 0; g < groups; g++) {
+        hipStream_t st = g == 0 ? c->stream : ws[g]->stream;
+        if (accumulate && overlap) {
+            HIP_TRY(hipEventRecord(ws[g]->ev_join, ws[g]->side));
+            HIP_TRY(hipStreamWaitEvent(st, ws[g]->ev_join, 0));
+        } else if (accumulate) {
+            HIP_TRY(mcrt::launch_march(args[g], 0, args[g].B, c->stats_on, st));
+        }
+        if (g) {
+            HIP_TRY(hipEventRecord(ws[g]->ev_done, st));
+            HIP_TRY(hipStreamWaitEvent(c->stream, ws[g]->ev_done, 0));
         }
     }
-    if (overlap) {
-        HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    } else if (accumulate) {
-        HIP_TRY(mcrt::launch_march(a, 0, a.B, c->stats_on, c->stream));
-    }
+    return MCRT_OK;
+}
+
+static uint32_t frame_groups(const mcrt_ctx *c)
+{
+    uint32_t g = MCRT_GROUPS_DEFAULT;
+    if (const char *e = getenv("MCRT_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 16) g = (uint32_t)v; }   // tuning knob
+    return c->stats_on ? 1u : g;
+}
+
+extern "C" int mcrt_trace_frames(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, float *rf_dev)
+{
+    CTX_TRY(c);
+    int rc = check_ready(c, e0, e1); if (rc) return rc;
+    if (!rf_dev) return set_error(MCRT_ERR_INVALID, "null rf_dev");
+    if (n_frames == 0 || n_frames > 64) return set_error(MCRT_ERR_LIMIT, "n_frames must be 1..64");
+    const uint32_t lines = (e1 - e0) * n_frames;
+    rc = ensure_acc(c, lines); if (rc) return rc;
+    rc = run_frame(c, frame, n_frames, e0, e1, true, frame_groups(c)); if (rc) return rc;
+    HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, lines, c->p.n_rows, c->stream));
+    c->acc_clean_ne = lines; c->acc_clean_rows = c->p.n_rows;
     return MCRT_OK;
 }
 
 extern "C" int mcrt_trace_frame(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32_t e1, float *rf_dev)
 {
-    CTX_TRY(c);
-    int rc = check_ready(c, e0, e1); if (rc) return rc;
-    if (!rf_dev) return set_error(MCRT_ERR_INVALID, "null rf_dev");
-    rc = ensure_acc(c, e1 - e0); if (rc) return rc;
-    rc = ensure_work(c, e1 - e0); if (rc) return rc;
-    mcrt::FrameArgs a; fill_args(c, a, frame, e0, e1);
-    rc = run_cast(c, a, true); if (rc) return rc;
-    HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, e1 - e0, c->p.n_rows, c->stream));
-    c->acc_clean_ne = e1 - e0; c->acc_clean_rows = c->p.n_rows;
-    return MCRT_OK;
+    return mcrt_trace_frames(c, frame, 1, e0, e1, rf_dev);
 }
 
-// copies the segment table to the host: segs [ne][S][B], seg_count [ne][S], hits [ne][S][B] (= segment.tri, -2 beyond the path's end)
+// copies the segment table (work set 0) to the host: segs [ne][S][B], seg_count [ne][S], hits [ne][S][B] (= segment.tri, -2 beyond the path's end)
 static int copy_out(mcrt_ctx *c, uint32_t ne, int32_t *hits, mcrt_segment *segs, uint32_t *seg_count)
 {
     const size_t np = (size_t)ne * c->p.n_samples, B = c->p.max_depth;
+    const Work &w = c->work[0];
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc = check_device_error(c); if (rc) return rc;
     std::vector<mcrt_segment> tmp;
     std::vector<uint32_t> cnt;
     if (!segs && hits) { tmp.resize(np * B); segs = tmp.data(); }
     if (!seg_count && hits) { cnt.resize(np); seg_count = cnt.data(); }
-    if (seg_count) HIP_TRY(hipMemcpy(seg_count, c->d_seg_count, np * 4, hipMemcpyDeviceToHost));
+    if (seg_count) HIP_TRY(hipMemcpy(seg_count, w.d_seg_count, np * 4, hipMemcpyDeviceToHost));
     if (segs) {
-        HIP_TRY(hipMemcpy(segs, c->d_segs, np * B * sizeof(mcrt_segment), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(segs, w.d_segs, np * B * sizeof(mcrt_segment), hipMemcpyDeviceToHost));
         for (size_t p = 0; p < np; p++)                         // slots beyond a path's end are unspecified on the device
             for (size_t b = seg_count[p]; b < B; b++) memset(&segs[p * B + b], 0, sizeof(mcrt_segment));
     }
@@ -483,7 +567,12 @@ extern "C" int mcrt_trace_frame_debug(mcrt_ctx *c, uint32_t frame, uint32_t e0, 
                                       int32_t *hits, mcrt_segment *segs, uint32_t *seg_count)
 {
     CTX_TRY(c);
-    int rc = mcrt_trace_frame(c, frame, e0, e1, rf_dev); if (rc) return rc;
+    int rc = check_ready(c, e0, e1); if (rc) return rc;
+    if (!rf_dev) return set_error(MCRT_ERR_INVALID, "null rf_dev");
+    rc = ensure_acc(c, e1 - e0); if (rc) return rc;
+    rc = run_frame(c, frame, 1, e0, e1, true, 1); if (rc) return rc;         // one group: the segment table is contiguous
+    HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, e1 - e0, c->p.n_rows, c->stream));
+    c->acc_clean_ne = e1 - e0; c->acc_clean_rows = c->p.n_rows;
     return copy_out(c, e1 - e0, hits, segs, seg_count);
 }
 
@@ -491,9 +580,7 @@ extern "C" int mcrt_cast_rays(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32_t
 {
     CTX_TRY(c);
     int rc = check_ready(c, e0, e1); if (rc) return rc;
-    rc = ensure_work(c, e1 - e0); if (rc) return rc;
-    mcrt::FrameArgs a; fill_args(c, a, frame, e0, e1);
-    rc = run_cast(c, a, false); if (rc) return rc;
+    rc = run_frame(c, frame, 1, e0, e1, false, 1); if (rc) return rc;
     return copy_out(c, e1 - e0, hits, segs, seg_count);
 }
 

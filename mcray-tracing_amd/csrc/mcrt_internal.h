@@ -6,6 +6,7 @@
 #define MCRT_STACK 64              // BVH4 traversal stack entries per path (LDS); trees needing more are rejected at upload
 #define MCRT_KSPLIT_DEFAULT 131072 // work items a small bounce of k_trace is cut into (pieces x rays)
 #define MCRT_KSPLIT_MAX 1048576
+#define MCRT_GROUPS_DEFAULT 1        // independent scan-line groups a frame is traced as (their kernels overlap)
 #define MCRT_MAX_ROWS 2048
 #define MCRT_MAX_BOUNCES 16
 

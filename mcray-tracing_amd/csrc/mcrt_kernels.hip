@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
         a.counts[MCRT_MAX_BOUNCES + 1 + pid] = (blocks < a.trace_blocks ? blocks : a.trace_blocks) * 64u;
     }
     if (pid >= np) return;
-    const uint32_t e_abs = a.e_begin + pid / a.S;
+    const uint32_t e_abs = a.e_begin + (pid / a.S) % a.ne_frame;      // several frames may be in flight: line = frame * ne_frame + scan-line
     const f3 from = mk(a.el_pos[3 * e_abs], a.el_pos[3 * e_abs + 1], a.el_pos[3 * e_abs + 2]);
     const f3 dir = mk(a.el_dir[3 * e_abs], a.el_dir[3 * e_abs + 1], a.el_dir[3 * e_abs + 2]);
     const float intensity = a.I0 / (float)a.S;
@@ -500,8 +500,9 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
             best.da = dot(best.n, f2) - dot(v0, best.n);
             best.mesh = __float_as_int(t1.w);
         }
-        const uint32_t e_abs = a.e_begin + pid / a.S;
-        Rng g; g.k0 = a.seed; g.k1 = a.frame; g.element = e_abs; g.sample = pid % a.S; g.bounce = b;
+        const uint32_t line = pid / a.S;
+        const uint32_t e_abs = a.e_begin + line % a.ne_frame;
+        Rng g; g.k0 = a.seed; g.k1 = a.frame + line / a.ne_frame; g.element = e_abs; g.sample = pid % a.S; g.bounce = b;
         const float4 m0 = a.mats[2 * media];   // imp, att, mu0, mu1  (second half: sigma, spec, shine, thick)
         const float att = m0.y;
 

@@ -297,3 +297,22 @@ def test_cpp_host_cli_matches_oracle(mcrt, orc, tex256, tmp_path):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     bad = subprocess.run([exe, str(tmp_path / "missing.scene")], capture_output=True, text=True)
     assert bad.returncode == 1 and "The program found an error" in bad.stdout
+
+
+def test_frames_in_flight_are_bit_identical(mcrt, orc, sphere, tex256):
+    """mcrt_trace_frames: several frame ids traced as one pass give exactly the images of one-at-a-time tracing"""
+    cfg, sd = sphere
+    E, S, F = 16, 128, 3
+    tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256)
+    dev = sim.ctx.alloc(F * E * sim.R * 4)
+    sim.ctx.trace_frames(7, F, dev)
+    batch = sim.ctx.d2h(dev, (F, E, sim.R))
+    for f in range(F):
+        sim.trace(7 + f)
+        one = sim.ctx.d2h(sim.rf_dev, (E, sim.R))
+        assert np.array_equal(batch[f].view(np.uint32), one.view(np.uint32))
+    osc, p, o = _oracle(orc, sd, tr, tex256, E, S)
+    o8 = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=8, want_hits=False, want_ref=False)
+    assert np.array_equal(batch[1].T.view(np.uint32), o8["rf"].view(np.uint32))
+    sim.ctx.free(dev)
+    sim.close()
