@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--scanlines", type=int, default=128, help="scan-lines per GPU")
     ap.add_argument("--rays", type=int, default=1024, help="sample paths per scan-line")
     ap.add_argument("--rows", type=int, default=465)
+    ap.add_argument("--tex-n", type=int, default=256, help="texture edge in voxels (256 = the reference; smaller only for cache experiments)")
     ap.add_argument("--frames-in-flight", type=int, default=8,
                     help="frames traced per pass (mcrt_trace_frames): a step is still ONE frame, but every kernel launch then carries the "
                          "rays of this many consecutive frames (1 = strict one-frame-at-a-time latency mode)")
@@ -88,11 +89,11 @@ def main():
     cfg, sd, label = build_workload(m, args.workload)
     tr = m.Transducer(E, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
     ctx = m.Context(local_rank)
-    ctx.set_params(n_elements=E, n_samples=S, n_rows=R, frequency=tr.frequency)
+    ctx.set_params(n_elements=E, n_samples=S, n_rows=R, frequency=tr.frequency, tex_n=args.tex_n)
     t0 = time.time()
     ctx.upload_scene(sd)
     t_bvh = time.time() - t0
-    ctx.upload_texture(None, 256)
+    ctx.upload_texture(None, args.tex_n)
     ctx.set_transducer(tr.pos, tr.dir)
     psf = m.Psf(freq=tr.frequency)
     stream = torch.cuda.current_stream()

@@ -407,7 +407,7 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne)
     HIP_TRY(hipDeviceSynchronize());
     free_work_buffers(w);
     const uint32_t B = c->p.max_depth;
-    HIP_TRY(hipMalloc(&w.d_st0, 16 * np)); HIP_TRY(hipMalloc(&w.d_st1, 16 * np)); HIP_TRY(hipMalloc(&w.d_st2, 16 * np));
+    HIP_TRY(hipMalloc(&w.d_st0, 32 * np)); HIP_TRY(hipMalloc(&w.d_st1, 32 * np)); HIP_TRY(hipMalloc(&w.d_st2, 32 * np));   // two halves: bounce parity
     HIP_TRY(hipMalloc(&w.d_ray0, 32 * np)); HIP_TRY(hipMalloc(&w.d_ray1, 32 * np)); HIP_TRY(hipMalloc(&w.d_key0, 8 * np)); HIP_TRY(hipMalloc(&w.d_key1, 8 * np));
     HIP_TRY(hipMalloc(&w.d_q0, 4 * np)); HIP_TRY(hipMalloc(&w.d_q1, 4 * np)); HIP_TRY(hipMalloc(&w.d_seg_count, 4 * np));
     HIP_TRY(hipMalloc(&w.d_counts, 4 * (2 * MCRT_MAX_BOUNCES + 1)));
@@ -417,13 +417,13 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne)
 }
 
 // kernel arguments for scan-lines [e0,e1) traced with work set w; acc_e0 = first scan-line of the frame's RF block
-static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, uint32_t acc_e0)
+static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, uint32_t acc_e0, uint32_t acc_ne)
 {
     memset(&a, 0, sizeof a);
     a.nodes = c->d_nodes; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
     a.el_pos = c->d_pos; a.el_dir = c->d_dir; a.row_thr = c->d_row_thr;
-    a.acc = c->d_acc ? c->d_acc + (size_t)(e0 - acc_e0) * c->p.n_rows : nullptr;
-    a.flags = c->d_flags ? c->d_flags + (size_t)(e0 - acc_e0) * ((c->p.n_rows + 31u) >> 5) : nullptr;
+    a.acc = c->d_acc; a.flags = c->d_flags;                 // the frame block [n_frames][acc_ne][R]; this group owns columns e0-acc_e0 ...
+    a.acc_stride = acc_ne; a.acc_off = e0 - acc_e0;
     a.st0 = w.d_st0; a.st1 = w.d_st1; a.st2 = w.d_st2; a.queue0 = w.d_q0; a.queue1 = w.d_q1;
     a.ray0 = w.d_ray0; a.ray1 = w.d_ray1; a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.segs = w.d_segs; a.seg_count = w.d_seg_count;
     a.stats = c->d_stats; a.error_flag = c->d_error; a.stamps = c->d_stats + 8;
@@ -433,9 +433,9 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     if (const char *e = getenv("MCRT_KSPLIT_LIMIT")) { long v = atol(e); if (v >= 0 && v <= MCRT_KSPLIT_MAX) a.ksplit_limit = (uint32_t)v; }   // tuning knob; 0 = off
     if (c->stats_on) a.ksplit_limit = 0;   // counting mode = one walk per ray, so the counts are the oracle's
     for (int i = 0; i < 3; i++) { a.scene_lo[i] = c->scene_lo[i]; a.scene_hi[i] = c->scene_hi[i]; }
-    a.trace_blocks = 1024;   // persistent k_trace: 4 waves/SIMD on 256 CUs; quads fetch further rays dynamically
+    a.trace_blocks = 1280;   // persistent k_trace: 5 waves/SIMD on 256 CUs; quads fetch further rays dynamically
     if (const char *e = getenv("MCRT_TRACE_BLOCKS")) { int v = atoi(e); if (v >= 1) a.trace_blocks = (uint32_t)v; }   // tuning knob
-    a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n;
+    a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n; a.tex_mask = (c->tex_n & (c->tex_n - 1u)) == 0u ? c->tex_n - 1u : 0u;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
     a.freq = c->p.frequency; a.eps = c->p.intensity_epsilon; a.I0 = c->p.initial_intensity; a.offs = c->p.ray_start_offset;
     a.sx = c->spacing[0]; a.sy = c->spacing[1]; a.sz = c->spacing[2]; a.tex_res = c->p.tex_res; a.axial_res_f = c->c.axial_res_f; a.pad_abs = c->bvh.pad_abs; a.tex_rcp = 1.0f / c->p.tex_res; a.fast_div = c->fast_div ? 1u : 0u;
@@ -475,7 +475,6 @@ static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArg
 static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, bool accumulate, uint32_t groups)
 {
     const uint32_t ne = e1 - e0;
-    if (n_frames > 1) groups = 1;
     if (groups > ne) groups = ne;
     if (groups < 1) groups = 1;
     if (groups > 16) groups = 16;
@@ -486,7 +485,7 @@ static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0
         int rc = get_work(c, g, &ws[g]); if (rc) return rc;
         const uint32_t b0 = e0 + (uint32_t)(((uint64_t)ne * g) / groups), b1 = e0 + (uint32_t)(((uint64_t)ne * (g + 1)) / groups);
         rc = ensure_work(c, *ws[g], (b1 - b0) * n_frames); if (rc) return rc;
-        fill_args(c, *ws[g], args[g], frame, n_frames, b0, b1, e0);
+        fill_args(c, *ws[g], args[g], frame, n_frames, b0, b1, e0, ne);
     }
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
     for (uint32_t g = 0; g < groups; g++) {

@@ -21,7 +21,7 @@
 #define MCRT_FETCH_BATCH 16         // queue positions a wavefront of k_trace claims per atomic
 #endif
 #ifndef MCRT_TRACE_WAVES
-#define MCRT_TRACE_WAVES 4          // waves per SIMD k_trace's register allocation must allow
+#define MCRT_TRACE_WAVES 5          // waves per SIMD k_trace's register allocation must allow
 #endif
 #ifndef MCRT_LEAF_BATCH
 #define MCRT_LEAF_BATCH 4          // leave the inner-node phase once this many of a wave's 16 paths are parked on a leaf
@@ -141,13 +141,13 @@ MCRT_DEV f3 random_unit_vector(f3 v, float cos_theta, const Rng &g)
 
 MCRT_DEV float std_max(float a, float b) { return (a < b) ? b : a; }
 
-MCRT_DEV uint32_t vox_index(float q, uint32_t n)
+MCRT_DEV uint32_t vox_index(float q, uint32_t n, uint32_t mask)
 {
     long long i;
     if (!(fabsf(q) < 9.2233720368547758e18f)) i = (long long)0x8000000000000000ull;
     else if (fabsf(q) < 2147483648.0f) i = (long long)(int)q;
     else i = (long long)q;
-    return ((uint32_t)i) % n;
+    return mask ? ((uint32_t)i & mask) : ((uint32_t)i) % n;   // mask = n-1 when n is a power of two (the reference's 256)
 }
 
 MCRT_DEV uint32_t steps_from(double q)
@@ -200,11 +200,32 @@ MCRT_DEV float div_res(float x, const FrameArgs &a)
 
 // one echo into the scan-line's fixed-point LDS bins (2^-52 units; integer adds commute, so the image does not depend
 // on the order lanes, waves or workgroups arrive in)
+// rint(echo * 2^52) for |echo| < 1024, built from the float's bits (exactly what the double multiply + rint gives: the product
+// is exact, so only echoes below 2^-29 need rounding at all -- round-to-nearest-even on the dropped mantissa bits)
+MCRT_DEV long long fix52(float echo)
+{
+    const uint32_t u = __float_as_uint(echo);
+    const int e = (int)((u >> 23) & 255u);
+    const uint32_t m = (u & 0x7fffffu) | (e ? 0x800000u : 0u);
+    const int sh = (e ? e : 1) - 98;                       // echo = m * 2^(e-150)  ->  echo * 2^52 = m * 2^(e-98)
+    long long v;
+    if (sh >= 0) v = (long long)((unsigned long long)m << sh);
+    else {
+        const int r = -sh;
+        if (r > 25) v = 0;
+        else {
+            const uint32_t q = m >> r, rem = m & ((1u << r) - 1u), half = 1u << (r - 1);
+            v = (long long)(q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u));
+        }
+    }
+    return (u >> 31) ? -v : v;
+}
+
 MCRT_DEV void rf_add(long long *bins, uint32_t *lflags, int row, float echo)
 {
     if (row < 0) return;
     if (!(fabsf(echo) < 1024.0f)) { atomicOr(&lflags[row >> 5], 1u << (row & 31)); return; }
-    const long long v = (long long)rint((double)echo * 4503599627370496.0);
+    const long long v = fix52(echo);
     if (v != 0) atomicAdd((unsigned long long *)&bins[row], (unsigned long long)v);
 }
 
@@ -481,7 +502,9 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
     unsigned long long st_seg = 0, st_hits = 0;
     if (valid) {
         pid = q_in[i];
-        const float4 s0 = a.st0[pid], s1 = a.st1[pid], s2 = a.st2[pid];
+        // path state lives in queue order (ping-pong halves by bounce parity), so a wavefront reads and writes it coalesced
+        const size_t sin = (size_t)(b & 1u) * a.ne * a.S + i;
+        const float4 s0 = a.st0[sin], s1 = a.st1[sin], s2 = a.st2[sin];
         from = mk(s0.x, s0.y, s0.z); intensity = s0.w;
         dir = mk(s1.x, s1.y, s1.z); media = __float_as_int(s1.w);
         dist_mm = __hiloint2double(__float_as_int(s2.y), __float_as_int(s2.x));
@@ -621,9 +644,10 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
                                                    : (uint32_t)__popcll(live_refl) + (uint32_t)__popcll(live & ~live_refl & below));
             q_out[pos] = pid;
             ((b & 1u) ? a.key0 : a.key1)[pos] = MCRT_KEY_MISS;            // the next bounce's closest-hit word of this ray
-            a.st0[pid] = make_float4(from.x, from.y, from.z, intensity);
-            a.st1[pid] = make_float4(dir.x, dir.y, dir.z, __int_as_float(media));
-            a.st2[pid] = make_float4(__int_as_float(__double2loint(dist_mm)), __int_as_float(__double2hiint(dist_mm)), __int_as_float(outside), 0.0f);
+            const size_t so = (size_t)((b + 1u) & 1u) * a.ne * a.S + pos;
+            a.st0[so] = make_float4(from.x, from.y, from.z, intensity);
+            a.st1[so] = make_float4(dir.x, dir.y, dir.z, __int_as_float(media));
+            a.st2[so] = make_float4(__int_as_float(__double2loint(dist_mm)), __int_as_float(__double2hiint(dist_mm)), __int_as_float(outside), 0.0f);
             const Ray r = make_ray(from, dir, intensity, a.mats[2 * media].y, a);
             rays_out[2 * (size_t)pos] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
             rays_out[2 * (size_t)pos + 1] = make_float4(r.to.y, r.to.z, 0.0f, 0.0f);
@@ -689,18 +713,16 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b_begin, ui
             // eight consecutive steps per iteration: lane j owns steps j and j+4, so two independent texture gathers per
             // lane (eight per segment) are in flight; every lane replays the cheap sequential recurrence (point, t, intensity)
             f3 myp[2]; double myt[2]; float myin[2]; bool myv[2];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                myp[h] = point; myt[h] = t; myin[h] = inten; myv[h] = false;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const bool vu = more && (step + (uint32_t)(4 * h + u) < steps) && (t < a.max_travel);   // the reference's loop test
-                    if (u == j) { myp[h] = point; myt[h] = t; myin[h] = inten; myv[h] = vu; }
-                    point = point + delta;                                                                 // ... and its loop tail
-                    t = t + a.time_step;
-                    inten *= k_att;
-                }
-            }
+            // advance j steps to this lane's first own step, capture, advance 4, capture, advance the remaining 4-j: the same
+            // eight sequential updates of (point, t, intensity) in every lane, without per-step selects
+            uint32_t sidx = step;
+#define MCRT_ADVANCE() { point = point + delta; t = t + a.time_step; inten *= k_att; sidx++; }
+            for (int u = 0; u < j; u++) MCRT_ADVANCE()
+            myp[0] = point; myt[0] = t; myin[0] = inten; myv[0] = more && sidx < steps && t < a.max_travel;       // the reference's loop test
+            MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE()
+            myp[1] = point; myt[1] = t; myin[1] = inten; myv[1] = more && sidx < steps && t < a.max_travel;
+            for (int u = j; u < 4; u++) MCRT_ADVANCE()
+#undef MCRT_ADVANCE
             step += 8u;
             more = more && step < steps && t < a.max_travel;
             float2 vox[2];
@@ -708,7 +730,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b_begin, ui
             for (int h = 0; h < 2; h++) {
                 vox[h] = make_float2(0.0f, 0.0f);
                 if (myv[h]) {
-                    const uint32_t vx = vox_index(div_res(myp[h].x, a), a.tex_n), vy = vox_index(div_res(myp[h].y, a), a.tex_n), vz = vox_index(div_res(myp[h].z, a), a.tex_n);
+                    const uint32_t vx = vox_index(div_res(myp[h].x, a), a.tex_n, a.tex_mask), vy = vox_index(div_res(myp[h].y, a), a.tex_n, a.tex_mask), vz = vox_index(div_res(myp[h].z, a), a.tex_n, a.tex_mask);
                     vox[h] = a.tex[((size_t)vx * a.tex_n + vy) * a.tex_n + vz];
                 }
             }
@@ -732,13 +754,15 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b_begin, ui
         if (lane == 0 && x) atomicAdd(&a.stats[4], (unsigned long long)x);
     }
     __syncthreads();
-    long long *gacc = a.acc + (size_t)e_local * R;
+    // row of the frame's RF block: [frame][scan-line of the whole block]; this launch covers scan-lines [acc_off, acc_off+ne_frame)
+    const size_t line = (size_t)(e_local / a.ne_frame) * a.acc_stride + a.acc_off + e_local % a.ne_frame;
+    long long *gacc = a.acc + line * R;
     for (uint32_t r = tid; r < R; r += nthr) {
         const long long v = bins[r];
         if (v != 0) atomicAdd((unsigned long long *)&gacc[r], (unsigned long long)v);
     }
     const uint32_t nf = (R + 31u) >> 5;
-    for (uint32_t r = tid; r < nf; r += nthr) { const uint32_t f = lflags[r]; if (f) atomicOr(&a.flags[(size_t)e_local * nf + r], f); }
+    for (uint32_t r = tid; r < nf; r += nthr) { const uint32_t f = lflags[r]; if (f) atomicOr(&a.flags[line * nf + r], f); }
 }
 
 // fixed-point bins -> float RF image [ne][R]; clears the bins for the next frame
@@ -866,6 +890,8 @@ __global__ void k_math_probe(int op, const double *x, const double *y, double *o
     case 9: r = (double)sqrtf((float)a); break;
     case 10: r = (double)((float)a / (float)b); break;
     case 11: r = det_pow_pos(a, b); break;
+    case 12: r = (double)(fix52((float)a) & 0x7fffffffll); break;          // low 31 bits of the fixed-point echo
+    case 13: r = (double)(fix52((float)a) >> 31); break;                    // the rest (arithmetic shift)
     default: break;
     }
     out[i] = r;

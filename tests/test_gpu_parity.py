@@ -72,6 +72,13 @@ def test_contract_math_on_gpu(mcrt, orc):
     g = ctx.debug_math(8, xb, yb)
     ref = np.array([orc.lib().orc_powf(a_, b_) for a_, b_ in zip(xb.tolist(), yb.tolist())], np.float64)
     assert np.array_equal(np.isnan(g), np.isnan(ref)) and np.array_equal(g[~np.isnan(g)], ref[~np.isnan(ref)])
+    # fixed-point echo conversion (integer construction in the kernel) == rint(echo * 2^52), incl. the sub-2^-29 rounding path
+    ech = np.concatenate([rng.normal(size=n) * 10.0 ** rng.uniform(-14, 2, n), (rng.uniform(-1, 1, n) * 2.0 ** -52 * rng.integers(1, 1 << 24, n)),
+                          [0.0, -0.0, 2.0 ** -53, 3 * 2.0 ** -54, 2.0 ** -29, 1023.99994, 1e-45, -1e-45]]).astype(np.float32)
+    ech = ech[np.abs(ech) < 1024]
+    lo = ctx.debug_math(12, ech.astype(np.float64)).astype(np.int64); hi = ctx.debug_math(13, ech.astype(np.float64)).astype(np.int64)
+    ref = np.rint(ech.astype(np.float64) * 2.0 ** 52).astype(np.int64)
+    assert np.array_equal((hi << 31) | lo, ref)
     # philox
     for ctr, key in [([0, 0, 0, 0], [0, 0]), ([0xffffffff] * 4, [0xffffffff] * 2), ([1, 2, 3, 4], [5, 6])]:
         assert np.array_equal(ctx.debug_philox(ctr, key), orc.philox(ctr, key))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-launch kernel durations of the last benchmark frame (rocprofv3 kernel trace)
 out=gpurun_out/timeline_$1; mkdir -p $out; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $out/kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out/kt -- python3 bench.py --steps 16 --warmup 8 --no-cpu-baseline ${BENCH_ARGS} > $out/bench.log 2>&1
 python3 - $out <<'PY'
 import csv, glob, sys
 out=sys.argv[1]
@@ -9,8 +9,12 @@ f=glob.glob(out+'/kt/*/*kernel_trace.csv')[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # last frame = from last k_init on
-idx=[i for i,r in enumerate(rows) if 'k_init' in r['Kernel_Name']]
-last=rows[idx[-1]:]
+gkey='Grid_Size_X' if 'Grid_Size_X' in rows[0] else 'Grid_Size'
+inits=[i for i,r in enumerate(rows) if 'k_init' in r['Kernel_Name']]
+big=max(int(rows[i][gkey]) for i in inits)
+idx=[i for i in inits if int(rows[i][gkey])==big]     # the largest passes (all frames in flight)
+nxt=[i for i in inits if i>idx[-1]]
+last=rows[idx[-1]:(nxt[0] if nxt else len(rows))]
 t0=int(last[0]['Start_Timestamp'])
 for r in last:
     n=r['Kernel_Name'].split('(')[0].replace('void mcrt::','').replace('mcrt::','')
