@@ -55,6 +55,7 @@ def main():
                     help="frames traced per pass (mcrt_trace_frames): a step is still ONE frame, but every kernel launch then carries the "
                          "rays of this many consecutive frames (1 = strict one-frame-at-a-time latency mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency-leg", action="store_true", help="skip the extra one-frame-at-a-time measurement (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for plumbing checks")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing check on a 1-GPU box: every rank uses GPU 0")
     args = ap.parse_args()
@@ -190,7 +191,7 @@ def main():
                          "other_stage_bytes_per_frame": other_bytes_frame,
                          "per_launch": {k: v / args.steps for k, v in st.items()}},
         }
-        if world == 1 and F > 1:
+        if world == 1 and F > 1 and not args.no_latency_leg:
             # the same workload strictly one frame at a time (each launch carries one frame's rays), for the record
             for f in range(args.warmup):
                 step_batch(2000 + f, 1)

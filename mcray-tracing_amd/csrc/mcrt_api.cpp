@@ -55,7 +55,8 @@ struct Work {
     hipEvent_t ev_bounce[MCRT_MAX_BOUNCES] = {}, ev_join = nullptr, ev_done = nullptr;
     float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr;
     unsigned long long *d_key0 = nullptr, *d_key1 = nullptr;
-    uint32_t *d_q0 = nullptr, *d_q1 = nullptr, *d_counts = nullptr, *d_seg_count = nullptr;
+    uint32_t *d_q = nullptr, *d_counts = nullptr, *d_seg_count = nullptr;
+    hipEvent_t ev_march[MCRT_MAX_BOUNCES] = {};
     mcrt_segment *d_segs = nullptr; size_t paths = 0; uint32_t depth = 0;
 };
 
@@ -176,8 +177,8 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
 static void free_work_buffers(Work &w)
 {
     hipFree(w.d_st0); hipFree(w.d_st1); hipFree(w.d_st2); hipFree(w.d_ray0); hipFree(w.d_ray1); hipFree(w.d_key0); hipFree(w.d_key1);
-    hipFree(w.d_q0); hipFree(w.d_q1); hipFree(w.d_counts); hipFree(w.d_seg_count); hipFree(w.d_segs);
-    w.d_st0 = w.d_st1 = w.d_st2 = w.d_ray0 = w.d_ray1 = nullptr; w.d_key0 = w.d_key1 = nullptr; w.d_q0 = w.d_q1 = w.d_counts = w.d_seg_count = nullptr;
+    hipFree(w.d_q); hipFree(w.d_counts); hipFree(w.d_seg_count); hipFree(w.d_segs);
+    w.d_st0 = w.d_st1 = w.d_st2 = w.d_ray0 = w.d_ray1 = nullptr; w.d_key0 = w.d_key1 = nullptr; w.d_q = w.d_counts = w.d_seg_count = nullptr;
     w.d_segs = nullptr; w.paths = 0; w.depth = 0;
 }
 
@@ -185,7 +186,7 @@ static void free_work(mcrt_ctx *c)
 {
     for (Work &w : c->work) {
         free_work_buffers(w);
-        for (int i = 0; i < MCRT_MAX_BOUNCES; i++) if (w.ev_bounce[i]) hipEventDestroy(w.ev_bounce[i]);
+        for (int i = 0; i < MCRT_MAX_BOUNCES; i++) { if (w.ev_bounce[i]) hipEventDestroy(w.ev_bounce[i]); if (w.ev_march[i]) hipEventDestroy(w.ev_march[i]); }
         if (w.ev_join) hipEventDestroy(w.ev_join);
         if (w.ev_done) hipEventDestroy(w.ev_done);
         if (w.side) hipStreamDestroy(w.side);
@@ -201,7 +202,7 @@ static int get_work(mcrt_ctx *c, size_t g, Work **out)
         Work w;
         if (!c->work.empty()) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
-        for (int i = 0; i < MCRT_MAX_BOUNCES; i++) HIP_TRY(hipEventCreateWithFlags(&w.ev_bounce[i], hipEventDisableTiming));
+        for (int i = 0; i < MCRT_MAX_BOUNCES; i++) { HIP_TRY(hipEventCreateWithFlags(&w.ev_bounce[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&w.ev_march[i], hipEventDisableTiming)); }
         HIP_TRY(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
         c->work.push_back(w);
@@ -409,7 +410,7 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne)
     const uint32_t B = c->p.max_depth;
     HIP_TRY(hipMalloc(&w.d_st0, 32 * np)); HIP_TRY(hipMalloc(&w.d_st1, 32 * np)); HIP_TRY(hipMalloc(&w.d_st2, 32 * np));   // two halves: bounce parity
     HIP_TRY(hipMalloc(&w.d_ray0, 32 * np)); HIP_TRY(hipMalloc(&w.d_ray1, 32 * np)); HIP_TRY(hipMalloc(&w.d_key0, 8 * np)); HIP_TRY(hipMalloc(&w.d_key1, 8 * np));
-    HIP_TRY(hipMalloc(&w.d_q0, 4 * np)); HIP_TRY(hipMalloc(&w.d_q1, 4 * np)); HIP_TRY(hipMalloc(&w.d_seg_count, 4 * np));
+    HIP_TRY(hipMalloc(&w.d_q, 12 * np)); HIP_TRY(hipMalloc(&w.d_seg_count, 4 * np));
     HIP_TRY(hipMalloc(&w.d_counts, 4 * (2 * MCRT_MAX_BOUNCES + 1)));
     HIP_TRY(hipMalloc(&w.d_segs, sizeof(mcrt_segment) * np * B));
     w.paths = np; w.depth = B;
@@ -424,7 +425,7 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     a.el_pos = c->d_pos; a.el_dir = c->d_dir; a.row_thr = c->d_row_thr;
     a.acc = c->d_acc; a.flags = c->d_flags;                 // the frame block [n_frames][acc_ne][R]; this group owns columns e0-acc_e0 ...
     a.acc_stride = acc_ne; a.acc_off = e0 - acc_e0;
-    a.st0 = w.d_st0; a.st1 = w.d_st1; a.st2 = w.d_st2; a.queue0 = w.d_q0; a.queue1 = w.d_q1;
+    a.st0 = w.d_st0; a.st1 = w.d_st1; a.st2 = w.d_st2; a.queue = w.d_q;
     a.ray0 = w.d_ray0; a.ray1 = w.d_ray1; a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.segs = w.d_segs; a.seg_count = w.d_seg_count;
     a.stats = c->d_stats; a.error_flag = c->d_error; a.stamps = c->d_stats + 8;
     a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
@@ -464,7 +465,10 @@ static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArg
     if (accumulate && overlap) {   // the segments of bounce b are final: accumulate them beside the next bounce's walk
         HIP_TRY(hipEventRecord(w.ev_bounce[b], st));
         HIP_TRY(hipStreamWaitEvent(w.side, w.ev_bounce[b], 0));
-        HIP_TRY(mcrt::launch_march(a, b, 1, c->stats_on, w.side));
+        HIP_TRY(mcrt::launch_march(a, b, c->stats_on, w.side));
+        HIP_TRY(hipEventRecord(w.ev_march[b], w.side));
+    } else if (accumulate) {
+        HIP_TRY(mcrt::launch_march(a, b, c->stats_on, st));
     }
     return MCRT_OK;
 }
@@ -502,8 +506,6 @@ static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0
         if (accumulate && overlap) {
             HIP_TRY(hipEventRecord(ws[g]->ev_join, ws[g]->side));
             HIP_TRY(hipStreamWaitEvent(st, ws[g]->ev_join, 0));
-        } else if (accumulate) {
-            HIP_TRY(mcrt::launch_march(args[g], 0, args[g].B, c->stats_on, st));
         }
         if (g) {
             HIP_TRY(hipEventRecord(ws[g]->ev_done, st));

@@ -18,7 +18,7 @@ struct FrameArgs {
     const double *row_thr;     // [R+1] row thresholds (see row_of)
     // per-frame work buffers; np = ne * S paths
     float4 *st0, *st1, *st2;   // [np] path state: from,intensity | dir,media | distance_traveled(f64),outside,-
-    uint32_t *queue0, *queue1; // [np] live path ids, ping-pong by bounce parity
+    uint32_t *queue;           // [3][np] live path ids of bounce b in buffer b % 3
     float4 *ray0, *ray1;       // [np][2] f2.xyz,to.x | to.yz,-,-   (indexed by queue position), ping-pong
     unsigned long long *key0, *key1;   // [np] closest hit per ray: fraction bits << 32 | triangle id (atomicMin), ping-pong by bounce parity
     const uint32_t *tri_slot;  // [T] triangle id -> position in the leaf-order triangle array
@@ -39,11 +39,10 @@ struct FrameArgs {
 
 struct ConvTaps { float ax[16]; float lat[32]; uint32_t n_ax, n_lat; };
 
-void march_shape(uint32_t S, uint32_t B, uint32_t ne, uint32_t &slots, uint32_t &chunks);
 hipError_t launch_init(const FrameArgs &a, hipStream_t st);
 hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
 hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
-hipError_t launch_march(const FrameArgs &a, uint32_t b_begin, uint32_t n_bounces, bool stats, hipStream_t st);
+hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
 hipError_t launch_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t ne, uint32_t R, hipStream_t st);
 hipError_t launch_convolve(float *img, float *tmp, uint32_t E, uint32_t R, const ConvTaps &taps, hipStream_t st);
 hipError_t launch_envelope(float *img, uint32_t E, uint32_t R, hipStream_t st);

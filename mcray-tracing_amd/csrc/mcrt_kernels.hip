@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
     a.st0[pid] = make_float4(from.x, from.y, from.z, intensity);
     a.st1[pid] = make_float4(dir.x, dir.y, dir.z, __int_as_float((int)a.start_mat));
     a.st2[pid] = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), 0.0f);      // distance_traveled (double) | outside | -
-    a.queue0[pid] = pid;
+    a.queue[pid] = pid;                                  // queue of bounce 0 (buffer 0 of three)
     a.seg_count[pid] = 0u;
     if (pid < a.ne) a.key0[pid] = MCRT_KEY_MISS;          // bounce 0: one closest-hit word per scan-line
     const Ray r = make_ray(from, dir, intensity, a.mats[2 * a.start_mat].y, a);
@@ -490,8 +490,9 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x * blockDim.x >= n) return;
     const int lane = threadIdx.x & 63;
-    const uint32_t *q_in = (b & 1u) ? a.queue1 : a.queue0;
-    uint32_t *q_out = (b & 1u) ? a.queue0 : a.queue1;
+    // three queue buffers: k_march of bounce b still reads buffer b%3 while k_shade of bounce b+1 fills (b+2)%3
+    const uint32_t *q_in = a.queue + (size_t)(b % 3u) * a.ne * a.S;
+    uint32_t *q_out = a.queue + (size_t)((b + 1u) % 3u) * a.ne * a.S;
     const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
     float4 *rays_out = (b & 1u) ? a.ray0 : a.ray1;
     const bool valid = i < n;
@@ -659,72 +660,92 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
     }
 }
 
-// ---- RF accumulation (main.cpp:112-140): one DPP quad per segment, four consecutive steps per iteration (lane j owns
-// step j: four independent texture gathers in flight), per-scan-line fixed-point bins in LDS ----
+// ---- RF accumulation (main.cpp:112-140) of the segments produced in bounce b.  A workgroup owns a range of the sample
+// slots of ONE scan-line ("line" = frame * ne_frame + scan-line), so its fixed-point bins live in LDS and are flushed once
+// with global integer atomics.  Inside it every wavefront runs its slots as a task pool: one DPP quad per segment, a quad
+// that has finished (or found a dead path's empty slot) takes the next slot, so short, long and missing segments do not wait
+// for each other.  Eight consecutive steps per iteration, lane j owns steps j and j+4 (eight texture gathers of a segment in
+// flight).
 template <bool STATS>
-__global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b_begin, uint32_t n_bounces, uint32_t march_slots, uint32_t march_chunks)
+__global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t chunks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, j = tid & 3, q = tid >> 2;
-    const uint32_t R = a.R;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, j = tid & 3;
+    const uint32_t R = a.R, nf = (R + 31u) >> 5;
     long long *bins = (long long *)smem;
     uint32_t *lflags = (uint32_t *)(bins + ((R + 1u) & ~1u));
-    double *thr = (double *)(lflags + ((((R + 31u) >> 5) + 3u) & ~3u));
+    double *thr = (double *)(lflags + ((nf + 3u) & ~3u));
     for (uint32_t r = tid; r < R; r += nthr) bins[r] = 0;
-    for (uint32_t r = tid; r < ((R + 31u) >> 5); r += nthr) lflags[r] = 0u;
+    for (uint32_t r = tid; r < nf; r += nthr) lflags[r] = 0u;
     for (uint32_t r = tid; r <= R; r += nthr) thr[r] = a.row_thr[r];
     __syncthreads();
 
-    const uint32_t e_local = blockIdx.x / march_chunks, chunk = blockIdx.x % march_chunks;
-    const uint32_t n_slots = a.S * n_bounces;                  // slot k -> bounce k / S, sample k % S: a wavefront's 16 segments share
-    unsigned long long st_steps = 0;                     // the bounce index, hence similar length and coherent texture lines
-    for (uint32_t it = 0; it < march_slots; it++) {
-        const uint32_t k = (chunk * march_slots + it) * 64u + (uint32_t)q;
-        const uint32_t bnc = b_begin + k / a.S, smp = k % a.S;
-        const size_t pid = (size_t)e_local * a.S + smp;
-        bool seg_valid = k < n_slots && bnc < a.seg_count[pid];
-        if (!__any(seg_valid)) continue;
-        float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0;
-        if (seg_valid) {
-            const float4 *sp = (const float4 *)(a.segs + pid * a.B + bnc);
-            g0 = sp[0]; g1 = sp[1]; g2 = sp[2]; g3 = sp[3];
-        }
-        // mcrt_segment: from[3] to[3] dir[3] refl init att | double dist | media tri
-        const f3 seg_from = mk(g0.x, g0.y, g0.z), seg_to = mk(g0.w, g1.x, g1.y), seg_dir = mk(g1.z, g1.w, g2.x);
-        const float seg_refl = g2.y, seg_init = g2.z, seg_att = g2.w;
-        const double seg_dist = __hiloint2double(__float_as_int(g3.y), __float_as_int(g3.x));
-        const int seg_media = seg_valid ? __float_as_int(g3.z) : 0;
+    const uint32_t line = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    // this wavefront's slot range: the line's S slots are cut into chunks*4 contiguous pieces
+    const uint32_t per = (a.S + chunks * 4u - 1u) / (chunks * 4u);
+    const uint32_t s_begin = min(a.S, (chunk * 4u + (uint32_t)wv) * per), s_end = min(a.S, s_begin + per);
+    const size_t pid0 = (size_t)line * a.S;
+    unsigned long long st_steps = 0;
 
-        const float4 s0 = a.mats[2 * seg_media], s1 = a.mats[2 * seg_media + 1];
-        const double t_start = (seg_dist * 1000.0) / a.sos_d;
-        const f3 df = seg_to - seg_from;
-        const float dist_f = sqrtf(dot(df, df)) * 10.0f;
-        const uint32_t steps = seg_valid ? steps_from((double)dist_f / a.axial_res_mm) : 0u;
-        const f3 delta = mk(a.axial_res_f * seg_dir.x, a.axial_res_f * seg_dir.y, a.axial_res_f * seg_dir.z);
-        f3 point = seg_from;
-        double t = t_start;
-        float inten = seg_init;
-        const float k_att = det_expf(-seg_att * a.axial_res_f * 0.01f * a.freq * 1.0f);
-        // scattering is exactly +0 for every voxel when mu0 == sigma == 0 (finite texture): the adds are no-ops
-        const bool silent = a.tex_finite && s0.z == 0.0f && s1.x == 0.0f;
-        uint32_t step = 0;
-        bool more = seg_valid && !silent && steps > 0u && t < a.max_travel;
-        while (__any(more)) {
-            // eight consecutive steps per iteration: lane j owns steps j and j+4, so two independent texture gathers per
-            // lane (eight per segment) are in flight; every lane replays the cheap sequential recurrence (point, t, intensity)
+    uint32_t cursor = s_begin;                               // wave-uniform: next unclaimed slot
+    bool busy = false;
+    f3 point = mk(0, 0, 0), delta = mk(0, 0, 0);
+    double t = 0.0, t_start = 0.0;
+    float inten = 0.0f, k_att = 0.0f, seg_refl = 0.0f, m_dens = 0.0f, m_sigma = 0.0f, m_mu = 0.0f;
+    uint32_t step = 0, steps = 0;
+    bool more = false;
+    for (;;) {
+        // ---- idle quads probe the next slots until at least half of the quads have a segment (or the range is exhausted) ----
+        while (cursor < s_end) {
+            const unsigned long long want = __ballot(!busy && j == 0);
+            if (__popcll(want) < 8) break;
+            const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~3)) - 1ull));
+            if (!busy && mine < s_end) {
+                const size_t pid = pid0 + mine;
+                if (b < a.seg_count[pid]) {
+                    const float4 *sp = (const float4 *)(a.segs + pid * a.B + b);
+                    const float4 g0 = sp[0], g1 = sp[1], g2 = sp[2], g3 = sp[3];
+                    // mcrt_segment: from[3] to[3] dir[3] refl init att | double dist | media tri
+                    const f3 seg_from = mk(g0.x, g0.y, g0.z), seg_to = mk(g0.w, g1.x, g1.y), seg_dir = mk(g1.z, g1.w, g2.x);
+                    seg_refl = g2.y; inten = g2.z;
+                    const float seg_att = g2.w;
+                    const double seg_dist = __hiloint2double(__float_as_int(g3.y), __float_as_int(g3.x));
+                    const int seg_media = __float_as_int(g3.z);
+                    const float4 s0 = a.mats[2 * seg_media], s1 = a.mats[2 * seg_media + 1];
+                    m_mu = s0.z; m_dens = s0.w; m_sigma = s1.x;
+                    t_start = (seg_dist * 1000.0) / a.sos_d;
+                    const f3 df = seg_to - seg_from;
+                    const float dist_f = sqrtf(dot(df, df)) * 10.0f;
+                    steps = steps_from((double)dist_f / a.axial_res_mm);
+                    delta = mk(a.axial_res_f * seg_dir.x, a.axial_res_f * seg_dir.y, a.axial_res_f * seg_dir.z);
+                    k_att = det_expf(-seg_att * a.axial_res_f * 0.01f * a.freq * 1.0f);
+                    point = seg_from; t = t_start; step = 0;
+                    // scattering is exactly +0 for every voxel when mu0 == sigma == 0 (finite texture): the adds are no-ops
+                    const bool silent = a.tex_finite && m_mu == 0.0f && m_sigma == 0.0f;
+                    more = !silent && steps > 0u && t < a.max_travel;
+                    busy = true;
+                }
+            }
+            const uint32_t nw = (uint32_t)__popcll(want);
+            cursor = (cursor + nw < s_end) ? cursor + nw : s_end;
+        }
+        if (!__any(busy)) { if (cursor >= s_end) break; else continue; }
+
+        // ---- eight steps of every running segment ----
+        if (busy && more) {
             f3 myp[2]; double myt[2]; float myin[2]; bool myv[2];
             // advance j steps to this lane's first own step, capture, advance 4, capture, advance the remaining 4-j: the same
             // eight sequential updates of (point, t, intensity) in every lane, without per-step selects
             uint32_t sidx = step;
 #define MCRT_ADVANCE() { point = point + delta; t = t + a.time_step; inten *= k_att; sidx++; }
             for (int u = 0; u < j; u++) MCRT_ADVANCE()
-            myp[0] = point; myt[0] = t; myin[0] = inten; myv[0] = more && sidx < steps && t < a.max_travel;       // the reference's loop test
+            myp[0] = point; myt[0] = t; myin[0] = inten; myv[0] = sidx < steps && t < a.max_travel;               // the reference's loop test
             MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE()
-            myp[1] = point; myt[1] = t; myin[1] = inten; myv[1] = more && sidx < steps && t < a.max_travel;
+            myp[1] = point; myt[1] = t; myin[1] = inten; myv[1] = sidx < steps && t < a.max_travel;
             for (int u = j; u < 4; u++) MCRT_ADVANCE()
 #undef MCRT_ADVANCE
             step += 8u;
-            more = more && step < steps && t < a.max_travel;
+            more = step < steps && t < a.max_travel;
             float2 vox[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -737,16 +758,18 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b_begin, ui
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 if (myv[h]) {
-                    const float scattering = vox[h].y >= s0.w ? vox[h].x * s1.x + s0.z : 0.0f;
+                    const float scattering = vox[h].y >= m_dens ? vox[h].x * m_sigma + m_mu : 0.0f;
                     rf_add(bins, lflags, row_of(myt[h], thr, R, a.inv_row_dt), myin[h] * scattering);
                     if (STATS) st_steps++;
                 }
             }
-        }
-        // boundary echo main.cpp:139
-        if (seg_valid && j == 0) {
-            const double te = t_start + a.time_step * (double)(uint32_t)(steps - 1u);
-            rf_add(bins, lflags, row_of(te, thr, R, a.inv_row_dt), seg_refl / (float)a.S);
+        } else if (busy) {
+            // ---- a finished segment: the boundary echo (main.cpp:139), then the quad is free ----
+            if (j == 0) {
+                const double te = t_start + a.time_step * (double)(uint32_t)(steps - 1u);
+                rf_add(bins, lflags, row_of(te, thr, R, a.inv_row_dt), seg_refl / (float)a.S);
+            }
+            busy = false;
         }
     }
     if (STATS) {
@@ -755,14 +778,12 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b_begin, ui
     }
     __syncthreads();
     // row of the frame's RF block: [frame][scan-line of the whole block]; this launch covers scan-lines [acc_off, acc_off+ne_frame)
-    const size_t line = (size_t)(e_local / a.ne_frame) * a.acc_stride + a.acc_off + e_local % a.ne_frame;
-    long long *gacc = a.acc + line * R;
+    const size_t row = (size_t)(line / a.ne_frame) * a.acc_stride + a.acc_off + line % a.ne_frame;
     for (uint32_t r = tid; r < R; r += nthr) {
         const long long v = bins[r];
-        if (v != 0) atomicAdd((unsigned long long *)&gacc[r], (unsigned long long)v);
+        if (v != 0) atomicAdd((unsigned long long *)&a.acc[row * R + r], (unsigned long long)v);
     }
-    const uint32_t nf = (R + 31u) >> 5;
-    for (uint32_t r = tid; r < nf; r += nthr) { const uint32_t f = lflags[r]; if (f) atomicOr(&a.flags[line * nf + r], f); }
+    for (uint32_t r = tid; r < nf; r += nthr) { const uint32_t f = lflags[r]; if (f) atomicOr(&a.flags[row * nf + r], f); }
 }
 
 // fixed-point bins -> float RF image [ne][R]; clears the bins for the next frame
@@ -927,19 +948,8 @@ __global__ void k_philox_probe(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c
 // ---------------------------------------------------------------------------------------------
 size_t march_lds_bytes(uint32_t R)
 {
-    size_t bins = (size_t)((R + 1u) & ~1u) * 8;
-    size_t flg = (size_t)((((R + 31u) >> 5) + 3u) & ~3u) * 4;
-    size_t thr = (size_t)((R + 2u) & ~1u) * 8;
+    const size_t bins = (size_t)((R + 1u) & ~1u) * 8, flg = (size_t)((((R + 31u) >> 5) + 3u) & ~3u) * 4, thr = (size_t)((R + 2u) & ~1u) * 8;
     return bins + flg + thr;
-}
-
-// each k_march block works through march_slots rounds of 64 segment slots; aim at ~4096 blocks per launch
-void march_shape(uint32_t S, uint32_t B, uint32_t ne, uint32_t &slots, uint32_t &chunks)
-{
-    const uint32_t rounds = (S * B + 63u) / 64u;                       // 64-slot rounds per scan-line
-    const uint32_t want = ne >= 4096u ? 1u : (4096u + ne - 1u) / ne;   // blocks per scan-line
-    slots = (rounds + want - 1u) / want; if (slots == 0u) slots = 1u;
-    chunks = (rounds + slots - 1u) / slots;
 }
 
 hipError_t launch_init(const FrameArgs &a, hipStream_t st)
@@ -971,15 +981,18 @@ hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
     return hipGetLastError();
 }
 
-// RF accumulation of the segments of bounces [b_begin, b_begin + n_bounces)
-hipError_t launch_march(const FrameArgs &a, uint32_t b_begin, uint32_t n_bounces, bool stats, hipStream_t st)
+// RF accumulation of the segments of bounce b
+hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st)
 {
-    uint32_t slots, chunks;
-    march_shape(a.S, n_bounces, a.ne, slots, chunks);
+    // chunks per scan-line: aim at ~4096 workgroups, at least 16 slots per wavefront
+    uint32_t chunks = a.ne >= 4096u ? 1u : (4096u + a.ne - 1u) / a.ne;
+    const uint32_t max_chunks = (a.S + 63u) / 64u;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1u) chunks = 1u;
     const dim3 grid(a.ne * chunks), blk(256);
     const size_t lds = march_lds_bytes(a.R);
-    if (stats) hipLaunchKernelGGL((k_march<true>), grid, blk, lds, st, a, b_begin, n_bounces, slots, chunks);
-    else hipLaunchKernelGGL((k_march<false>), grid, blk, lds, st, a, b_begin, n_bounces, slots, chunks);
+    if (stats) hipLaunchKernelGGL((k_march<true>), grid, blk, lds, st, a, b, chunks);
+    else hipLaunchKernelGGL((k_march<false>), grid, blk, lds, st, a, b, chunks);
     return hipGetLastError();
 }
 
