@@ -7,8 +7,8 @@
 A "step" is one frame of the hot path over synthetic input already resident in HBM:
 clear -> trace (BVH closest-hit + interface sampling) -> RF accumulation -> [RCCL all-gather of the
 scan-line blocks when N > 1] -> PSF convolution.  Each rank traces 128 scan-lines x 1024 sample paths
-(weak scaling: the frame has 128*N scan-lines).  By default 8 consecutive frames are in flight per
-pass (mcrt_trace_frames: every launch carries 8 frames' rays; images are bit-identical to
+(weak scaling: the frame has 128*N scan-lines).  By default 16 consecutive frames are in flight per
+pass (mcrt_trace_frames: every launch carries 16 frames' rays; images are bit-identical to
 one-at-a-time tracing); `--frames-in-flight 1` is the strict latency mode, also reported in the
 JSON as `one_frame_at_a_time`.  The JSON line carries the live roofline figure of the
 dominant kernel (k_trace: counted algorithmic bytes / HIP-event kernel time) and a CPU baseline (the
@@ -44,14 +44,14 @@ def build_workload(m, name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="random1m")
     ap.add_argument("--scanlines", type=int, default=128, help="scan-lines per GPU")
     ap.add_argument("--rays", type=int, default=1024, help="sample paths per scan-line")
     ap.add_argument("--rows", type=int, default=465)
     ap.add_argument("--tex-n", type=int, default=256, help="texture edge in voxels (256 = the reference; smaller only for cache experiments)")
-    ap.add_argument("--frames-in-flight", type=int, default=8,
+    ap.add_argument("--frames-in-flight", type=int, default=16,
                     help="frames traced per pass (mcrt_trace_frames): a step is still ONE frame, but every kernel launch then carries the "
                          "rays of this many consecutive frames (1 = strict one-frame-at-a-time latency mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,10 +126,15 @@ def main():
             for f in range(nf):
                 ctx.convolve(frames[f], E, R, psf.axial_kernel, psf.lateral_kernel)
 
+    def passes(count):
+        """split `count` frames into the fewest passes of at most F frames, as even as possible (20 with F=16 -> 10 + 10)"""
+        n_pass = max(1, -(-count // F))
+        base, rem = divmod(count, n_pass)
+        return [base + (1 if i < rem else 0) for i in range(n_pass)]
+
     def run_steps(first, count):
         f = first
-        while f < first + count:
-            nf = min(F, first + count - f)
+        for nf in passes(count):
             step_batch(f, nf)
             f += nf
 
@@ -144,8 +149,7 @@ def main():
     #  rays of a small bounce into pieces, whose extra visits are overhead, not algorithmic bytes)
     ctx.enable_stats(True); ctx.get_stats(reset=True)
     f = 0
-    while f < args.steps:
-        nf = min(F, args.steps - f)
+    for nf in passes(args.steps):
         ctx.trace_frames(f, nf, rf_local, e0, e1)
         f += nf
     st = ctx.get_stats(reset=True)
@@ -213,7 +217,7 @@ def main():
 def pmc_traffic(args):
     """HBM-side bytes per k_trace launch from the committed rocprofv3 PMC passes of this same command
     (profiles/round1/pmc_k_trace.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction applied); null for other workloads."""
-    if (args.workload, args.scanlines, args.rays, args.rows, args.gpus, args.frames_in_flight) != ("random1m", 128, 1024, 465, 1, 8):
+    if (args.workload, args.scanlines, args.rays, args.rows, args.gpus, args.frames_in_flight) != ("random1m", 128, 1024, 465, 1, 16):
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "round1", "pmc_k_trace.json")) as f:

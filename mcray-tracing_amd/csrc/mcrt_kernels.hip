@@ -17,6 +17,12 @@
 #include "mcrt_detmath.h"
 #include "mcrt_kernels.h"
 
+#ifndef MCRT_MARCH_H
+#define MCRT_MARCH_H 2               // RF steps per lane and iteration of k_march (a quad does 4*H consecutive steps)
+#endif
+#ifndef MCRT_MARCH_REFILL
+#define MCRT_MARCH_REFILL 4          // k_march hands out new segments while at least this many of a wave's 16 quads are idle
+#endif
 #ifndef MCRT_FETCH_BATCH
 #define MCRT_FETCH_BATCH 16         // queue positions a wavefront of k_trace claims per atomic
 #endif
@@ -698,7 +704,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
         // ---- idle quads probe the next slots until at least half of the quads have a segment (or the range is exhausted) ----
         while (cursor < s_end) {
             const unsigned long long want = __ballot(!busy && j == 0);
-            if (__popcll(want) < 8) break;
+            if (__popcll(want) < MCRT_MARCH_REFILL) break;
             const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~3)) - 1ull));
             if (!busy && mine < s_end) {
                 const size_t pid = pid0 + mine;
@@ -733,22 +739,24 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
 
         // ---- eight steps of every running segment ----
         if (busy && more) {
-            f3 myp[2]; double myt[2]; float myin[2]; bool myv[2];
-            // advance j steps to this lane's first own step, capture, advance 4, capture, advance the remaining 4-j: the same
-            // eight sequential updates of (point, t, intensity) in every lane, without per-step selects
+            f3 myp[MCRT_MARCH_H]; double myt[MCRT_MARCH_H]; float myin[MCRT_MARCH_H]; bool myv[MCRT_MARCH_H];
+            // advance j steps to this lane's first own step, capture, advance 4, capture, ... advance the remaining 4-j: the same
+            // 4*H sequential updates of (point, t, intensity) in every lane, without per-step selects
             uint32_t sidx = step;
 #define MCRT_ADVANCE() { point = point + delta; t = t + a.time_step; inten *= k_att; sidx++; }
             for (int u = 0; u < j; u++) MCRT_ADVANCE()
-            myp[0] = point; myt[0] = t; myin[0] = inten; myv[0] = sidx < steps && t < a.max_travel;               // the reference's loop test
-            MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE()
-            myp[1] = point; myt[1] = t; myin[1] = inten; myv[1] = sidx < steps && t < a.max_travel;
+#pragma unroll
+            for (int h = 0; h < MCRT_MARCH_H; h++) {
+                myp[h] = point; myt[h] = t; myin[h] = inten; myv[h] = sidx < steps && t < a.max_travel;           // the reference's loop test
+                if (h + 1 < MCRT_MARCH_H) { MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE() }
+            }
             for (int u = j; u < 4; u++) MCRT_ADVANCE()
 #undef MCRT_ADVANCE
-            step += 8u;
+            step += 4u * MCRT_MARCH_H;
             more = step < steps && t < a.max_travel;
-            float2 vox[2];
+            float2 vox[MCRT_MARCH_H];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+            for (int h = 0; h < MCRT_MARCH_H; h++) {
                 vox[h] = make_float2(0.0f, 0.0f);
                 if (myv[h]) {
                     const uint32_t vx = vox_index(div_res(myp[h].x, a), a.tex_n, a.tex_mask), vy = vox_index(div_res(myp[h].y, a), a.tex_n, a.tex_mask), vz = vox_index(div_res(myp[h].z, a), a.tex_n, a.tex_mask);
@@ -756,7 +764,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
                 }
             }
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+            for (int h = 0; h < MCRT_MARCH_H; h++) {
                 if (myv[h]) {
                     const float scattering = vox[h].y >= m_dens ? vox[h].x * m_sigma + m_mu : 0.0f;
                     rf_add(bins, lflags, row_of(myt[h], thr, R, a.inv_row_dt), myin[h] * scattering);
