@@ -1,0 +1,38 @@
+"""The oracle under AddressSanitizer + UBSan (CPU build only; GPU sanitizers are not available on the pool): a small frame
+through every code path -- brute force, BVH2 and BVH4 walks, thickness draw, vessels, convolution, envelope, scan conversion."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_oracle_runs_clean_under_asan_ubsan(mcrt):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libmcrt_oracle_asan.so"], stdout=subprocess.DEVNULL)
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    code = textwrap.dedent("""
+        import sys, ctypes, numpy as np
+        sys.path.insert(0, %r)
+        import mcray_tracing_amd as m
+        from oracle import orc
+        orc._LIB = None
+        orc.build = lambda force=False: %r
+        cfg, meshes = m.synth.liver_scene(1)
+        sd = m.scene_io.build_scene(cfg, meshes)
+        nodes, btri, n4, _ = m.host_build_bvh4(sd.tri, sd.tri_mesh)
+        tr = m.Transducer(6, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
+        tex = orc.texture(8)
+        osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri)); osc.set_bvh4(n4)
+        p = orc.default_params(n_elements=6, n_samples=9, tex_n=8)
+        outs = [osc.trace_frame(p, tr.pos, tr.dir, tex, use_bvh=k, want_segs=True) for k in (0, 1, 2)]
+        assert all(np.array_equal(outs[0]["hits"], o["hits"]) and np.array_equal(outs[0]["rf_fix"], o["rf_fix"]) for o in outs)
+        ax, lat = orc.psf()
+        img = orc.envelope(orc.convolve(np.nan_to_num(outs[0]["rf"]), ax, lat))
+        sc = orc.scan_convert(img)
+        print("OK", int((outs[0]["hits"] >= 0).sum()), float(np.abs(sc).sum()) >= 0)
+    """) % (ROOT, os.path.join(ROOT, "oracle", "libmcrt_oracle_asan.so"))
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
