@@ -51,13 +51,13 @@ static Consts derive_consts(const mcrt_params &p)
 // a frame can be traced as independent groups whose kernels overlap (the long walks that end one group's bounce run beside the
 // bulk of another's).
 struct Work {
-    hipStream_t stream = nullptr, side = nullptr;
-    hipEvent_t ev_bounce[MCRT_MAX_BOUNCES] = {}, ev_join = nullptr, ev_done = nullptr;
+    hipStream_t stream = nullptr, side[MCRT_SIDE_STREAMS] = {};   // k_march of bounce b runs on side[b % n]: the tail of one overlaps the next
+    hipEvent_t ev_bounce[MCRT_MAX_BOUNCES] = {}, ev_join[MCRT_SIDE_STREAMS] = {}, ev_done = nullptr;
     float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr;
     unsigned long long *d_key0 = nullptr, *d_key1 = nullptr;
     uint32_t *d_q = nullptr, *d_counts = nullptr, *d_seg_count = nullptr;
     hipEvent_t ev_march[MCRT_MAX_BOUNCES] = {};
-    mcrt_segment *d_segs = nullptr; size_t paths = 0; uint32_t depth = 0;
+    mcrt_segment *d_segs = nullptr; float4 *d_mrec = nullptr; size_t paths = 0; uint32_t depth = 0;
 };
 
 struct mcrt_ctx {
@@ -88,7 +88,9 @@ struct mcrt_ctx {
     float *d_tmp = nullptr; size_t tmp_cap = 0;
     // row thresholds (exact replacement of the per-echo double division) and the verified fast division by tex_res
     double *d_row_thr = nullptr; uint32_t thr_rows = 0; double thr_dt = 0.0;
-    float verified_res = 0.0f; bool fast_div = false;
+    float verified_res = 0.0f; bool fast_div = false, fast_div_all = false;
+    // per-material table of k_march (depends on the materials, the axial step and the frequency)
+    float4 *d_mtab = nullptr; uint32_t mtab_n = 0; float mtab_key[2] = { 0.0f, 0.0f }; bool mtab_valid = false;
     // scan-conversion maps
     float *d_map_col = nullptr, *d_map_row = nullptr; uint32_t map_key[6] = { 0, 0, 0, 0, 0, 0 }; double map_keyd[2] = { 0, 0 };
     // instrumentation
@@ -118,7 +120,18 @@ static int prepare_tables(mcrt_ctx *c)
         HIP_TRY(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
         hipFree(d_bad);
         c->fast_div = (bad == 0) && !getenv("MCRT_NO_FAST_DIV");
+        c->fast_div_all = c->fast_div && c->p.tex_res > 1e-16f && !getenv("MCRT_NO_LEAN");
         c->verified_res = c->p.tex_res;
+    }
+    if (c->have_scene && (!c->mtab_valid || c->mtab_key[0] != c->c.axial_res_f || c->mtab_key[1] != c->p.frequency)) {
+        if (c->mtab_n < c->n_mat) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            hipFree(c->d_mtab); c->d_mtab = nullptr; c->mtab_n = 0;
+            HIP_TRY(hipMalloc(&c->d_mtab, 16 * (size_t)c->n_mat));
+            c->mtab_n = c->n_mat;
+        }
+        HIP_TRY(mcrt::launch_material_table(c->d_mats, c->n_mat, c->c.axial_res_f, c->p.frequency, c->d_mtab, c->stream));
+        c->mtab_key[0] = c->c.axial_res_f; c->mtab_key[1] = c->p.frequency; c->mtab_valid = true;
     }
     return MCRT_OK;
 }
@@ -165,7 +178,7 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     mcrt_default_params(&c->p);
     c->c = derive_consts(c->p);
     c->stream = c->own_stream;
-    if (hipMalloc(&c->d_stats, 32 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_stats, 0, 32 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc(&c->d_stats, 128 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_stats, 0, 128 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_error, 4) != hipSuccess || hipMemset(c->d_error, 0, 4) != hipSuccess) {
         hipStreamDestroy(c->own_stream); delete c; return set_error(MCRT_ERR_HIP, "hipMalloc failed");
     }
@@ -177,9 +190,9 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
 static void free_work_buffers(Work &w)
 {
     hipFree(w.d_st0); hipFree(w.d_st1); hipFree(w.d_st2); hipFree(w.d_ray0); hipFree(w.d_ray1); hipFree(w.d_key0); hipFree(w.d_key1);
-    hipFree(w.d_q); hipFree(w.d_counts); hipFree(w.d_seg_count); hipFree(w.d_segs);
+    hipFree(w.d_q); hipFree(w.d_counts); hipFree(w.d_seg_count); hipFree(w.d_segs); hipFree(w.d_mrec);
     w.d_st0 = w.d_st1 = w.d_st2 = w.d_ray0 = w.d_ray1 = nullptr; w.d_key0 = w.d_key1 = nullptr; w.d_q = w.d_counts = w.d_seg_count = nullptr;
-    w.d_segs = nullptr; w.paths = 0; w.depth = 0;
+    w.d_segs = nullptr; w.d_mrec = nullptr; w.paths = 0; w.depth = 0;
 }
 
 static void free_work(mcrt_ctx *c)
@@ -187,9 +200,8 @@ static void free_work(mcrt_ctx *c)
     for (Work &w : c->work) {
         free_work_buffers(w);
         for (int i = 0; i < MCRT_MAX_BOUNCES; i++) { if (w.ev_bounce[i]) hipEventDestroy(w.ev_bounce[i]); if (w.ev_march[i]) hipEventDestroy(w.ev_march[i]); }
-        if (w.ev_join) hipEventDestroy(w.ev_join);
+        for (int i = 0; i < MCRT_SIDE_STREAMS; i++) { if (w.ev_join[i]) hipEventDestroy(w.ev_join[i]); if (w.side[i]) hipStreamDestroy(w.side[i]); }
         if (w.ev_done) hipEventDestroy(w.ev_done);
-        if (w.side) hipStreamDestroy(w.side);
         if (w.stream) hipStreamDestroy(w.stream);
     }
     c->work.clear();
@@ -201,9 +213,8 @@ static int get_work(mcrt_ctx *c, size_t g, Work **out)
     while (c->work.size() <= g) {
         Work w;
         if (!c->work.empty()) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
+        for (int i = 0; i < MCRT_SIDE_STREAMS; i++) { HIP_TRY(hipStreamCreateWithFlags(&w.side[i], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&w.ev_join[i], hipEventDisableTiming)); }
         for (int i = 0; i < MCRT_MAX_BOUNCES; i++) { HIP_TRY(hipEventCreateWithFlags(&w.ev_bounce[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&w.ev_march[i], hipEventDisableTiming)); }
-        HIP_TRY(hipEventCreateWithFlags(&w.ev_join, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
         c->work.push_back(w);
     }
@@ -228,7 +239,7 @@ extern "C" int mcrt_destroy(mcrt_ctx *c)
     free_scene(c);
     free_work(c);
     hipFree(c->d_tex); hipFree(c->d_pos); hipFree(c->d_dir); hipFree(c->d_acc); hipFree(c->d_flags); hipFree(c->d_tmp);
-    hipFree(c->d_map_col); hipFree(c->d_map_row); hipFree(c->d_stats); hipFree(c->d_row_thr); hipFree(c->d_error);
+    hipFree(c->d_map_col); hipFree(c->d_map_row); hipFree(c->d_stats); hipFree(c->d_row_thr); hipFree(c->d_error); hipFree(c->d_mtab);
     for (auto &e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (c->ev_start) hipEventDestroy(c->ev_start);
     hipStreamDestroy(c->own_stream);
@@ -306,8 +317,8 @@ extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *
     HIP_TRY(hipMemcpy(c->d_meshes, meshes, sizeof(mcrt_mesh) * (size_t)n_mesh, hipMemcpyHostToDevice));
     c->n_mesh = n_mesh; c->n_mat = n_mat; c->start_mat = start_mat;
     for (int i = 0; i < 3; i++) c->spacing[i] = spacing[i];
-    c->have_scene = true;
-    return MCRT_OK;
+    c->have_scene = true; c->mtab_valid = false;
+    return prepare_tables(c);
 }
 
 extern "C" int mcrt_get_bvh(mcrt_ctx *c, mcrt_bvh *out)
@@ -413,6 +424,7 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne)
     HIP_TRY(hipMalloc(&w.d_q, 12 * np)); HIP_TRY(hipMalloc(&w.d_seg_count, 4 * np));
     HIP_TRY(hipMalloc(&w.d_counts, 4 * (2 * MCRT_MAX_BOUNCES + 1)));
     HIP_TRY(hipMalloc(&w.d_segs, sizeof(mcrt_segment) * np * B));
+    HIP_TRY(hipMalloc(&w.d_mrec, 48 * np * B));
     w.paths = np; w.depth = B;
     return MCRT_OK;
 }
@@ -426,13 +438,13 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     a.acc = c->d_acc; a.flags = c->d_flags;                 // the frame block [n_frames][acc_ne][R]; this group owns columns e0-acc_e0 ...
     a.acc_stride = acc_ne; a.acc_off = e0 - acc_e0;
     a.st0 = w.d_st0; a.st1 = w.d_st1; a.st2 = w.d_st2; a.queue = w.d_q;
-    a.ray0 = w.d_ray0; a.ray1 = w.d_ray1; a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.segs = w.d_segs; a.seg_count = w.d_seg_count;
+    a.ray0 = w.d_ray0; a.ray1 = w.d_ray1; a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.segs = w.d_segs; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
     a.stats = c->d_stats; a.error_flag = c->d_error; a.stamps = c->d_stats + 8;
     a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
     a.e_begin = e0; a.ne_frame = e1 - e0; a.ne = (e1 - e0) * n_frames;   // n_frames consecutive frame ids traced as one pass
     a.ksplit_limit = MCRT_KSPLIT_DEFAULT;   // bounces with fewer rays than this are cut into pieces (see k_trace)
     if (const char *e = getenv("MCRT_KSPLIT_LIMIT")) { long v = atol(e); if (v >= 0 && v <= MCRT_KSPLIT_MAX) a.ksplit_limit = (uint32_t)v; }   // tuning knob; 0 = off
-    if (c->stats_on) a.ksplit_limit = 0;   // counting mode = one walk per ray, so the counts are the oracle's
+    if (c->stats_on) a.ksplit_limit = 0;   // counting mode = one walk per ray, so the counts are those of a plain closest-hit walk
     for (int i = 0; i < 3; i++) { a.scene_lo[i] = c->scene_lo[i]; a.scene_hi[i] = c->scene_hi[i]; }
     a.trace_blocks = 1280;   // persistent k_trace: 5 waves/SIMD on 256 CUs; quads fetch further rays dynamically
     if (const char *e = getenv("MCRT_TRACE_BLOCKS")) { int v = atoi(e); if (v >= 1) a.trace_blocks = (uint32_t)v; }   // tuning knob
@@ -440,8 +452,22 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
     a.freq = c->p.frequency; a.eps = c->p.intensity_epsilon; a.I0 = c->p.initial_intensity; a.offs = c->p.ray_start_offset;
     a.sx = c->spacing[0]; a.sy = c->spacing[1]; a.sz = c->spacing[2]; a.tex_res = c->p.tex_res; a.axial_res_f = c->c.axial_res_f; a.pad_abs = c->bvh.pad_abs; a.tex_rcp = 1.0f / c->p.tex_res; a.fast_div = c->fast_div ? 1u : 0u;
+    // k_march's branch-free texture lookup: power-of-two texture, verified division, |x / res| < 2^31
+    a.tex_shift = 0; while ((1u << a.tex_shift) < c->tex_n) a.tex_shift++;
+    a.lean_bound = 0.0f;
+    if (c->fast_div_all && a.tex_mask && a.tex_shift <= 10u) {
+        const float lim = 2147483648.0f * c->p.tex_res * (1.0f - 0x1p-20f);
+        a.lean_bound = lim < 1e18f ? lim : 1e18f;
+        if (!(a.lean_bound > 0.0f)) a.lean_bound = 0.0f;
+    }
     a.axial_res_mm = c->c.axial_res_mm; a.time_step = c->c.time_step_us; a.row_dt = c->c.row_dt_us;
     a.max_travel = c->c.max_travel_us; a.sos_d = (double)c->p.speed_of_sound; a.inv_row_dt = 1.0 / c->c.row_dt_us;
+}
+
+static uint32_t side_streams()
+{
+    static const uint32_t n = [] { uint32_t v = MCRT_SIDE_STREAMS_DEFAULT; if (const char *e = getenv("MCRT_MARCH_STREAMS")) { int x = atoi(e); if (x >= 1 && x <= MCRT_SIDE_STREAMS) v = (uint32_t)x; } return v; }();   // tuning knob
+    return n;
 }
 
 // one bounce of one group: k_trace + k_shade on the group's stream, k_march of the finished segments on its side stream.
@@ -464,9 +490,10 @@ static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArg
     HIP_TRY(mcrt::launch_shade(a, b, c->stats_on, st));
     if (accumulate && overlap) {   // the segments of bounce b are final: accumulate them beside the next bounce's walk
         HIP_TRY(hipEventRecord(w.ev_bounce[b], st));
-        HIP_TRY(hipStreamWaitEvent(w.side, w.ev_bounce[b], 0));
-        HIP_TRY(mcrt::launch_march(a, b, c->stats_on, w.side));
-        HIP_TRY(hipEventRecord(w.ev_march[b], w.side));
+        hipStream_t side = w.side[b % side_streams()];
+        HIP_TRY(hipStreamWaitEvent(side, w.ev_bounce[b], 0));
+        HIP_TRY(mcrt::launch_march(a, b, c->stats_on, side));
+        HIP_TRY(hipEventRecord(w.ev_march[b], side));
     } else if (accumulate) {
         HIP_TRY(mcrt::launch_march(a, b, c->stats_on, st));
     }
@@ -476,7 +503,7 @@ static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArg
 // scene::cast_rays (scene.cpp:50-183) [+ the accumulation loop] for scan-lines [e0,e1), split into `groups` independent
 // pipelines whose kernels run concurrently.  Everything is ordered after what is already queued on the context's stream, and
 // the context's stream waits for all of it.
-static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, bool accumulate, uint32_t groups)
+static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, bool accumulate, uint32_t groups, bool want_segs)
 {
     const uint32_t ne = e1 - e0;
     if (groups > ne) groups = ne;
@@ -490,6 +517,7 @@ static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0
         const uint32_t b0 = e0 + (uint32_t)(((uint64_t)ne * g) / groups), b1 = e0 + (uint32_t)(((uint64_t)ne * (g + 1)) / groups);
         rc = ensure_work(c, *ws[g], (b1 - b0) * n_frames); if (rc) return rc;
         fill_args(c, *ws[g], args[g], frame, n_frames, b0, b1, e0, ne);
+        args[g].want_segs = want_segs ? 1u : 0u;
     }
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
     for (uint32_t g = 0; g < groups; g++) {
@@ -504,8 +532,10 @@ static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0
     for (uint32_t g = 0; g < groups; g++) {
         hipStream_t st = g == 0 ? c->stream : ws[g]->stream;
         if (accumulate && overlap) {
-            HIP_TRY(hipEventRecord(ws[g]->ev_join, ws[g]->side));
-            HIP_TRY(hipStreamWaitEvent(st, ws[g]->ev_join, 0));
+            for (uint32_t i = 0; i < side_streams(); i++) {
+                HIP_TRY(hipEventRecord(ws[g]->ev_join[i], ws[g]->side[i]));
+                HIP_TRY(hipStreamWaitEvent(st, ws[g]->ev_join[i], 0));
+            }
         }
         if (g) {
             HIP_TRY(hipEventRecord(ws[g]->ev_done, st));
@@ -530,7 +560,7 @@ extern "C" int mcrt_trace_frames(mcrt_ctx *c, uint32_t frame, uint32_t n_frames,
     if (n_frames == 0 || n_frames > 64) return set_error(MCRT_ERR_LIMIT, "n_frames must be 1..64");
     const uint32_t lines = (e1 - e0) * n_frames;
     rc = ensure_acc(c, lines); if (rc) return rc;
-    rc = run_frame(c, frame, n_frames, e0, e1, true, frame_groups(c)); if (rc) return rc;
+    rc = run_frame(c, frame, n_frames, e0, e1, true, frame_groups(c), false); if (rc) return rc;
     HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, lines, c->p.n_rows, c->stream));
     c->acc_clean_ne = lines; c->acc_clean_rows = c->p.n_rows;
     return MCRT_OK;
@@ -571,7 +601,7 @@ extern "C" int mcrt_trace_frame_debug(mcrt_ctx *c, uint32_t frame, uint32_t e0, 
     int rc = check_ready(c, e0, e1); if (rc) return rc;
     if (!rf_dev) return set_error(MCRT_ERR_INVALID, "null rf_dev");
     rc = ensure_acc(c, e1 - e0); if (rc) return rc;
-    rc = run_frame(c, frame, 1, e0, e1, true, 1); if (rc) return rc;         // one group: the segment table is contiguous
+    rc = run_frame(c, frame, 1, e0, e1, true, 1, true); if (rc) return rc;   // one group: the segment table is contiguous
     HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, e1 - e0, c->p.n_rows, c->stream));
     c->acc_clean_ne = e1 - e0; c->acc_clean_rows = c->p.n_rows;
     return copy_out(c, e1 - e0, hits, segs, seg_count);
@@ -581,7 +611,7 @@ extern "C" int mcrt_cast_rays(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32_t
 {
     CTX_TRY(c);
     int rc = check_ready(c, e0, e1); if (rc) return rc;
-    rc = run_frame(c, frame, 1, e0, e1, false, 1); if (rc) return rc;
+    rc = run_frame(c, frame, 1, e0, e1, false, 1, true); if (rc) return rc;
     return copy_out(c, e1 - e0, hits, segs, seg_count);
 }
 
@@ -704,13 +734,13 @@ extern "C" int mcrt_get_stats(mcrt_ctx *c, mcrt_stats *out, int reset)
     return MCRT_OK;
 }
 
-// diagnostic builds (-DMCRT_STAMP): per-phase cycle sums of k_trace; zeros otherwise
-extern "C" int mcrt_debug_stamps(mcrt_ctx *c, uint64_t out[16], int reset)
+// diagnostic builds (-DMCRT_STAMP): per-phase cycle sums of k_trace [0,16) and its per-bounce launch timeline [16,80); zeros otherwise
+extern "C" int mcrt_debug_stamps(mcrt_ctx *c, uint64_t out[80], int reset)
 {
     CTX_TRY(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out, c->d_stats + 8, 16 * 8, hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(c->d_stats + 8, 0, 16 * 8));
+    HIP_TRY(hipMemcpy(out, c->d_stats + 8, 80 * 8, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(c->d_stats + 8, 0, 80 * 8));
     return MCRT_OK;
 }
 

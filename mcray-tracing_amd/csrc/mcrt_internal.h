@@ -7,6 +7,8 @@
 #define MCRT_KSPLIT_DEFAULT 131072 // work items a small bounce of k_trace is cut into (pieces x rays)
 #define MCRT_KSPLIT_MAX 1048576
 #define MCRT_GROUPS_DEFAULT 1        // independent scan-line groups a frame is traced as (their kernels overlap)
+#define MCRT_SIDE_STREAMS 4         // streams k_march launches rotate over
+#define MCRT_SIDE_STREAMS_DEFAULT 1
 #define MCRT_MAX_ROWS 2048
 #define MCRT_MAX_BOUNCES 16
 

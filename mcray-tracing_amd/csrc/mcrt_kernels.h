@@ -23,17 +23,19 @@ struct FrameArgs {
     unsigned long long *key0, *key1;   // [np] closest hit per ray: fraction bits << 32 | triangle id (atomicMin), ping-pong by bounce parity
     const uint32_t *tri_slot;  // [T] triangle id -> position in the leaf-order triangle array
     uint32_t *counts;          // [MAX_BOUNCES+1] live rays per bounce, then [MAX_BOUNCES] queue cursors of the persistent walk
-    mcrt_segment *segs;        // [np][B]
+    mcrt_segment *segs;        // [np][B]   written only when want_segs (mcrt_cast_rays / mcrt_trace_frame_debug)
+    float4 *mrec;              // [np][B][3] what k_march needs of a segment: from,refl | delta,intensity | t_start(f64),steps,media
+    const float4 *mtab;        // [M] per material, for k_march: mu0, mu1, sigma, per-step attenuation factor
     uint32_t *seg_count;       // [np]
     long long *acc;            // [ne][R] fixed-point RF accumulators (2^-52 units)
     uint32_t *flags;           // [ne][(R+31)/32] non-finite flags
     unsigned long long *stats; // [6]
     uint32_t *error_flag;      // device word, bit 0: traversal stack overflow
-    unsigned long long *stamps; // [16] diagnostic build (-DMCRT_STAMP) only
+    unsigned long long *stamps; // [80] diagnostic build (-DMCRT_STAMP) only
     // sizes / parameters
-    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, acc_stride, acc_off, trace_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div;
+    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, acc_stride, acc_off, trace_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift;
     float scene_lo[3], scene_hi[3];   // bounds of the whole BVH
-    float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs, tex_rcp;
+    float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs, tex_rcp, lean_bound;
     double axial_res_mm, time_step, row_dt, max_travel, sos_d, inv_row_dt;
 };
 
@@ -50,6 +52,7 @@ hipError_t launch_remap(const float *img, uint32_t E, uint32_t R, const float *m
 hipError_t launch_transpose(const float *in, float *out, uint32_t E, uint32_t R, hipStream_t st);
 hipError_t launch_math_probe(int op, const double *x, const double *y, double *out, uint32_t n, hipStream_t st);
 hipError_t launch_verify_div(float res, float rcp, unsigned long long *bad, hipStream_t st);
+hipError_t launch_material_table(const float4 *mats, uint32_t n_mat, float axial_res_f, float freq, float4 *mtab, hipStream_t st);
 hipError_t launch_philox_probe(const uint32_t c[4], const uint32_t k[2], uint32_t *out, hipStream_t st);
 
 }  // namespace mcrt

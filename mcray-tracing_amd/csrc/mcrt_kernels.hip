@@ -64,6 +64,29 @@ MCRT_DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tlow, float tcap, float &tm
     return tmin <= tmax;
 }
 
+// The same test on a BVH4 child record (lo.xyz hi.x | hi.y hi.z ..) with the six plane distances computed as three
+// float pairs (v_pk_add_f32 / v_pk_mul_f32): identical IEEE operations, half the instructions.  The ray's origin and
+// reciprocal direction are kept in the matching pair order.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct RayPairs { v2f o_xy, o_zx, o_yz, i_xy, i_zx, i_yz; };
+MCRT_DEV RayPairs ray_pairs(f3 o, f3 inv)
+{
+    RayPairs r;
+    r.o_xy = (v2f){ o.x, o.y }; r.o_zx = (v2f){ o.z, o.x }; r.o_yz = (v2f){ o.y, o.z };
+    r.i_xy = (v2f){ inv.x, inv.y }; r.i_zx = (v2f){ inv.z, inv.x }; r.i_yz = (v2f){ inv.y, inv.z };
+    return r;
+}
+MCRT_DEV bool slab_pairs(v2f lo_xy, v2f loz_hix, v2f hi_yz, const RayPairs &r, float tlow, float tcap, float &tmin_o, float &tmax_o)
+{
+    const v2f a = (lo_xy - r.o_xy) * r.i_xy;        // t0x t0y
+    const v2f b = (loz_hix - r.o_zx) * r.i_zx;      // t0z t1x
+    const v2f c = (hi_yz - r.o_yz) * r.i_yz;        // t1y t1z
+    float tmin = fmaxf(fmaxf(fminf(a.x, b.y), fminf(a.y, c.x)), fmaxf(fminf(b.x, c.y), tlow));
+    float tmax = fminf(fminf(fmaxf(a.x, b.y), fmaxf(a.y, c.x)), fminf(fmaxf(b.x, c.y), tcap));
+    tmin_o = tmin; tmax_o = tmax;
+    return tmin <= tmax;
+}
+
 // btTriangleRaycastCallback::processTriangle (Bullet) behind the triangle's own padded-bounds test; contract
 // rules: the fraction must lie inside the ray's overlap with those bounds; ties -> smaller triangle id.
 MCRT_DEV void tri_test(f3 v0, f3 v1, f3 v2, int id, int mesh, f3 from, f3 to, f3 inv, float pad_abs, float t_lo, Hit &best)
@@ -97,6 +120,42 @@ MCRT_DEV void tri_test(f3 v0, f3 v1, f3 v2, int id, int mesh, f3 from, f3 to, f3
             if (dot(cp1, n) >= edge_tol) {
                 f3 cp2 = cross(v2p, v0p);
                 if (dot(cp2, n) >= edge_tol) { best.frac = frac; best.tri = id; best.mesh = mesh; best.n = n; best.da = da; }
+            }
+        }
+    }
+}
+
+// the walk only needs (fraction, triangle): k_shade recomputes the plane of the winner
+struct Best { float frac; int tri; };
+MCRT_DEV void tri_test_walk(f3 v0, f3 v1, f3 v2, int id, f3 from, f3 to, const RayPairs &rp, float pad_abs, float t_lo, Best &best)
+{
+    f3 v10 = v1 - v0, v20 = v2 - v0;
+    f3 n = cross(v10, v20);
+    float dist = dot(v0, n);
+    float da = dot(n, from) - dist;
+    float db = dot(n, to) - dist;
+    if (da * db >= 0.0f) return;
+    float proj = da - db;
+    float frac = da / proj;
+    if (frac < best.frac || (frac == best.frac && id < best.tri)) {
+        f3 lo = mk(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)));
+        f3 hi = mk(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)));
+        float ext = fmaxf(fmaxf(fmaxf(0.0f, hi.x - lo.x), hi.y - lo.y), hi.z - lo.z);
+        const float pad = 2e-4f * ext + pad_abs;
+        float tmin, tmax;
+        if (!slab_pairs((v2f){ lo.x - pad, lo.y - pad }, (v2f){ lo.z - pad, hi.x + pad }, (v2f){ hi.y + pad, hi.z + pad }, rp, 0.0f, 1.0f, tmin, tmax)) return;
+        if (!(frac >= tmin && frac <= tmax && frac >= t_lo)) return;
+        float edge_tol = dot(n, n) * -0.0001f;
+        float s = 1.0f - frac;
+        f3 p = mk(s * from.x + frac * to.x, s * from.y + frac * to.y, s * from.z + frac * to.z);
+        f3 v0p = v0 - p, v1p = v1 - p;
+        f3 cp0 = cross(v0p, v1p);
+        if (dot(cp0, n) >= edge_tol) {
+            f3 v2p = v2 - p;
+            f3 cp1 = cross(v1p, v2p);
+            if (dot(cp1, n) >= edge_tol) {
+                f3 cp2 = cross(v2p, v0p);
+                if (dot(cp2, n) >= edge_tol) { best.frac = frac; best.tri = id; }
             }
         }
     }
@@ -180,13 +239,16 @@ constexpr int QP_XOR2 = 0x4E;   // quad_perm [2,3,0,1]
 // row = (int)(t / row_dt) if that quotient is < R, else -1 (rfimage.h:33-40), WITHOUT the double division:
 // thr[r] (host-computed, mcrt_row_thresholds) is the smallest double t whose IEEE quotient fl(t/row_dt) is >= r, so the
 // row is the largest r with thr[r] <= t.  Exactly equivalent to the division for every double t >= 0.
-MCRT_DEV int row_of(double t, const double *thr, uint32_t R, double inv_dt)
+MCRT_DEV int row_of(double t, const double *thr, uint32_t R, double inv_dt, double thr_end)
 {
-    if (!(t < thr[R]) || !(t >= 0.0)) return -1;
-    int r = (int)(t * inv_dt);
+    if (!(t < thr_end) || !(t >= 0.0)) return -1;
+    int r = (int)(t * inv_dt);                                   // within one row of the answer
     r = r < 0 ? 0 : (r > (int)R - 1 ? (int)R - 1 : r);
-    while (t < thr[r]) r--;
-    while (t >= thr[r + 1]) r++;
+    const double lo = thr[r], hi = thr[r + 1];
+    if ((t < lo) | !(t < hi)) {                                  // the estimate missed by a rounding: walk to the row
+        while (t < thr[r]) r--;
+        while (t >= thr[r + 1]) r++;
+    }
     return r;
 }
 
@@ -203,6 +265,28 @@ MCRT_DEV float div_res(float x, const FrameArgs &a)
     }
     return x / a.tex_res;
 }
+
+// texture cell of a point, volume.h:46-61 (x / resolution, (int) cast, modulo), for any texture size and magnitude
+MCRT_DEV size_t vox_cell(f3 p, const FrameArgs &a)
+{
+    const uint32_t vx = vox_index(div_res(p.x, a), a.tex_n, a.tex_mask), vy = vox_index(div_res(p.y, a), a.tex_n, a.tex_mask), vz = vox_index(div_res(p.z, a), a.tex_n, a.tex_mask);
+    return ((size_t)vx * a.tex_n + vy) * a.tex_n + vz;
+}
+// the same cell when every coordinate is below lean_bound in magnitude and the size is a power of two: branch-free.
+// |x / res| < 2^31 there, and the corrected reciprocal multiply is the verified quotient for |x| > 1e-18 and x == 0; for
+// the tiny values in between both it and the true quotient are below 1 in magnitude (tex_res > 1e-16), so the cell is 0
+// either way.
+MCRT_DEV uint32_t vox_lean1(float x, const FrameArgs &a)
+{
+    const float q0 = x * a.tex_rcp;
+    const float r = fmaf(-q0, a.tex_res, x);
+    return (uint32_t)(int)fmaf(r, a.tex_rcp, q0) & a.tex_mask;
+}
+MCRT_DEV uint32_t vox_cell_lean(f3 p, const FrameArgs &a)
+{
+    return (((vox_lean1(p.x, a) << a.tex_shift) | vox_lean1(p.y, a)) << a.tex_shift) | vox_lean1(p.z, a);
+}
+MCRT_DEV float abs_sum(f3 p) { return (fabsf(p.x) + fabsf(p.y)) + fabsf(p.z); }   // >= every |coordinate|; NaN/inf propagate
 
 // one echo into the scan-line's fixed-point LDS bins (2^-52 units; integer adds commute, so the image does not depend
 // on the order lanes, waves or workgroups arrive in)
@@ -315,11 +399,11 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 {
     __shared__ int stack[MCRT_STACK * 64];          // [MCRT_STACK][64 quads]: entry sp of quad q at sp*64 + q -> conflict-free
     const int tid = threadIdx.x, lane = tid & 63, j = tid & 3, q = tid >> 2;
-    const uint32_t n_rays = (b == 0u) ? a.ne : a.counts[b];     // rays to walk in this launch
+    const uint32_t n_rays = (b == 0u) ? a.ne : a.counts[b];     // rays of this bounce (= closest-hit words)
     // When a bounce has far fewer rays than the GPU has lanes, each ray is cut into K sub-ranges of its parameter interval
     // inside the scene bounds and the K pieces are walked by K different quads: the launch then lasts as long as the longest
-    // PIECE instead of the longest ray.  Sub-ranges are half-open and partition [0,1), so the minimum (fraction, id) over
-    // the pieces (taken in k_shade) is exactly the single-walk answer.
+    // PIECE instead of the longest ray.  Sub-ranges are half-open and partition [0,1), and every find goes through the ray's
+    // atomicMin word, so the result is exactly the single-walk answer.
     const uint32_t K = ksplit(n_rays, a.ksplit_limit);
     const uint32_t n = n_rays * K;                              // work items
     if (blockIdx.x * 64u >= n) return;
@@ -330,12 +414,24 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
     unsigned long long st_nodes = 0, st_tris = 0, st_q = 0;
 
     uint32_t i = blockIdx.x * 64u + (uint32_t)q;                 // the first ray of each quad is assigned statically
-    bool walking = false, exhausted = false;
-    f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1), inv = mk(1, 1, 1);
+    uint32_t ray_id = 0;
+#ifdef MCRT_STAMP
+    int nsteps = 0;
+#endif
+    bool exhausted = false;
+    f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1);
+    RayPairs rp = ray_pairs(f2, mk(1, 1, 1));
     float t_lo = 0.0f;
-    Hit best; best.frac = 1.0f; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
-    int sp = 0, cur = 0;
+    Best best; best.frac = 1.0f; best.tri = -1;
+    // the walk's state is ONE register: cur >= 0 = inner node to visit, cur < 0 = ~(leaf descriptor) to test, CUR_IDLE = no
+    // walk in progress (a value no leaf descriptor takes), so "which quads are where" is a single integer compare
+    constexpr int CUR_IDLE = (int)0x80000000;
+    int sp = 0, cur = CUR_IDLE;
     bool fresh = true;                                           // this quad needs a ray
+    const uint32_t bit_j = 1u << j, bits_j = 17u << j;
+#define MCRT_ON_INNER(c) __builtin_amdgcn_sicmp((c), -1, 38)                          /* mask of lanes with c >= 0     (ICMP_SGT) */
+#define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)        /* mask of lanes on a leaf        (ICMP_UGT) */
+#define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)                     /* mask of lanes in a walk        (ICMP_NE)  */
 #ifdef MCRT_STAMP
     unsigned long long sc_refill = 0, sc_p1 = 0, sc_p2 = 0, sc_n1 = 0, sc_n2 = 0, sc_outer = 0, sc_t0 = __builtin_readcyclecounter(), sc_act1 = 0, sc_act2 = 0;
 #define STAMP(var) { const unsigned long long t_ = __builtin_readcyclecounter(); var += t_ - sc_t0; sc_t0 = t_; }
@@ -343,14 +439,22 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 #define STAMP(var)
 #endif
     uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
+#ifdef MCRT_STAMP
+    // launch timeline of bounce b (100 MHz wall clock): earliest wave start, earliest "queue is empty", latest wave end
+    const unsigned long long wc_start = wall_clock64();
+    if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 0], ~wc_start);
+#endif
     for (;;) {
         // ---- finished rays: report, then ask for the next ray ----
         // The closest hit of a ray is ONE 64-bit word, (fraction bits << 32 | triangle id): fractions are in [0,1), so their bit
         // patterns order like the values and an integer atomicMin IS the contract's rule (smaller fraction, then smaller id).
         // The K pieces of a ray therefore just race their finds into the ray's word.
-        if (!walking && !fresh && !exhausted) {
+        if (cur == CUR_IDLE && !fresh && !exhausted) {
+#ifdef MCRT_STAMP
+            if (j == 0 && b > 0u) { atomicAdd(&a.stamps[60 + (nsteps > 0 ? 32 - __clz(nsteps) : 0)], 1ull); }   // histogram of node visits per walk (log2 bins)
+#endif
             if (j == 0 && best.tri >= 0)
-                atomicMin(&keys[i % n_rays], ((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri);
+                atomicMin(&keys[ray_id], ((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri);
             fresh = true; i = 0xffffffffu;
         }
         // ---- (re)fill: quads without a ray take the next queue positions ----
@@ -365,6 +469,9 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                 base = __shfl(base, 0, 64);
                 pool_next = base; pool_end = base + MCRT_FETCH_BATCH;
                 if (base >= n) queue_empty = true;
+#ifdef MCRT_STAMP
+                if (queue_empty && lane == 0) atomicMax(&a.stamps[16 + 4 * b + 1], ~(unsigned long long)wall_clock64());
+#endif
             }
             if (need && i == 0xffffffffu) {
                 const uint32_t mine = pool_next + (uint32_t)__popcll(dynm & ((1ull << (lane & ~3)) - 1ull));
@@ -376,11 +483,13 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
         }
         if (need && i != 0xffffffffu) {
             if (i < n) {
-                const uint32_t ray = i % n_rays, piece = i / n_rays;     // the pieces of one ray land in different wavefronts
-                const float4 r0 = rays[2 * (size_t)ray * ray_stride], r1 = rays[2 * (size_t)ray * ray_stride + 1];
+                const uint32_t piece = i / n_rays;                       // the pieces of one ray land in different wavefronts
+                ray_id = i % n_rays;
+                const float4 r0 = rays[2 * (size_t)ray_id * ray_stride], r1 = rays[2 * (size_t)ray_id * ray_stride + 1];
                 f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
                 const f3 d = to - f2;
-                inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                rp = ray_pairs(f2, inv);
                 t_lo = 0.0f;
                 float t_hi = 1.0f;
                 if (K > 1u) {
@@ -391,38 +500,46 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                         if (piece + 1u < K) t_hi = tin + w * ((float)(piece + 1u) / (float)K);
                     } else if (piece > 0u) t_hi = 0.0f;                  // the ray misses the scene: piece 0 reports the miss
                 }
-                best.frac = t_hi; best.tri = -1; best.mesh = 0; best.n = mk(0, 0, 0); best.da = 0;
-                sp = 0; cur = 0; walking = a.n_nodes != 0u && t_lo < t_hi; fresh = false;   // (not walking: an immediate miss)
+#ifdef MCRT_STAMP
+                nsteps = 0;
+#endif
+                best.frac = t_hi; best.tri = -1;
+                sp = 0; cur = (a.n_nodes != 0u && t_lo < t_hi) ? 0 : CUR_IDLE; fresh = false;   // (idle: an immediate miss)
                 if (STATS && j == 0 && piece == 0u) st_q++;
             } else exhausted = true;
         }
         STAMP(sc_refill)
-        if (!__any(walking)) { if (!__any(!exhausted)) break; else continue; }
+        if (MCRT_WALKING(cur) == 0ull) { if (!__any(!exhausted)) break; else continue; }
 
         // ---- phase 1: inner nodes, until enough rays are parked on a leaf (their triangle code then runs once for all) ----
+        const float tcap = fminf(1.0f, best.frac);               // best only changes in phase 2
         for (;;) {
-            const unsigned long long inner = __ballot(walking && cur >= 0);
+            const unsigned long long inner = MCRT_ON_INNER(cur);
             if (inner == 0ull) break;
-            if (__popcll(__ballot(walking && cur < 0)) >= 4 * MCRT_LEAF_BATCH) break;
+            if (__popcll(MCRT_ON_LEAF(cur)) >= 4 * MCRT_LEAF_BATCH) break;
 #ifdef MCRT_STAMP
             sc_n1++; sc_act1 += __popcll(inner);
 #endif
-            if (walking && cur >= 0) {
+            if (cur >= 0) {
                 const float4 *N = a.nodes + 8 * (size_t)cur + 2 * j;
                 const float4 A = N[0], B = N[1];               // lo.xyz hi.x | hi.y hi.z ref pad
                 if (STATS && j == 0) st_nodes++;
+#ifdef MCRT_STAMP
+                nsteps++;
+#endif
                 const int ref = __float_as_int(B.z);
                 float tn, tx;
-                const float tcap = fminf(1.0f, best.frac);
-                const bool hit = slab(mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), f2, inv, t_lo, tcap, tn, tx) && ref != MCRT_BVH4_EMPTY;
+                const bool hit = slab_pairs((v2f){ A.x, A.y }, (v2f){ A.z, A.w }, (v2f){ B.x, B.y }, rp, t_lo, tcap, tn, tx) && ref != MCRT_BVH4_EMPTY;
                 // Next node = the NEAREST hit child (t_near >= 0, so its bit pattern orders like the value; ties -> lowest slot);
                 // the other hit children are stacked in slot order.  Visiting order only affects the work done, never the hit.
                 const uint32_t key = hit ? __float_as_uint(tn) : 0xffffffffu;
                 uint32_t kmin = min(key, (uint32_t)dpp_i<QP_XOR1>((int)key));
                 kmin = min(kmin, (uint32_t)dpp_i<QP_XOR2>((int)kmin));
-                const int qsh = lane & ~3;
-                const uint32_t hit4 = (uint32_t)(__ballot(hit) >> qsh) & 15u;                 // the quad's four hit bits
-                const uint32_t eq4 = (uint32_t)(__ballot(hit && key == kmin) >> qsh) & 15u;
+                // the quad's hit bits (low nibble) and nearest-candidate bits (high nibble), OR-ed across its lanes
+                int w = hit ? (int)((key == kmin) ? bits_j : bit_j) : 0;
+                w |= dpp_i<QP_XOR1>(w);
+                w |= dpp_i<QP_XOR2>(w);
+                const uint32_t hit4 = (uint32_t)w & 15u, eq4 = (uint32_t)w >> 4;
                 const int nh = __popc(hit4);
                 const int jn = __ffs((int)eq4) - 1;                                            // slot of the nearest child
                 int cand = (j == jn) ? ref : 0;
@@ -430,10 +547,10 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                 cand |= dpp_i<QP_XOR2>(cand);
                 if (nh == 0) {
                     if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
-                    else walking = false;
+                    else cur = CUR_IDLE;
                 } else {                                       // mcrt_upload_scene rejected trees that need more than MCRT_STACK entries
                     const uint32_t others = hit4 & ~(1u << jn);
-                    if (hit && j != jn) stack[(sp + __popc(others & ((1u << j) - 1u))) * 64 + q] = ref;
+                    if (hit && j != jn) stack[(sp + __popc(others & (bit_j - 1u))) * 64 + q] = ref;
                     sp += nh - 1;
                     cur = cand;
                 }
@@ -441,41 +558,47 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
         }
         STAMP(sc_p1)
 #ifdef MCRT_STAMP
-        { const unsigned long long lm = __ballot(walking && cur < 0); if (lm) { sc_n2++; sc_act2 += __popcll(lm); } }
+        { const unsigned long long lm = MCRT_ON_LEAF(cur); if (lm) { sc_n2++; sc_act2 += __popcll(lm); } }
 #endif
         // ---- phase 2: the parked leaves -- lane j tests triangle j ----
-        if (walking && cur < 0) {
+        if ((uint32_t)cur > 0x80000000u) {
             const uint32_t v = (uint32_t)~cur;
             const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-            Hit mine = best;
+            Best mine = best;
             for (uint32_t k = (uint32_t)j; k < cnt; k += 4u) {
                 const float4 *T = a.tris + 3 * (size_t)(first + k);
                 const float4 t0 = T[0], t1 = T[1], t2 = T[2];
-                tri_test(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), __float_as_int(t1.w), f2, to, inv, a.pad_abs, t_lo, mine);
+                tri_test_walk(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), f2, to, rp, a.pad_abs, t_lo, mine);
             }
             if (STATS && j == 0) st_tris += cnt;
+            // quad minimum of (fraction, id): fractions are >= 0, so the 64-bit word (fraction bits, id) orders like the contract's
+            // rule; an unchanged lane still holds the common `best`, which never ties with a new find
 #define MCRT_QUAD_MIN(CTRL)                                                                                             \
             {                                                                                                           \
-                const float of = dpp_f<CTRL>(mine.frac); const int ot = dpp_i<CTRL>(mine.tri), om = dpp_i<CTRL>(mine.mesh); \
-                const float onx = dpp_f<CTRL>(mine.n.x), ony = dpp_f<CTRL>(mine.n.y), onz = dpp_f<CTRL>(mine.n.z), oda = dpp_f<CTRL>(mine.da); \
-                if (of < mine.frac || (of == mine.frac && ot < mine.tri)) { mine.frac = of; mine.tri = ot; mine.mesh = om; mine.n = mk(onx, ony, onz); mine.da = oda; } \
+                const float of = dpp_f<CTRL>(mine.frac); const int ot = dpp_i<CTRL>(mine.tri);                          \
+                if (of < mine.frac || (of == mine.frac && (uint32_t)ot < (uint32_t)mine.tri)) { mine.frac = of; mine.tri = ot; } \
             }
             MCRT_QUAD_MIN(QP_XOR1)
             MCRT_QUAD_MIN(QP_XOR2)
 #undef MCRT_QUAD_MIN
             best = mine;
             if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
-            else walking = false;
+            else cur = CUR_IDLE;
         }
         STAMP(sc_p2)
 #ifdef MCRT_STAMP
         sc_outer++;
 #endif
     }
+#undef MCRT_ON_INNER
+#undef MCRT_ON_LEAF
+#undef MCRT_WALKING
 #ifdef MCRT_STAMP
     if (lane == 0) {   // diagnostic build only: per-phase cycles and iteration counts, summed over wavefronts
         atomicAdd(&a.stamps[0], sc_refill); atomicAdd(&a.stamps[1], sc_p1); atomicAdd(&a.stamps[2], sc_p2); atomicAdd(&a.stamps[3], sc_n1);
         atomicAdd(&a.stamps[4], sc_n2); atomicAdd(&a.stamps[5], sc_outer); atomicAdd(&a.stamps[6], sc_act1); atomicAdd(&a.stamps[7], sc_act2); atomicAdd(&a.stamps[8], 1ull);
+        const unsigned long long wc_end = wall_clock64();
+        atomicMax(&a.stamps[16 + 4 * b + 2], wc_end); atomicAdd(&a.stamps[16 + 4 * b + 3], wc_end - wc_start);
     }
 #endif
     if (STATS) {
@@ -623,14 +746,28 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
         }
         if (STATS) st_seg++;
 
-        // ray_physics::segment (ray.h:28-36) -> slot [path][bounce]
-        mcrt_segment sg;
-        sg.from[0] = seg_from.x; sg.from[1] = seg_from.y; sg.from[2] = seg_from.z;
-        sg.to[0] = seg_to.x; sg.to[1] = seg_to.y; sg.to[2] = seg_to.z;
-        sg.dir[0] = seg_dir.x; sg.dir[1] = seg_dir.y; sg.dir[2] = seg_dir.z;
-        sg.reflected_intensity = seg_refl; sg.initial_intensity = seg_init; sg.attenuation = att;
-        sg.distance_traveled = seg_dist; sg.media = seg_media; sg.tri = seg_tri;
-        a.segs[(size_t)pid * a.B + b] = sg;
+        // what the accumulation loop needs of this segment (main.cpp:112-121), computed once here by one lane instead of by
+        // every lane of k_march's quad: start time, step count, the per-step advance
+        {
+            const f3 df = seg_to - seg_from;
+            const float dist_f = sqrtf(dot(df, df)) * 10.0f;
+            const uint32_t steps = steps_from((double)dist_f / a.axial_res_mm);
+            const double t_start = (seg_dist * 1000.0) / a.sos_d;
+            float4 *mr = a.mrec + 3 * ((size_t)pid * a.B + b);
+            mr[0] = make_float4(seg_from.x, seg_from.y, seg_from.z, seg_refl);
+            mr[1] = make_float4(a.axial_res_f * seg_dir.x, a.axial_res_f * seg_dir.y, a.axial_res_f * seg_dir.z, seg_init);
+            mr[2] = make_float4(__int_as_float(__double2loint(t_start)), __int_as_float(__double2hiint(t_start)), __uint_as_float(steps), __int_as_float(seg_media));
+        }
+        // ray_physics::segment (ray.h:28-36) -> slot [path][bounce], for the callers that ask for the segments themselves
+        if (a.want_segs) {
+            mcrt_segment sg;
+            sg.from[0] = seg_from.x; sg.from[1] = seg_from.y; sg.from[2] = seg_from.z;
+            sg.to[0] = seg_to.x; sg.to[1] = seg_to.y; sg.to[2] = seg_to.z;
+            sg.dir[0] = seg_dir.x; sg.dir[1] = seg_dir.y; sg.dir[2] = seg_dir.z;
+            sg.reflected_intensity = seg_refl; sg.initial_intensity = seg_init; sg.attenuation = att;
+            sg.distance_traveled = seg_dist; sg.media = seg_media; sg.tri = seg_tri;
+            a.segs[(size_t)pid * a.B + b] = sg;
+        }
         a.seg_count[pid] = b + 1u;
         alive = alive && (b + 1u < a.B);
     }
@@ -694,12 +831,16 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     unsigned long long st_steps = 0;
 
     uint32_t cursor = s_begin;                               // wave-uniform: next unclaimed slot
+    const double thr_end = a.row_thr[R];
     bool busy = false;
+    // lane j of a quad carries the segment's running state (point, time, intensity) j steps AHEAD of the quad's base step:
+    // every lane does the same sequential updates the reference does, shifted, and owns steps j, j+4, j+8, ...
     f3 point = mk(0, 0, 0), delta = mk(0, 0, 0);
     double t = 0.0, t_start = 0.0;
     float inten = 0.0f, k_att = 0.0f, seg_refl = 0.0f, m_dens = 0.0f, m_sigma = 0.0f, m_mu = 0.0f;
-    uint32_t step = 0, steps = 0;
+    uint32_t sidx = 0, steps = 0;
     bool more = false;
+#define MCRT_ADVANCE() { point = point + delta; t = t + a.time_step; inten *= k_att; }
     for (;;) {
         // ---- idle quads probe the next slots until at least half of the quads have a segment (or the range is exhausted) ----
         while (cursor < s_end) {
@@ -709,26 +850,21 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
             if (!busy && mine < s_end) {
                 const size_t pid = pid0 + mine;
                 if (b < a.seg_count[pid]) {
-                    const float4 *sp = (const float4 *)(a.segs + pid * a.B + b);
-                    const float4 g0 = sp[0], g1 = sp[1], g2 = sp[2], g3 = sp[3];
-                    // mcrt_segment: from[3] to[3] dir[3] refl init att | double dist | media tri
-                    const f3 seg_from = mk(g0.x, g0.y, g0.z), seg_to = mk(g0.w, g1.x, g1.y), seg_dir = mk(g1.z, g1.w, g2.x);
-                    seg_refl = g2.y; inten = g2.z;
-                    const float seg_att = g2.w;
-                    const double seg_dist = __hiloint2double(__float_as_int(g3.y), __float_as_int(g3.x));
-                    const int seg_media = __float_as_int(g3.z);
-                    const float4 s0 = a.mats[2 * seg_media], s1 = a.mats[2 * seg_media + 1];
-                    m_mu = s0.z; m_dens = s0.w; m_sigma = s1.x;
-                    t_start = (seg_dist * 1000.0) / a.sos_d;
-                    const f3 df = seg_to - seg_from;
-                    const float dist_f = sqrtf(dot(df, df)) * 10.0f;
-                    steps = steps_from((double)dist_f / a.axial_res_mm);
-                    delta = mk(a.axial_res_f * seg_dir.x, a.axial_res_f * seg_dir.y, a.axial_res_f * seg_dir.z);
-                    k_att = det_expf(-seg_att * a.axial_res_f * 0.01f * a.freq * 1.0f);
-                    point = seg_from; t = t_start; step = 0;
+                    const float4 *mr = a.mrec + 3 * (pid * a.B + b);
+                    const float4 g0 = mr[0], g1 = mr[1], g2 = mr[2];
+                    const float4 mt = a.mtab[__float_as_int(g2.w)];
+                    point = mk(g0.x, g0.y, g0.z); seg_refl = g0.w;
+                    delta = mk(g1.x, g1.y, g1.z); inten = g1.w;
+                    t_start = __hiloint2double(__float_as_int(g2.y), __float_as_int(g2.x));
+                    steps = __float_as_uint(g2.z);
+                    m_mu = mt.x; m_dens = mt.y; m_sigma = mt.z; k_att = mt.w;
+                    t = t_start; sidx = (uint32_t)j;
                     // scattering is exactly +0 for every voxel when mu0 == sigma == 0 (finite texture): the adds are no-ops
                     const bool silent = a.tex_finite && m_mu == 0.0f && m_sigma == 0.0f;
                     more = !silent && steps > 0u && t < a.max_travel;
+                    if (j > 0) MCRT_ADVANCE()
+                    if (j > 1) MCRT_ADVANCE()
+                    if (j > 2) MCRT_ADVANCE()
                     busy = true;
                 }
             }
@@ -737,37 +873,32 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
         }
         if (!__any(busy)) { if (cursor >= s_end) break; else continue; }
 
-        // ---- eight steps of every running segment ----
+        // ---- 4*H steps of every running segment ----
         if (busy && more) {
             f3 myp[MCRT_MARCH_H]; double myt[MCRT_MARCH_H]; float myin[MCRT_MARCH_H]; bool myv[MCRT_MARCH_H];
-            // advance j steps to this lane's first own step, capture, advance 4, capture, ... advance the remaining 4-j: the same
-            // 4*H sequential updates of (point, t, intensity) in every lane, without per-step selects
-            uint32_t sidx = step;
-#define MCRT_ADVANCE() { point = point + delta; t = t + a.time_step; inten *= k_att; sidx++; }
-            for (int u = 0; u < j; u++) MCRT_ADVANCE()
+            float reach = 0.0f;
 #pragma unroll
             for (int h = 0; h < MCRT_MARCH_H; h++) {
                 myp[h] = point; myt[h] = t; myin[h] = inten; myv[h] = sidx < steps && t < a.max_travel;           // the reference's loop test
-                if (h + 1 < MCRT_MARCH_H) { MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE() }
+                reach += abs_sum(point);
+                MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE()
+                sidx += 4u;
             }
-            for (int u = j; u < 4; u++) MCRT_ADVANCE()
-#undef MCRT_ADVANCE
-            step += 4u * MCRT_MARCH_H;
-            more = step < steps && t < a.max_travel;
+            // the quad goes on while its base step (lane 0's) passes the loop test
+            more = dpp_i<QP_BCAST(0)>((sidx < steps && t < a.max_travel) ? 1 : 0) != 0;
             float2 vox[MCRT_MARCH_H];
+            if (reach < a.lean_bound) {
 #pragma unroll
-            for (int h = 0; h < MCRT_MARCH_H; h++) {
-                vox[h] = make_float2(0.0f, 0.0f);
-                if (myv[h]) {
-                    const uint32_t vx = vox_index(div_res(myp[h].x, a), a.tex_n, a.tex_mask), vy = vox_index(div_res(myp[h].y, a), a.tex_n, a.tex_mask), vz = vox_index(div_res(myp[h].z, a), a.tex_n, a.tex_mask);
-                    vox[h] = a.tex[((size_t)vx * a.tex_n + vy) * a.tex_n + vz];
-                }
+                for (int h = 0; h < MCRT_MARCH_H; h++) vox[h] = a.tex[vox_cell_lean(myp[h], a)];
+            } else {
+#pragma unroll
+                for (int h = 0; h < MCRT_MARCH_H; h++) vox[h] = myv[h] ? a.tex[vox_cell(myp[h], a)] : make_float2(0.0f, 0.0f);
             }
 #pragma unroll
             for (int h = 0; h < MCRT_MARCH_H; h++) {
                 if (myv[h]) {
                     const float scattering = vox[h].y >= m_dens ? vox[h].x * m_sigma + m_mu : 0.0f;
-                    rf_add(bins, lflags, row_of(myt[h], thr, R, a.inv_row_dt), myin[h] * scattering);
+                    rf_add(bins, lflags, row_of(myt[h], thr, R, a.inv_row_dt, thr_end), myin[h] * scattering);
                     if (STATS) st_steps++;
                 }
             }
@@ -775,11 +906,12 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
             // ---- a finished segment: the boundary echo (main.cpp:139), then the quad is free ----
             if (j == 0) {
                 const double te = t_start + a.time_step * (double)(uint32_t)(steps - 1u);
-                rf_add(bins, lflags, row_of(te, thr, R, a.inv_row_dt), seg_refl / (float)a.S);
+                rf_add(bins, lflags, row_of(te, thr, R, a.inv_row_dt, thr_end), seg_refl / (float)a.S);
             }
             busy = false;
         }
     }
+#undef MCRT_ADVANCE
     if (STATS) {
         long long x = wave_sum_i64((long long)st_steps);
         if (lane == 0 && x) atomicAdd(&a.stats[4], (unsigned long long)x);
@@ -944,6 +1076,16 @@ __global__ void k_verify_div(float res, float rcp, unsigned long long *bad)
     if (local) atomicAdd(bad, local);
 }
 
+// per material, what k_march reads: mu0, mu1, sigma and the per-step attenuation factor of main.cpp:118-119
+// (the segment's attenuation is its medium's, so the factor depends on the material only)
+__global__ void k_material_table(const float4 *mats, uint32_t n_mat, float axial_res_f, float freq, float4 *mtab)
+{
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_mat) return;
+    const float4 s0 = mats[2 * m], s1 = mats[2 * m + 1];
+    mtab[m] = make_float4(s0.z, s0.w, s1.x, det_expf(-s0.y * axial_res_f * 0.01f * freq * 1.0f));
+}
+
 __global__ void k_philox_probe(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *out)
 {
     uint32_t o[4];
@@ -993,7 +1135,8 @@ hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
 hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st)
 {
     // chunks per scan-line: aim at ~4096 workgroups, at least 16 slots per wavefront
-    uint32_t chunks = a.ne >= 4096u ? 1u : (4096u + a.ne - 1u) / a.ne;
+    static const uint32_t target = [] { uint32_t v = 4096u; if (const char *e = getenv("MCRT_MARCH_BLOCKS")) { int x = atoi(e); if (x >= 1) v = (uint32_t)x; } return v; }();   // tuning knob
+    uint32_t chunks = a.ne >= target ? 1u : (target + a.ne - 1u) / a.ne;
     const uint32_t max_chunks = (a.S + 63u) / 64u;
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1u) chunks = 1u;
@@ -1049,6 +1192,12 @@ hipError_t launch_math_probe(int op, const double *x, const double *y, double *o
 hipError_t launch_verify_div(float res, float rcp, unsigned long long *bad, hipStream_t st)
 {
     hipLaunchKernelGGL(k_verify_div, dim3(256 * 16), dim3(256), 0, st, res, rcp, bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_material_table(const float4 *mats, uint32_t n_mat, float axial_res_f, float freq, float4 *mtab, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_material_table, dim3((n_mat + 63u) / 64u), dim3(64), 0, st, mats, n_mat, axial_res_f, freq, mtab);
     return hipGetLastError();
 }
 

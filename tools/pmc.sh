@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes for the k_trace kernel (separate rocprofv3 runs per counter group, as the pool requires)
+# PMC passes for one kernel (PMC_KERNEL, default k_trace<false>): separate rocprofv3 runs per counter group, as the pool requires
 out=gpurun_out/pmc_$1; mkdir -p $out; export TMPDIR=/tmp
 B="python3 bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-latency-leg ${BENCH_ARGS}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-latency-leg ${BENCH_ARGS} > $out/stats.log 2>&1

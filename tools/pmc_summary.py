@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 output dirs (kernel stats + PMC passes) of tools/pmc.sh into one JSON + text table."""
 import csv, glob, json, os, sys, collections
+KERNEL = os.environ.get("PMC_KERNEL", "k_trace<false>")   # substring of the kernel the counters are reported for
 out = sys.argv[1]
 res = {"kernel_stats": [], "pmc": {}}
 for f in glob.glob(out + "/stats/*/*kernel_stats.csv"):
@@ -13,7 +14,7 @@ for d in sorted(glob.glob(out + "/*/")):
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
-            if "k_trace<false>" in k:
+            if KERNEL in k:
                 for c, x in v.items():
                     res["pmc"][c] = {"avg_per_launch": sum(x) / len(x), "launches": len(x), "pass": os.path.basename(d.rstrip("/"))}
 json.dump(res, open(out + "/summary.json", "w"), indent=1)

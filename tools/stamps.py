@@ -1,23 +1,27 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase cycle shares of k_trace from a -DMCRT_STAMP build (MCRT_LIB=.../libmcrt_hip_stamp.so)."""
+"""Diagnostic: per-phase cycle shares and the per-bounce launch timeline of k_trace from a -DMCRT_STAMP build
+(MCRT_LIB=.../libmcrt_hip_stamp.so).  usage: stamps.py [rays] [frames_in_flight]"""
 import os, sys, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mcray_tracing_amd as m
+import torch
 rays = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 cfg, meshes = m.synth.random_scene(1_000_000, 8, 12345)
 sd = m.scene_io.build_scene(cfg, meshes)
 tr = m.Transducer(128, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
 sim = m.Simulator(sd, tr, n_samples=rays)
-out = (C.c_uint64 * 16)()
+ctx = sim.ctx
+rf = torch.empty((F, 128, sim.R), dtype=torch.float32, device="cuda")
+out = (C.c_uint64 * 80)()
 for f in range(3):
-    sim.trace(f)
-sim.ctx.synchronize()
-sim.ctx.L.mcrt_debug_stamps(sim.ctx.h, out, 1)
-for f in range(5):
-    sim.trace(f)
-sim.ctx.synchronize()
-sim.ctx.L.mcrt_debug_stamps(sim.ctx.h, out, 1)
+    ctx.trace_frames(f * F, F, rf, 0, 128)
+ctx.synchronize()
+ctx.L.mcrt_debug_stamps(ctx.h, out, 1)
+ctx.trace_frames(100, F, rf, 0, 128)          # ONE pass: the timeline slots hold min/max over what ran since the reset
+ctx.synchronize()
+ctx.L.mcrt_debug_stamps(ctx.h, out, 1)
 v = [int(x) for x in out]
 names = ["refill cyc", "phase1 cyc", "phase2 cyc", "phase1 iters", "phase2 iters", "outer iters", "active lanes p1 (sum)", "active lanes p2 (sum)", "waves"]
 for n, x in zip(names, v): print("%-24s %16d" % (n, x))
@@ -25,3 +29,19 @@ tot = v[0] + v[1] + v[2]
 print("shares: refill %.1f%%  phase1 %.1f%%  phase2 %.1f%%" % (100 * v[0] / tot, 100 * v[1] / tot, 100 * v[2] / tot))
 print("cycles per phase-1 iteration %.0f (avg active lanes %.1f/64); per phase-2 iteration %.0f (avg parked lanes %.1f/64)" % (v[1] / max(v[3], 1), v[6] / max(v[3], 1), v[2] / max(v[4], 1), v[7] / max(v[4], 1)))
 print("per wave: %.0f cycles, %.1f node iterations, %.1f leaf iterations" % (tot / v[8], v[3] / v[8], v[4] / v[8]))
+M = (1 << 64) - 1
+print("bounce   launch us   queue empty at us (share of launch)   mean wave lifetime us")
+for b in range(10):
+    s0, s1, e, life = v[16 + 4 * b: 20 + 4 * b]
+    if e == 0: continue
+    start, empty = M - s0, (M - s1) if s1 else None
+    dur = (e - start) / 100.0
+    em = (empty - start) / 100.0 if empty is not None else float("nan")
+    print("%4d   %10.1f   %10.1f (%.0f%%)   %10.1f" % (b, dur, em, 100 * em / dur if dur else 0, life / 100.0 / 5120))
+h = v[60:77]
+tot_h = sum(h) or 1
+print("node visits per walk (bounces >= 1), log2 bins: share of walks / share of visits (bin midpoint estimate)")
+est = [h[k] * (1.5 * 2 ** (k - 1) if k > 0 else 0) for k in range(len(h))]
+te = sum(est) or 1
+for k, x in enumerate(h):
+    if x: print("  < %6d : %6.2f%%  %6.2f%%" % (2 ** k, 100 * x / tot_h, 100 * est[k] / te))
