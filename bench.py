@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=16,
                     help="frames traced per pass (mcrt_trace_frames): a step is still ONE frame, but every kernel launch then carries the "
                          "rays of this many consecutive frames (1 = strict one-frame-at-a-time latency mode)")
+    ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="BVH builder: host binned SAH (default) or the device LBVH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the extra one-frame-at-a-time measurement (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for plumbing checks")
@@ -92,6 +93,7 @@ def main():
     ctx = m.Context(local_rank)
     ctx.set_params(n_elements=E, n_samples=S, n_rows=R, frequency=tr.frequency, tex_n=args.tex_n)
     t0 = time.time()
+    ctx.set_bvh_builder(args.bvh)
     ctx.upload_scene(sd)
     t_bvh = time.time() - t0
     ctx.upload_texture(None, args.tex_n)
@@ -187,7 +189,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s; %d scan-lines x %d rays per GPU, %d RF rows, max depth 10" % (label, E_local, S, R),
                        "scan_lines_total": E, "rays_per_scan_line": S, "triangles": int(sd.n_tri), "parallelism": "scanline-shard x%d" % world, "frames_in_flight": F,
-                       "bvh_build_s": round(t_bvh, 3)},
+                       "bvh_builder": args.bvh, "bvh_build_s": round(t_bvh, 3)},
             "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms, "launches": k_n,

@@ -115,12 +115,24 @@ int mcrt_synchronize(mcrt_ctx *ctx);
 int mcrt_default_params(mcrt_params *p);
 int mcrt_set_params(mcrt_ctx *ctx, const mcrt_params *p);
 
+/* Which builder mcrt_upload_scene / mcrt_update_triangles use for the BVH that replaces the per-mesh
+ * btBvhTriangleMeshShape of scene.cpp:306-309:
+ *   MCRT_BVH_HOST_SAH     binned-SAH build on the host (default; best trees, seconds for 1 M triangles)
+ *   MCRT_BVH_DEVICE_LBVH  Morton-order LBVH built on the GPU (milliseconds; for moving geometry, the interactive path
+ *                         the reference prepares in inputmanager.cpp:117-121 / transducer.h:82-118).  Needs >= 8 triangles.
+ * Images do not depend on the builder: the closest-hit contract is independent of the hierarchy. */
+enum { MCRT_BVH_HOST_SAH = 0, MCRT_BVH_DEVICE_LBVH = 1 };
+int mcrt_set_bvh_builder(mcrt_ctx *ctx, int builder);
+
 /* Geometry in WORLD space (scene.cpp:313-324 already applied: v*scaling + deltas*scaling^2 + origin),
- * triangles in OBJ face order, meshes in scene order.  Builds the BVH on the host and uploads it.
+ * triangles in OBJ face order, meshes in scene order.  Builds the BVH (see mcrt_set_bvh_builder) and uploads it.
  * materials: [n_mat][8] = impedance, attenuation, mu0, mu1, sigma, specularity, shininess, thickness. */
 int mcrt_upload_scene(mcrt_ctx *ctx, const float *tri_xyz /*[T][9]*/, const uint32_t *tri_mesh /*[T]*/, uint32_t n_tri,
                       const mcrt_mesh *meshes, uint32_t n_mesh, const float *materials, uint32_t n_mat,
                       uint32_t start_mat, const float spacing[3]);
+/* New vertex positions for the uploaded scene's triangles (same count, same order, same mesh / material tables):
+ * re-indexes them with the selected builder.  tri_xyz may be a host or a device pointer. */
+int mcrt_update_triangles(mcrt_ctx *ctx, const float *tri_xyz /*[T][9]*/, uint32_t n_tri);
 /* voxels [n^3][2] = {texture_noise, scattering_probability}; NULL => generate the reference's texture */
 int mcrt_upload_texture(mcrt_ctx *ctx, const float *voxels, uint32_t n);
 int mcrt_set_transducer(mcrt_ctx *ctx, const float *pos /*[E][3]*/, const float *dir /*[E][3]*/, uint32_t n_elements);

@@ -144,6 +144,20 @@ class Context:
         check(self.L.mcrt_upload_scene(self.h, ptr(sd.tri), ptr(sd.tri_mesh), sd.n_tri, C.cast(meshes, C.c_void_p), len(sd.meshes),
                                        ptr(sd.materials), sd.materials.shape[0], sd.start_mat, ptr(sp)))
 
+    def set_bvh_builder(self, builder):
+        """'sah' (host, default) or 'lbvh' (built on the GPU); applies to the next upload_scene / update_triangles"""
+        kind = {"sah": 0, "lbvh": 1}[builder] if isinstance(builder, str) else int(builder)
+        check(self.L.mcrt_set_bvh_builder(self.h, kind))
+
+    def update_triangles(self, tri):
+        """new vertex positions [T,9] (numpy array, or a CUDA torch tensor) for the uploaded scene's triangles"""
+        if isinstance(tri, np.ndarray):
+            tri = np.ascontiguousarray(tri, np.float32).reshape(-1, 9)
+            n = tri.shape[0]
+        else:
+            n = tri.numel() // 9
+        check(self.L.mcrt_update_triangles(self.h, ptr(tri), n))
+
     def upload_texture(self, vox=None, n=256):
         if vox is not None:
             vox = np.ascontiguousarray(vox, np.float32)
@@ -156,7 +170,8 @@ class Context:
     def get_bvh(self):
         b = Bvh()
         check(self.L.mcrt_get_bvh(self.h, C.byref(b)))
-        nodes = np.frombuffer(C.string_at(b.nodes, 64 * b.n_nodes), dtype=NODE_DTYPE).copy()
+        # (a tree built on the device has no BVH2: n_nodes == 0)
+        nodes = np.frombuffer(C.string_at(b.nodes, 64 * b.n_nodes), dtype=NODE_DTYPE).copy() if b.n_nodes else np.zeros(0, NODE_DTYPE)
         btri = np.frombuffer(C.string_at(b.tri, 48 * b.n_tri), dtype=np.float32).reshape(-1, 12).copy()
         return nodes, btri, int(b.max_depth)
 
@@ -264,8 +279,9 @@ class Simulator:
     """
 
     def __init__(self, scene_data, transducer, n_samples=5, n_rows=None, device=0, seed=0x5EED, psf=None, texture=None,
-                 max_depth=10, sanitize_tir=0, tex_n=256):
+                 max_depth=10, sanitize_tir=0, tex_n=256, bvh_builder="sah"):
         self.ctx = Context(device)
+        self.ctx.set_bvh_builder(bvh_builder)
         self.tr = transducer
         E = transducer.n_elements
         self.ctx.set_params(n_elements=E, n_samples=n_samples, frequency=transducer.frequency, seed=seed, max_depth=max_depth,

@@ -4,6 +4,7 @@
 #include "../../include/mcrt.h"
 #include "mcrt_internal.h"
 #include "mcrt_kernels.h"
+#include "mcrt_lbvh.h"
 
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -75,6 +76,8 @@ struct mcrt_ctx {
     uint4 *d_meshes = nullptr;
     uint32_t *d_tri_slot = nullptr;
     uint32_t n_mesh = 0, n_mat = 0, start_mat = 0;
+    int builder = MCRT_BVH_HOST_SAH; bool host_bvh_stale = false;   // device-built tree: host copies are downloaded on demand
+    std::vector<uint32_t> tri_mesh;   // per-triangle mesh index of the uploaded scene (for mcrt_update_triangles)
     float scene_lo[3] = { 0, 0, 0 }, scene_hi[3] = { 0, 0, 0 };
     float spacing[3] = { 1, 1, 1 };
     bool have_scene = false;
@@ -272,6 +275,103 @@ extern "C" int mcrt_set_params(mcrt_ctx *c, const mcrt_params *p)
     return prepare_tables(c);
 }
 
+// builds the BVH over tri[n_tri][9] (host or device pointer) with the context's builder and installs it on the device
+static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
+{
+    hipFree(c->d_nodes); hipFree(c->d_tris); hipFree(c->d_tri_slot); c->d_nodes = c->d_tris = nullptr; c->d_tri_slot = nullptr;
+    mcrt_free_bvh(&c->bvh); mcrt_free_bvh4(&c->bvh4);
+    c->host_bvh_stale = false;
+    if (c->builder == MCRT_BVH_DEVICE_LBVH) {
+        float *d_tri = nullptr; uint32_t *d_mesh = nullptr;
+        HIP_TRY(hipMalloc(&d_tri, 36 * (size_t)n_tri));
+        if (hipMalloc(&d_mesh, 4 * (size_t)n_tri) != hipSuccess) { hipFree(d_tri); return set_error(MCRT_ERR_NOMEM, "out of device memory"); }
+        mcrt::LbvhResult r;
+        int rc = MCRT_OK;
+        if (hipMemcpyAsync(d_tri, tri, 36 * (size_t)n_tri, hipMemcpyDefault, c->stream) != hipSuccess ||
+            hipMemcpyAsync(d_mesh, c->tri_mesh.data(), 4 * (size_t)n_tri, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            rc = set_error(MCRT_ERR_HIP, "triangle upload failed");
+        if (!rc) rc = mcrt::lbvh_build(d_tri, d_mesh, n_tri, c->stream, &r);
+        hipFree(d_tri); hipFree(d_mesh);
+        if (rc) return rc;
+        c->d_nodes = r.d_nodes; c->d_tris = r.d_tris; c->d_tri_slot = r.d_tri_slot;
+        c->bvh.n_nodes = 0; c->bvh.n_tri = n_tri; c->bvh.max_depth = r.max_depth; c->bvh.pad_abs = r.pad_abs; c->bvh.nodes = nullptr; c->bvh.tri = nullptr;
+        c->bvh4.n_nodes = r.n_nodes4; c->bvh4.max_stack = r.max_stack; c->bvh4.nodes = nullptr;
+        c->host_bvh_stale = true;
+        for (int i = 0; i < 3; i++) { c->scene_lo[i] = r.lo[i]; c->scene_hi[i] = r.hi[i]; }
+        if (c->bvh4.max_stack > MCRT_STACK)
+            return set_error(MCRT_ERR_LIMIT, "device-built BVH4 needs a %u-entry traversal stack, the kernel has %d", c->bvh4.max_stack, MCRT_STACK);
+        return MCRT_OK;
+    }
+    std::vector<float> host_copy;
+    {   // the host builder reads host memory
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, tri) == hipSuccess && at.type == hipMemoryTypeDevice) {
+            host_copy.resize((size_t)n_tri * 9);
+            HIP_TRY(hipMemcpy(host_copy.data(), tri, 36 * (size_t)n_tri, hipMemcpyDeviceToHost));
+            tri = host_copy.data();
+        } else (void)hipGetLastError();
+    }
+    int rc = mcrt_build_bvh(tri, c->tri_mesh.data(), n_tri, &c->bvh);
+    if (rc) return rc;
+    rc = mcrt_build_bvh4(&c->bvh, &c->bvh4);
+    if (rc) return rc;
+    for (int i = 0; i < 3; i++) { c->scene_lo[i] = INFINITY; c->scene_hi[i] = -INFINITY; }
+    for (int k = 0; k < 4; k++) {
+        const mcrt_bvh4_child &ch = c->bvh4.nodes[0].c[k];
+        if (ch.ref == MCRT_BVH4_EMPTY) continue;
+        const float hi[3] = { ch.hi_x, ch.hi_y, ch.hi_z };
+        for (int i = 0; i < 3; i++) { c->scene_lo[i] = std::min(c->scene_lo[i], ch.lo[i]); c->scene_hi[i] = std::max(c->scene_hi[i], hi[i]); }
+    }
+    if (c->bvh4.max_stack > MCRT_STACK)
+        return set_error(MCRT_ERR_LIMIT, "BVH4 needs a %u-entry traversal stack, the kernel has %d", c->bvh4.max_stack, MCRT_STACK);
+    HIP_TRY(hipMalloc(&c->d_nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes));
+    HIP_TRY(hipMalloc(&c->d_tris, 48 * (size_t)n_tri));
+    HIP_TRY(hipMemcpy(c->d_nodes, c->bvh4.nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_tris, c->bvh.tri, 48 * (size_t)n_tri, hipMemcpyHostToDevice));
+    {   // triangle id -> leaf-order slot (k_shade re-derives the winning triangle's normal from its vertices)
+        std::vector<uint32_t> slot(n_tri);
+        for (uint32_t k = 0; k < n_tri; k++) { uint32_t id; memcpy(&id, &c->bvh.tri[(size_t)k * 12 + 3], 4); slot[id] = k; }
+        HIP_TRY(hipMalloc(&c->d_tri_slot, 4 * (size_t)n_tri));
+        HIP_TRY(hipMemcpy(c->d_tri_slot, slot.data(), 4 * (size_t)n_tri, hipMemcpyHostToDevice));
+    }
+    return MCRT_OK;
+}
+
+// host copies of a device-built tree, for mcrt_get_bvh / mcrt_get_bvh4
+static int download_bvh(mcrt_ctx *c)
+{
+    if (!c->host_bvh_stale) return MCRT_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->bvh.tri = (float *)malloc(48 * (size_t)c->bvh.n_tri);
+    c->bvh4.nodes = (mcrt_bvh4_node *)malloc(sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes);
+    if (!c->bvh.tri || !c->bvh4.nodes) return set_error(MCRT_ERR_NOMEM, "out of memory");
+    HIP_TRY(hipMemcpy(c->bvh.tri, c->d_tris, 48 * (size_t)c->bvh.n_tri, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c->bvh4.nodes, c->d_nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes, hipMemcpyDeviceToHost));
+    c->host_bvh_stale = false;
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_set_bvh_builder(mcrt_ctx *c, int builder)
+{
+    CTX_TRY(c);
+    if (builder != MCRT_BVH_HOST_SAH && builder != MCRT_BVH_DEVICE_LBVH) return set_error(MCRT_ERR_INVALID, "unknown BVH builder %d", builder);
+    c->builder = builder;
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_update_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
+{
+    CTX_TRY(c);
+    if (!c->have_scene) return set_error(MCRT_ERR_INVALID, "no scene uploaded");
+    if (!tri) return set_error(MCRT_ERR_INVALID, "null triangles");
+    if (n_tri != c->bvh.n_tri || n_tri == 0) return set_error(MCRT_ERR_INVALID, "the scene has %u triangles, the update has %u", c->bvh.n_tri, n_tri);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_scene = false;                           // a failed rebuild leaves no scene
+    int rc = index_triangles(c, tri, n_tri); if (rc) return rc;
+    c->have_scene = true;
+    return MCRT_OK;
+}
+
 extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *tri_mesh, uint32_t n_tri,
                                  const mcrt_mesh *meshes, uint32_t n_mesh, const float *mats, uint32_t n_mat,
                                  uint32_t start_mat, const float spacing[3])
@@ -287,29 +387,8 @@ extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_scene(c);
     if (n_tri) {
-        int rc = mcrt_build_bvh(tri, tri_mesh, n_tri, &c->bvh);
-        if (rc) return rc;
-        rc = mcrt_build_bvh4(&c->bvh, &c->bvh4);
-        if (rc) return rc;
-        for (int i = 0; i < 3; i++) { c->scene_lo[i] = INFINITY; c->scene_hi[i] = -INFINITY; }
-        for (int k = 0; k < 4; k++) {
-            const mcrt_bvh4_child &ch = c->bvh4.nodes[0].c[k];
-            if (ch.ref == MCRT_BVH4_EMPTY) continue;
-            const float hi[3] = { ch.hi_x, ch.hi_y, ch.hi_z };
-            for (int i = 0; i < 3; i++) { c->scene_lo[i] = std::min(c->scene_lo[i], ch.lo[i]); c->scene_hi[i] = std::max(c->scene_hi[i], hi[i]); }
-        }
-        if (c->bvh4.max_stack > MCRT_STACK)
-            return set_error(MCRT_ERR_LIMIT, "BVH4 needs a %u-entry traversal stack, the kernel has %d", c->bvh4.max_stack, MCRT_STACK);
-        HIP_TRY(hipMalloc(&c->d_nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes));
-        HIP_TRY(hipMalloc(&c->d_tris, 48 * (size_t)n_tri));
-        HIP_TRY(hipMemcpy(c->d_nodes, c->bvh4.nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_tris, c->bvh.tri, 48 * (size_t)n_tri, hipMemcpyHostToDevice));
-        {   // triangle id -> leaf-order slot (k_shade re-derives the winning triangle's normal from its vertices)
-            std::vector<uint32_t> slot(n_tri);
-            for (uint32_t k = 0; k < n_tri; k++) { uint32_t id; memcpy(&id, &c->bvh.tri[(size_t)k * 12 + 3], 4); slot[id] = k; }
-            HIP_TRY(hipMalloc(&c->d_tri_slot, 4 * (size_t)n_tri));
-            HIP_TRY(hipMemcpy(c->d_tri_slot, slot.data(), 4 * (size_t)n_tri, hipMemcpyHostToDevice));
-        }
+        c->tri_mesh.assign(tri_mesh, tri_mesh + n_tri);
+        int rc = index_triangles(c, tri, n_tri); if (rc) return rc;
     }
     HIP_TRY(hipMalloc(&c->d_mats, 32 * (size_t)n_mat));
     HIP_TRY(hipMemcpy(c->d_mats, mats, 32 * (size_t)n_mat, hipMemcpyHostToDevice));
@@ -325,6 +404,7 @@ extern "C" int mcrt_get_bvh(mcrt_ctx *c, mcrt_bvh *out)
 {
     if (!c || !out) return set_error(MCRT_ERR_INVALID, "null argument");
     if (!c->have_scene) return set_error(MCRT_ERR_INVALID, "no scene uploaded");
+    { int rc = download_bvh(c); if (rc) return rc; }
     *out = c->bvh;
     return MCRT_OK;
 }
@@ -333,6 +413,7 @@ extern "C" int mcrt_get_bvh4(mcrt_ctx *c, mcrt_bvh4 *out)
 {
     if (!c || !out) return set_error(MCRT_ERR_INVALID, "null argument");
     if (!c->have_scene) return set_error(MCRT_ERR_INVALID, "no scene uploaded");
+    { int rc = download_bvh(c); if (rc) return rc; }
     *out = c->bvh4;
     return MCRT_OK;
 }

@@ -9,6 +9,7 @@
 #define MCRT_GROUPS_DEFAULT 1        // independent scan-line groups a frame is traced as (their kernels overlap)
 #define MCRT_SIDE_STREAMS 4         // streams k_march launches rotate over
 #define MCRT_SIDE_STREAMS_DEFAULT 1
+#define MCRT_LBVH_LEAF 1             // device builder: triangles per leaf (1..4); measured best at 1, like the SAH builder's own leaves
 #define MCRT_MAX_ROWS 2048
 #define MCRT_MAX_BOUNCES 16
 

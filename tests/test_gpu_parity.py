@@ -323,3 +323,56 @@ def test_frames_in_flight_are_bit_identical(mcrt, orc, sphere, tex256):
     assert np.array_equal(batch[1].T.view(np.uint32), o8["rf"].view(np.uint32))
     sim.ctx.free(dev)
     sim.close()
+
+
+def test_device_lbvh_gives_the_same_frames(mcrt, orc, tex256):
+    """the BVH built on the GPU (Morton LBVH -> BVH4) is a different tree, yet hits, segments and the RF image
+    are bit-identical to the host SAH tree's and to the oracle's (the closest-hit contract does not depend on the hierarchy);
+    the oracle also walks the downloaded device-built tree and must count exactly the GPU's node visits"""
+    cfg, meshes = mcrt.synth.random_scene(100000, 8, seed=99)
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    E, S = 32, 256
+    tr, sah = _sim(mcrt, cfg, sd, E, S, texture=tex256)
+    h0, s0, c0 = sah.ctx.trace_frame_debug(3, sah.rf_dev, want_segs=True)
+    rf0 = sah.ctx.export_rf(sah.rf_dev, E, sah.R)
+    sah.close()
+    tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256, bvh_builder="lbvh")
+    h1, s1, c1 = sim.ctx.trace_frame_debug(3, sim.rf_dev, want_segs=True)
+    rf1 = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    assert np.array_equal(h0, h1) and np.array_equal(c0, c1) and s0.tobytes() == s1.tobytes()
+    assert np.array_equal(rf0.view(np.uint32), rf1.view(np.uint32))
+    # the device-built tree, walked by the oracle
+    nodes4, max_stack = sim.ctx.get_bvh4()
+    _, btri, depth = sim.ctx.get_bvh()
+    assert sorted(btri[:, 3].view(np.uint32).tolist()) == list(range(sd.n_tri))          # every triangle exactly once
+    assert 1 <= max_stack <= 64 and depth >= 10
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
+    osc.set_bvh4(nodes4, btri)
+    p = orc.default_params(n_elements=E, n_samples=S)
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=3, use_bvh=2, n_threads=16)
+    assert np.array_equal(h1, o["hits"])
+    _assert_rf(rf1, o)
+    sim.ctx.enable_stats(True); sim.ctx.get_stats(reset=True)
+    sim.trace(3); st = sim.ctx.get_stats()
+    sim.ctx.enable_stats(False)
+    p0 = orc.default_params(n_elements=E, n_samples=S, max_depth=1)
+    o0 = osc.trace_frame(p0, tr.pos, tr.dir, tex256, frame_id=3, use_bvh=2, n_threads=16, want_ref=False, want_fix=False)["stats"]
+    for k in ("queries", "nodes_visited", "tris_tested"):       # bounce 0 is walked once per scan-line on the GPU
+        assert st[k] == o["stats"][k] - o0[k] + o0[k] // S, k
+    # moved geometry: re-index on the device, compare with a fresh host-SAH context
+    moved = sd.tri.reshape(-1, 3, 3).copy()
+    moved[:, :, 1] += 0.37 * np.sin(moved[:, :, 0])                # a smooth deformation
+    moved = moved.reshape(-1, 9).astype(np.float32)
+    sim.ctx.update_triangles(moved)
+    h2, _, c2 = sim.ctx.trace_frame_debug(4, sim.rf_dev, want_segs=True)
+    rf2 = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    sim.close()
+    import copy
+    sd2 = copy.copy(sd); sd2.tri = moved
+    tr, ref = _sim(mcrt, cfg, sd2, E, S, texture=tex256)
+    h3, _, c3 = ref.ctx.trace_frame_debug(4, ref.rf_dev, want_segs=True)
+    rf3 = ref.ctx.export_rf(ref.rf_dev, E, ref.R)
+    ref.close()
+    assert np.array_equal(h2, h3) and np.array_equal(c2, c3)
+    assert np.array_equal(rf2.view(np.uint32), rf3.view(np.uint32))
+    assert not np.array_equal(h2, h1)
