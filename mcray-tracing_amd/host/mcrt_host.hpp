@@ -134,7 +134,10 @@ inline void load_obj_triangles(const std::string &path, std::vector<float> &tri9
     while (std::getline(f, line)) {
         std::istringstream is(line);
         std::string tag; is >> tag;
-        if (tag == "v") { std::array<float, 3> p{}; is >> p[0] >> p[1] >> p[2]; v.push_back(p); }
+        if (tag == "v") {   // decimal -> double -> float, like the reference's (float)atof (tiny_obj_loader.cpp parseFloat)
+            double d[3] = { 0, 0, 0 }; is >> d[0] >> d[1] >> d[2];
+            v.push_back({ (float)d[0], (float)d[1], (float)d[2] });
+        }
         else if (tag == "f") {
             std::vector<long> idx; std::string tok;
             while (is >> tok) { long i = std::strtol(tok.c_str(), nullptr, 10); idx.push_back(i > 0 ? i - 1 : (long)v.size() + i); }

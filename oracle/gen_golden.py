@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Regenerates tests/golden/ref_probe.json from the REFERENCE's own headers.
+"""Regenerates tests/golden/ref_probe.json and tests/golden/obj_soup.json from the REFERENCE's own sources.
 
 Runs oracle/_ref/ref_probe (built by `make -C oracle ref` from /root/reference/src/psf.h,
 src/volume.h and include/units/units.h, compiled where they lie).  Only works in the
@@ -17,5 +17,15 @@ data["_generated_by"] = "oracle/gen_golden.py (oracle/ref_probe.cpp compiled aga
 out = os.path.join(here, "..", "tests", "golden", "ref_probe.json")
 with open(out, "w") as f:
     json.dump(data, f, separators=(",", ":"))
+    f.write("\n")
+print("wrote", os.path.normpath(out), os.path.getsize(out), "bytes")
+
+# the reference's OBJ path (tiny_obj_loader.cpp + the conversion loop of objloader.h) on tests/golden/tricky.obj
+obj = os.path.join(here, "..", "tests", "golden", "tricky.obj")
+soup = json.loads(subprocess.check_output([os.path.join(here, "_ref", "ref_obj_probe"), obj]))
+soup["_generated_by"] = "oracle/gen_golden.py (oracle/ref_obj_probe.cpp + the reference's src/wavefront/tiny_obj_loader.cpp) on tests/golden/tricky.obj"
+out = os.path.join(here, "..", "tests", "golden", "obj_soup.json")
+with open(out, "w") as f:
+    json.dump(soup, f, separators=(",", ":"))
     f.write("\n")
 print("wrote", os.path.normpath(out), os.path.getsize(out), "bytes")
