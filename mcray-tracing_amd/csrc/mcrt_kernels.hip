@@ -17,6 +17,9 @@
 #include "mcrt_detmath.h"
 #include "mcrt_kernels.h"
 
+#ifndef MCRT_SHADE_WAVES
+#define MCRT_SHADE_WAVES 5             // k_shade wavefronts per SIMD the register budget is set for
+#endif
 #ifndef MCRT_MARCH_H
 #define MCRT_MARCH_H 2               // RF steps per lane and iteration of k_march (a quad does 4*H consecutive steps)
 #endif
@@ -613,7 +616,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 
 // ---- interface interaction (scene.cpp:122-165, ray.cpp:11-97): one lane per live ray ----
 template <bool STATS>
-__global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
+__global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, uint32_t b)
 {
     const uint32_t n = a.counts[b];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -753,7 +756,7 @@ __global__ void __launch_bounds__(256) k_shade(FrameArgs a, uint32_t b)
             const float dist_f = sqrtf(dot(df, df)) * 10.0f;
             const uint32_t steps = steps_from((double)dist_f / a.axial_res_mm);
             const double t_start = (seg_dist * 1000.0) / a.sos_d;
-            float4 *mr = a.mrec + 3 * ((size_t)pid * a.B + b);
+            float4 *mr = a.mrec + 3 * ((size_t)b * a.ne * a.S + pid);    // [bounce][path]: neighbouring paths are neighbours in memory
             mr[0] = make_float4(seg_from.x, seg_from.y, seg_from.z, seg_refl);
             mr[1] = make_float4(a.axial_res_f * seg_dir.x, a.axial_res_f * seg_dir.y, a.axial_res_f * seg_dir.z, seg_init);
             mr[2] = make_float4(__int_as_float(__double2loint(t_start)), __int_as_float(__double2hiint(t_start)), __uint_as_float(steps), __int_as_float(seg_media));
@@ -850,7 +853,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
             if (!busy && mine < s_end) {
                 const size_t pid = pid0 + mine;
                 if (b < a.seg_count[pid]) {
-                    const float4 *mr = a.mrec + 3 * (pid * a.B + b);
+                    const float4 *mr = a.mrec + 3 * ((size_t)b * a.ne * a.S + pid);
                     const float4 g0 = mr[0], g1 = mr[1], g2 = mr[2];
                     const float4 mt = a.mtab[__float_as_int(g2.w)];
                     point = mk(g0.x, g0.y, g0.z); seg_refl = g0.w;
