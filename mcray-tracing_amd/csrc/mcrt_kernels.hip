@@ -844,11 +844,22 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     uint32_t sidx = 0, steps = 0;
     bool more = false;
 #define MCRT_ADVANCE() { point = point + delta; t = t + a.time_step; inten *= k_att; }
+#ifdef MCRT_STAMP
+    unsigned long long mc_iter = 0, mc_step_it = 0, mc_step_quads = 0, mc_fin_it = 0, mc_refill = 0;
+#endif
     for (;;) {
+#ifdef MCRT_STAMP
+        mc_iter++;
+        { const unsigned long long sm = __ballot(busy && more && j == 0), fm = __ballot(busy && !more && j == 0);
+          if (sm) { mc_step_it++; mc_step_quads += __popcll(sm); } if (fm) mc_fin_it++; }
+#endif
         // ---- idle quads probe the next slots until at least half of the quads have a segment (or the range is exhausted) ----
         while (cursor < s_end) {
             const unsigned long long want = __ballot(!busy && j == 0);
             if (__popcll(want) < MCRT_MARCH_REFILL) break;
+#ifdef MCRT_STAMP
+            mc_refill++;
+#endif
             const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~3)) - 1ull));
             if (!busy && mine < s_end) {
                 const size_t pid = pid0 + mine;
@@ -915,6 +926,9 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
         }
     }
 #undef MCRT_ADVANCE
+#ifdef MCRT_STAMP
+    if (lane == 0) { atomicAdd(&a.stamps[9], mc_iter); atomicAdd(&a.stamps[10], mc_step_it); atomicAdd(&a.stamps[11], mc_step_quads); atomicAdd(&a.stamps[12], mc_fin_it); atomicAdd(&a.stamps[13], mc_refill); atomicAdd(&a.stamps[14], 1ull); }
+#endif
     if (STATS) {
         long long x = wave_sum_i64((long long)st_steps);
         if (lane == 0 && x) atomicAdd(&a.stats[4], (unsigned long long)x);
