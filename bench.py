@@ -252,7 +252,13 @@ def cpu_baseline(m, sd, tr, ctx, S, R):
         for i in range(reps):
             osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=i, e_begin=0, e_end=n_el, use_bvh=2, n_threads=cores, want_hits=False)
         dt = time.perf_counter() - t0
+    # (a) of BASELINE.md's plan: one thread, how the reference itself runs (scene.cpp:74 has its OpenMP pragma commented out)
+    n1 = min(tr.n_elements, 4)
+    t0 = time.perf_counter()
+    osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=0, e_begin=0, e_end=n1, use_bvh=2, n_threads=1, want_hits=False)
+    dt1 = time.perf_counter() - t0
     return {"value": n_el * S * reps / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "single_thread": {"value": n1 * S / dt1, "unit": "rays/s", "cores": 1, "sample": "%d scan-lines x %d rays, one thread" % (n1, S), "seconds": dt1},
             "sample": "%d scan-lines x %d rays x %d frame(s) of the same workload, OpenMP over scan-lines (trace + RF accumulation, no PSF)" % (n_el, S, reps),
             "seconds": dt}
 
