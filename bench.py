@@ -240,6 +240,7 @@ def cpu_baseline(m, sd, tr, ctx, S, R):
     tex = orc.texture(256)
     n_el = min(tr.n_elements, max(cores, 8))
     p = orc.default_params(n_elements=tr.n_elements, n_samples=S, n_rows=R)
+    osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=99, e_begin=0, e_end=min(n_el, 16), use_bvh=2, n_threads=cores, want_hits=False)   # untimed: thread pool, page faults
     t0 = time.perf_counter()
     osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=0, e_begin=0, e_end=n_el, use_bvh=2, n_threads=cores, want_hits=False)
     dt = time.perf_counter() - t0
@@ -253,7 +254,7 @@ def cpu_baseline(m, sd, tr, ctx, S, R):
             osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=i, e_begin=0, e_end=n_el, use_bvh=2, n_threads=cores, want_hits=False)
         dt = time.perf_counter() - t0
     # (a) of BASELINE.md's plan: one thread, how the reference itself runs (scene.cpp:74 has its OpenMP pragma commented out)
-    n1 = min(tr.n_elements, 4)
+    n1 = min(tr.n_elements, 16)
     t0 = time.perf_counter()
     osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=0, e_begin=0, e_end=n1, use_bvh=2, n_threads=1, want_hits=False)
     dt1 = time.perf_counter() - t0

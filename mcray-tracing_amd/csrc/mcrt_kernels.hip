@@ -775,16 +775,24 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
         alive = alive && (b + 1u < a.B);
     }
 
-    // survivors -> next bounce's queue (ballot + prefix, one atomic per wave).  Inside the wavefront's block the reflected rays
+    // survivors -> next bounce's queue (ballot + prefix; ONE atomic per workgroup: tens of thousands of returning atomics on the
+    // single counter would serialise in L2 and bound the kernel).  Inside a wavefront's block the reflected rays
     // come first, then the refracted ones, each in queue order: the samples of a scan-line that took the same decisions stay
     // adjacent, so the 16 rays of a k_trace wavefront mostly belong to one tight bundle (same nodes, similar walk length).
+    __shared__ uint32_t wave_live[4], block_base;
     const unsigned long long live = __ballot(alive);
     const unsigned long long live_refl = __ballot(alive && reflected);
+    const int wv = threadIdx.x >> 6;
+    if (lane == 0) wave_live[wv] = (uint32_t)__popcll(live);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = wave_live[0] + wave_live[1] + wave_live[2] + wave_live[3];
+        block_base = total ? atomicAdd(&a.counts[b + 1u], total) : 0u;
+    }
+    __syncthreads();
     if (live) {
-        const int leader = __ffsll((long long)live) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&a.counts[b + 1u], (uint32_t)__popcll(live));
-        base = __shfl(base, leader, 64);
+        uint32_t base = block_base;
+        for (int w = 0; w < wv; w++) base += wave_live[w];
         if (alive) {
             const unsigned long long below = (1ull << lane) - 1ull;
             const uint32_t pos = base + (reflected ? (uint32_t)__popcll(live_refl & below)
