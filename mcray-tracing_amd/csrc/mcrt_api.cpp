@@ -216,7 +216,12 @@ static int get_work(mcrt_ctx *c, size_t g, Work **out)
     while (c->work.size() <= g) {
         Work w;
         if (!c->work.empty()) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-        for (int i = 0; i < MCRT_SIDE_STREAMS; i++) { HIP_TRY(hipStreamCreateWithFlags(&w.side[i], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&w.ev_join[i], hipEventDisableTiming)); }
+        // k_march runs beside the next bounce's walk on a LOW-priority stream: k_trace / k_shade are the critical chain, and
+        // their workgroups must not queue behind k_march's (measured: k_shade took 0.4-0.7 ms instead of 0.1 ms when they did)
+        int prio_low = 0, prio_high = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        if (getenv("MCRT_NO_PRIORITY")) prio_low = 0;   // tuning knob
+        for (int i = 0; i < MCRT_SIDE_STREAMS; i++) { HIP_TRY(hipStreamCreateWithPriority(&w.side[i], hipStreamNonBlocking, prio_low)); HIP_TRY(hipEventCreateWithFlags(&w.ev_join[i], hipEventDisableTiming)); }
         for (int i = 0; i < MCRT_MAX_BOUNCES; i++) { HIP_TRY(hipEventCreateWithFlags(&w.ev_bounce[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&w.ev_march[i], hipEventDisableTiming)); }
         HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
         c->work.push_back(w);
