@@ -56,7 +56,7 @@ struct Work {
     hipEvent_t ev_bounce[MCRT_MAX_BOUNCES] = {}, ev_join[MCRT_SIDE_STREAMS] = {}, ev_done = nullptr;
     float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr;
     unsigned long long *d_key0 = nullptr, *d_key1 = nullptr;
-    uint32_t *d_q = nullptr, *d_counts = nullptr, *d_seg_count = nullptr;
+    uint32_t *d_q = nullptr, *d_counts = nullptr, *d_seg_count = nullptr, *d_cursors = nullptr;
     hipEvent_t ev_march[MCRT_MAX_BOUNCES] = {};
     mcrt_segment *d_segs = nullptr; float4 *d_mrec = nullptr; size_t paths = 0; uint32_t depth = 0;
 };
@@ -193,7 +193,7 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
 static void free_work_buffers(Work &w)
 {
     hipFree(w.d_st0); hipFree(w.d_st1); hipFree(w.d_st2); hipFree(w.d_ray0); hipFree(w.d_ray1); hipFree(w.d_key0); hipFree(w.d_key1);
-    hipFree(w.d_q); hipFree(w.d_counts); hipFree(w.d_seg_count); hipFree(w.d_segs); hipFree(w.d_mrec);
+    hipFree(w.d_q); hipFree(w.d_counts); hipFree(w.d_seg_count); hipFree(w.d_cursors); w.d_cursors = nullptr; hipFree(w.d_segs); hipFree(w.d_mrec);
     w.d_st0 = w.d_st1 = w.d_st2 = w.d_ray0 = w.d_ray1 = nullptr; w.d_key0 = w.d_key1 = nullptr; w.d_q = w.d_counts = w.d_seg_count = nullptr;
     w.d_segs = nullptr; w.d_mrec = nullptr; w.paths = 0; w.depth = 0;
 }
@@ -509,6 +509,7 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne)
     HIP_TRY(hipMalloc(&w.d_ray0, 32 * np)); HIP_TRY(hipMalloc(&w.d_ray1, 32 * np)); HIP_TRY(hipMalloc(&w.d_key0, 8 * np)); HIP_TRY(hipMalloc(&w.d_key1, 8 * np));
     HIP_TRY(hipMalloc(&w.d_q, 12 * np)); HIP_TRY(hipMalloc(&w.d_seg_count, 4 * np));
     HIP_TRY(hipMalloc(&w.d_counts, 4 * (2 * MCRT_MAX_BOUNCES + 1)));
+    HIP_TRY(hipMalloc(&w.d_cursors, 4 * (size_t)MCRT_MAX_BOUNCES * MCRT_XCDS * MCRT_CURSOR_STRIDE));
     HIP_TRY(hipMalloc(&w.d_segs, sizeof(mcrt_segment) * np * B));
     HIP_TRY(hipMalloc(&w.d_mrec, 48 * np * B));
     w.paths = np; w.depth = B;
@@ -524,7 +525,7 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     a.acc = c->d_acc; a.flags = c->d_flags;                 // the frame block [n_frames][acc_ne][R]; this group owns columns e0-acc_e0 ...
     a.acc_stride = acc_ne; a.acc_off = e0 - acc_e0;
     a.st0 = w.d_st0; a.st1 = w.d_st1; a.st2 = w.d_st2; a.queue = w.d_q;
-    a.ray0 = w.d_ray0; a.ray1 = w.d_ray1; a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.segs = w.d_segs; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
+    a.ray0 = w.d_ray0; a.ray1 = w.d_ray1; a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.cursors = w.d_cursors; a.segs = w.d_segs; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
     a.stats = c->d_stats; a.error_flag = c->d_error; a.stamps = c->d_stats + 8;
     a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
     a.e_begin = e0; a.ne_frame = e1 - e0; a.ne = (e1 - e0) * n_frames;   // n_frames consecutive frame ids traced as one pass

@@ -10,6 +10,9 @@
 #define MCRT_SIDE_STREAMS 4         // streams k_march launches rotate over
 #define MCRT_SIDE_STREAMS_DEFAULT 1
 #define MCRT_LBVH_LEAF 1             // device builder: triangles per leaf (1..4); measured best at 1, like the SAH builder's own leaves
+#define MCRT_XCDS 8                   // XCDs of the MI355X = sub-queues of a bounce's ray queue (see k_trace)
+#define MCRT_CURSOR_STRIDE 64         // uint32 between two queue cursors: 256 B, so they sit in different L2 lines / channels
+#define MCRT_XCD_MIN_ITEMS 262144     // bounces with fewer work items use a single queue
 #define MCRT_MAX_ROWS 2048
 #define MCRT_MAX_BOUNCES 16
 
