@@ -851,7 +851,11 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     for (uint32_t r = tid; r <= R; r += nthr) thr[r] = a.row_thr[r];
     __syncthreads();
 
-    const uint32_t line = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    // XCD-aware numbering: workgroup w runs on XCD w % 8; give every XCD a CONTIGUOUS range of scan-lines, so that the texture
+    // cells its segments touch (neighbouring scan-lines cross the same tissue) are shared in ITS L2
+    uint32_t bid = blockIdx.x;
+    if (gridDim.x % MCRT_XCDS == 0u) bid = (blockIdx.x % MCRT_XCDS) * (gridDim.x / MCRT_XCDS) + blockIdx.x / MCRT_XCDS;
+    const uint32_t line = bid / chunks, chunk = bid % chunks;
     // this wavefront's slot range: the line's S slots are cut into chunks*4 contiguous pieces
     const uint32_t per = (a.S + chunks * 4u - 1u) / (chunks * 4u);
     const uint32_t s_begin = min(a.S, (chunk * 4u + (uint32_t)wv) * per), s_end = min(a.S, s_begin + per);
