@@ -364,7 +364,7 @@ MCRT_DEV Ray make_ray(f3 from, f3 dir, float intensity, float att, const FrameAr
 
 __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 {
-    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t np = a.ne * a.S;
     if (pid == 0) { a.counts[0] = np; for (uint32_t b = 1; b <= a.B; b++) a.counts[b] = 0u; }
     // queue cursors of the persistent k_trace launches live behind the counts: they start past the statically assigned rays
@@ -376,19 +376,28 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
     }
     if (pid < MCRT_MAX_BOUNCES * MCRT_XCDS) a.cursors[(size_t)pid * MCRT_CURSOR_STRIDE] = 0u;   // k_trace's queue cursors (relative, see there)
     if (pid >= np) return;
-    const uint32_t e_abs = a.e_begin + (pid / a.S) % a.ne_frame;      // several frames may be in flight: line = frame * ne_frame + scan-line
+    // Queue position -> path.  Paths are numbered frame-major (pid = (frame * ne_frame + scan-line) * S + sample) but QUEUED
+    // scan-line-major: the F frames of a scan-line sit next to each other.  The queue is swept in order, so the rays in flight
+    // then belong to a few scan-lines (times all frames) and walk the same part of the BVH; later bounces inherit the order
+    // from the order-preserving compaction of k_shade.
+    const uint32_t F = a.ne / a.ne_frame;
+    const uint32_t pos = pid;                                          // this thread fills queue position `pos`
+    const uint32_t qline = pos / a.S, sample = pos % a.S;
+    const uint32_t scan = qline / F, fr = qline % F;
+    pid = (fr * a.ne_frame + scan) * a.S + sample;
+    const uint32_t e_abs = a.e_begin + scan;
     const f3 from = mk(a.el_pos[3 * e_abs], a.el_pos[3 * e_abs + 1], a.el_pos[3 * e_abs + 2]);
     const f3 dir = mk(a.el_dir[3 * e_abs], a.el_dir[3 * e_abs + 1], a.el_dir[3 * e_abs + 2]);
     const float intensity = a.I0 / (float)a.S;
-    a.st0[pid] = make_float4(from.x, from.y, from.z, intensity);
-    a.st1[pid] = make_float4(dir.x, dir.y, dir.z, __int_as_float((int)a.start_mat));
-    a.st2[pid] = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), 0.0f);      // distance_traveled (double) | outside | -
-    a.queue[pid] = pid;                                  // queue of bounce 0 (buffer 0 of three)
+    a.st0[pos] = make_float4(from.x, from.y, from.z, intensity);
+    a.st1[pos] = make_float4(dir.x, dir.y, dir.z, __int_as_float((int)a.start_mat));
+    a.st2[pos] = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), 0.0f);      // distance_traveled (double) | outside | -
+    a.queue[pos] = pid;                                  // queue of bounce 0 (buffer 0 of three)
     a.seg_count[pid] = 0u;
-    if (pid < a.ne) a.key0[pid] = MCRT_KEY_MISS;          // bounce 0: one closest-hit word per scan-line
+    if (pos < a.ne) a.key0[pos] = MCRT_KEY_MISS;          // bounce 0: one closest-hit word per queued scan-line
     const Ray r = make_ray(from, dir, intensity, a.mats[2 * a.start_mat].y, a);
-    a.ray0[2 * pid] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
-    a.ray0[2 * pid + 1] = make_float4(r.to.y, r.to.z, 0.0f, 0.0f);
+    a.ray0[2 * pos] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
+    a.ray0[2 * pos + 1] = make_float4(r.to.y, r.to.z, 0.0f, 0.0f);
 }
 
 // ---- closest hit: FOUR lanes (one DPP quad) own one ray; a wavefront holds 16 rays.  Each lane fetches ONE 32-byte
@@ -661,7 +670,7 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
         outside = __float_as_int(s2.z);
         const float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
         const f3 f2 = mk(r0.x, r0.y, r0.z), to = mk(r0.w, r1.x, r1.y);
-        const size_t hi = (b == 0u) ? (size_t)(pid / a.S) : (size_t)i;          // bounce 0: one walk per scan-line (see k_trace)
+        const size_t hi = (b == 0u) ? (size_t)(i / a.S) : (size_t)i;            // bounce 0: one walk per queued scan-line (see k_trace, k_init)
         const unsigned long long key = ((b & 1u) ? a.key1 : a.key0)[hi];
         Hit best; best.frac = __uint_as_float((uint32_t)(key >> 32)); best.tri = (int)(uint32_t)key; best.da = 0.0f; best.mesh = 0; best.n = mk(0, 0, 0);
         if (best.tri >= 0) {
@@ -855,7 +864,9 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     // cells its segments touch (neighbouring scan-lines cross the same tissue) are shared in ITS L2
     uint32_t bid = blockIdx.x;
     if (gridDim.x % MCRT_XCDS == 0u) bid = (blockIdx.x % MCRT_XCDS) * (gridDim.x / MCRT_XCDS) + blockIdx.x / MCRT_XCDS;
-    const uint32_t line = bid / chunks, chunk = bid % chunks;
+    // ... and within it the F frames of a scan-line one after the other (they cross exactly the same tissue)
+    const uint32_t F = a.ne / a.ne_frame, ol = bid / chunks, chunk = bid % chunks;
+    const uint32_t line = (ol % F) * a.ne_frame + ol / F;
     // this wavefront's slot range: the line's S slots are cut into chunks*4 contiguous pieces
     const uint32_t per = (a.S + chunks * 4u - 1u) / (chunks * 4u);
     const uint32_t s_begin = min(a.S, (chunk * 4u + (uint32_t)wv) * per), s_end = min(a.S, s_begin + per);
