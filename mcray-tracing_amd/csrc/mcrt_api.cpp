@@ -298,7 +298,14 @@ static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
         if (!rc) rc = mcrt::lbvh_build(d_tri, d_mesh, n_tri, c->stream, &r);
         hipFree(d_tri); hipFree(d_mesh);
         if (rc) return rc;
-        c->d_nodes = r.d_nodes; c->d_tris = r.d_tris; c->d_tri_slot = r.d_tri_slot;
+        c->d_nodes = r.d_nodes; c->d_tri_slot = r.d_tri_slot;
+        {   // the walk's 96-byte records from the builder's 48-byte leaf-order array
+            hipError_t e = hipMalloc(&c->d_tris, 96 * (size_t)n_tri);
+            if (e == hipSuccess) e = mcrt::launch_expand_tris(r.d_tris, n_tri, r.pad_abs, c->d_tris, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            hipFree(r.d_tris);
+            if (e != hipSuccess) return set_error(MCRT_ERR_HIP, "triangle records: %s", hipGetErrorString(e));
+        }
         c->bvh.n_nodes = 0; c->bvh.n_tri = n_tri; c->bvh.max_depth = r.max_depth; c->bvh.pad_abs = r.pad_abs; c->bvh.nodes = nullptr; c->bvh.tri = nullptr;
         c->bvh4.n_nodes = r.n_nodes4; c->bvh4.max_stack = r.max_stack; c->bvh4.nodes = nullptr;
         c->host_bvh_stale = true;
@@ -330,9 +337,17 @@ static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
     if (c->bvh4.max_stack > MCRT_STACK)
         return set_error(MCRT_ERR_LIMIT, "BVH4 needs a %u-entry traversal stack, the kernel has %d", c->bvh4.max_stack, MCRT_STACK);
     HIP_TRY(hipMalloc(&c->d_nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes));
-    HIP_TRY(hipMalloc(&c->d_tris, 48 * (size_t)n_tri));
     HIP_TRY(hipMemcpy(c->d_nodes, c->bvh4.nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_tris, c->bvh.tri, 48 * (size_t)n_tri, hipMemcpyHostToDevice));
+    {   // the walk's 96-byte records from the builder's 48-byte leaf-order array
+        float4 *d_in = nullptr;
+        HIP_TRY(hipMalloc(&d_in, 48 * (size_t)n_tri));
+        hipError_t e = hipMalloc(&c->d_tris, 96 * (size_t)n_tri);
+        if (e == hipSuccess) e = hipMemcpy(d_in, c->bvh.tri, 48 * (size_t)n_tri, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = mcrt::launch_expand_tris(d_in, n_tri, c->bvh.pad_abs, c->d_tris, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(d_in);
+        if (e != hipSuccess) return set_error(MCRT_ERR_HIP, "triangle records: %s", hipGetErrorString(e));
+    }
     {   // triangle id -> leaf-order slot (k_shade re-derives the winning triangle's normal from its vertices)
         std::vector<uint32_t> slot(n_tri);
         for (uint32_t k = 0; k < n_tri; k++) { uint32_t id; memcpy(&id, &c->bvh.tri[(size_t)k * 12 + 3], 4); slot[id] = k; }
@@ -350,7 +365,16 @@ static int download_bvh(mcrt_ctx *c)
     c->bvh.tri = (float *)malloc(48 * (size_t)c->bvh.n_tri);
     c->bvh4.nodes = (mcrt_bvh4_node *)malloc(sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes);
     if (!c->bvh.tri || !c->bvh4.nodes) return set_error(MCRT_ERR_NOMEM, "out of memory");
-    HIP_TRY(hipMemcpy(c->bvh.tri, c->d_tris, 48 * (size_t)c->bvh.n_tri, hipMemcpyDeviceToHost));
+    {   // back from the walk's 96-byte records to the ABI's 48-byte layout (v0|id, v1|mesh, v2|0)
+        std::vector<float> rec((size_t)c->bvh.n_tri * 24);
+        HIP_TRY(hipMemcpy(rec.data(), c->d_tris, 96 * (size_t)c->bvh.n_tri, hipMemcpyDeviceToHost));
+        for (size_t t = 0; t < c->bvh.n_tri; t++) {
+            const float *r = &rec[t * 24]; float *o = &c->bvh.tri[t * 12];
+            o[0] = r[12]; o[1] = r[13]; o[2] = r[14]; o[3] = r[7];      // v0 | id   (id rides with the padded lo)
+            o[4] = r[16]; o[5] = r[17]; o[6] = r[18]; o[7] = r[11];     // v1 | mesh (mesh with the padded hi)
+            o[8] = r[20]; o[9] = r[21]; o[10] = r[22]; o[11] = 0.0f;
+        }
+    }
     HIP_TRY(hipMemcpy(c->bvh4.nodes, c->d_nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes, hipMemcpyDeviceToHost));
     c->host_bvh_stale = false;
     return MCRT_OK;

@@ -90,78 +90,36 @@ MCRT_DEV bool slab_pairs(v2f lo_xy, v2f loz_hix, v2f hi_yz, const RayPairs &r, f
     return tmin <= tmax;
 }
 
-// btTriangleRaycastCallback::processTriangle (Bullet) behind the triangle's own padded-bounds test; contract
-// rules: the fraction must lie inside the ray's overlap with those bounds; ties -> smaller triangle id.
-MCRT_DEV void tri_test(f3 v0, f3 v1, f3 v2, int id, int mesh, f3 from, f3 to, f3 inv, float pad_abs, float t_lo, Hit &best)
-{
-    f3 v10 = v1 - v0, v20 = v2 - v0;
-    f3 n = cross(v10, v20);
-    float dist = dot(v0, n);
-    float da = dot(n, from) - dist;
-    float db = dot(n, to) - dist;
-    if (da * db >= 0.0f) return;
-    float proj = da - db;
-    float frac = da / proj;
-    if (frac < best.frac || (frac == best.frac && id < best.tri)) {
-        f3 lo = mk(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)));
-        f3 hi = mk(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)));
-        float ext = fmaxf(fmaxf(fmaxf(0.0f, hi.x - lo.x), hi.y - lo.y), hi.z - lo.z);
-        const float pad = 2e-4f * ext + pad_abs;
-        lo = mk(lo.x - pad, lo.y - pad, lo.z - pad);
-        hi = mk(hi.x + pad, hi.y + pad, hi.z + pad);
-        float tmin, tmax;
-        if (!slab(lo, hi, from, inv, 0.0f, 1.0f, tmin, tmax)) return;
-        if (!(frac >= tmin && frac <= tmax && frac >= t_lo)) return;
-        float edge_tol = dot(n, n) * -0.0001f;
-        float s = 1.0f - frac;
-        f3 p = mk(s * from.x + frac * to.x, s * from.y + frac * to.y, s * from.z + frac * to.z);
-        f3 v0p = v0 - p, v1p = v1 - p;
-        f3 cp0 = cross(v0p, v1p);
-        if (dot(cp0, n) >= edge_tol) {
-            f3 v2p = v2 - p;
-            f3 cp1 = cross(v1p, v2p);
-            if (dot(cp1, n) >= edge_tol) {
-                f3 cp2 = cross(v2p, v0p);
-                if (dot(cp2, n) >= edge_tol) { best.frac = frac; best.tri = id; best.mesh = mesh; best.n = n; best.da = da; }
-            }
-        }
-    }
-}
-
-// the walk only needs (fraction, triangle): k_shade recomputes the plane of the winner
+// the walk only needs (fraction, triangle): k_shade looks the plane of the winner up again
 struct Best { float frac; int tri; };
-MCRT_DEV void tri_test_walk(f3 v0, f3 v1, f3 v2, int id, f3 from, f3 to, const RayPairs &rp, float pad_abs, float t_lo, Best &best)
+
+// The walk's triangle record, 6 x float4 = 96 B, from the 48-byte (v0|id, v1|mesh, v2|-) leaf-order array:
+//   n.xyz | dot(v0,n)      plane of Bullet's processTriangle: n = (v1-v0) x (v2-v0)
+//   lo.xyz - pad | id      the triangle's own padded bounds (contract: pad = 2e-4 * largest extent + pad_abs),
+//   hi.xyz + pad | mesh    bit for bit what the builders put around the leaves
+//   v0 | v1 | v2           for the edge tests
+// Every expression is the contract's (as in mcrt_build_bvh), evaluated once per triangle here instead of once
+// per test.
+__global__ void k_expand_tris(const float4 *in, uint32_t n_tri, float pad_abs, float4 *out)
 {
-    f3 v10 = v1 - v0, v20 = v2 - v0;
-    f3 n = cross(v10, v20);
-    float dist = dot(v0, n);
-    float da = dot(n, from) - dist;
-    float db = dot(n, to) - dist;
-    if (da * db >= 0.0f) return;
-    float proj = da - db;
-    float frac = da / proj;
-    if (frac < best.frac || (frac == best.frac && id < best.tri)) {
-        f3 lo = mk(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)));
-        f3 hi = mk(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)));
-        float ext = fmaxf(fmaxf(fmaxf(0.0f, hi.x - lo.x), hi.y - lo.y), hi.z - lo.z);
-        const float pad = 2e-4f * ext + pad_abs;
-        float tmin, tmax;
-        if (!slab_pairs((v2f){ lo.x - pad, lo.y - pad }, (v2f){ lo.z - pad, hi.x + pad }, (v2f){ hi.y + pad, hi.z + pad }, rp, 0.0f, 1.0f, tmin, tmax)) return;
-        if (!(frac >= tmin && frac <= tmax && frac >= t_lo)) return;
-        float edge_tol = dot(n, n) * -0.0001f;
-        float s = 1.0f - frac;
-        f3 p = mk(s * from.x + frac * to.x, s * from.y + frac * to.y, s * from.z + frac * to.z);
-        f3 v0p = v0 - p, v1p = v1 - p;
-        f3 cp0 = cross(v0p, v1p);
-        if (dot(cp0, n) >= edge_tol) {
-            f3 v2p = v2 - p;
-            f3 cp1 = cross(v1p, v2p);
-            if (dot(cp1, n) >= edge_tol) {
-                f3 cp2 = cross(v2p, v0p);
-                if (dot(cp2, n) >= edge_tol) { best.frac = frac; best.tri = id; }
-            }
-        }
-    }
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tri) return;
+    const float4 t0 = in[3 * (size_t)t], t1 = in[3 * (size_t)t + 1], t2 = in[3 * (size_t)t + 2];
+    const f3 v0 = xyz(t0), v1 = xyz(t1), v2 = xyz(t2);
+    const f3 v10 = v1 - v0, v20 = v2 - v0;
+    const f3 n = cross(v10, v20);
+    const float dist = dot(v0, n);
+    f3 lo = mk(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)));
+    f3 hi = mk(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)));
+    const float ext = fmaxf(fmaxf(fmaxf(0.0f, hi.x - lo.x), hi.y - lo.y), hi.z - lo.z);
+    const float pad = 2e-4f * ext + pad_abs;
+    float4 *o = out + 6 * (size_t)t;
+    o[0] = make_float4(n.x, n.y, n.z, dist);
+    o[1] = make_float4(lo.x - pad, lo.y - pad, lo.z - pad, t0.w);
+    o[2] = make_float4(hi.x + pad, hi.y + pad, hi.z + pad, t1.w);
+    o[3] = make_float4(v0.x, v0.y, v0.z, 0.0f);
+    o[4] = make_float4(v1.x, v1.y, v1.z, 0.0f);
+    o[5] = make_float4(v2.x, v2.y, v2.z, 0.0f);
 }
 
 struct Rng { uint32_t k0, k1, element, sample, bounce; };
@@ -453,6 +411,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
     int sp = 0, cur = CUR_IDLE;
     bool fresh = true;                                           // this quad needs a ray
     const uint32_t bit_j = 1u << j, bits_j = 17u << j;
+    const int role_a = (j == 3) ? 1 : 3 + j, role_b = (j == 3) ? 2 : 3 + (j + 1) % 3;   // which records of a triangle this lane reads (phase 2)
 #define MCRT_ON_INNER(c) __builtin_amdgcn_sicmp((c), -1, 38)                          /* mask of lanes with c >= 0     (ICMP_SGT) */
 #define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)        /* mask of lanes on a leaf        (ICMP_UGT) */
 #define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)                     /* mask of lanes in a walk        (ICMP_NE)  */
@@ -587,28 +546,43 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 #ifdef MCRT_STAMP
         { const unsigned long long lm = MCRT_ON_LEAF(cur); if (lm) { sc_n2++; sc_act2 += __popcll(lm); } }
 #endif
-        // ---- phase 2: the parked leaves -- lane j tests triangle j ----
+        // ---- phase 2: the parked leaves.  The four lanes of a ray share ONE triangle test (btTriangleRaycastCallback::
+        // processTriangle behind the padded-bounds rule): every lane evaluates the plane and the fraction from the triangle's
+        // stored normal and offset, then lanes 0-2 each take one edge test and lane 3 the ray's overlap with the triangle's
+        // stored padded bounds; the verdict is the AND over the quad.  Same IEEE operations as a sequential test, split over
+        // lanes -- the stored normal / offset / bounds are the contract's expressions, evaluated by k_expand_tris.
         if ((uint32_t)cur > 0x80000000u) {
             const uint32_t v = (uint32_t)~cur;
             const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-            Best mine = best;
-            for (uint32_t k = (uint32_t)j; k < cnt; k += 4u) {
-                const float4 *T = a.tris + 3 * (size_t)(first + k);
-                const float4 t0 = T[0], t1 = T[1], t2 = T[2];
-                tri_test_walk(xyz(t0), xyz(t1), xyz(t2), __float_as_int(t0.w), f2, to, rp, a.pad_abs, t_lo, mine);
+            for (uint32_t k = 0; k < cnt; k++) {               // quad-uniform; the builders make (mostly) one-triangle leaves
+                const float4 *T = a.tris + 6 * (size_t)(first + k);
+                const float4 P = T[0];                          // n.xyz | dot(v0, n)
+                const float4 A = T[role_a], B = T[role_b];      // lane 3: padded lo | id, padded hi | mesh;  lane j < 3: v_j, v_(j+1)%3
+                const f3 n = xyz(P);
+                const float da = dot(n, f2) - P.w;
+                const float db = dot(n, to) - P.w;
+                if (da * db >= 0.0f) continue;
+                const int id = dpp_i<QP_BCAST(3)>(__float_as_int(A.w));
+                const float proj = da - db;
+                const float frac = da / proj;
+                if (!(frac < best.frac || (frac == best.frac && id < best.tri)) || !(frac >= t_lo)) continue;
+                bool ok;
+                if (j == 3) {
+                    float tmin, tmax;
+                    ok = slab_pairs((v2f){ A.x, A.y }, (v2f){ A.z, B.x }, (v2f){ B.y, B.z }, rp, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax;
+                } else {
+                    const float edge_tol = dot(n, n) * -0.0001f;
+                    const float s = 1.0f - frac;
+                    const f3 p = mk(s * f2.x + frac * to.x, s * f2.y + frac * to.y, s * f2.z + frac * to.z);
+                    const f3 ap = xyz(A) - p, bp = xyz(B) - p;
+                    ok = dot(cross(ap, bp), n) >= edge_tol;
+                }
+                int all = ok ? 1 : 0;
+                all &= dpp_i<QP_XOR1>(all);
+                all &= dpp_i<QP_XOR2>(all);
+                if (all) { best.frac = frac; best.tri = id; }
             }
             if (STATS && j == 0) st_tris += cnt;
-            // quad minimum of (fraction, id): fractions are >= 0, so the 64-bit word (fraction bits, id) orders like the contract's
-            // rule; an unchanged lane still holds the common `best`, which never ties with a new find
-#define MCRT_QUAD_MIN(CTRL)                                                                                             \
-            {                                                                                                           \
-                const float of = dpp_f<CTRL>(mine.frac); const int ot = dpp_i<CTRL>(mine.tri);                          \
-                if (of < mine.frac || (of == mine.frac && (uint32_t)ot < (uint32_t)mine.tri)) { mine.frac = of; mine.tri = ot; } \
-            }
-            MCRT_QUAD_MIN(QP_XOR1)
-            MCRT_QUAD_MIN(QP_XOR2)
-#undef MCRT_QUAD_MIN
-            best = mine;
             if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
             else cur = CUR_IDLE;
         }
@@ -674,13 +648,12 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
         const unsigned long long key = ((b & 1u) ? a.key1 : a.key0)[hi];
         Hit best; best.frac = __uint_as_float((uint32_t)(key >> 32)); best.tri = (int)(uint32_t)key; best.da = 0.0f; best.mesh = 0; best.n = mk(0, 0, 0);
         if (best.tri >= 0) {
-            // plane normal, mesh and the origin-side value of the winning triangle, recomputed exactly as tri_test() does
-            const float4 *T = a.tris + 3 * (size_t)a.tri_slot[best.tri];
-            const float4 t0 = T[0], t1 = T[1], t2 = T[2];
-            const f3 v0 = xyz(t0), v10 = xyz(t1) - v0, v20 = xyz(t2) - v0;
-            best.n = cross(v10, v20);
-            best.da = dot(best.n, f2) - dot(v0, best.n);
-            best.mesh = __float_as_int(t1.w);
+            // plane normal, mesh and the origin-side value of the winning triangle, as the walk's test evaluated them
+            const float4 *T = a.tris + 6 * (size_t)a.tri_slot[best.tri];
+            const float4 P = T[0], t2 = T[2];
+            best.n = xyz(P);
+            best.da = dot(best.n, f2) - P.w;
+            best.mesh = __float_as_int(t2.w);
         }
         const uint32_t line = pid / a.S;
         const uint32_t e_abs = a.e_begin + line % a.ne_frame;
@@ -1249,6 +1222,12 @@ hipError_t launch_math_probe(int op, const double *x, const double *y, double *o
 hipError_t launch_verify_div(float res, float rcp, unsigned long long *bad, hipStream_t st)
 {
     hipLaunchKernelGGL(k_verify_div, dim3(256 * 16), dim3(256), 0, st, res, rcp, bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_tris(const float4 *in48, uint32_t n_tri, float pad_abs, float4 *out96, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_expand_tris, dim3((n_tri + 255u) / 256u), dim3(256), 0, st, in48, n_tri, pad_abs, out96);
     return hipGetLastError();
 }
 
