@@ -283,6 +283,8 @@ extern "C" int mcrt_set_params(mcrt_ctx *c, const mcrt_params *p)
 // builds the BVH over tri[n_tri][9] (host or device pointer) with the context's builder and installs it on the device
 static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
 {
+    // k_trace addresses nodes (128 B) and triangle records (96 B) with 32-bit byte offsets
+    if (n_tri >= (1u << 25)) return set_error(MCRT_ERR_LIMIT, "%u triangles: the walk addresses at most 2^25 (4 GB of 96-byte records)", n_tri);
     hipFree(c->d_nodes); hipFree(c->d_tris); hipFree(c->d_tri_slot); c->d_nodes = c->d_tris = nullptr; c->d_tri_slot = nullptr;
     mcrt_free_bvh(&c->bvh); mcrt_free_bvh4(&c->bvh4);
     c->host_bvh_stale = false;

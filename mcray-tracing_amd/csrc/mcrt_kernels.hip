@@ -410,8 +410,8 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
     constexpr int CUR_IDLE = (int)0x80000000;
     int sp = 0, cur = CUR_IDLE;
     bool fresh = true;                                           // this quad needs a ray
-    const uint32_t bit_j = 1u << j, bits_j = 17u << j;
-    const int role_a = (j == 3) ? 1 : 3 + j, role_b = (j == 3) ? 2 : 3 + (j + 1) % 3;   // which records of a triangle this lane reads (phase 2)
+    const uint32_t bit_j = 1u << j, bits_j = 17u << j, lane_off = (uint32_t)j << 5;
+    const uint32_t role_a = 16u * (uint32_t)((j == 3) ? 1 : 3 + j), role_b = 16u * (uint32_t)((j == 3) ? 2 : 3 + (j + 1) % 3);   // byte offsets of the two records of a triangle this lane reads (phase 2)
 #define MCRT_ON_INNER(c) __builtin_amdgcn_sicmp((c), -1, 38)                          /* mask of lanes with c >= 0     (ICMP_SGT) */
 #define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)        /* mask of lanes on a leaf        (ICMP_UGT) */
 #define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)                     /* mask of lanes in a walk        (ICMP_NE)  */
@@ -507,7 +507,8 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
             sc_n1++; sc_act1 += __popcll(inner);
 #endif
             if (cur >= 0) {
-                const float4 *N = a.nodes + 8 * (size_t)cur + 2 * j;
+                // 32-bit byte offset from the (uniform) array base: one VALU op and the scalar-base addressing mode
+                const float4 *N = (const float4 *)((const char *)a.nodes + (((uint32_t)cur << 7) + lane_off));
                 const float4 A = N[0], B = N[1];               // lo.xyz hi.x | hi.y hi.z ref pad
                 if (STATS && j == 0) st_nodes++;
 #ifdef MCRT_STAMP
@@ -555,9 +556,9 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
             const uint32_t v = (uint32_t)~cur;
             const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
             for (uint32_t k = 0; k < cnt; k++) {               // quad-uniform; the builders make (mostly) one-triangle leaves
-                const float4 *T = a.tris + 6 * (size_t)(first + k);
-                const float4 P = T[0];                          // n.xyz | dot(v0, n)
-                const float4 A = T[role_a], B = T[role_b];      // lane 3: padded lo | id, padded hi | mesh;  lane j < 3: v_j, v_(j+1)%3
+                const char *T = (const char *)a.tris + (first + k) * 96u;      // (32-bit offsets: the upload rejects >= 2^28 triangles)
+                const float4 P = *(const float4 *)T;            // n.xyz | dot(v0, n)
+                const float4 A = *(const float4 *)(T + role_a), B = *(const float4 *)(T + role_b);      // lane 3: padded lo | id, padded hi | mesh;  lane j < 3: v_j, v_(j+1)%3
                 const f3 n = xyz(P);
                 const float da = dot(n, f2) - P.w;
                 const float db = dot(n, to) - P.w;
