@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
     constexpr int CUR_IDLE = (int)0x80000000;
     int sp = 0, cur = CUR_IDLE;
     bool fresh = true;                                           // this quad needs a ray
-    const uint32_t bit_j = 1u << j, bits_j = 17u << j, lane_off = (uint32_t)j << 5;
+    const uint32_t bit_j = 1u << j, lane_off = (uint32_t)j << 5;
     const uint32_t role_a = 16u * (uint32_t)((j == 3) ? 1 : 3 + j), role_b = 16u * (uint32_t)((j == 3) ? 2 : 3 + (j + 1) % 3);   // byte offsets of the two records of a triangle this lane reads (phase 2)
 #define MCRT_ON_INNER(c) __builtin_amdgcn_sicmp((c), -1, 38)                          /* mask of lanes with c >= 0     (ICMP_SGT) */
 #define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)        /* mask of lanes on a leaf        (ICMP_UGT) */
@@ -517,19 +517,19 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                 const int ref = __float_as_int(B.z);
                 float tn, tx;
                 const bool hit = slab_pairs((v2f){ A.x, A.y }, (v2f){ A.z, A.w }, (v2f){ B.x, B.y }, rp, t_lo, tcap, tn, tx) && ref != MCRT_BVH4_EMPTY;
-                // Next node = the NEAREST hit child (t_near >= 0, so its bit pattern orders like the value; ties -> lowest slot);
-                // the other hit children are stacked in slot order.  Visiting order only affects the work done, never the hit.
-                const uint32_t key = hit ? __float_as_uint(tn) : 0xffffffffu;
+                // Next node = the NEAREST hit child: t_near >= 0, so its bit pattern orders like the value; the two lowest bits are
+                // replaced by the slot number, which makes the key unique in the quad (nearly equal distances go by slot).
+                // The other hit children are stacked in slot order.  Visiting order only affects the work done, never the hit.
+                const uint32_t key = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)j) : 0xffffffffu;
                 uint32_t kmin = min(key, (uint32_t)dpp_i<QP_XOR1>((int)key));
                 kmin = min(kmin, (uint32_t)dpp_i<QP_XOR2>((int)kmin));
-                // the quad's hit bits (low nibble) and nearest-candidate bits (high nibble), OR-ed across its lanes
-                int w = hit ? (int)((key == kmin) ? bits_j : bit_j) : 0;
+                int w = hit ? (int)bit_j : 0;                   // the quad's hit bits, OR-ed across its lanes
                 w |= dpp_i<QP_XOR1>(w);
                 w |= dpp_i<QP_XOR2>(w);
-                const uint32_t hit4 = (uint32_t)w & 15u, eq4 = (uint32_t)w >> 4;
+                const uint32_t hit4 = (uint32_t)w;
                 const int nh = __popc(hit4);
-                const int jn = __ffs((int)eq4) - 1;                                            // slot of the nearest child
-                int cand = (j == jn) ? ref : 0;
+                const int jn = (int)(kmin & 3u);                // slot of the nearest child (when there is one)
+                int cand = (key == kmin) ? ref : 0;
                 cand |= dpp_i<QP_XOR1>(cand);
                 cand |= dpp_i<QP_XOR2>(cand);
                 if (nh == 0) {
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                     else cur = CUR_IDLE;
                 } else {                                       // mcrt_upload_scene rejected trees that need more than MCRT_STACK entries
                     const uint32_t others = hit4 & ~(1u << jn);
-                    if (hit && j != jn) stack[(sp + __popc(others & (bit_j - 1u))) * 64 + q] = ref;
+                    if (hit && key != kmin) stack[(sp + __popc(others & (bit_j - 1u))) * 64 + q] = ref;
                     sp += nh - 1;
                     cur = cand;
                 }

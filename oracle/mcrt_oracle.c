@@ -458,8 +458,9 @@ static void walk_bvh(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stats
     if (st) { st->nodes_visited += nn; st->tris_tested += nt; }
 }
 
-/* BVH4 walk in the GPU kernel's order: children hit are visited nearest-first (ties: lower slot), the others
- * are stacked so that they pop in ascending order; a leaf's triangles are all tested. */
+/* BVH4 walk in the GPU kernel's order: children hit are visited nearest-first -- by the bit pattern of t_near with its two
+ * lowest bits replaced by the slot number (the kernel's unique per-quad key) --, the others are stacked so that they pop in
+ * ascending slot order; a leaf's triangles are all tested. */
 typedef struct { float lo[3]; float hix, hiy, hiz; int32_t ref; uint32_t pad; } orc_bvh4_child;
 #define ORC_BVH4_EMPTY ((int32_t)0x80000000)
 static void walk_bvh4(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stats *st)
@@ -480,10 +481,10 @@ static void walk_bvh4(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stat
             for (int k = 0; k < 4; k++) {
                 float hi[3] = { N[k].hix, N[k].hiy, N[k].hiz }, tn, tx;
                 int h = slab(N[k].lo, hi, from, inv, tcap, &tn, &tx) && N[k].ref != ORC_BVH4_EMPTY;
-                key[k] = h ? f2u(tn) : 0xffffffffu; ref[k] = N[k].ref; nh += h;   /* t_near >= 0: bits order like the value */
+                key[k] = h ? ((f2u(tn) & ~3u) | (uint32_t)k) : 0xffffffffu; ref[k] = N[k].ref; nh += h;   /* t_near >= 0: bits order like the value */
             }
             if (nh > 0) {
-                /* the kernel's order: nearest hit child next (ties: lowest slot), the others stacked in slot order */
+                /* the kernel's order: smallest key next, the others stacked in slot order */
                 int jn = -1;
                 for (int k = 0; k < 4; k++) if (key[k] != 0xffffffffu && (jn < 0 || key[k] < key[jn])) jn = k;
                 int32_t next = ref[jn];
