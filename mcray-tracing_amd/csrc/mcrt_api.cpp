@@ -314,6 +314,7 @@ static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
         for (int i = 0; i < 3; i++) { c->scene_lo[i] = r.lo[i]; c->scene_hi[i] = r.hi[i]; }
         if (c->bvh4.max_stack > MCRT_STACK)
             return set_error(MCRT_ERR_LIMIT, "device-built BVH4 needs a %u-entry traversal stack, the kernel has %d", c->bvh4.max_stack, MCRT_STACK);
+        if (c->bvh4.n_nodes >= (1u << 25)) return set_error(MCRT_ERR_LIMIT, "%u BVH4 nodes: the walk addresses at most 2^25", c->bvh4.n_nodes);
         return MCRT_OK;
     }
     std::vector<float> host_copy;
@@ -338,6 +339,7 @@ static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
     }
     if (c->bvh4.max_stack > MCRT_STACK)
         return set_error(MCRT_ERR_LIMIT, "BVH4 needs a %u-entry traversal stack, the kernel has %d", c->bvh4.max_stack, MCRT_STACK);
+    if (c->bvh4.n_nodes >= (1u << 25)) return set_error(MCRT_ERR_LIMIT, "%u BVH4 nodes: the walk addresses at most 2^25", c->bvh4.n_nodes);
     HIP_TRY(hipMalloc(&c->d_nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes));
     HIP_TRY(hipMemcpy(c->d_nodes, c->bvh4.nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes, hipMemcpyHostToDevice));
     {   // the walk's 96-byte records from the builder's 48-byte leaf-order array

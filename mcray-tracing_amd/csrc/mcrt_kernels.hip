@@ -84,8 +84,14 @@ MCRT_DEV bool slab_pairs(v2f lo_xy, v2f loz_hix, v2f hi_yz, const RayPairs &r, f
     const v2f a = (lo_xy - r.o_xy) * r.i_xy;        // t0x t0y
     const v2f b = (loz_hix - r.o_zx) * r.i_zx;      // t0z t1x
     const v2f c = (hi_yz - r.o_yz) * r.i_yz;        // t1y t1z
-    float tmin = fmaxf(fmaxf(fminf(a.x, b.y), fminf(a.y, c.x)), fmaxf(fminf(b.x, c.y), tlow));
-    float tmax = fminf(fminf(fmaxf(a.x, b.y), fmaxf(a.y, c.x)), fminf(fmaxf(b.x, c.y), tcap));
+    // The final combination is written as the four machine instructions it is: through fmaxf/fminf the compiler re-quiets the
+    // loop-invariant tlow / tcap operands (v_max x,x) in every iteration, which the NaN-dropping min/max do not need.
+    float lo3 = fminf(b.x, c.y), hi3 = fmaxf(b.x, c.y), tmin, tmax;
+    const float lo1 = fminf(a.x, b.y), lo2 = fminf(a.y, c.x), hi1 = fmaxf(a.x, b.y), hi2 = fmaxf(a.y, c.x);
+    asm("v_max_f32 %0, %1, %2" : "=v"(lo3) : "v"(lo3), "v"(tlow));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmin) : "v"(lo1), "v"(lo2), "v"(lo3));
+    asm("v_min_f32 %0, %1, %2" : "=v"(hi3) : "v"(hi3), "v"(tcap));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(hi1), "v"(hi2), "v"(hi3));
     tmin_o = tmin; tmax_o = tmax;
     return tmin <= tmax;
 }
