@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
         // patterns order like the values and an integer atomicMin IS the contract's rule (smaller fraction, then smaller id).
         // The K pieces of a ray therefore just race their finds into the ray's word.
         if (cur == CUR_IDLE && !fresh && !exhausted) {
-#ifdef MCRT_STAMP
+#ifdef MCRT_STAMP_HIST   /* (with -DMCRT_STAMP; its same-address atomics slow the kernel ~10x, so the timeline is then meaningless) */
             if (j == 0 && b > 0u) { atomicAdd(&a.stamps[60 + (nsteps > 0 ? 32 - __clz(nsteps) : 0)], 1ull); }   // histogram of node visits per walk (log2 bins)
 #endif
             if (j == 0 && best.tri >= 0)
