@@ -35,7 +35,7 @@ a gpurun box, packaged by `tools/package_profiles.py`; this file is written by `
 ray) in %.3f ms = %.2f TB/s = **%.2f of the 8 TB/s HBM figure** (alone on the GPU: %.0f µs = %.2f TB/s).  Fabric-side traffic
 (2 × FETCH_SIZE + WRITE_SIZE) = %.3f GB, %.0f× less: %.0f %% of node/triangle reads hit the vector L1 (the queue is swept in order, so
 the rays in flight belong to a few scan-lines and walk the same nodes), %.0f %% of the rest hit L2, average L1→L2 read latency
-%.0f cycles — the BVH (58 + 48 MB) is served on-die and HBM itself is nearly idle.  The kernel issues %.0f M wave-level VALU
+%.0f cycles — the BVH (58 MB of nodes + 96 MB of triangle records) is served on-die and HBM itself is nearly idle.  The kernel issues %.0f M wave-level VALU
 instructions per launch; at 4 cycles each on a 16-lane SIMD that is **%.0f %% of the SIMD cycles** of the %.2f M busy cycles per CU
 (`derived.valu_busy_share`), at %.0f %% lane utilisation (16 rays per wavefront, each waits for the wave's longest walk; leaves are
 tested in a separate phase with few lanes).  Its queue counter takes one returning atomic per 16 rays, ≈ 0.8 ms of serialised L2
