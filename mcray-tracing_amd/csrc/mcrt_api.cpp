@@ -536,7 +536,7 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne)
     HIP_TRY(hipMalloc(&w.d_st0, 32 * np)); HIP_TRY(hipMalloc(&w.d_st1, 32 * np)); HIP_TRY(hipMalloc(&w.d_st2, 32 * np));   // two halves: bounce parity
     HIP_TRY(hipMalloc(&w.d_ray0, 32 * np)); HIP_TRY(hipMalloc(&w.d_ray1, 32 * np)); HIP_TRY(hipMalloc(&w.d_key0, 8 * np)); HIP_TRY(hipMalloc(&w.d_key1, 8 * np));
     HIP_TRY(hipMalloc(&w.d_q, 12 * np)); HIP_TRY(hipMalloc(&w.d_seg_count, 4 * np));
-    HIP_TRY(hipMalloc(&w.d_counts, 4 * (2 * MCRT_MAX_BOUNCES + 1)));
+    HIP_TRY(hipMalloc(&w.d_counts, 4 * (MCRT_MAX_BOUNCES + 1)));
     HIP_TRY(hipMalloc(&w.d_cursors, 4 * (size_t)MCRT_MAX_BOUNCES * MCRT_XCDS * MCRT_CURSOR_STRIDE));
     HIP_TRY(hipMalloc(&w.d_segs, sizeof(mcrt_segment) * np * B));
     HIP_TRY(hipMalloc(&w.d_mrec, 48 * np * B));

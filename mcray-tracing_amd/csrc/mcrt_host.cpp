@@ -135,7 +135,7 @@ extern "C" int mcrt_build_bvh(const float *tri, const uint32_t *tri_mesh, uint32
     for (uint32_t t = 0; t < n_tri; t++) {
         const float *v = tri + (size_t)t * 9;
         Prim &p = b.prims[t];
-        // must equal the kernel's tri_bounds() bit for bit: node boxes are unions of exactly these boxes
+        // must equal k_expand_tris' padded bounds bit for bit: node boxes are unions of exactly these boxes
         float ext = 0.f;
         for (int a = 0; a < 3; a++) {
             float l = fminf(v[a], fminf(v[3 + a], v[6 + a]));

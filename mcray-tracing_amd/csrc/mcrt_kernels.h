@@ -22,7 +22,7 @@ struct FrameArgs {
     float4 *ray0, *ray1;       // [np][2] f2.xyz,to.x | to.yz,-,-   (indexed by queue position), ping-pong
     unsigned long long *key0, *key1;   // [np] closest hit per ray: fraction bits << 32 | triangle id (atomicMin), ping-pong by bounce parity
     const uint32_t *tri_slot;  // [T] triangle id -> position in the leaf-order triangle array
-    uint32_t *counts;          // [MAX_BOUNCES+1] live rays per bounce, then [MAX_BOUNCES] queue cursors of the persistent walk
+    uint32_t *counts;          // [MAX_BOUNCES+1] live rays per bounce
     uint32_t *cursors;         // [MAX_BOUNCES][MCRT_XCDS][MCRT_CURSOR_STRIDE] queue cursors of the persistent walk, one per XCD sub-queue
     mcrt_segment *segs;        // [np][B]   written only when want_segs (mcrt_cast_rays / mcrt_trace_frame_debug)
     float4 *mrec;              // [B][np][3] what k_march needs of a segment: from,refl | delta,intensity | t_start(f64),steps,media

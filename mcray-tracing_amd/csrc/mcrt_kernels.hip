@@ -331,13 +331,6 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
     uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t np = a.ne * a.S;
     if (pid == 0) { a.counts[0] = np; for (uint32_t b = 1; b <= a.B; b++) a.counts[b] = 0u; }
-    // queue cursors of the persistent k_trace launches live behind the counts: they start past the statically assigned rays
-    if (pid < MCRT_MAX_BOUNCES) {
-        uint32_t upper = (pid == 0u) ? a.ne : np;                          // launch_trace()'s grid for bounce pid
-        if (upper < a.ksplit_limit) upper = a.ksplit_limit;
-        const uint32_t blocks = (upper + 63u) / 64u;
-        a.counts[MCRT_MAX_BOUNCES + 1 + pid] = (blocks < a.trace_blocks ? blocks : a.trace_blocks) * 64u;
-    }
     if (pid < MCRT_MAX_BOUNCES * MCRT_XCDS) a.cursors[(size_t)pid * MCRT_CURSOR_STRIDE] = 0u;   // k_trace's queue cursors (relative, see there)
     if (pid >= np) return;
     // Queue position -> path.  Paths are numbered frame-major (pid = (frame * ne_frame + scan-line) * S + sample) but QUEUED
@@ -366,9 +359,9 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 
 // ---- closest hit: FOUR lanes (one DPP quad) own one ray; a wavefront holds 16 rays.  Each lane fetches ONE 32-byte
 // child record of the BVH4 node (the quad reads the node's 128 contiguous bytes), tests its box, and the quad ranks the
-// hit children with DPP exchanges; leaves hold <= 4 triangles, one per lane.  Traversal stacks live in LDS.
+// hit children with DPP exchanges; a leaf's triangle is tested by the quad together (see phase 2).  Traversal stacks live in LDS.
 // The kernel is PERSISTENT over the bounce's ray queue: a quad whose ray is finished writes its hit record and takes the
-// next unclaimed ray (wave-aggregated atomic on the queue cursor), so a wavefront's lanes do not idle behind its longest
+// next unclaimed ray (from a wave-private pool refilled with one atomic on its XCD's queue cursor), so a wavefront's lanes do not idle behind its longest
 // walk.  Bounce 0 is special: every sample path of a scan-line starts as a copy of the same first_ray (scene.cpp:83-101),
 // so only ONE ray per scan-line is walked and k_shade hands the hit to all S samples.
 template <bool STATS>

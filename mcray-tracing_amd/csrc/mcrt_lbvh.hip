@@ -4,7 +4,7 @@
 // the host's seconds-long SAH build (the reference's own hook for this is inputmanager.cpp:117-121).
 //
 // The tree's SHAPE is free: the closest-hit contract makes the result independent of the hierarchy as long
-// as (1) leaves carry the triangles' own padded bounds, computed exactly as tri_test() / the host builder compute them,
+// as (1) leaves carry the triangles' own padded bounds, computed exactly as k_expand_tris / the host builder compute them,
 // and (2) node boxes are exact unions of their children's.  Both hold here, so images traced through this tree are
 // bit-identical to those traced through the host's SAH tree (tests/test_gpu_parity.py::test_device_lbvh_*).
 //
@@ -63,7 +63,7 @@ __global__ void k_scale(const float *tri, size_t n9, Scal *s)
 
 __global__ void k_pad(Scal *s) { s->pad_abs = 4e-6f * fmaxf(__uint_as_float(s->scale_bits), 1e-3f); }   // == mcrt_build_bvh
 
-// padded bounds of triangle t -- bit for bit what tri_test_walk() (mcrt_kernels.hip) and mcrt_build_bvh (mcrt_host.cpp) compute
+// padded bounds of triangle t -- bit for bit what k_expand_tris (mcrt_kernels.hip) and mcrt_build_bvh (mcrt_host.cpp) compute
 __global__ void k_prims(const float *tri, uint32_t n, Scal *s, float4 *plo, float4 *phi, float4 *pc)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
