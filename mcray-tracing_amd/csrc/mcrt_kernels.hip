@@ -435,8 +435,11 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 #ifdef MCRT_STAMP_HIST   /* (with -DMCRT_STAMP; its same-address atomics slow the kernel ~10x, so the timeline is then meaningless) */
             if (j == 0 && b > 0u) { atomicAdd(&a.stamps[60 + (nsteps > 0 ? 32 - __clz(nsteps) : 0)], 1ull); }   // histogram of node visits per walk (log2 bins)
 #endif
-            if (j == 0 && best.tri >= 0)
-                atomicMin(&keys[ray_id], ((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri);
+            if (j == 0 && best.tri >= 0) {
+                const unsigned long long word = ((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri;
+                if (K == 1u) keys[ray_id] = word;               // the only walker of this ray: a plain store
+                else atomicMin(&keys[ray_id], word);
+            }
             fresh = true; i = 0xffffffffu;
         }
         // ---- (re)fill: quads without a ray take the next queue positions ----
