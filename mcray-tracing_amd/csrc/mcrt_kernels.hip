@@ -17,6 +17,9 @@
 #include "mcrt_detmath.h"
 #include "mcrt_kernels.h"
 
+#ifndef MCRT_REFILL_BATCH
+#define MCRT_REFILL_BATCH 4           // k_trace fetches and sets up new rays once this many of a wavefront's 16 quads are without one
+#endif
 #ifndef MCRT_SHADE_WAVES
 #define MCRT_SHADE_WAVES 5             // k_shade wavefronts per SIMD the register budget is set for
 #endif
@@ -431,6 +434,10 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
         // The closest hit of a ray is ONE 64-bit word, (fraction bits << 32 | triangle id): fractions are in [0,1), so their bit
         // patterns order like the values and an integer atomicMin IS the contract's rule (smaller fraction, then smaller id).
         // The K pieces of a ray therefore just race their finds into the ray's word.
+        // (the report / fetch / set-up code below runs for the whole wavefront however few quads need it, so it waits until
+        //  MCRT_REFILL_BATCH quads are without a walk -- or nobody walks at all)
+        const bool do_refill = __popcll(__ballot(cur == CUR_IDLE && !exhausted && j == 0)) >= MCRT_REFILL_BATCH || MCRT_WALKING(cur) == 0ull;
+        if (do_refill) {
         if (cur == CUR_IDLE && !fresh && !exhausted) {
 #ifdef MCRT_STAMP_HIST   /* (with -DMCRT_STAMP; its same-address atomics slow the kernel ~10x, so the timeline is then meaningless) */
             if (j == 0 && b > 0u) { atomicAdd(&a.stamps[60 + (nsteps > 0 ? 32 - __clz(nsteps) : 0)], 1ull); }   // histogram of node visits per walk (log2 bins)
@@ -496,6 +503,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                 if (STATS && j == 0 && piece == 0u) st_q++;
             } else exhausted = true;
         }
+        }   // do_refill
         STAMP(sc_refill)
         if (MCRT_WALKING(cur) == 0ull) { if (!__any(!exhausted)) break; else continue; }
 
