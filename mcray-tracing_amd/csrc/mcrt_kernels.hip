@@ -877,37 +877,49 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
         { const unsigned long long sm = __ballot(busy && more && j == 0), fm = __ballot(busy && !more && j == 0);
           if (sm) { mc_step_it++; mc_step_quads += __popcll(sm); } if (fm) mc_fin_it++; }
 #endif
-        // ---- idle quads probe the next slots until at least half of the quads have a segment (or the range is exhausted) ----
-        while (cursor < s_end) {
-            const unsigned long long want = __ballot(!busy && j == 0);
-            if (__popcll(want) < MCRT_MARCH_REFILL) break;
-#ifdef MCRT_STAMP
-            mc_refill++;
-#endif
-            const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~3)) - 1ull));
-            if (!busy && mine < s_end) {
-                const size_t pid = pid0 + mine;
-                if (b < a.seg_count[pid]) {
-                    const float4 *mr = a.mrec + 3 * ((size_t)b * a.ne * a.S + pid);
-                    const float4 g0 = mr[0], g1 = mr[1], g2 = mr[2];
-                    const float4 mt = a.mtab[__float_as_int(g2.w)];
-                    point = mk(g0.x, g0.y, g0.z); seg_refl = g0.w;
-                    delta = mk(g1.x, g1.y, g1.z); inten = g1.w;
-                    t_start = __hiloint2double(__float_as_int(g2.y), __float_as_int(g2.x));
-                    steps = __float_as_uint(g2.z);
-                    m_mu = mt.x; m_dens = mt.y; m_sigma = mt.z; k_att = mt.w;
-                    t = t_start; sidx = (uint32_t)j;
-                    // scattering is exactly +0 for every voxel when mu0 == sigma == 0 (finite texture): the adds are no-ops
-                    const bool silent = a.tex_finite && m_mu == 0.0f && m_sigma == 0.0f;
-                    more = !silent && steps > 0u && t < a.max_travel;
-                    if (j > 0) MCRT_ADVANCE()
-                    if (j > 1) MCRT_ADVANCE()
-                    if (j > 2) MCRT_ADVANCE()
-                    busy = true;
+        // ---- finished segments and idle quads.  The boundary echo of a finished segment (main.cpp:139) and the probing of new
+        // slots are code the whole wavefront runs however few quads need it, so both wait until MCRT_MARCH_REFILL quads are
+        // finished or idle (or nothing is left to step) ----
+        const bool fin = busy && !more;
+        if (__popcll(__ballot((!busy || fin) && j == 0)) >= MCRT_MARCH_REFILL || !__any(busy && more)) {
+            if (fin) {
+                if (j == 0) {
+                    const double te = t_start + a.time_step * (double)(uint32_t)(steps - 1u);
+                    rf_add(bins, lflags, row_of(te, thr, R, a.inv_row_dt, thr_end), seg_refl / (float)a.S);
                 }
+                busy = false;
             }
-            const uint32_t nw = (uint32_t)__popcll(want);
-            cursor = (cursor + nw < s_end) ? cursor + nw : s_end;
+            while (cursor < s_end) {
+                const unsigned long long want = __ballot(!busy && j == 0);
+                if (__popcll(want) < MCRT_MARCH_REFILL) break;
+#ifdef MCRT_STAMP
+                mc_refill++;
+#endif
+                const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~3)) - 1ull));
+                if (!busy && mine < s_end) {
+                    const size_t pid = pid0 + mine;
+                    if (b < a.seg_count[pid]) {
+                        const float4 *mr = a.mrec + 3 * ((size_t)b * a.ne * a.S + pid);
+                        const float4 g0 = mr[0], g1 = mr[1], g2 = mr[2];
+                        const float4 mt = a.mtab[__float_as_int(g2.w)];
+                        point = mk(g0.x, g0.y, g0.z); seg_refl = g0.w;
+                        delta = mk(g1.x, g1.y, g1.z); inten = g1.w;
+                        t_start = __hiloint2double(__float_as_int(g2.y), __float_as_int(g2.x));
+                        steps = __float_as_uint(g2.z);
+                        m_mu = mt.x; m_dens = mt.y; m_sigma = mt.z; k_att = mt.w;
+                        t = t_start; sidx = (uint32_t)j;
+                        // scattering is exactly +0 for every voxel when mu0 == sigma == 0 (finite texture): the adds are no-ops
+                        const bool silent = a.tex_finite && m_mu == 0.0f && m_sigma == 0.0f;
+                        more = !silent && steps > 0u && t < a.max_travel;
+                        if (j > 0) MCRT_ADVANCE()
+                        if (j > 1) MCRT_ADVANCE()
+                        if (j > 2) MCRT_ADVANCE()
+                        busy = true;
+                    }
+                }
+                const uint32_t nw = (uint32_t)__popcll(want);
+                cursor = (cursor + nw < s_end) ? cursor + nw : s_end;
+            }
         }
         if (!__any(busy)) { if (cursor >= s_end) break; else continue; }
 
@@ -940,13 +952,6 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
                     if (STATS) st_steps++;
                 }
             }
-        } else if (busy) {
-            // ---- a finished segment: the boundary echo (main.cpp:139), then the quad is free ----
-            if (j == 0) {
-                const double te = t_start + a.time_step * (double)(uint32_t)(steps - 1u);
-                rf_add(bins, lflags, row_of(te, thr, R, a.inv_row_dt, thr_end), seg_refl / (float)a.S);
-            }
-            busy = false;
         }
     }
 #undef MCRT_ADVANCE
