@@ -376,3 +376,33 @@ def test_device_lbvh_gives_the_same_frames(mcrt, orc, tex256):
     assert np.array_equal(h2, h3) and np.array_equal(c2, c3)
     assert np.array_equal(rf2.view(np.uint32), rf3.view(np.uint32))
     assert not np.array_equal(h2, h1)
+
+
+def test_update_and_builder_error_paths(mcrt, sphere):
+    cfg, sd = sphere
+    ctx = mcrt.Context(0)
+    with pytest.raises(mcrt.McrtError, match="no scene uploaded"):
+        ctx.update_triangles(sd.tri)
+    with pytest.raises(mcrt.McrtError, match="unknown BVH builder"):
+        ctx.set_bvh_builder(7)
+    ctx.upload_scene(sd)
+    with pytest.raises(mcrt.McrtError, match="triangles, the update has 100"):     # an update keeps the triangle count
+        ctx.update_triangles(sd.tri[:100])
+    ctx.update_triangles(sd.tri)                                                  # and succeeds with the right one
+    ctx.close()
+
+
+def test_device_lbvh_on_the_liver_scene(mcrt, orc, tex256):
+    """the device builder on closed, well-shaped meshes (vessels, thickness draw, scaling 0.1): same frame as the SAH tree"""
+    cfg, meshes = mcrt.synth.liver_scene(3)
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    E, S = 32, 128
+    out = []
+    for builder in ("sah", "lbvh"):
+        tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256, bvh_builder=builder)
+        hits, segs, cnt = sim.ctx.trace_frame_debug(9, sim.rf_dev, want_segs=True)
+        out.append((hits, segs.tobytes(), cnt, sim.ctx.export_rf(sim.rf_dev, E, sim.R)))
+        sim.close()
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2])
+    assert np.array_equal(out[0][3].view(np.uint32), out[1][3].view(np.uint32))
+    assert (out[0][0] >= 0).sum() > E * S
