@@ -106,7 +106,7 @@ struct Best { float frac; int tri; };
 //   n.xyz | dot(v0,n)      plane of Bullet's processTriangle: n = (v1-v0) x (v2-v0)
 //   lo.xyz - pad | id      the triangle's own padded bounds (contract: pad = 2e-4 * largest extent + pad_abs),
 //   hi.xyz + pad | mesh    bit for bit what the builders put around the leaves
-//   v0 | v1 | v2           for the edge tests
+//   v0 | v1 | v2           for the edge tests, each with the edge tolerance -1e-4 |n|^2 in .w
 // Every expression is the contract's (as in mcrt_build_bvh), evaluated once per triangle here instead of once
 // per test.
 __global__ void k_expand_tris(const float4 *in, uint32_t n_tri, float pad_abs, float4 *out)
@@ -126,9 +126,10 @@ __global__ void k_expand_tris(const float4 *in, uint32_t n_tri, float pad_abs, f
     o[0] = make_float4(n.x, n.y, n.z, dist);
     o[1] = make_float4(lo.x - pad, lo.y - pad, lo.z - pad, t0.w);
     o[2] = make_float4(hi.x + pad, hi.y + pad, hi.z + pad, t1.w);
-    o[3] = make_float4(v0.x, v0.y, v0.z, 0.0f);
-    o[4] = make_float4(v1.x, v1.y, v1.z, 0.0f);
-    o[5] = make_float4(v2.x, v2.y, v2.z, 0.0f);
+    const float edge_tol = dot(n, n) * -0.0001f;              // processTriangle's edge tolerance, -1e-4 |n|^2
+    o[3] = make_float4(v0.x, v0.y, v0.z, edge_tol);
+    o[4] = make_float4(v1.x, v1.y, v1.z, edge_tol);
+    o[5] = make_float4(v2.x, v2.y, v2.z, edge_tol);
 }
 
 struct Rng { uint32_t k0, k1, element, sample, bounce; };
@@ -582,7 +583,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                     float tmin, tmax;
                     ok = slab_pairs((v2f){ A.x, A.y }, (v2f){ A.z, B.x }, (v2f){ B.y, B.z }, rp, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax;
                 } else {
-                    const float edge_tol = dot(n, n) * -0.0001f;
+                    const float edge_tol = A.w;                  // -1e-4 |n|^2, stored
                     const float s = 1.0f - frac;
                     const f3 p = mk(s * f2.x + frac * to.x, s * f2.y + frac * to.y, s * f2.z + frac * to.z);
                     const f3 ap = xyz(A) - p, bp = xyz(B) - p;
