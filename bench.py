@@ -130,7 +130,9 @@ def main():
 
     def passes(count):
         """split `count` frames into the fewest passes of at most F frames, as even as possible (20 with F=16 -> 10 + 10)"""
-        n_pass = max(1, -(-count // F))
+        if count <= 0:
+            return []
+        n_pass = -(-count // F)
         base, rem = divmod(count, n_pass)
         return [base + (1 if i < rem else 0) for i in range(n_pass)]
 
