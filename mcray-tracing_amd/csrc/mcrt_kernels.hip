@@ -223,6 +223,15 @@ MCRT_DEV int row_of(double t, const double *thr, uint32_t R, double inv_dt, doub
     return r;
 }
 
+// the same row when a good guess is at hand (k_march: the row of the lane's previous step + 4): two threshold reads confirm it
+MCRT_DEV int row_near(double t, int guess, const double *thr, uint32_t R, double inv_dt, double thr_end)
+{
+    const int r = guess < 0 ? 0 : (guess > (int)R - 1 ? (int)R - 1 : guess);
+    const double lo = thr[r], hi = thr[r + 1];
+    if ((t >= lo) & (t < hi)) return r;                          // (false for NaN, negative times and times beyond the image)
+    return row_of(t, thr, R, inv_dt, thr_end);
+}
+
 // x / tex_res, correctly rounded, as two fmas around a multiply by the rounded reciprocal (Markstein's correction).
 // Used only when the GPU itself has verified (k_verify_div, exhaustive over the gated range) that the sequence
 // equals IEEE division for this tex_res; otherwise, and outside the gate, the division instruction sequence is used.
@@ -868,6 +877,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     float inten = 0.0f, k_att = 0.0f, seg_refl = 0.0f, m_dens = 0.0f, m_sigma = 0.0f, m_mu = 0.0f;
     uint32_t sidx = 0, steps = 0;
     bool more = false;
+    int row_guess = 0;
 #define MCRT_ADVANCE() { point = point + delta; t = t + a.time_step; inten *= k_att; }
 #ifdef MCRT_STAMP
     unsigned long long mc_iter = 0, mc_step_it = 0, mc_step_quads = 0, mc_fin_it = 0, mc_refill = 0;
@@ -915,6 +925,8 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
                         if (j > 0) MCRT_ADVANCE()
                         if (j > 1) MCRT_ADVANCE()
                         if (j > 2) MCRT_ADVANCE()
+                        // first guess of this lane's RF row; afterwards each own step lies four steps (~4.003 rows) further
+                        row_guess = (t >= 0.0 && t < thr_end) ? (int)(t * a.inv_row_dt) : 0;
                         busy = true;
                     }
                 }
@@ -949,7 +961,9 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
             for (int h = 0; h < MCRT_MARCH_H; h++) {
                 if (myv[h]) {
                     const float scattering = vox[h].y >= m_dens ? vox[h].x * m_sigma + m_mu : 0.0f;
-                    rf_add(bins, lflags, row_of(myt[h], thr, R, a.inv_row_dt, thr_end), myin[h] * scattering);
+                    const int row = row_near(myt[h], row_guess, thr, R, a.inv_row_dt, thr_end);
+                    rf_add(bins, lflags, row, myin[h] * scattering);
+                    row_guess = (row >= 0 ? row : row_guess) + 4;
                     if (STATS) st_steps++;
                 }
             }
