@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
     if (pos < a.ne) a.key0[pos] = MCRT_KEY_MISS;          // bounce 0: one closest-hit word per queued scan-line
     const Ray r = make_ray(from, dir, intensity, a.mats[2 * a.start_mat].y, a);
     a.ray0[2 * pos] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
-    a.ray0[2 * pos + 1] = make_float4(r.to.y, r.to.z, 0.0f, 0.0f);
+    a.ray0[2 * pos + 1] = make_float4(r.to.y, r.to.z, 1.0f / (r.to.x - r.f2.x), 1.0f / (r.to.y - r.f2.y));   // + two of the three reciprocals the walk needs
 }
 
 // ---- closest hit: FOUR lanes (one DPP quad) own one ray; a wavefront holds 16 rays.  Each lane fetches ONE 32-byte
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                 const float4 r0 = rays[2 * (size_t)ray_id * ray_stride], r1 = rays[2 * (size_t)ray_id * ray_stride + 1];
                 f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
                 const f3 d = to - f2;
-                const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                const f3 inv = mk(r1.z, r1.w, 1.0f / d.z);             // x and y reciprocals come with the ray record
                 rp = ray_pairs(f2, inv);
                 t_lo = 0.0f;
                 float t_hi = 1.0f;
@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
             a.st2[so] = make_float4(__int_as_float(__double2loint(dist_mm)), __int_as_float(__double2hiint(dist_mm)), __int_as_float(outside), 0.0f);
             const Ray r = make_ray(from, dir, intensity, a.mats[2 * media].y, a);
             rays_out[2 * (size_t)pos] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
-            rays_out[2 * (size_t)pos + 1] = make_float4(r.to.y, r.to.z, 0.0f, 0.0f);
+            rays_out[2 * (size_t)pos + 1] = make_float4(r.to.y, r.to.z, 1.0f / (r.to.x - r.f2.x), 1.0f / (r.to.y - r.f2.y));   // (one lane divides here instead of four in k_trace)
         }
     }
     if (STATS) {
