@@ -23,11 +23,14 @@
 #ifndef MCRT_SHADE_WAVES
 #define MCRT_SHADE_WAVES 5             // k_shade wavefronts per SIMD the register budget is set for
 #endif
+#ifndef MCRT_MARCH_G
+#define MCRT_MARCH_G 2               // lanes that share a segment in k_march (4 or 2; measured 515 vs 524 us per launch)
+#endif
 #ifndef MCRT_MARCH_H
-#define MCRT_MARCH_H 2               // RF steps per lane and iteration of k_march (a quad does 4*H consecutive steps)
+#define MCRT_MARCH_H (8 / MCRT_MARCH_G)   // RF steps per lane and iteration of k_march (a group does G*H consecutive steps)
 #endif
 #ifndef MCRT_MARCH_REFILL
-#define MCRT_MARCH_REFILL 4          // k_march hands out new segments while at least this many of a wave's 16 quads are idle
+#define MCRT_MARCH_REFILL (16 / MCRT_MARCH_G)   // k_march hands out new segments while at least this many of a wave's groups are idle or finished (a quarter of them)
 #endif
 #ifndef MCRT_FETCH_BATCH
 #define MCRT_FETCH_BATCH 16         // queue positions a wavefront of k_trace claims per atomic
@@ -308,7 +311,7 @@ MCRT_DEV void rf_add(long long *bins, uint32_t *lflags, int row, float echo)
 //     k_trace         closest hit of every live ray: quad-cooperative BVH4 walk                 4 lanes / ray
 //     k_shade         thickness draw, travel, hit_boundary, segment record, next ray;           1 lane  / ray
 //                     survivors are compacted into the next bounce's queue (wave ballot + prefix)
-//   k_march           RF accumulation of every segment (main.cpp:112-140)                       4 lanes / segment
+//   k_march           RF accumulation of every segment (main.cpp:112-140)                       2 lanes / segment
 //
 // Every stage therefore runs with full wavefronts of lanes doing the same thing: dead paths cost nothing after the
 // bounce they die in, the fp64-heavy interface physics is not replicated, and the lean walk kernel keeps 8 waves/SIMD.
@@ -836,15 +839,15 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
 
 // ---- RF accumulation (main.cpp:112-140) of the segments produced in bounce b.  A workgroup owns a range of the sample
 // slots of ONE scan-line ("line" = frame * ne_frame + scan-line), so its fixed-point bins live in LDS and are flushed once
-// with global integer atomics.  Inside it every wavefront runs its slots as a task pool: one DPP quad per segment, a quad
-// that has finished (or found a dead path's empty slot) takes the next slot, so short, long and missing segments do not wait
-// for each other.  Eight consecutive steps per iteration, lane j owns steps j and j+4 (eight texture gathers of a segment in
-// flight).
+// with global integer atomics.  Inside it every wavefront runs its slots as a task pool: a group of MCRT_MARCH_G lanes per
+// segment; a group that has finished (or found a dead path's empty slot) takes the next slot, so short, long and missing
+// segments do not wait for each other.  Eight consecutive steps per iteration, lane j of the group owns steps j, j+G, ...
+// (that many texture gathers per lane in flight).
 template <bool STATS>
 __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t chunks)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, j = tid & 3;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, j = tid & (MCRT_MARCH_G - 1);
     const uint32_t R = a.R, nf = (R + 31u) >> 5;
     long long *bins = (long long *)smem;
     uint32_t *lflags = (uint32_t *)(bins + ((R + 1u) & ~1u));
@@ -870,8 +873,9 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     uint32_t cursor = s_begin;                               // wave-uniform: next unclaimed slot
     const double thr_end = a.row_thr[R];
     bool busy = false;
-    // lane j of a quad carries the segment's running state (point, time, intensity) j steps AHEAD of the quad's base step:
-    // every lane does the same sequential updates the reference does, shifted, and owns steps j, j+4, j+8, ...
+    // A GROUP of MCRT_MARCH_G lanes (a DPP quad, or half of one) owns a segment.  Lane j of the group carries the segment's running
+    // state (point, time, intensity) j steps AHEAD of the group's base step: every lane does the same sequential updates the
+    // reference does, shifted, and owns steps j, j+G, j+2G, ...
     f3 point = mk(0, 0, 0), delta = mk(0, 0, 0);
     double t = 0.0, t_start = 0.0;
     float inten = 0.0f, k_att = 0.0f, seg_refl = 0.0f, m_dens = 0.0f, m_sigma = 0.0f, m_mu = 0.0f;
@@ -906,7 +910,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
 #ifdef MCRT_STAMP
                 mc_refill++;
 #endif
-                const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~3)) - 1ull));
+                const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~(MCRT_MARCH_G - 1))) - 1ull));
                 if (!busy && mine < s_end) {
                     const size_t pid = pid0 + mine;
                     if (b < a.seg_count[pid]) {
@@ -922,10 +926,9 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
                         // scattering is exactly +0 for every voxel when mu0 == sigma == 0 (finite texture): the adds are no-ops
                         const bool silent = a.tex_finite && m_mu == 0.0f && m_sigma == 0.0f;
                         more = !silent && steps > 0u && t < a.max_travel;
-                        if (j > 0) MCRT_ADVANCE()
-                        if (j > 1) MCRT_ADVANCE()
-                        if (j > 2) MCRT_ADVANCE()
-                        // first guess of this lane's RF row; afterwards each own step lies four steps (~4.003 rows) further
+#pragma unroll
+                        for (int u = 1; u < MCRT_MARCH_G; u++) if (j >= u) MCRT_ADVANCE()
+                        // first guess of this lane's RF row; afterwards each own step lies G steps (a little over G rows) further
                         row_guess = (t >= 0.0 && t < thr_end) ? (int)(t * a.inv_row_dt) : 0;
                         busy = true;
                     }
@@ -936,7 +939,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
         }
         if (!__any(busy)) { if (cursor >= s_end) break; else continue; }
 
-        // ---- 4*H steps of every running segment ----
+        // ---- G*H steps of every running segment ----
         if (busy && more) {
             f3 myp[MCRT_MARCH_H]; double myt[MCRT_MARCH_H]; float myin[MCRT_MARCH_H]; bool myv[MCRT_MARCH_H];
             float reach = 0.0f;
@@ -944,11 +947,12 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
             for (int h = 0; h < MCRT_MARCH_H; h++) {
                 myp[h] = point; myt[h] = t; myin[h] = inten; myv[h] = sidx < steps && t < a.max_travel;           // the reference's loop test
                 reach += abs_sum(point);
-                MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE() MCRT_ADVANCE()
-                sidx += 4u;
+#pragma unroll
+                for (int u = 0; u < MCRT_MARCH_G; u++) MCRT_ADVANCE()
+                sidx += (uint32_t)MCRT_MARCH_G;
             }
             // the quad goes on while its base step (lane 0's) passes the loop test
-            more = dpp_i<QP_BCAST(0)>((sidx < steps && t < a.max_travel) ? 1 : 0) != 0;
+            more = dpp_i<MCRT_MARCH_G == 4 ? QP_BCAST(0) : 0xA0>((sidx < steps && t < a.max_travel) ? 1 : 0) != 0;   // (0xA0: quad_perm [0,0,2,2])
             float2 vox[MCRT_MARCH_H];
             if (reach < a.lean_bound) {
 #pragma unroll
@@ -963,7 +967,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
                     const float scattering = vox[h].y >= m_dens ? vox[h].x * m_sigma + m_mu : 0.0f;
                     const int row = row_near(myt[h], row_guess, thr, R, a.inv_row_dt, thr_end);
                     rf_add(bins, lflags, row, myin[h] * scattering);
-                    row_guess = (row >= 0 ? row : row_guess) + 4;
+                    row_guess = (row >= 0 ? row : row_guess) + MCRT_MARCH_G;
                     if (STATS) st_steps++;
                 }
             }
