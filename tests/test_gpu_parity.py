@@ -406,3 +406,24 @@ def test_device_lbvh_on_the_liver_scene(mcrt, orc, tex256):
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2])
     assert np.array_equal(out[0][3].view(np.uint32), out[1][3].view(np.uint32))
     assert (out[0][0] >= 0).sum() > E * S
+
+
+def test_large_passes_use_the_per_xcd_queues(mcrt, orc, sphere, tex256):
+    """bounces with >= 262144 work items are walked through eight per-XCD sub-queues (k_trace) and queued scan-line-major:
+    a 6-frame pass of 64 x 1024 paths (393216 in the first bounces) must equal the same frames traced one at a time (single queue),
+    and one of them is checked against the oracle"""
+    cfg, sd = sphere
+    E, S, F = 64, 1024, 6
+    tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256)
+    dev = sim.ctx.alloc(F * E * sim.R * 4)
+    sim.ctx.trace_frames(20, F, dev)
+    batch = sim.ctx.d2h(dev, (F, E, sim.R))
+    for f in range(F):
+        sim.trace(20 + f)
+        one = sim.ctx.d2h(sim.rf_dev, (E, sim.R))
+        assert np.array_equal(batch[f].view(np.uint32), one.view(np.uint32)), f
+    osc, p, o = _oracle(orc, sd, tr, tex256, E, S, threads=32)
+    o22 = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=22, n_threads=32, want_hits=False, want_ref=False)
+    assert np.array_equal(batch[2].T.view(np.uint32), o22["rf"].view(np.uint32))
+    sim.ctx.free(dev)
+    sim.close()
