@@ -23,14 +23,8 @@
 #ifndef MCRT_SHADE_WAVES
 #define MCRT_SHADE_WAVES 5             // k_shade wavefronts per SIMD the register budget is set for
 #endif
-#ifndef MCRT_MARCH_G
-#define MCRT_MARCH_G 2               // lanes that share a segment in k_march (4 or 2; measured 515 vs 524 us per launch)
-#endif
-#ifndef MCRT_MARCH_H
-#define MCRT_MARCH_H (8 / MCRT_MARCH_G)   // RF steps per lane and iteration of k_march (a group does G*H consecutive steps)
-#endif
-#ifndef MCRT_MARCH_REFILL
-#define MCRT_MARCH_REFILL (16 / MCRT_MARCH_G)   // k_march hands out new segments while at least this many of a wave's groups are idle or finished (a quarter of them)
+#ifndef MCRT_MARCH_PAIRS_FROM
+#define MCRT_MARCH_PAIRS_FROM 1048576    // k_march: lane pairs per segment for passes with at least this many paths, quads below
 #endif
 #ifndef MCRT_FETCH_BATCH
 #define MCRT_FETCH_BATCH 16         // queue positions a wavefront of k_trace claims per atomic
@@ -839,15 +833,17 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
 
 // ---- RF accumulation (main.cpp:112-140) of the segments produced in bounce b.  A workgroup owns a range of the sample
 // slots of ONE scan-line ("line" = frame * ne_frame + scan-line), so its fixed-point bins live in LDS and are flushed once
-// with global integer atomics.  Inside it every wavefront runs its slots as a task pool: a group of MCRT_MARCH_G lanes per
+// with global integer atomics.  Inside it every wavefront runs its slots as a task pool: a group of G lanes (template parameter: 2 or 4) per
 // segment; a group that has finished (or found a dead path's empty slot) takes the next slot, so short, long and missing
 // segments do not wait for each other.  Eight consecutive steps per iteration, lane j of the group owns steps j, j+G, ...
 // (that many texture gathers per lane in flight).
-template <bool STATS>
+template <bool STATS, int G>
 __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t chunks)
 {
+    constexpr int H = 8 / G;                 // RF steps per lane and iteration: a group does G*H = 8 consecutive steps
+    constexpr int REFILL = 16 / G;           // new segments are handed out while at least a quarter of the wavefront's groups are idle or finished
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, j = tid & (MCRT_MARCH_G - 1);
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, j = tid & (G - 1);
     const uint32_t R = a.R, nf = (R + 31u) >> 5;
     long long *bins = (long long *)smem;
     uint32_t *lflags = (uint32_t *)(bins + ((R + 1u) & ~1u));
@@ -873,7 +869,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     uint32_t cursor = s_begin;                               // wave-uniform: next unclaimed slot
     const double thr_end = a.row_thr[R];
     bool busy = false;
-    // A GROUP of MCRT_MARCH_G lanes (a DPP quad, or half of one) owns a segment.  Lane j of the group carries the segment's running
+    // A GROUP of G lanes (a DPP quad, or half of one) owns a segment.  Lane j of the group carries the segment's running
     // state (point, time, intensity) j steps AHEAD of the group's base step: every lane does the same sequential updates the
     // reference does, shifted, and owns steps j, j+G, j+2G, ...
     f3 point = mk(0, 0, 0), delta = mk(0, 0, 0);
@@ -893,10 +889,10 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
           if (sm) { mc_step_it++; mc_step_quads += __popcll(sm); } if (fm) mc_fin_it++; }
 #endif
         // ---- finished segments and idle quads.  The boundary echo of a finished segment (main.cpp:139) and the probing of new
-        // slots are code the whole wavefront runs however few quads need it, so both wait until MCRT_MARCH_REFILL quads are
+        // slots are code the whole wavefront runs however few quads need it, so both wait until REFILL quads are
         // finished or idle (or nothing is left to step) ----
         const bool fin = busy && !more;
-        if (__popcll(__ballot((!busy || fin) && j == 0)) >= MCRT_MARCH_REFILL || !__any(busy && more)) {
+        if (__popcll(__ballot((!busy || fin) && j == 0)) >= REFILL || !__any(busy && more)) {
             if (fin) {
                 if (j == 0) {
                     const double te = t_start + a.time_step * (double)(uint32_t)(steps - 1u);
@@ -906,11 +902,11 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
             }
             while (cursor < s_end) {
                 const unsigned long long want = __ballot(!busy && j == 0);
-                if (__popcll(want) < MCRT_MARCH_REFILL) break;
+                if (__popcll(want) < REFILL) break;
 #ifdef MCRT_STAMP
                 mc_refill++;
 #endif
-                const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~(MCRT_MARCH_G - 1))) - 1ull));
+                const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~(G - 1))) - 1ull));
                 if (!busy && mine < s_end) {
                     const size_t pid = pid0 + mine;
                     if (b < a.seg_count[pid]) {
@@ -927,7 +923,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
                         const bool silent = a.tex_finite && m_mu == 0.0f && m_sigma == 0.0f;
                         more = !silent && steps > 0u && t < a.max_travel;
 #pragma unroll
-                        for (int u = 1; u < MCRT_MARCH_G; u++) if (j >= u) MCRT_ADVANCE()
+                        for (int u = 1; u < G; u++) if (j >= u) MCRT_ADVANCE()
                         // first guess of this lane's RF row; afterwards each own step lies G steps (a little over G rows) further
                         row_guess = (t >= 0.0 && t < thr_end) ? (int)(t * a.inv_row_dt) : 0;
                         busy = true;
@@ -941,33 +937,33 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
 
         // ---- G*H steps of every running segment ----
         if (busy && more) {
-            f3 myp[MCRT_MARCH_H]; double myt[MCRT_MARCH_H]; float myin[MCRT_MARCH_H]; bool myv[MCRT_MARCH_H];
+            f3 myp[H]; double myt[H]; float myin[H]; bool myv[H];
             float reach = 0.0f;
 #pragma unroll
-            for (int h = 0; h < MCRT_MARCH_H; h++) {
+            for (int h = 0; h < H; h++) {
                 myp[h] = point; myt[h] = t; myin[h] = inten; myv[h] = sidx < steps && t < a.max_travel;           // the reference's loop test
                 reach += abs_sum(point);
 #pragma unroll
-                for (int u = 0; u < MCRT_MARCH_G; u++) MCRT_ADVANCE()
-                sidx += (uint32_t)MCRT_MARCH_G;
+                for (int u = 0; u < G; u++) MCRT_ADVANCE()
+                sidx += (uint32_t)G;
             }
             // the quad goes on while its base step (lane 0's) passes the loop test
-            more = dpp_i<MCRT_MARCH_G == 4 ? QP_BCAST(0) : 0xA0>((sidx < steps && t < a.max_travel) ? 1 : 0) != 0;   // (0xA0: quad_perm [0,0,2,2])
-            float2 vox[MCRT_MARCH_H];
+            more = dpp_i<G == 4 ? QP_BCAST(0) : 0xA0>((sidx < steps && t < a.max_travel) ? 1 : 0) != 0;   // (0xA0: quad_perm [0,0,2,2])
+            float2 vox[H];
             if (reach < a.lean_bound) {
 #pragma unroll
-                for (int h = 0; h < MCRT_MARCH_H; h++) vox[h] = a.tex[vox_cell_lean(myp[h], a)];
+                for (int h = 0; h < H; h++) vox[h] = a.tex[vox_cell_lean(myp[h], a)];
             } else {
 #pragma unroll
-                for (int h = 0; h < MCRT_MARCH_H; h++) vox[h] = myv[h] ? a.tex[vox_cell(myp[h], a)] : make_float2(0.0f, 0.0f);
+                for (int h = 0; h < H; h++) vox[h] = myv[h] ? a.tex[vox_cell(myp[h], a)] : make_float2(0.0f, 0.0f);
             }
 #pragma unroll
-            for (int h = 0; h < MCRT_MARCH_H; h++) {
+            for (int h = 0; h < H; h++) {
                 if (myv[h]) {
                     const float scattering = vox[h].y >= m_dens ? vox[h].x * m_sigma + m_mu : 0.0f;
                     const int row = row_near(myt[h], row_guess, thr, R, a.inv_row_dt, thr_end);
                     rf_add(bins, lflags, row, myin[h] * scattering);
-                    row_guess = (row >= 0 ? row : row_guess) + MCRT_MARCH_G;
+                    row_guess = (row >= 0 ? row : row_guess) + G;
                     if (STATS) st_steps++;
                 }
             }
@@ -1207,8 +1203,11 @@ hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
     if (chunks < 1u) chunks = 1u;
     const dim3 grid(a.ne * chunks), blk(256);
     const size_t lds = march_lds_bytes(a.R);
-    if (stats) hipLaunchKernelGGL((k_march<true>), grid, blk, lds, st, a, b, chunks);
-    else hipLaunchKernelGGL((k_march<false>), grid, blk, lds, st, a, b, chunks);
+    // lanes per segment: pairs give the higher throughput when there is plenty of work (515 vs 524 us per launch with 16 frames in
+    // flight), quads the shorter iterations that matter when one frame at a time is traced (2.19 vs 2.37 ms per frame)
+    const bool pairs = (size_t)a.ne * a.S >= (size_t)MCRT_MARCH_PAIRS_FROM;
+    if (stats) { if (pairs) hipLaunchKernelGGL((k_march<true, 2>), grid, blk, lds, st, a, b, chunks); else hipLaunchKernelGGL((k_march<true, 4>), grid, blk, lds, st, a, b, chunks); }
+    else { if (pairs) hipLaunchKernelGGL((k_march<false, 2>), grid, blk, lds, st, a, b, chunks); else hipLaunchKernelGGL((k_march<false, 4>), grid, blk, lds, st, a, b, chunks); }
     return hipGetLastError();
 }
 
