@@ -7,8 +7,8 @@
 A "step" is one frame of the hot path over synthetic input already resident in HBM:
 clear -> trace (BVH closest-hit + interface sampling) -> RF accumulation -> [RCCL all-gather of the
 scan-line blocks when N > 1] -> PSF convolution.  Each rank traces 128 scan-lines x 1024 sample paths
-(weak scaling: the frame has 128*N scan-lines).  By default 16 consecutive frames are in flight per
-pass (mcrt_trace_frames: every launch carries 16 frames' rays; images are bit-identical to
+(weak scaling: the frame has 128*N scan-lines).  By default 32 consecutive frames are in flight per
+pass (mcrt_trace_frames: every launch carries 32 frames' rays; images are bit-identical to
 one-at-a-time tracing); `--frames-in-flight 1` is the strict latency mode, also reported in the
 JSON as `one_frame_at_a_time`.  The JSON line carries the live roofline figure of the
 dominant kernel (k_trace: counted algorithmic bytes / HIP-event kernel time) and a CPU baseline (the
@@ -44,14 +44,14 @@ def build_workload(m, name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--workload", default="random1m")
     ap.add_argument("--scanlines", type=int, default=128, help="scan-lines per GPU")
     ap.add_argument("--rays", type=int, default=1024, help="sample paths per scan-line")
     ap.add_argument("--rows", type=int, default=465)
     ap.add_argument("--tex-n", type=int, default=256, help="texture edge in voxels (256 = the reference; smaller only for cache experiments)")
-    ap.add_argument("--frames-in-flight", type=int, default=16,
+    ap.add_argument("--frames-in-flight", type=int, default=32,
                     help="frames traced per pass (mcrt_trace_frames): a step is still ONE frame, but every kernel launch then carries the "
                          "rays of this many consecutive frames (1 = strict one-frame-at-a-time latency mode)")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="BVH builder: host binned SAH (default) or the device LBVH")
@@ -221,7 +221,7 @@ def main():
 def pmc_traffic(args):
     """HBM-side bytes per k_trace launch from the committed rocprofv3 PMC passes of this same command
     (profiles/round1/pmc_k_trace.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction applied); null for other workloads."""
-    if (args.workload, args.scanlines, args.rays, args.rows, args.gpus, args.frames_in_flight) != ("random1m", 128, 1024, 465, 1, 16):
+    if (args.workload, args.scanlines, args.rays, args.rows, args.gpus, args.frames_in_flight) != ("random1m", 128, 1024, 465, 1, 32):
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "round1", "pmc_k_trace.json")) as f:

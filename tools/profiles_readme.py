@@ -18,13 +18,13 @@ valu_total = 10 * sum(pm[k]["valu_instructions"] for k in pm)
 txt = """# profiles/round1 — MI355X (gfx950), ROCm 7.2, final round-1 pipeline
 
 Workload of every file: `bench.py` defaults = synthetic 1 M random triangles, 128 scan-lines × 1024 sample paths per frame, 465 RF
-rows, max depth 10, one GPU, **16 frames in flight per pass** (`mcrt_trace_frames`; each launch carries 16 frames' rays, images
+rows, max depth 10, one GPU, **32 frames in flight per pass** (`mcrt_trace_frames`; each launch carries 32 frames' rays, images
 bit-identical to one-at-a-time tracing).  Produced by `tools/pmc.sh`, `tools/timeline.sh`, `tools/kstats.sh` and `python bench.py` on
 a gpurun box, packaged by `tools/package_profiles.py`; this file is written by `tools/profiles_readme.py` from the files beside it.
 
 | file | what |
 |---|---|
-| `kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-latency-leg`. `k_trace<false>` (timed build): **%.1f µs average per launch** (%s launches = 3 passes × 10 bounces; kernels overlap as in production). `k_*<true>` = the counting build, used untimed for the algorithmic bytes. |
+| `kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 64 --warmup 32 --no-cpu-baseline --no-latency-leg`. `k_trace<false>` (timed build): **%.1f µs average per launch** (%s launches = 3 passes × 10 bounces; kernels overlap as in production). `k_*<true>` = the counting build, used untimed for the algorithmic bytes. |
 | `bench_unprofiled.json` | `python bench.py` un-profiled: `roofline.kernel_ms` = %.3f ms from HIP events on the launching stream — agrees with the rocprof average.  **%.1f M rays/s, %.3f ms/frame (%.0f frames/s)**; strictly one frame at a time: %.1f M rays/s, %.2f ms/frame; CPU oracle on the box's %d cores: %.2f M rays/s (one thread: %.1f k rays/s). |
 | `pmc_k_trace.json`, `pmc_k_march.json`, `pmc_k_shade.json` | separate `--pmc` passes (kernels run one at a time under `--pmc`), per-launch averages + derived figures |
 | `kernels_standalone.txt` | the same stats with `MCRT_NO_OVERLAP=1` (every kernel alone on the GPU): `k_trace` %.0f µs, `k_march` %.0f µs, `k_shade` %.0f µs per launch |
@@ -38,8 +38,8 @@ the rays in flight belong to a few scan-lines and walk the same nodes), %.0f %% 
 %.0f cycles — the BVH (58 MB of nodes + 96 MB of triangle records) is served on-die and HBM itself is nearly idle.  The kernel issues %.0f M wave-level VALU
 instructions per launch; at 4 cycles each on a 16-lane SIMD that is **%.0f %% of the SIMD cycles** of the %.2f M busy cycles per CU
 (`derived.valu_busy_share`), at %.0f %% lane utilisation (16 rays per wavefront, each waits for the wave's longest walk; leaves are
-tested in a separate phase with few lanes).  Its queue counter takes one returning atomic per 16 rays, ≈ 0.8 ms of serialised L2
-atomics per launch — the second wall it stands against (DESIGN.md 5).
+tested in a separate phase).  With a single queue cursor, its one returning atomic per 16 rays cost ≈ 0.8 ms of serialised L2
+atomics per launch; the queue therefore has one cursor per XCD (DESIGN.md 5).
 
 **k_march** shows the largest *summed* duration in `kernel_stats.csv` (%.0f µs × %s) because it runs on the side stream for the
 whole pass, sharing the SIMDs with `k_trace`/`k_shade`.  Its algorithmic bytes are small (8-B texture gather per RF step + 48-B march
@@ -63,6 +63,6 @@ One frame at a time (`--frames-in-flight 1`) every launch is latency-bound — a
        pm["k_trace"]["valu_instructions"] / 1e6, 100 * pm["k_trace"]["valu_busy_share"], pm["k_trace"]["kernel_cycles_per_cu"] / 1e6, 100 * pm["k_trace"]["valu_lane_utilisation"],
        float(m["AverageNs"]) / 1e3, m["Calls"], 100 * pm["k_march"]["valu_busy_share"],
        pm["k_shade"]["traffic_bytes_per_launch"] / 1e6, alone.get("k_shade<false>", 0), pm["k_shade"]["traffic_bytes_per_launch"] / max(alone.get("k_shade<false>", 1), 1) / 1e6,
-       valu_total / 1e9, 4 * valu_total / 1024 / 1e6, 4 * valu_total / 1024 / 1.9e9 * 1e3, b["ms_per_step"] * 16)
+       valu_total / 1e9, 4 * valu_total / 1024 / 1e6, 4 * valu_total / 1024 / 1.9e9 * 1e3, b["ms_per_step"] * 32)
 open(os.path.join(dst, "README.md"), "w").write(txt)
 print(txt[:400])
