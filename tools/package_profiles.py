@@ -11,7 +11,7 @@ shutil.copy(os.path.join(out, "pmc_" + tag, "stats.log"), os.path.join(dst, "ben
 shutil.copy(os.path.join(out, "timeline_%s.txt" % tag), os.path.join(dst, "frame_timeline.txt"))
 line = [l for l in open(os.path.join(out, "bench_%s.json" % tag)) if l.startswith("{")][-1]
 open(os.path.join(dst, "bench_unprofiled.json"), "w").write(line)
-for kernel, name in (("k_trace<false>", "pmc_k_trace.json"), ("k_march<false>", "pmc_k_march.json"), ("k_shade<false>", "pmc_k_shade.json")):
+for kernel, name in (("k_trace<false", "pmc_k_trace.json"), ("k_march<false", "pmc_k_march.json"), ("k_shade<false", "pmc_k_shade.json")):
     env = dict(os.environ, PMC_KERNEL=kernel)
     subprocess.check_output([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), os.path.join(out, "pmc_" + tag)], env=env)
     d = json.load(open(os.path.join(out, "pmc_" + tag, "summary.json")))

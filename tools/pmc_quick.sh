@@ -10,7 +10,7 @@ for f in glob.glob(sys.argv[1] + '/q1/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         agg[r['Kernel_Name'].split('(')[0].replace('void mcrt::', '')][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in sorted(agg.items()):
-    if '<false>' not in k: continue
+    if '<false' not in k: continue
     a = {c: sum(x) / len(x) for c, x in v.items()}
     print("%-16s n=%3d  VALU %7.1f M  SALU %7.1f M  VMEM_RD %6.2f M  LDS %6.2f M  busy cycles/CU %6.2f M  VALU busy %4.1f%%  lane util %4.1f%%" % (
         k, len(v['SQ_INSTS_VALU']), a['SQ_INSTS_VALU'] / 1e6, a['SQ_INSTS_SALU'] / 1e6, a['SQ_INSTS_VMEM_RD'] / 1e6, a['SQ_INSTS_LDS'] / 1e6, a['SQ_BUSY_CU_CYCLES'] / 256e6,

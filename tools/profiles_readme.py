@@ -4,14 +4,17 @@ import csv, json, os, sys
 dst = sys.argv[1]
 b = json.loads(open(os.path.join(dst, "bench_unprofiled.json")).read())
 r = b["roofline"]
-ks = {row["Name"].split("(")[0].replace("void mcrt::", ""): row for row in csv.DictReader(open(os.path.join(dst, "kernel_stats.csv")))}
+ks = {}
+for row in csv.DictReader(open(os.path.join(dst, "kernel_stats.csv"))):
+    name = row["Name"].split("(")[0].replace("void mcrt::", "")
+    ks[name.split(",")[0].rstrip(">") + (">" if "<" in name else "")] = row      # k_march<false, 2> -> k_march<false>
 pm = {k: json.load(open(os.path.join(dst, "pmc_%s.json" % k)))["derived"] for k in ("k_trace", "k_march", "k_shade")}
 alone = {}
 p = os.path.join(dst, "kernels_standalone.txt")
 if os.path.exists(p):
     for line in open(p):
         for k in ("k_trace<false>", "k_march<false>", "k_shade<false>"):
-            if k in line and " avg " in line:
+            if k[:-1] in line and " avg " in line:
                 alone[k] = float(line.split(" avg ")[1].split()[0])
 t = ks["k_trace<false>"]; m = ks["k_march<false>"]; s = ks["k_shade<false>"]
 valu_total = 10 * sum(pm[k]["valu_instructions"] for k in pm)
