@@ -75,7 +75,7 @@ struct mcrt_ctx {
     float4 *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr;
     uint4 *d_meshes = nullptr;
     uint32_t *d_tri_slot = nullptr;
-    uint32_t n_mesh = 0, n_mat = 0, start_mat = 0;
+    uint32_t n_mesh = 0, n_mat = 0, start_mat = 0, n_cu = 256;
     int builder = MCRT_BVH_HOST_SAH; bool host_bvh_stale = false;   // device-built tree: host copies are downloaded on demand
     std::vector<uint32_t> tri_mesh;   // per-triangle mesh index of the uploaded scene (for mcrt_update_triangles)
     float scene_lo[3] = { 0, 0, 0 }, scene_hi[3] = { 0, 0, 0 };
@@ -174,6 +174,7 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     mcrt_ctx *c = new (std::nothrow) mcrt_ctx();
     if (!c) return set_error(MCRT_ERR_NOMEM, "out of host memory");
     c->device = device;
+    if (prop.multiProcessorCount > 0) c->n_cu = (uint32_t)prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(MCRT_ERR_HIP, "hipStreamCreate failed"); }
     c->stream = c->own_stream;
     hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming);
@@ -561,7 +562,7 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     if (const char *e = getenv("MCRT_KSPLIT_LIMIT")) { long v = atol(e); if (v >= 0 && v <= MCRT_KSPLIT_MAX) a.ksplit_limit = (uint32_t)v; }   // tuning knob; 0 = off
     if (c->stats_on) a.ksplit_limit = 0;   // counting mode = one walk per ray, so the counts are those of a plain closest-hit walk
     for (int i = 0; i < 3; i++) { a.scene_lo[i] = c->scene_lo[i]; a.scene_hi[i] = c->scene_hi[i]; }
-    a.trace_blocks = 1280;   // persistent k_trace: 5 waves/SIMD on 256 CUs; quads fetch further rays dynamically
+    a.trace_blocks = c->n_cu * 5u;   // persistent k_trace: 5 waves/SIMD = 5 four-wave workgroups per CU (1280 on the MI355X's 256 CUs)
     if (const char *e = getenv("MCRT_TRACE_BLOCKS")) { int v = atoi(e); if (v >= 1) a.trace_blocks = (uint32_t)v; }   // tuning knob
     a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n; a.tex_mask = (c->tex_n & (c->tex_n - 1u)) == 0u ? c->tex_n - 1u : 0u;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
