@@ -942,7 +942,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
 #pragma unroll
             for (int h = 0; h < H; h++) {
                 myp[h] = point; myt[h] = t; myin[h] = inten; myv[h] = sidx < steps && t < a.max_travel;           // the reference's loop test
-                reach += abs_sum(point);
+                if (h == 0 || h == H - 1) reach += abs_sum(point);   // every coordinate moves monotonically: first and last bound them all
 #pragma unroll
                 for (int u = 0; u < G; u++) MCRT_ADVANCE()
                 sidx += (uint32_t)G;
