@@ -57,7 +57,6 @@ struct Work {
     float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr;
     unsigned long long *d_key0 = nullptr, *d_key1 = nullptr;
     uint32_t *d_q = nullptr, *d_counts = nullptr, *d_seg_count = nullptr, *d_cursors = nullptr;
-    hipEvent_t ev_march[MCRT_MAX_BOUNCES] = {};
     mcrt_segment *d_segs = nullptr; float4 *d_mrec = nullptr; size_t paths = 0; uint32_t depth = 0;
 };
 
@@ -203,7 +202,7 @@ static void free_work(mcrt_ctx *c)
 {
     for (Work &w : c->work) {
         free_work_buffers(w);
-        for (int i = 0; i < MCRT_MAX_BOUNCES; i++) { if (w.ev_bounce[i]) hipEventDestroy(w.ev_bounce[i]); if (w.ev_march[i]) hipEventDestroy(w.ev_march[i]); }
+        for (int i = 0; i < MCRT_MAX_BOUNCES; i++) { if (w.ev_bounce[i]) hipEventDestroy(w.ev_bounce[i]); }
         for (int i = 0; i < MCRT_SIDE_STREAMS; i++) { if (w.ev_join[i]) hipEventDestroy(w.ev_join[i]); if (w.side[i]) hipStreamDestroy(w.side[i]); }
         if (w.ev_done) hipEventDestroy(w.ev_done);
         if (w.stream) hipStreamDestroy(w.stream);
@@ -223,7 +222,7 @@ static int get_work(mcrt_ctx *c, size_t g, Work **out)
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
         if (getenv("MCRT_NO_PRIORITY")) prio_low = 0;   // tuning knob
         for (int i = 0; i < MCRT_SIDE_STREAMS; i++) { HIP_TRY(hipStreamCreateWithPriority(&w.side[i], hipStreamNonBlocking, prio_low)); HIP_TRY(hipEventCreateWithFlags(&w.ev_join[i], hipEventDisableTiming)); }
-        for (int i = 0; i < MCRT_MAX_BOUNCES; i++) { HIP_TRY(hipEventCreateWithFlags(&w.ev_bounce[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&w.ev_march[i], hipEventDisableTiming)); }
+        for (int i = 0; i < MCRT_MAX_BOUNCES; i++) HIP_TRY(hipEventCreateWithFlags(&w.ev_bounce[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
         c->work.push_back(w);
     }
@@ -536,7 +535,7 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne)
     const uint32_t B = c->p.max_depth;
     HIP_TRY(hipMalloc(&w.d_st0, 32 * np)); HIP_TRY(hipMalloc(&w.d_st1, 32 * np)); HIP_TRY(hipMalloc(&w.d_st2, 32 * np));   // two halves: bounce parity
     HIP_TRY(hipMalloc(&w.d_ray0, 32 * np)); HIP_TRY(hipMalloc(&w.d_ray1, 32 * np)); HIP_TRY(hipMalloc(&w.d_key0, 8 * np)); HIP_TRY(hipMalloc(&w.d_key1, 8 * np));
-    HIP_TRY(hipMalloc(&w.d_q, 12 * np)); HIP_TRY(hipMalloc(&w.d_seg_count, 4 * np));
+    HIP_TRY(hipMalloc(&w.d_q, 8 * np)); HIP_TRY(hipMalloc(&w.d_seg_count, 4 * np));
     HIP_TRY(hipMalloc(&w.d_counts, 4 * (MCRT_MAX_BOUNCES + 1)));
     HIP_TRY(hipMalloc(&w.d_cursors, 4 * (size_t)MCRT_MAX_BOUNCES * MCRT_XCDS * MCRT_CURSOR_STRIDE));
     HIP_TRY(hipMalloc(&w.d_segs, sizeof(mcrt_segment) * np * B));
@@ -609,7 +608,6 @@ static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArg
         hipStream_t side = w.side[b % side_streams()];
         HIP_TRY(hipStreamWaitEvent(side, w.ev_bounce[b], 0));
         HIP_TRY(mcrt::launch_march(a, b, c->stats_on, side));
-        HIP_TRY(hipEventRecord(w.ev_march[b], side));
     } else if (accumulate) {
         HIP_TRY(mcrt::launch_march(a, b, c->stats_on, st));
     }

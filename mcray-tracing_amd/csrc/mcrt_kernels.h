@@ -18,7 +18,7 @@ struct FrameArgs {
     const double *row_thr;     // [R+1] row thresholds (see row_of)
     // per-frame work buffers; np = ne * S paths
     float4 *st0, *st1, *st2;   // [np] path state: from,intensity | dir,media | distance_traveled(f64),outside,-
-    uint32_t *queue;           // [3][np] live path ids of bounce b in buffer b % 3
+    uint32_t *queue;           // [2][np] live path ids of bounce b in buffer b & 1
     float4 *ray0, *ray1;       // [np][2] f2.xyz,to.x | to.yz, 1/d.x, 1/d.y   (d = to - f2; indexed by queue position), ping-pong
     unsigned long long *key0, *key1;   // [np] closest hit per ray: fraction bits << 32 | triangle id (atomicMin), ping-pong by bounce parity
     const uint32_t *tri_slot;  // [T] triangle id -> position in the leaf-order triangle array

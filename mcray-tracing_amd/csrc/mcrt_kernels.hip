@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
     a.st0[pos] = make_float4(from.x, from.y, from.z, intensity);
     a.st1[pos] = make_float4(dir.x, dir.y, dir.z, __int_as_float((int)a.start_mat));
     a.st2[pos] = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), 0.0f);      // distance_traveled (double) | outside | -
-    a.queue[pos] = pid;                                  // queue of bounce 0 (buffer 0 of three)
+    a.queue[pos] = pid;                                  // queue of bounce 0 (buffer 0 of two)
     a.seg_count[pid] = 0u;
     if (pos < a.ne) a.key0[pos] = MCRT_KEY_MISS;          // bounce 0: one closest-hit word per queued scan-line
     const Ray r = make_ray(from, dir, intensity, a.mats[2 * a.start_mat].y, a);
@@ -640,9 +640,9 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x * blockDim.x >= n) return;
     const int lane = threadIdx.x & 63;
-    // three queue buffers: k_march of bounce b still reads buffer b%3 while k_shade of bounce b+1 fills (b+2)%3
-    const uint32_t *q_in = a.queue + (size_t)(b % 3u) * a.ne * a.S;
-    uint32_t *q_out = a.queue + (size_t)((b + 1u) % 3u) * a.ne * a.S;
+    // two queue buffers, ping-pong by bounce parity (like the path state)
+    const uint32_t *q_in = a.queue + (size_t)(b & 1u) * a.ne * a.S;
+    uint32_t *q_out = a.queue + (size_t)((b + 1u) & 1u) * a.ne * a.S;
     const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
     float4 *rays_out = (b & 1u) ? a.ray0 : a.ray1;
     const bool valid = i < n;
