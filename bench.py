@@ -125,8 +125,7 @@ def main():
         else:
             frames = rf_local
         if rank == 0:
-            for f in range(nf):
-                ctx.convolve(frames[f], E, R, psf.axial_kernel, psf.lateral_kernel)
+            ctx.convolve_frames(frames, nf, E, R, psf.axial_kernel, psf.lateral_kernel)      # all nf images in one launch per pass
 
     def passes(count):
         """split `count` frames into the fewest passes of at most F frames, as even as possible (20 with F=16 -> 10 + 10)"""

@@ -155,6 +155,9 @@ int mcrt_cast_rays(mcrt_ctx *ctx, uint32_t frame_id, uint32_t e_begin, uint32_t 
 /* rf_image::convolve (rfimage.h:93-123) in place on a device image [E][R]; tmp_dev same size or NULL */
 int mcrt_convolve(mcrt_ctx *ctx, float *rf_dev, uint32_t n_elements, uint32_t n_rows,
                   const float *axial, uint32_t n_ax, const float *lateral, uint32_t n_lat);
+/* the same on the n_frames images [n_frames][E][R] of an mcrt_trace_frames pass, in one launch per convolution pass */
+int mcrt_convolve_frames(mcrt_ctx *ctx, float *rf_dev, uint32_t n_frames, uint32_t n_elements, uint32_t n_rows,
+                         const float *axial, uint32_t n_ax, const float *lateral, uint32_t n_lat);
 /* rf_image::envelope (rfimage.h:54-91) in place on a device image [E][R] */
 int mcrt_envelope(mcrt_ctx *ctx, float *rf_dev, uint32_t n_elements, uint32_t n_rows);
 /* rf_image::postprocess scan conversion (rfimage.h:125-140,183-215), exact bilinear;

@@ -225,6 +225,11 @@ class Context:
         check(self.L.mcrt_cast_rays(self.h, frame_id, e_begin, e_end, ptr(segs), ptr(cnt), ptr(hits)))
         return segs, cnt, hits
 
+    def convolve_frames(self, rf_dev, n_frames, n_elements, n_rows, axial, lateral):
+        """rf_image::convolve on the [n_frames][E][R] images of a trace_frames pass, one launch per convolution pass"""
+        ax = np.ascontiguousarray(axial, np.float32); lat = np.ascontiguousarray(lateral, np.float32)
+        check(self.L.mcrt_convolve_frames(self.h, ptr(rf_dev), n_frames, n_elements, n_rows, ptr(ax), ax.size, ptr(lat), lat.size))
+
     def convolve(self, rf_dev, n_elements, n_rows, axial, lateral):
         ax = np.ascontiguousarray(axial, np.float32); lat = np.ascontiguousarray(lateral, np.float32)
         check(self.L.mcrt_convolve(self.h, ptr(rf_dev), n_elements, n_rows, ptr(ax), ax.size, ptr(lat), lat.size))

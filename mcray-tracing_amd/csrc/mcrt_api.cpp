@@ -740,16 +740,21 @@ static int ensure_tmp(mcrt_ctx *c, size_t n)
     return MCRT_OK;
 }
 
-extern "C" int mcrt_convolve(mcrt_ctx *c, float *rf_dev, uint32_t E, uint32_t R, const float *ax, uint32_t n_ax, const float *lat, uint32_t n_lat)
+extern "C" int mcrt_convolve_frames(mcrt_ctx *c, float *rf_dev, uint32_t n_frames, uint32_t E, uint32_t R, const float *ax, uint32_t n_ax, const float *lat, uint32_t n_lat)
 {
     CTX_TRY(c);
-    if (!rf_dev || !ax || !lat || E == 0 || R == 0) return set_error(MCRT_ERR_INVALID, "mcrt_convolve: bad arguments");
+    if (!rf_dev || !ax || !lat || E == 0 || R == 0 || n_frames == 0) return set_error(MCRT_ERR_INVALID, "mcrt_convolve: bad arguments");
     if (n_ax == 0 || n_ax > 16 || n_lat == 0 || n_lat > 32) return set_error(MCRT_ERR_LIMIT, "kernel sizes must be 1..16 axial, 1..32 lateral");
-    int rc = ensure_tmp(c, (size_t)E * R); if (rc) return rc;
+    int rc = ensure_tmp(c, (size_t)n_frames * E * R); if (rc) return rc;
     mcrt::ConvTaps t; memset(&t, 0, sizeof t);
     memcpy(t.ax, ax, 4 * n_ax); memcpy(t.lat, lat, 4 * n_lat); t.n_ax = n_ax; t.n_lat = n_lat;
-    HIP_TRY(mcrt::launch_convolve(rf_dev, c->d_tmp, E, R, t, c->stream));
+    HIP_TRY(mcrt::launch_convolve(rf_dev, c->d_tmp, n_frames, E, R, t, c->stream));
     return MCRT_OK;
+}
+
+extern "C" int mcrt_convolve(mcrt_ctx *c, float *rf_dev, uint32_t E, uint32_t R, const float *ax, uint32_t n_ax, const float *lat, uint32_t n_lat)
+{
+    return mcrt_convolve_frames(c, rf_dev, 1, E, R, ax, n_ax, lat, n_lat);
 }
 
 extern "C" int mcrt_envelope(mcrt_ctx *c, float *rf_dev, uint32_t E, uint32_t R)

@@ -1006,10 +1006,11 @@ __global__ void k_clear_flags(uint32_t *flags, size_t n)
 }
 
 // rfimage.h:96-108 on the scan-line-major image: tmp[e][row] = sum_k img[e][row+k]*ax[k], row in [na, R-na)
-__global__ void k_conv_axial(const float *img, float *tmp, uint32_t E, uint32_t R, ConvTaps taps)
+// (both passes take a stack of n_img images [n_img][E][R] at once: one launch for all the frames of a pass)
+__global__ void k_conv_axial(const float *img, float *tmp, uint32_t n_img, uint32_t E, uint32_t R, ConvTaps taps)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)E * R) return;
+    if (i >= (size_t)n_img * E * R) return;
     const int row = (int)(i % R), na = (int)taps.n_ax;
     if (row < na || row >= (int)R - na) return;
     float conv = 0;
@@ -1017,11 +1018,11 @@ __global__ void k_conv_axial(const float *img, float *tmp, uint32_t E, uint32_t 
     tmp[i] = conv;
 }
 // rfimage.h:111-122: img[col][row] = sum_k tmp[col+k][row]*lat[k], row in [na,R-na), col in [nl/2, E-nl)
-__global__ void k_conv_lateral(const float *tmp, float *img, uint32_t E, uint32_t R, ConvTaps taps)
+__global__ void k_conv_lateral(const float *tmp, float *img, uint32_t n_img, uint32_t E, uint32_t R, ConvTaps taps)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)E * R) return;
-    const int row = (int)(i % R), col = (int)(i / R), na = (int)taps.n_ax, nl = (int)taps.n_lat;
+    if (i >= (size_t)n_img * E * R) return;
+    const int row = (int)(i % R), col = (int)((i / R) % E), na = (int)taps.n_ax, nl = (int)taps.n_lat;
     if (row < na || row >= (int)R - na) return;
     if (col < nl / 2 || col >= (int)E - nl) return;
     float conv = 0;
@@ -1220,12 +1221,12 @@ hipError_t launch_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t 
     return hipGetLastError();
 }
 
-hipError_t launch_convolve(float *img, float *tmp, uint32_t E, uint32_t R, const ConvTaps &taps, hipStream_t st)
+hipError_t launch_convolve(float *img, float *tmp, uint32_t n_img, uint32_t E, uint32_t R, const ConvTaps &taps, hipStream_t st)
 {
-    const size_t n = (size_t)E * R;
+    const size_t n = (size_t)n_img * E * R;
     const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(k_conv_axial, grid, blk, 0, st, (const float *)img, tmp, E, R, taps);
-    hipLaunchKernelGGL(k_conv_lateral, grid, blk, 0, st, (const float *)tmp, img, E, R, taps);
+    hipLaunchKernelGGL(k_conv_axial, grid, blk, 0, st, (const float *)img, tmp, n_img, E, R, taps);
+    hipLaunchKernelGGL(k_conv_lateral, grid, blk, 0, st, (const float *)tmp, img, n_img, E, R, taps);
     return hipGetLastError();
 }
 

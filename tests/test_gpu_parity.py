@@ -321,6 +321,12 @@ def test_frames_in_flight_are_bit_identical(mcrt, orc, sphere, tex256):
     osc, p, o = _oracle(orc, sd, tr, tex256, E, S)
     o8 = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=8, want_hits=False, want_ref=False)
     assert np.array_equal(batch[1].T.view(np.uint32), o8["rf"].view(np.uint32))
+    # mcrt_convolve_frames on the whole pass == mcrt_convolve frame by frame
+    sim.ctx.convolve_frames(dev, F, E, sim.R, sim.psf.axial_kernel, sim.psf.lateral_kernel)
+    conv = sim.ctx.d2h(dev, (F, E, sim.R))
+    for f in range(F):
+        sim.trace(7 + f); sim.convolve()
+        assert np.array_equal(conv[f].view(np.uint32), sim.ctx.d2h(sim.rf_dev, (E, sim.R)).view(np.uint32))
     sim.ctx.free(dev)
     sim.close()
 
