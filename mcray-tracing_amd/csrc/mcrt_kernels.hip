@@ -33,7 +33,7 @@
 #define MCRT_TRACE_WAVES 5          // waves per SIMD k_trace's register allocation must allow
 #endif
 #ifndef MCRT_LEAF_BATCH
-#define MCRT_LEAF_BATCH 4          // leave the inner-node phase once this many of a wave's 16 paths are parked on a leaf
+#define MCRT_LEAF_BATCH 5          // leave the inner-node phase once this many of a wave's 16 paths are parked on a leaf
 #endif
 
 namespace mcrt {
@@ -841,7 +841,10 @@ template <bool STATS, int G>
 __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t chunks)
 {
     constexpr int H = 8 / G;                 // RF steps per lane and iteration: a group does G*H = 8 consecutive steps
-    constexpr int REFILL = 16 / G;           // new segments are handed out while at least a quarter of the wavefront's groups are idle or finished
+#ifndef MCRT_MARCH_REFILL_DIV
+#define MCRT_MARCH_REFILL_DIV 4
+#endif
+    constexpr int REFILL = (64 / G) / MCRT_MARCH_REFILL_DIV;   // new segments are handed out while at least a quarter of the wavefront's groups are idle or finished
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, j = tid & (G - 1);
     const uint32_t R = a.R, nf = (R + 31u) >> 5;
