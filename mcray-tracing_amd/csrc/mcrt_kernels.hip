@@ -399,11 +399,13 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
     // dry moves on to the next one, so the XCDs finish together.  Bounces with few items use one queue.
     const uint32_t X = (n >= (uint32_t)MCRT_XCD_MIN_ITEMS) ? (uint32_t)MCRT_XCDS : 1u;
     if (X == 1u && blockIdx.x * 64u >= n) return;
-    uint32_t cur_x = blockIdx.x % X, visited = 0;                // wave-uniform: the sub-queue this wavefront draws from
-#define MCRT_SUB_LO(sq) ((uint32_t)(((unsigned long long)n * (sq)) / X))
-#define MCRT_SUB_STATIC(sq) (((gridDim.x - (sq) + X - 1u) / X) * 64u)      /* items of sub-queue sq assigned statically (one per quad) */
+    const uint32_t x_shift = (X == 1u) ? 0u : 3u;
+    static_assert(MCRT_XCDS == 8, "the sub-queue arithmetic shifts by 3");
+    uint32_t cur_x = blockIdx.x & (X - 1u), visited = 0;                // wave-uniform: the sub-queue this wavefront draws from
+#define MCRT_SUB_LO(sq) ((uint32_t)(((unsigned long long)n * (sq)) >> x_shift))      /* X is 1 or 8: shifts, not divisions */
+#define MCRT_SUB_STATIC(sq) (((gridDim.x - (sq) + X - 1u) >> x_shift) * 64u)      /* items of sub-queue sq assigned statically (one per quad) */
     uint32_t *cursors = a.cursors + (size_t)b * MCRT_XCDS * MCRT_CURSOR_STRIDE;
-    uint32_t i = MCRT_SUB_LO(cur_x) + (blockIdx.x / X) * 64u + (uint32_t)q;     // the first item of each quad is assigned statically
+    uint32_t i = MCRT_SUB_LO(cur_x) + (blockIdx.x >> x_shift) * 64u + (uint32_t)q;     // the first item of each quad is assigned statically
     if (i >= MCRT_SUB_LO(cur_x + 1u)) i = 0xffffffffu;                          // (a short sub-queue: fetch dynamically)
     uint32_t ray_id = 0;
 #ifdef MCRT_STAMP
@@ -470,7 +472,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                 const unsigned long long start = (unsigned long long)MCRT_SUB_LO(cur_x) + MCRT_SUB_STATIC(cur_x) + base;
                 if (start < hi) { pool_next = (uint32_t)start; pool_end = min((uint32_t)start + (uint32_t)MCRT_FETCH_BATCH, hi); }
                 else if (++visited >= X) queue_empty = true;             // every sub-queue has run dry
-                else cur_x = (cur_x + 1u) % X;                           // this one has: help the next XCD's
+                else cur_x = (cur_x + 1u) & (X - 1u);                    // this one has: help the next XCD's
 #ifdef MCRT_STAMP
                 if (queue_empty && lane == 0) atomicMax(&a.stamps[16 + 4 * b + 1], ~(unsigned long long)wall_clock64());
 #endif
@@ -485,8 +487,9 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
         }
         if (need && i != 0xffffffffu) {
             if (i < n) {
-                const uint32_t piece = i / n_rays;                       // the pieces of one ray land in different wavefronts
-                ray_id = i % n_rays;
+                uint32_t piece = 0u;                                     // the pieces of one ray land in different wavefronts
+                if (K == 1u) ray_id = i;                                 // (no division on the common path)
+                else { piece = i / n_rays; ray_id = i - piece * n_rays; }
                 const float4 r0 = rays[2 * (size_t)ray_id * ray_stride], r1 = rays[2 * (size_t)ray_id * ray_stride + 1];
                 f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
                 const f3 d = to - f2;
