@@ -676,9 +676,9 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
             best.da = dot(best.n, f2) - P.w;
             best.mesh = __float_as_int(t2.w);
         }
-        const uint32_t line = pid / a.S;
-        const uint32_t e_abs = a.e_begin + line % a.ne_frame;
-        Rng g; g.k0 = a.seed; g.k1 = a.frame + line / a.ne_frame; g.element = e_abs; g.sample = pid % a.S; g.bounce = b;
+        const uint32_t line = pid / a.S, fr = line / a.ne_frame;      // (two divisions; the remainders by multiply-subtract)
+        const uint32_t e_abs = a.e_begin + (line - fr * a.ne_frame);
+        Rng g; g.k0 = a.seed; g.k1 = a.frame + fr; g.element = e_abs; g.sample = pid - line * a.S; g.bounce = b;
         const float4 m0 = a.mats[2 * media];   // imp, att, mu0, mu1  (second half: sigma, spec, shine, thick)
         const float att = m0.y;
 
