@@ -433,3 +433,45 @@ def test_large_passes_use_the_per_xcd_queues(mcrt, orc, sphere, tex256):
     assert np.array_equal(batch[2].T.view(np.uint32), o22["rf"].view(np.uint32))
     sim.ctx.free(dev)
     sim.close()
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_randomised_configurations(mcrt, orc, case):
+    """a sweep over shapes and parameters nobody picked by hand: odd element / sample / row counts, depths 1..16, both builders,
+    textures of several sizes, TIR sanitising on and off, frequency, seed, frames in flight -- hits and RF bit for bit"""
+    rng = np.random.default_rng(1000 + case)
+    if case % 3 == 0:
+        cfg, meshes = mcrt.synth.random_scene(int(rng.integers(2000, 30000)), 8, seed=int(rng.integers(1, 1000)))
+    elif case % 3 == 1:
+        cfg, meshes = mcrt.synth.liver_scene(int(rng.integers(1, 3)))
+    else:
+        cfg, meshes = mcrt.synth.sphere_scene(int(rng.integers(1, 4)))
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    E, S = int(rng.integers(1, 40)), int(rng.integers(1, 200))
+    R, B = int(rng.integers(20, 700)), int(rng.integers(1, 17))
+    tex_n = int(rng.choice([4, 16, 37, 64]))
+    freq = float(rng.choice([2.5, 4.5, 7.0]))
+    sanitize = int(rng.integers(0, 2))
+    seed = int(rng.integers(0, 2 ** 31))
+    F = int(rng.integers(1, 5))
+    builder = "lbvh" if (case % 2 and sd.n_tri >= 8) else "sah"
+    tex = rng.normal(size=(tex_n, tex_n, tex_n, 2)).astype(np.float32)
+    tr = mcrt.Transducer(E, frequency=freq, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
+    sim = mcrt.Simulator(sd, tr, n_samples=S, n_rows=R, texture=tex, tex_n=tex_n, max_depth=B, sanitize_tir=sanitize, seed=seed, bvh_builder=builder)
+    frame0 = int(rng.integers(0, 1000))
+    dev = sim.ctx.alloc(F * E * R * 4)
+    sim.ctx.trace_frames(frame0, F, dev)
+    batch = sim.ctx.d2h(dev, (F, E, R))
+    hits, _, _ = sim.ctx.trace_frame_debug(frame0 + F - 1, sim.rf_dev)
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
+    nodes4, _ = sim.ctx.get_bvh4()
+    _, btri, _ = sim.ctx.get_bvh()
+    osc.set_bvh4(nodes4, btri)
+    p = orc.default_params(n_elements=E, n_samples=S, n_rows=R, max_depth=B, tex_n=tex_n, frequency=freq, sanitize_tir=sanitize, seed=seed)
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=frame0 + F - 1, use_bvh=2, n_threads=16, want_ref=False)
+    what = dict(case=case, E=E, S=S, R=R, B=B, tex_n=tex_n, freq=freq, sanitize=sanitize, F=F, builder=builder, tris=sd.n_tri)
+    assert np.array_equal(hits, o["hits"]), what
+    got, want = batch[F - 1].T.view(np.uint32), o["rf"].view(np.uint32)
+    assert np.array_equal(got, want), what
+    sim.ctx.free(dev)
+    sim.close()
