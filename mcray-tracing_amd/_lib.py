@@ -56,7 +56,7 @@ assert NODE_DTYPE.itemsize == 64 and SEGMENT_DTYPE.itemsize == 64 and C.sizeof(B
 
 # every symbol include/mcrt.h declares (tests/test_abi.py checks the .so exports each one)
 SYMBOLS = ["mcrt_last_error", "mcrt_version", "mcrt_device_count", "mcrt_create", "mcrt_destroy", "mcrt_set_stream",
-           "mcrt_synchronize", "mcrt_default_params", "mcrt_set_params", "mcrt_set_bvh_builder", "mcrt_upload_scene", "mcrt_update_triangles", "mcrt_upload_texture",
+           "mcrt_synchronize", "mcrt_default_params", "mcrt_set_params", "mcrt_set_bvh_builder", "mcrt_upload_scene", "mcrt_update_triangles", "mcrt_refit_triangles", "mcrt_upload_texture",
            "mcrt_set_transducer", "mcrt_trace_frame", "mcrt_trace_frames", "mcrt_trace_frame_debug", "mcrt_cast_rays", "mcrt_convolve", "mcrt_convolve_frames",
            "mcrt_envelope", "mcrt_scan_convert", "mcrt_export_rf", "mcrt_alloc", "mcrt_free", "mcrt_memcpy_d2h",
            "mcrt_memcpy_h2d", "mcrt_enable_stats", "mcrt_get_stats", "mcrt_enable_timing", "mcrt_get_kernel_time",
@@ -94,7 +94,7 @@ def load_library():
         "mcrt_convolve": [vp, vp, u32, u32, vp, u32, vp, u32], "mcrt_envelope": [vp, vp, u32, u32],
         "mcrt_scan_convert": [vp, vp, u32, u32, C.c_double, C.c_double, vp, u32, u32],
         "mcrt_convolve_frames": [vp, vp, u32, u32, u32, vp, u32, vp, u32],
-        "mcrt_set_bvh_builder": [vp, i32], "mcrt_update_triangles": [vp, vp, u32],
+        "mcrt_set_bvh_builder": [vp, i32], "mcrt_update_triangles": [vp, vp, u32], "mcrt_refit_triangles": [vp, vp, u32],
         "mcrt_export_rf": [vp, vp, u32, u32, vp], "mcrt_alloc": [vp, C.c_size_t, C.POINTER(vp)], "mcrt_free": [vp, vp],
         "mcrt_memcpy_d2h": [vp, vp, vp, C.c_size_t], "mcrt_memcpy_h2d": [vp, vp, vp, C.c_size_t],
         "mcrt_enable_stats": [vp, i32], "mcrt_get_stats": [vp, C.POINTER(Stats), i32],

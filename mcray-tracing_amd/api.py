@@ -158,6 +158,15 @@ class Context:
             n = tri.numel() // 9
         check(self.L.mcrt_update_triangles(self.h, ptr(tri), n))
 
+    def refit_triangles(self, tri):
+        """new vertex positions [T,9] for the uploaded triangles, keeping the tree: boxes are refitted on the GPU"""
+        if isinstance(tri, np.ndarray):
+            tri = np.ascontiguousarray(tri, np.float32).reshape(-1, 9)
+            n = tri.shape[0]
+        else:
+            n = tri.numel() // 9
+        check(self.L.mcrt_refit_triangles(self.h, ptr(tri), n))
+
     def upload_texture(self, vox=None, n=256):
         if vox is not None:
             vox = np.ascontiguousarray(vox, np.float32)

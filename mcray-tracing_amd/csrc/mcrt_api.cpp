@@ -405,6 +405,31 @@ extern "C" int mcrt_update_triangles(mcrt_ctx *c, const float *tri, uint32_t n_t
     return MCRT_OK;
 }
 
+extern "C" int mcrt_refit_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
+{
+    CTX_TRY(c);
+    if (!c->have_scene) return set_error(MCRT_ERR_INVALID, "no scene uploaded");
+    if (!tri) return set_error(MCRT_ERR_INVALID, "null triangles");
+    if (n_tri != c->bvh.n_tri || n_tri == 0) return set_error(MCRT_ERR_INVALID, "the scene has %u triangles, the update has %u", c->bvh.n_tri, n_tri);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float *d_tri = nullptr;
+    HIP_TRY(hipMalloc(&d_tri, 36 * (size_t)n_tri));
+    int rc = MCRT_OK;
+    if (hipMemcpyAsync(d_tri, tri, 36 * (size_t)n_tri, hipMemcpyDefault, c->stream) != hipSuccess) rc = set_error(MCRT_ERR_HIP, "triangle upload failed");
+    float pad = 0.0f, lo[3], hi[3];
+    if (!rc) rc = mcrt::bvh_refit(d_tri, n_tri, c->d_nodes, c->bvh4.n_nodes, c->d_tris, c->stream, &pad, lo, hi);
+    hipFree(d_tri);
+    if (rc) { c->have_scene = false; return rc; }           // a failed refit leaves no scene
+    c->bvh.pad_abs = pad;
+    for (int i = 0; i < 3; i++) { c->scene_lo[i] = lo[i]; c->scene_hi[i] = hi[i]; }
+    // the host copies (and the host builder's BVH2, which has no refitted counterpart) are out of date: downloaded on demand
+    free(c->bvh.nodes); c->bvh.nodes = nullptr; c->bvh.n_nodes = 0;
+    free(c->bvh.tri); c->bvh.tri = nullptr;
+    free(c->bvh4.nodes); c->bvh4.nodes = nullptr;
+    c->host_bvh_stale = true;
+    return MCRT_OK;
+}
+
 extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *tri_mesh, uint32_t n_tri,
                                  const mcrt_mesh *meshes, uint32_t n_mesh, const float *mats, uint32_t n_mat,
                                  uint32_t start_mat, const float spacing[3])

@@ -265,6 +265,92 @@ __global__ void k_stack(const int *parent_int, const uint32_t *is4, const uint8_
     if ((threadIdx.x & 63) == 0 && need) atomicMax(&s->max_stack, need);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// REFIT: new vertex positions, same tree.  The topology (which triangles share a leaf, which nodes share a parent) is kept, every
+// box is recomputed bottom-up from the triangles' new padded bounds -- exact unions again, so the closest-hit contract holds and
+// frames equal those of a freshly built tree.  For deformations that keep the spatial order roughly intact this is ~10x cheaper
+// than a rebuild and keeps the quality of a host SAH tree.
+//   k_refit_records   the walk's 96-byte triangle record of every leaf-order slot from the new vertices (as k_expand_tris)
+//   k_refit_links     parent node and slot of every BVH4 node, number of inner children per node
+//   k_refit_nodes     per node: boxes of its leaf children from the records; then the LAST arrival at a node (its own thread and
+//                     the threads coming up from its inner children) computes the node's union and carries it to the parent
+__global__ void k_refit_records(const float *tri, const float4 *old_rec, uint32_t n_tri, const Scal *s, float4 *rec)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_tri) return;
+    const float4 id_rec = old_rec[6 * (size_t)slot + 1], mesh_rec = old_rec[6 * (size_t)slot + 2];
+    const uint32_t id = __float_as_uint(id_rec.w);
+    const float *v = tri + (size_t)id * 9;
+    const float v0x = v[0], v0y = v[1], v0z = v[2], v1x = v[3], v1y = v[4], v1z = v[5], v2x = v[6], v2y = v[7], v2z = v[8];
+    // the contract's expressions, exactly as k_expand_tris (mcrt_kernels.hip) evaluates them
+    const float ax = v1x - v0x, ay = v1y - v0y, az = v1z - v0z, bx = v2x - v0x, by = v2y - v0y, bz = v2z - v0z;
+    const float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    const float dist = v0x * nx + v0y * ny + v0z * nz;
+    const float lx = fminf(v0x, fminf(v1x, v2x)), ly = fminf(v0y, fminf(v1y, v2y)), lz = fminf(v0z, fminf(v1z, v2z));
+    const float hx = fmaxf(v0x, fmaxf(v1x, v2x)), hy = fmaxf(v0y, fmaxf(v1y, v2y)), hz = fmaxf(v0z, fmaxf(v1z, v2z));
+    const float ext = fmaxf(fmaxf(fmaxf(0.0f, hx - lx), hy - ly), hz - lz);
+    const float pad = 2e-4f * ext + s->pad_abs;
+    const float edge_tol = (nx * nx + ny * ny + nz * nz) * -0.0001f;
+    float4 *o = rec + 6 * (size_t)slot;
+    o[0] = make_float4(nx, ny, nz, dist);
+    o[1] = make_float4(lx - pad, ly - pad, lz - pad, id_rec.w);
+    o[2] = make_float4(hx + pad, hy + pad, hz + pad, mesh_rec.w);
+    o[3] = make_float4(v0x, v0y, v0z, edge_tol);
+    o[4] = make_float4(v1x, v1y, v1z, edge_tol);
+    o[5] = make_float4(v2x, v2y, v2z, edge_tol);
+}
+
+__global__ void k_refit_links(const float4 *nodes, uint32_t n4, int *parent, uint32_t *inner, uint32_t *arrived)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    uint32_t cnt = 0;
+    for (int k = 0; k < 4; k++) {
+        const int ref = __float_as_int(nodes[8 * (size_t)i + 2 * k + 1].z);
+        if (ref >= 0) { parent[ref] = (int)(i * 4u + (uint32_t)k); cnt++; }
+    }
+    inner[i] = cnt; arrived[i] = 0u;
+    if (i == 0) parent[0] = -1;
+}
+
+__global__ void k_refit_nodes(float4 *nodes, uint32_t n4, const float4 *rec, const int *parent, const uint32_t *inner, uint32_t *arrived, float4 *root_box)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    for (int k = 0; k < 4; k++) {                       // this node's leaf children: union of their triangles' padded bounds
+        const int ref = __float_as_int(nodes[8 * (size_t)i + 2 * k + 1].z);
+        if (ref >= 0 || ref == MCRT_BVH4_EMPTY) continue;
+        const uint32_t v = (uint32_t)~ref, first = v >> 3, cnt = (v & 7u) + 1u;
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (uint32_t t = 0; t < cnt; t++) {
+            const float4 l = rec[6 * (size_t)(first + t) + 1], h = rec[6 * (size_t)(first + t) + 2];
+            lo[0] = fminf(lo[0], l.x); lo[1] = fminf(lo[1], l.y); lo[2] = fminf(lo[2], l.z);
+            hi[0] = fmaxf(hi[0], h.x); hi[1] = fmaxf(hi[1], h.y); hi[2] = fmaxf(hi[2], h.z);
+        }
+        nodes[8 * (size_t)i + 2 * k] = make_float4(lo[0], lo[1], lo[2], hi[0]);
+        nodes[8 * (size_t)i + 2 * k + 1] = make_float4(hi[1], hi[2], __int_as_float(ref), 0.0f);
+    }
+    uint32_t n = i;
+    for (;;) {
+        __threadfence();                                       // what this thread wrote is visible before it signs in
+        if (atomicAdd(&arrived[n], 1u) != inner[n]) return;     // not the last of (own thread + inner children) to arrive at n
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (int k = 0; k < 4; k++) {
+            const float4 A = load_coherent(&nodes[8 * (size_t)n + 2 * k]), B = load_coherent(&nodes[8 * (size_t)n + 2 * k + 1]);
+            if (__float_as_int(B.z) == MCRT_BVH4_EMPTY) continue;
+            lo[0] = fminf(lo[0], A.x); lo[1] = fminf(lo[1], A.y); lo[2] = fminf(lo[2], A.z);
+            hi[0] = fmaxf(hi[0], A.w); hi[1] = fmaxf(hi[1], B.x); hi[2] = fmaxf(hi[2], B.y);
+        }
+        const int p = parent[n];
+        if (p < 0) { root_box[0] = make_float4(lo[0], lo[1], lo[2], 0.0f); root_box[1] = make_float4(hi[0], hi[1], hi[2], 0.0f); return; }
+        const uint32_t pn = (uint32_t)p >> 2, pk = (uint32_t)p & 3u;
+        const float ref = nodes[8 * (size_t)pn + 2 * pk + 1].z;      // (the reference itself never changes)
+        nodes[8 * (size_t)pn + 2 * pk] = make_float4(lo[0], lo[1], lo[2], hi[0]);
+        nodes[8 * (size_t)pn + 2 * pk + 1] = make_float4(hi[1], hi[2], ref, 0.0f);
+        n = pn;
+    }
+}
+
 struct Temp {
     std::vector<void *> p;
     ~Temp() { for (void *x : p) hipFree(x); }
@@ -339,6 +425,31 @@ int lbvh_build(const float *tri_dev, const uint32_t *mesh_dev, uint32_t n_tri, h
     out->n_nodes4 = n4; out->max_stack = hs.max_stack; out->max_depth = hs.max_depth; out->pad_abs = hs.pad_abs;
     out->lo[0] = root_lo.x; out->lo[1] = root_lo.y; out->lo[2] = root_lo.z;
     out->hi[0] = root_hi.x; out->hi[1] = root_hi.y; out->hi[2] = root_hi.z;
+    return MCRT_OK;
+}
+
+int bvh_refit(const float *tri_dev, uint32_t n_tri, float4 *d_nodes, uint32_t n_nodes4, float4 *d_recs, hipStream_t st, float *pad_abs, float lo[3], float hi[3])
+{
+    if (n_tri == 0 || n_nodes4 == 0) return set_error(MCRT_ERR_INVALID, "refit: no tree");
+    Temp tmp;
+    Scal *s = nullptr; float4 *new_rec = nullptr, *root = nullptr; int *parent = nullptr; uint32_t *inner = nullptr, *arrived = nullptr;
+    LB_TRY(tmp.get(&s, 1)); LB_TRY(tmp.get(&new_rec, 6 * (size_t)n_tri)); LB_TRY(tmp.get(&root, 2));
+    LB_TRY(tmp.get(&parent, n_nodes4)); LB_TRY(tmp.get(&inner, n_nodes4)); LB_TRY(tmp.get(&arrived, n_nodes4));
+    const dim3 blk(256), grid_t((n_tri + 255u) / 256u), grid_n((n_nodes4 + 255u) / 256u);
+    hipLaunchKernelGGL(k_scal_init, dim3(1), dim3(1), 0, st, s);
+    hipLaunchKernelGGL(k_scale, dim3(1024), blk, 0, st, tri_dev, (size_t)n_tri * 9, s);
+    hipLaunchKernelGGL(k_pad, dim3(1), dim3(1), 0, st, s);
+    hipLaunchKernelGGL(k_refit_records, grid_t, blk, 0, st, tri_dev, (const float4 *)d_recs, n_tri, (const Scal *)s, new_rec);
+    LB_TRY(hipMemcpyAsync(d_recs, new_rec, 96 * (size_t)n_tri, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_refit_links, grid_n, blk, 0, st, (const float4 *)d_nodes, n_nodes4, parent, inner, arrived);
+    hipLaunchKernelGGL(k_refit_nodes, grid_n, blk, 0, st, d_nodes, n_nodes4, (const float4 *)d_recs, (const int *)parent, (const uint32_t *)inner, arrived, root);
+    Scal hs; float4 rb[2];
+    LB_TRY(hipMemcpyAsync(&hs, s, sizeof hs, hipMemcpyDeviceToHost, st));
+    LB_TRY(hipMemcpyAsync(rb, root, sizeof rb, hipMemcpyDeviceToHost, st));
+    LB_TRY(hipStreamSynchronize(st));
+    LB_TRY(hipGetLastError());
+    *pad_abs = hs.pad_abs;
+    lo[0] = rb[0].x; lo[1] = rb[0].y; lo[2] = rb[0].z; hi[0] = rb[1].x; hi[1] = rb[1].y; hi[2] = rb[1].z;
     return MCRT_OK;
 }
 

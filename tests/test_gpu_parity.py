@@ -475,3 +475,44 @@ def test_randomised_configurations(mcrt, orc, case):
     assert np.array_equal(got, want), what
     sim.ctx.free(dev)
     sim.close()
+
+
+@pytest.mark.parametrize("builder", ["sah", "lbvh"])
+def test_refit_keeps_frames_exact(mcrt, orc, tex256, builder):
+    """mcrt_refit_triangles: moved vertices, same tree, boxes refitted on the GPU -- the frame equals that of a context built on
+    the moved geometry, and the oracle walking the downloaded refitted tree counts the GPU's node visits"""
+    cfg, meshes = mcrt.synth.random_scene(50000, 8, seed=7)
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    E, S = 24, 192
+    tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256, bvh_builder=builder)
+    sim.trace(0)
+    moved = sd.tri.reshape(-1, 3, 3).copy()
+    moved[:, :, 2] += 0.25 * np.cos(0.7 * moved[:, :, 0]) + 0.1 * moved[:, :, 1]        # smooth deformation + shear
+    moved = moved.reshape(-1, 9).astype(np.float32)
+    sim.ctx.refit_triangles(moved)
+    h1, _, c1 = sim.ctx.trace_frame_debug(6, sim.rf_dev, want_segs=True)
+    rf1 = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    nodes4, max_stack = sim.ctx.get_bvh4()
+    _, btri, _ = sim.ctx.get_bvh()
+    assert np.array_equal(btri[np.argsort(btri[:, 3].view(np.uint32))][:, [0, 1, 2, 4, 5, 6, 8, 9, 10]], moved)   # the records carry the new vertices
+    sim.ctx.enable_stats(True); sim.ctx.get_stats(reset=True)
+    sim.trace(6); st = sim.ctx.get_stats()
+    sim.ctx.enable_stats(False)
+    sim.close()
+    import copy
+    sd2 = copy.copy(sd); sd2.tri = moved
+    tr, ref = _sim(mcrt, cfg, sd2, E, S, texture=tex256)
+    h2, _, c2 = ref.ctx.trace_frame_debug(6, ref.rf_dev, want_segs=True)
+    rf2 = ref.ctx.export_rf(ref.rf_dev, E, ref.R)
+    ref.close()
+    assert np.array_equal(h1, h2) and np.array_equal(c1, c2)
+    assert np.array_equal(rf1.view(np.uint32), rf2.view(np.uint32))
+    osc = orc.OracleScene(moved, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
+    osc.set_bvh4(nodes4, btri)
+    p = orc.default_params(n_elements=E, n_samples=S)
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=6, use_bvh=2, n_threads=16, want_ref=False)
+    p0 = orc.default_params(n_elements=E, n_samples=S, max_depth=1)
+    o0 = osc.trace_frame(p0, tr.pos, tr.dir, tex256, frame_id=6, use_bvh=2, n_threads=16, want_ref=False, want_fix=False)["stats"]
+    assert np.array_equal(h1, o["hits"])
+    for k in ("queries", "nodes_visited", "tris_tested"):
+        assert st[k] == o["stats"][k] - o0[k] + o0[k] // S, k
