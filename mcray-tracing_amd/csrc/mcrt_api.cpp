@@ -47,12 +47,12 @@ static Consts derive_consts(const mcrt_params &p)
     return c;
 }
 
-// Per-frame work set of ONE wavefront pipeline: path state, queues, rays, closest-hit words, segments, and the two streams it
-// runs on (k_march of bounce b runs on `side` beside k_trace of bounce b+1).  A context owns several so that the scan-lines of
-// a frame can be traced as independent groups whose kernels overlap (the long walks that end one group's bounce run beside the
-// bulk of another's).
+// Work set of ONE wavefront pipeline: path state, queues, rays, closest-hit words, march records (segments on request), and the
+// streams it runs on (k_march of bounce b runs on a low-priority side stream beside k_trace of bounce b+1).  A context can own
+// several, to trace the scan-lines of a pass as independent groups on separate streams (MCRT_GROUPS, a tuning knob: one group
+// measured best).
 struct Work {
-    hipStream_t stream = nullptr, side[MCRT_SIDE_STREAMS] = {};   // k_march of bounce b runs on side[b % n]: the tail of one overlaps the next
+    hipStream_t stream = nullptr, side[MCRT_SIDE_STREAMS] = {};   // k_march of bounce b runs on side[b % n] (n = 1 unless MCRT_MARCH_STREAMS says otherwise)
     hipEvent_t ev_bounce[MCRT_MAX_BOUNCES] = {}, ev_join[MCRT_SIDE_STREAMS] = {}, ev_done = nullptr;
     float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr;
     unsigned long long *d_key0 = nullptr, *d_key1 = nullptr;
