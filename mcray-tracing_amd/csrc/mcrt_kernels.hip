@@ -428,6 +428,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 #define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)                     /* mask of lanes in a walk        (ICMP_NE)  */
 #ifdef MCRT_STAMP
     unsigned long long sc_refill = 0, sc_p1 = 0, sc_p2 = 0, sc_n1 = 0, sc_n2 = 0, sc_outer = 0, sc_t0 = __builtin_readcyclecounter(), sc_act1 = 0, sc_act2 = 0;
+    unsigned long long sc_nodes = 0, sc_pops = 0, sc_pop_dead = 0; bool from_pop = false;
 #define STAMP(var) { const unsigned long long t_ = __builtin_readcyclecounter(); var += t_ - sc_t0; sc_t0 = t_; }
 #else
 #define STAMP(var)
@@ -552,6 +553,10 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                 int cand = (key == kmin) ? ref : 0;
                 cand |= dpp_i<QP_XOR1>(cand);
                 cand |= dpp_i<QP_XOR2>(cand);
+#ifdef MCRT_STAMP
+                if (j == 0) { sc_nodes++; if (from_pop) { sc_pops++; if (nh == 0) sc_pop_dead++; } }
+                from_pop = nh == 0;
+#endif
                 if (nh == 0) {
                     if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
                     else cur = CUR_IDLE;
@@ -604,6 +609,9 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
                 if (all) { best.frac = frac; best.tri = id; }
             }
             if (STATS && j == 0) st_tris += cnt;
+#ifdef MCRT_STAMP
+            from_pop = true;
+#endif
             if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
             else cur = CUR_IDLE;
         }
@@ -618,9 +626,11 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 #undef MCRT_ON_LEAF
 #undef MCRT_WALKING
 #ifdef MCRT_STAMP
+    const long long pop_x = wave_sum_i64((long long)sc_nodes), pop_y = wave_sum_i64((long long)sc_pops), pop_z = wave_sum_i64((long long)sc_pop_dead);
     if (lane == 0) {   // diagnostic build only: per-phase cycles and iteration counts, summed over wavefronts
         atomicAdd(&a.stamps[0], sc_refill); atomicAdd(&a.stamps[1], sc_p1); atomicAdd(&a.stamps[2], sc_p2); atomicAdd(&a.stamps[3], sc_n1);
         atomicAdd(&a.stamps[4], sc_n2); atomicAdd(&a.stamps[5], sc_outer); atomicAdd(&a.stamps[6], sc_act1); atomicAdd(&a.stamps[7], sc_act2); atomicAdd(&a.stamps[8], 1ull);
+        atomicAdd(&a.stamps[56], (unsigned long long)pop_x); atomicAdd(&a.stamps[57], (unsigned long long)pop_y); atomicAdd(&a.stamps[58], (unsigned long long)pop_z);
         const unsigned long long wc_end = wall_clock64();
         atomicMax(&a.stamps[16 + 4 * b + 2], wc_end); atomicAdd(&a.stamps[16 + 4 * b + 3], wc_end - wc_start);
     }
