@@ -6,24 +6,45 @@
 
 A "step" is one frame of the hot path over synthetic input already resident in HBM:
 clear -> trace (BVH closest-hit + interface sampling) -> RF accumulation -> [RCCL all-gather of the
-scan-line blocks when N > 1] -> PSF convolution.  Each rank traces 128 scan-lines x 1024 sample paths
-(weak scaling: the frame has 128*N scan-lines).  By default 32 consecutive frames are in flight per
-pass (mcrt_trace_frames: every launch carries 32 frames' rays; images are bit-identical to
-one-at-a-time tracing); `--frames-in-flight 1` is the strict latency mode, also reported in the
-JSON as `one_frame_at_a_time`.  The JSON line carries the live roofline figure of the
-dominant kernel (k_trace: counted algorithmic bytes / HIP-event kernel time) and a CPU baseline (the
-oracle = port of the reference algorithm, timed on this box's host cores on a bounded sample).
+scan-line blocks when N > 1] -> PSF convolution.  Weak scaling by default (each rank traces
+`--scanlines` = 128 scan-lines x 1024 sample paths; the frame has 128*N scan-lines);
+`--scanlines-total E` fixes the frame instead (strong scaling: BASELINE C4 = 256 x 8192,
+C5 = 512 x 16384 sharded over 2/4/8 GPUs).
+
+Frames are traced `--frames-in-flight` at a time (mcrt_trace_frames: every launch carries that many
+consecutive frames' rays; images are bit-identical to one-at-a-time tracing); K steps are cut into
+the fewest, evenly sized passes.  Passes are DOUBLE-BUFFERED: the all-gather + PSF convolution of
+pass k run on a second stream beside the trace of pass k+1.  The timed region is EXACTLY K steps
+between barrier + synchronize pairs; it is repeated (at least 5 times, at least ~0.6 s in total)
+and the MEDIAN repeat is reported.  `--frames-in-flight 1` is the strict latency mode, also
+reported as `one_frame_at_a_time`.
+
+The JSON line carries
+  roofline      dominant kernel (k_trace) against the roof that binds it -- VALU issue, calibrated by
+                tools/valu_roof.hip (profiles/round2/valu_roof.json) -- plus the measured HBM share
+                (`hbm_measured_frac`: fabric bytes from rocprofv3 PMC passes of this same command, taken
+                live in child processes at the same pass size) and the cache-served algorithmic rate;
+  cpu_baseline  the oracle (a port of the reference algorithm) on this box's host cores;
+  parity_check  frame 0 of the timed workload against the oracle, bit for bit.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMD = 1024           # 256 CUs x 4 SIMD-32
+TRACE_KERNEL = "k_trace<false"
 
 
 def build_workload(m, name):
@@ -41,13 +62,14 @@ def build_workload(m, name):
     return cfg, m.scene_io.build_scene(cfg, meshes), label
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--workload", default="random1m")
-    ap.add_argument("--scanlines", type=int, default=128, help="scan-lines per GPU")
+    ap.add_argument("--scanlines", type=int, default=128, help="scan-lines per GPU (weak scaling)")
+    ap.add_argument("--scanlines-total", type=int, default=0, help="scan-lines of the whole frame, sharded over the GPUs (strong scaling); overrides --scanlines")
     ap.add_argument("--rays", type=int, default=1024, help="sample paths per scan-line")
     ap.add_argument("--rows", type=int, default=465)
     ap.add_argument("--tex-n", type=int, default=256, help="texture edge in voxels (256 = the reference; smaller only for cache experiments)")
@@ -55,12 +77,81 @@ def main():
                     help="frames traced per pass (mcrt_trace_frames): a step is still ONE frame, but every kernel launch then carries the "
                          "rays of this many consecutive frames (1 = strict one-frame-at-a-time latency mode)")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="BVH builder: host binned SAH (default) or the device LBVH")
+    ap.add_argument("--min-time", type=float, default=0.6, help="the K-step timed region is repeated until this many seconds are covered (>= 5 repeats)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the extra one-frame-at-a-time measurement (profiling runs)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not take the live rocprofv3 PMC passes (HBM traffic, VALU instructions of k_trace)")
+    ap.add_argument("--no-overlap", action="store_true", help="gather + PSF on the trace stream (no double buffering)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the process rocprofv3 profiles: warm-up + one K-step region, nothing else
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for plumbing checks")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing check on a 1-GPU box: every rank uses GPU 0")
-    args = ap.parse_args()
+    ap.add_argument("--check-gather", action="store_true", help="rank 0 re-traces the last pass alone (all scan-lines in one process) and compares it with "
+                                                                "the sharded + gathered + convolved frames bit for bit (`gather_check` in the JSON)")
+    return ap.parse_args()
 
+
+def passes(count, F):
+    """split `count` frames into the fewest passes of at most F frames, as even as possible (20 with F=16 -> 10 + 10)"""
+    if count <= 0:
+        return []
+    n_pass = -(-count // F)
+    base, rem = divmod(count, n_pass)
+    return [base + (1 if i < rem else 0) for i in range(n_pass)]
+
+
+class Pipeline:
+    """trace -> gather -> PSF over double-buffered passes.  The context's kernels run on `s_trace`; the collective and the
+    convolution of a finished pass on `s_post`, ordered by events, so they overlap the next pass's trace."""
+
+    def __init__(self, torch, dist, ctx, psf, rank, world, E, e0, e1, R, F, backend, overlap):
+        from mcray_tracing_amd.dist import gather_rf
+        self.torch, self.dist, self.ctx, self.psf, self.gather_rf = torch, dist, ctx, psf, gather_rf
+        self.rank, self.world, self.E, self.e0, self.e1, self.R, self.F, self.backend = rank, world, E, e0, e1, R, F, backend
+        self.s_trace = torch.cuda.Stream()
+        self.s_post = torch.cuda.Stream() if overlap else self.s_trace
+        self.buf = [torch.zeros((F, e1 - e0, R), dtype=torch.float32, device="cuda") for _ in range(2)]
+        self.ev_traced = [torch.cuda.Event() for _ in range(2)]
+        self.ev_posted = [torch.cuda.Event() for _ in range(2)]
+        self.frames = None          # the last pass's gathered + convolved images [nf][E][R] (rank 0)
+        self.last = (0, 0)          # (first frame id, frames) of the last pass
+        self.k = 0
+        ctx.set_stream(self.s_trace.cuda_stream)
+
+    def run_pass(self, frame, nf):
+        torch, i = self.torch, self.k & 1
+        self.k += 1
+        rf = self.buf[i]
+        self.s_trace.wait_event(self.ev_posted[i])              # the pass that used this buffer two passes ago is done with it
+        self.ctx.set_stream(self.s_trace.cuda_stream)
+        self.ctx.trace_frames(frame, nf, rf, self.e0, self.e1)
+        self.ev_traced[i].record(self.s_trace)
+        self.s_post.wait_event(self.ev_traced[i])
+        with torch.cuda.stream(self.s_post):
+            # ONE collective per pass (RCCL all-gather over xGMI of the [nf][E/N][R] blocks), then the PSF on the gathered frames
+            frames = self.gather_rf(rf[:nf], self.E, self.R, self.dist if self.world > 1 else None)
+            if self.rank == 0:
+                self.ctx.set_stream(self.s_post.cuda_stream)
+                self.ctx.convolve_frames(frames, nf, self.E, self.R, self.psf.axial_kernel, self.psf.lateral_kernel)
+                self.ctx.set_stream(self.s_trace.cuda_stream)
+            self.frames = frames
+        self.last = (frame, nf)
+        self.ev_posted[i].record(self.s_post)
+
+    def run_steps(self, first, count, F=None):
+        f = first
+        for nf in passes(count, F or self.F):
+            self.run_pass(f, nf)
+            f += nf
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+
+def main():
+    args = parse_args()
     import numpy as np
     import torch
     import mcray_tracing_amd as m
@@ -85,9 +176,15 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+        seen = dist.get_world_size()
+        assert seen == world, "the process group has %d ranks, WORLD_SIZE says %d" % (seen, world)
 
-    E_local, S, R = args.scanlines, args.rays, args.rows
-    E = E_local * world
+    from mcray_tracing_amd.dist import shard_range
+    S, R = args.rays, args.rows
+    strong = args.scanlines_total > 0
+    E = args.scanlines_total if strong else args.scanlines * world
+    e0, e1 = shard_range(rank, world, E)
+    E_local = e1 - e0
     cfg, sd, label = build_workload(m, args.workload)
     tr = m.Transducer(E, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
     ctx = m.Context(local_rank)
@@ -99,117 +196,108 @@ def main():
     ctx.upload_texture(None, args.tex_n)
     ctx.set_transducer(tr.pos, tr.dir)
     psf = m.Psf(freq=tr.frequency)
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)
+    F = max(1, min(args.frames_in_flight, 64))
+    K, W = args.steps, args.warmup
+    pipe = Pipeline(torch, dist, ctx, psf, rank, world, E, e0, e1, R, F, args.backend, not args.no_overlap)
 
-    from mcray_tracing_amd.dist import shard_range
-    assert E % world == 0
-    e0, e1 = shard_range(rank, world, E)
-    F = max(1, args.frames_in_flight)
-    rf_local = torch.zeros((F, E_local, R), dtype=torch.float32, device="cuda")
+    if args.pmc_child:
+        # the process the PMC passes profile: the same warm-up and ONE K-step region, same pass sizes, nothing else
+        pipe.run_steps(1000, max(W, 1)); pipe.sync()
+        pipe.run_steps(0, K); pipe.sync()
+        ctx.close()
+        return
 
-    def step_batch(frame, nf):
-        """nf consecutive frames (nf = 1 unless --frames-in-flight): trace -> gather -> PSF convolution of each frame"""
-        ctx.trace_frames(frame, nf, rf_local, e0, e1)
-        if world > 1:
-            # ONE RCCL all-gather over xGMI per pass: every rank contributes its [nf][E/N][R] block; frame f of the result is the
-            # concatenation of the ranks' scan-line blocks, made contiguous for the convolution
-            gathered = torch.empty((world, nf, E_local, R), dtype=torch.float32, device="cuda")
-            if args.backend == "nccl":
-                dist.all_gather_into_tensor(gathered, rf_local[:nf].contiguous())
-            else:
-                parts = [torch.empty((nf, E_local, R)) for _ in range(world)]
-                dist.all_gather(parts, rf_local[:nf].cpu())
-                gathered = torch.stack(parts).cuda()
-            frames = gathered.permute(1, 0, 2, 3).reshape(nf, E, R).contiguous()
-        else:
-            frames = rf_local
-        if rank == 0:
-            ctx.convolve_frames(frames, nf, E, R, psf.axial_kernel, psf.lateral_kernel)      # all nf images in one launch per pass
-
-    def passes(count):
-        """split `count` frames into the fewest passes of at most F frames, as even as possible (20 with F=16 -> 10 + 10)"""
-        if count <= 0:
-            return []
-        n_pass = -(-count // F)
-        base, rem = divmod(count, n_pass)
-        return [base + (1 if i < rem else 0) for i in range(n_pass)]
-
-    def run_steps(first, count):
-        f = first
-        for nf in passes(count):
-            step_batch(f, nf)
-            f += nf
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- counted algorithmic bytes of the timed frames (instrumented build of the same kernel, untimed) ----
+    # ---- counted algorithmic work of the K timed frames (counting build of the same kernels, untimed) ----
     # (the counting build walks every ray once, i.e. exactly the oracle's node/triangle visits: the timed kernel may cut the
-    #  rays of a small bounce into pieces, whose extra visits are overhead, not algorithmic bytes)
+    #  rays of a small bounce into pieces, whose extra visits are overhead, not algorithmic work)
     ctx.enable_stats(True); ctx.get_stats(reset=True)
-    f = 0
-    for nf in passes(args.steps):
-        ctx.trace_frames(f, nf, rf_local, e0, e1)
-        f += nf
+    pipe.run_steps(0, K); pipe.sync()
     st = ctx.get_stats(reset=True)
     ctx.enable_stats(False)
     # Algorithmic bytes (SURVEY 8(d), adapted to the 128-B BVH4 nodes).  The dominant kernel is k_trace, launched once per
-    # bounce: per closest-hit query nodes*128 B + triangles*48 B + the 32-B ray read and 32-B hit record written.
-    trace_bytes_frame = (st["nodes_visited"] * 128 + st["tris_tested"] * 48 + st["queries"] * 64) / args.steps
+    # bounce and pass: per closest-hit query nodes*128 B + triangles*48 B + the 32-B ray read and 32-B hit record written.
+    trace_bytes_frame = (st["nodes_visited"] * 128 + st["tris_tested"] * 48 + st["queries"] * 64) / K
     # the rest of the frame, for the record: 64-B segment written + read, 8-B texture gather per RF step, RF block + bins
-    other_bytes_frame = (st["segments"] * 128 + st["rf_steps"] * 8) / args.steps + E_local * R * (4 + 8)
+    other_bytes_frame = (st["segments"] * 128 + st["rf_steps"] * 8) / K + E_local * R * (4 + 8)
 
-    run_steps(1000, args.warmup)
+    # ---- the timed region: EXACTLY K steps between barrier + synchronize pairs, repeated; the median repeat is reported ----
+    pipe.run_steps(1000, W)
     ctx.enable_timing(True); ctx.kernel_time(reset=True)
-    sync()
-    t0 = time.perf_counter()
-    run_steps(0, args.steps)
-    sync()
-    dt = time.perf_counter() - t0
-    k_ms, k_n = ctx.kernel_time(reset=True)
+    reps, total, n_rep = [], 0.0, 0
+    while n_rep < 5 or (total < args.min_time and n_rep < 200):
+        pipe.sync()
+        t0 = time.perf_counter()
+        pipe.run_steps(0, K)
+        pipe.sync()
+        dt = time.perf_counter() - t0
+        dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)       # MAX over ranks (every rank then takes the same loop decisions)
+        dt = float(dt_t.item())
+        reps.append(dt); total += dt; n_rep += 1
+    k_ms, k_n = ctx.kernel_time(reset=True)                    # HIP events around every k_trace launch, on the launching stream
     ctx.enable_timing(False)
-    launches_per_frame = k_n / args.steps                   # max_depth bounces (x groups) / frames per pass
+    dt = statistics.median(reps)
+    launches_per_frame = k_n / (K * n_rep)                     # max_depth bounces / frames per pass
     alg_bytes = trace_bytes_frame / launches_per_frame
 
-    dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-    dt = float(dt_t.item())
-
     if rank == 0:
-        rays = E * S * args.steps
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        gather_check = None
+        if args.check_gather:
+            # the sharded path against one process tracing every scan-line: same frames, bit for bit (PSF included)
+            f0, nf = pipe.last
+            torch.cuda.synchronize()                               # (rank 0 only: no collective here)
+            alone = torch.zeros((nf, E, R), dtype=torch.float32, device="cuda")
+            ctx.set_stream(pipe.s_trace.cuda_stream)
+            ctx.trace_frames(f0, nf, alone, 0, E)
+            ctx.convolve_frames(alone, nf, E, R, psf.axial_kernel, psf.lateral_kernel)
+            torch.cuda.synchronize()
+            gather_check = {"equal": bool(torch.equal(alone.view(torch.int32), pipe.frames.view(torch.int32))), "frames": nf, "first_frame": f0,
+                                   "scan_lines": E, "ranks": world, "backend": args.backend, "nonzero": int(torch.count_nonzero(alone).item())}
+        rays = E * S * K
+        alg_gbs = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        pass_sizes = passes(K, F)
         out = {
             "metric": "rays/sec (Monte-Carlo sample paths traced + accumulated + PSF-convolved per second)",
-            "value": rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "frames_per_sec": args.steps / dt, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value": rays / dt, "unit": "rays/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "frames_per_sec": K / dt, "higher_is_better": True,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s; %d scan-lines x %d rays per GPU, %d RF rows, max depth 10" % (label, E_local, S, R),
-                       "scan_lines_total": E, "rays_per_scan_line": S, "triangles": int(sd.n_tri), "parallelism": "scanline-shard x%d" % world, "frames_in_flight": F,
-                       "bvh_builder": args.bvh, "bvh_build_s": round(t_bvh, 3)},
-            "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms, "launches": k_n,
-                         "launches_per_frame": launches_per_frame, "trace_bytes_per_frame": trace_bytes_frame,
-                         "other_stage_bytes_per_frame": other_bytes_frame,
-                         "per_launch": {k: v / args.steps for k, v in st.items()}},
+                       "scan_lines_total": E, "rays_per_scan_line": S, "triangles": int(sd.n_tri), "parallelism": "scanline-shard x%d" % world,
+                       "frames_in_flight": F, "passes_per_timed_region": pass_sizes, "timed_region_repeats": n_rep,
+                       "timed_seconds_total": total, "repeat_ms_per_step_min_median_max": [min(reps) / K * 1e3, dt / K * 1e3, max(reps) / K * 1e3],
+                       "overlap_gather_psf_with_next_trace": not args.no_overlap, "bvh_builder": args.bvh, "bvh_build_s": round(t_bvh, 3)},
         }
+        roof = {"kernel": "k_trace", "kernel_ms": k_ms, "launches": k_n, "launches_per_frame": launches_per_frame,
+                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps_cache_served": alg_gbs,
+                "trace_bytes_per_frame": trace_bytes_frame, "other_stage_bytes_per_frame": other_bytes_frame,
+                "per_frame": {k: v / K for k, v in st.items()}}
+        pmc = None
+        if world == 1 and not args.no_pmc:
+            pmc = live_pmc(args)
+        if pmc is None:
+            pmc = committed_pmc(args, pass_sizes)
+        roof.update(roofline_from(pmc, k_ms, alg_gbs))
+        out["roofline"] = roof
         if world == 1 and F > 1 and not args.no_latency_leg:
             # the same workload strictly one frame at a time (each launch carries one frame's rays), for the record
-            for f in range(args.warmup):
-                step_batch(2000 + f, 1)
-            sync(); t1 = time.perf_counter()
-            for f in range(args.steps):
-                step_batch(f, 1)
-            sync(); dt1 = time.perf_counter() - t1
-            out["one_frame_at_a_time"] = {"value": E * S * args.steps / dt1, "unit": "rays/s", "ms_per_step": dt1 / args.steps * 1e3,
-                                          "frames_per_sec": args.steps / dt1}
+            pipe.run_steps(2000, min(W, 16), F=1)
+            lat = []
+            for _ in range(3):
+                pipe.sync(); t1 = time.perf_counter()
+                pipe.run_steps(0, K, F=1)
+                pipe.sync(); lat.append(time.perf_counter() - t1)
+            dt1 = statistics.median(lat)
+            out["one_frame_at_a_time"] = {"value": E * S * K / dt1, "unit": "rays/s", "ms_per_step": dt1 / K * 1e3, "frames_per_sec": K / dt1}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(m, sd, tr, ctx, S, R)
+            # frame 0 of the timed workload, traced the way the timed region traces it (first pass), before the PSF
+            ctx.set_stream(pipe.s_trace.cuda_stream)
+            ctx.trace_frames(0, pass_sizes[0], pipe.buf[0], e0, e1)
+            pipe.sync()
+            rf0 = pipe.buf[0][0].cpu().numpy()                 # [E][R]
+            out["cpu_baseline"], out["parity_check"] = cpu_baseline(m, sd, tr, ctx, S, R, rf0)
+        if gather_check is not None:
+            out["gather_check"] = gather_check
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
@@ -217,52 +305,153 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(args):
-    """HBM-side bytes per k_trace launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/round1/pmc_k_trace.json: (2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction applied); null for other workloads."""
-    if (args.workload, args.scanlines, args.rays, args.rows, args.gpus, args.frames_in_flight) != ("random1m", 128, 1024, 465, 1, 32):
-        return None
+# ------------------------------------------------------------------------------------------------ roofline
+def valu_calibration():
+    """profiles/round2/valu_roof.json (tools/valu_roof.hip on the MI355X): the VALU issue ceiling in wave-instructions per
+    cycle and SIMD, and the clock the chip holds while issuing at that rate"""
     try:
-        with open(os.path.join(ROOT, "profiles", "round1", "pmc_k_trace.json")) as f:
-            return json.load(f)["derived"]["traffic_bytes_per_k_trace_launch"]
+        with open(os.path.join(ROOT, "profiles", "round2", "valu_roof.json")) as f:
+            d = json.load(f)
+        best = None
+        for r in d["results"]:
+            if r["class"] == "v_fma_f32 independent" and r["waves_per_simd"] >= 2:
+                if best is None or r["simd_ipc"] > best["simd_ipc"]:
+                    best = r
+        mix = [r for r in d["results"] if r["class"].startswith("BVH4 node-step mix") and r["waves_per_simd"] == 5]
+        return {"ipc_per_simd": best["simd_ipc"], "clock_ghz": best["clock_ghz"], "source": "profiles/round2/valu_roof.json",
+                "node_step_mix_ipc_at_5_waves": mix[0]["simd_ipc"] if mix else None}
+    except Exception:
+        # MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles on the SIMD-32 once >= 2 waves share a SIMD; 2.4 GHz max clock
+        return {"ipc_per_simd": 0.5, "clock_ghz": 2.4, "source": "MI355X_MICROARCH.md (no calibration file)", "node_step_mix_ipc_at_5_waves": None}
+
+
+def roofline_from(pmc, k_ms, alg_gbs):
+    """k_trace against the roof that binds it.  The BVH is served from L1/L2/Infinity Cache (fabric traffic is a few per cent of
+    the HBM peak), so the binding roof is VALU issue: achieved = wave-level VALU instructions per second (SQ_INSTS_VALU of the
+    launch / its duration), peak = 1024 SIMDs x calibrated instructions per cycle x calibrated clock."""
+    cal = valu_calibration()
+    peak = N_SIMD * cal["ipc_per_simd"] * cal["clock_ghz"]            # G wave-instructions / s
+    r = {"bound": "valu", "unit": "Ginstr/s", "peak": peak, "peak_source": cal,
+         "hbm_peak_GBps": HBM_PEAK_GBS, "algorithmic_over_hbm_peak": alg_gbs / HBM_PEAK_GBS}
+    if pmc and pmc.get("valu_instructions_per_launch") and k_ms > 0:
+        ach = pmc["valu_instructions_per_launch"] / (k_ms * 1e-3) / 1e9
+        r.update({"achieved": ach, "frac": ach / peak})
+    else:
+        r.update({"achieved": None, "frac": None})
+    if pmc and pmc.get("traffic_bytes_per_launch") is not None and k_ms > 0:
+        r["traffic"] = pmc["traffic_bytes_per_launch"]
+        r["hbm_measured_GBps"] = pmc["traffic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9
+        r["hbm_measured_frac"] = r["hbm_measured_GBps"] / HBM_PEAK_GBS
+    else:
+        r["traffic"] = None; r["hbm_measured_frac"] = None
+    r["pmc"] = pmc
+    return r
+
+
+def _pmc_rows(d):
+    agg = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if TRACE_KERNEL in row["Kernel_Name"]:
+                agg.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    return agg
+
+
+def live_pmc(args):
+    """rocprofv3 --pmc passes of THIS command (same workload, same pass sizes) in child processes; per k_trace launch:
+    fabric-side bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE reports half the bytes of wide reads,
+    MI355X_MICROARCH.md, HBM section; separate passes because the TCC counters do not fit one) and SQ_INSTS_VALU."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", str(args.steps), "--warmup", str(min(args.warmup, args.frames_in_flight)),
+             "--workload", args.workload, "--scanlines", str(args.scanlines), "--scanlines-total", str(args.scanlines_total), "--rays", str(args.rays),
+             "--rows", str(args.rows), "--tex-n", str(args.tex_n), "--frames-in-flight", str(args.frames_in_flight), "--bvh", args.bvh]
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="mcrt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for name, ctrs in (("sq", ["SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES", "SQ_WAVES"]), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+            d = os.path.join(tmp, name)
+            r = subprocess.run([exe, "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            rows = _pmc_rows(d)
+            if r.returncode != 0 or not rows:
+                return None
+            for c, v in rows.items():
+                got[c] = (sum(v) / len(v), len(v))
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    try:
+        return {"source": "live: rocprofv3 --pmc child passes of this command (same pass sizes), per k_trace launch",
+                "launches_profiled": got["SQ_INSTS_VALU"][1],
+                "valu_instructions_per_launch": got["SQ_INSTS_VALU"][0], "busy_cu_cycles_per_launch": got["SQ_BUSY_CU_CYCLES"][0] / 256.0,
+                "fetch_size_kib": got["FETCH_SIZE"][0], "write_size_kib": got["WRITE_SIZE"][0],
+                "traffic_bytes_per_launch": (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0}
+    except KeyError:
+        return None
+
+
+def committed_pmc(args, pass_sizes):
+    """fallback when no live pass could be taken: the committed passes, ONLY when they were taken on this configuration and
+    pass size -- labelled as such"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round2", "pmc_bench.json")) as f:
+            d = json.load(f)
+        key = [args.workload, args.scanlines, args.scanlines_total, args.rays, args.rows, args.gpus, pass_sizes]
+        if d.get("config_key") != key:
+            return None
+        p = dict(d["pmc"])
+        p["source"] = "file: profiles/round2/pmc_bench.json (%s)" % d.get("taken_at", "?")
+        return p
     except Exception:
         return None
 
 
-def cpu_baseline(m, sd, tr, ctx, S, R):
+# ------------------------------------------------------------------------------------------------ CPU baseline + parity
+def cpu_baseline(m, sd, tr, ctx, S, R, rf0):
     """The oracle (a port of the reference algorithm; the reference binary itself needs Bullet + OpenCV and cannot be
-    built) timed on this box's host cores on a bounded sample of the same workload: the first scan-lines of frame 0,
-    OpenMP over scan-lines, walking the same BVH as the GPU."""
+    built) timed on this box's host cores on a bounded sample of the same workload: whole frames, tasks = (scan-line x block
+    of samples) so that every core has work, walking the same BVH as the GPU; at least 5 s.  Its frame 0 doubles as the
+    parity check of the timed workload: the GPU's frame-0 RF image (fixed-point contract) must equal it bit for bit."""
+    import numpy as np
     from oracle import orc
     cores = os.cpu_count() or 1
     nodes, btri, _ = ctx.get_bvh()
     osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
     osc.set_bvh4(ctx.get_bvh4()[0])
     tex = orc.texture(256)
-    n_el = min(tr.n_elements, max(cores, 8))
-    p = orc.default_params(n_elements=tr.n_elements, n_samples=S, n_rows=R)
-    osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=99, e_begin=0, e_end=min(n_el, 16), use_bvh=2, n_threads=cores, want_hits=False)   # untimed: thread pool, page faults
+    E = tr.n_elements
+    p = orc.default_params(n_elements=E, n_samples=S, n_rows=R)
+    kw = dict(use_bvh=2, n_threads=cores, want_hits=False, want_ref=False)
+    osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=99, e_begin=0, e_end=min(E, 8), **kw)   # untimed: thread pool, page faults
     t0 = time.perf_counter()
-    osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=0, e_begin=0, e_end=n_el, use_bvh=2, n_threads=cores, want_hits=False)
-    dt = time.perf_counter() - t0
-    # keep the sample between ~10 and 30 s of CPU work
-    reps = 1
-    while dt * cores * reps < 10.0 and reps < 64:
-        reps *= 2
-    if reps > 1:
-        t0 = time.perf_counter()
-        for i in range(reps):
-            osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=i, e_begin=0, e_end=n_el, use_bvh=2, n_threads=cores, want_hits=False)
+    frames, o0 = 0, None
+    while True:
+        o = osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=frames, **kw)
+        if frames == 0:
+            o0 = o
+        frames += 1
         dt = time.perf_counter() - t0
-    # (a) of BASELINE.md's plan: one thread, how the reference itself runs (scene.cpp:74 has its OpenMP pragma commented out)
-    n1 = min(tr.n_elements, 16)
-    t0 = time.perf_counter()
-    osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=0, e_begin=0, e_end=n1, use_bvh=2, n_threads=1, want_hits=False)
-    dt1 = time.perf_counter() - t0
-    return {"value": n_el * S * reps / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+        if dt >= 5.0 or frames >= 64:
+            break
+    want = o0["rf"]                                             # [R][E]
+    got = np.ascontiguousarray(rf0.T)
+    parity = {"rf_bit_exact": bool(np.array_equal(got.view(np.uint32), want.view(np.uint32))), "frame": 0, "scan_lines": int(E),
+              "paths": int(E * S), "what": "fixed-point RF image of frame 0 of the timed workload (traced in the timed pass size), GPU vs oracle, before the PSF"}
+    # one thread, how the reference itself runs (scene.cpp:74 has its OpenMP pragma commented out)
+    n1 = min(E, 8)
+    t1 = time.perf_counter()
+    osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=0, e_begin=0, e_end=n1, use_bvh=2, n_threads=1, want_hits=False, want_ref=False)
+    dt1 = time.perf_counter() - t1
+    base = {"value": E * S * frames / dt, "unit": "rays/s", "cores": cores, "kind": "port",
             "single_thread": {"value": n1 * S / dt1, "unit": "rays/s", "cores": 1, "sample": "%d scan-lines x %d rays, one thread" % (n1, S), "seconds": dt1},
-            "sample": "%d scan-lines x %d rays x %d frame(s) of the same workload, OpenMP over scan-lines (trace + RF accumulation, no PSF)" % (n_el, S, reps),
+            "sample": "%d whole frame(s) of %d scan-lines x %d rays of the same workload, OpenMP over (scan-line x sample-block) tasks on %d threads "
+                      "(trace + RF accumulation, no PSF)" % (frames, E, S, cores),
             "seconds": dt}
+    return base, parity
 
 
 if __name__ == "__main__":

@@ -28,7 +28,8 @@ int set_error(int code, const char *fmt, ...)
 }  // namespace mcrt
 using mcrt::set_error;
 
-#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return set_error(MCRT_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+// (an allocation the device cannot satisfy is MCRT_ERR_NOMEM, every other HIP failure MCRT_ERR_HIP)
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); return set_error(e_ == hipErrorOutOfMemory ? MCRT_ERR_NOMEM : MCRT_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
 #define CTX_TRY(ctx) do { if (!(ctx)) return set_error(MCRT_ERR_INVALID, "null context"); HIP_TRY(hipSetDevice((ctx)->device)); } while (0)
 
 struct Consts {   // main.cpp:23-37, rfimage.h:48-51,178-180 evaluated at run time
@@ -57,11 +58,32 @@ struct Work {
     float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr;
     unsigned long long *d_key0 = nullptr, *d_key1 = nullptr;
     uint32_t *d_q = nullptr, *d_counts = nullptr, *d_seg_count = nullptr, *d_cursors = nullptr;
-    mcrt_segment *d_segs = nullptr; float4 *d_mrec = nullptr; size_t paths = 0; uint32_t depth = 0;
+    mcrt_segment *d_segs = nullptr; size_t segs_cap = 0;       // [paths][depth], only for the callers that ask for segments
+    int32_t *d_hits = nullptr; size_t hits_cap = 0;            // [paths][depth], only for the callers that ask for hit indices
+    float4 *d_mrec = nullptr; size_t paths = 0; uint32_t depth = 0;
 };
+
+// tuning knobs from the environment, read ONCE at mcrt_create (never on the frame path)
+struct Knobs {
+    uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 4096;
+    bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false;
+};
+static Knobs read_knobs()
+{
+    Knobs k;
+    if (const char *e = getenv("MCRT_KSPLIT_LIMIT")) { long v = atol(e); if (v >= 0 && v <= MCRT_KSPLIT_MAX) k.ksplit_limit = (uint32_t)v; }   // 0 = off
+    if (const char *e = getenv("MCRT_TRACE_BLOCKS")) { int v = atoi(e); if (v >= 1) k.trace_blocks = (uint32_t)v; }
+    if (const char *e = getenv("MCRT_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 16) k.groups = (uint32_t)v; }
+    if (const char *e = getenv("MCRT_MARCH_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= MCRT_SIDE_STREAMS) k.march_streams = (uint32_t)v; }
+    if (const char *e = getenv("MCRT_MARCH_BLOCKS")) { int v = atoi(e); if (v >= 1) k.march_blocks = (uint32_t)v; }
+    k.no_overlap = getenv("MCRT_NO_OVERLAP") != nullptr; k.no_priority = getenv("MCRT_NO_PRIORITY") != nullptr;
+    k.no_fast_div = getenv("MCRT_NO_FAST_DIV") != nullptr; k.no_lean = getenv("MCRT_NO_LEAN") != nullptr;
+    return k;
+}
 
 struct mcrt_ctx {
     int device = 0;
+    Knobs knobs;
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<Work> work;                               // one per concurrent scan-line group (see mcrt_trace_frame)
     hipEvent_t ev_start = nullptr;
@@ -121,8 +143,8 @@ static int prepare_tables(mcrt_ctx *c)
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
         hipFree(d_bad);
-        c->fast_div = (bad == 0) && !getenv("MCRT_NO_FAST_DIV");
-        c->fast_div_all = c->fast_div && c->p.tex_res > 1e-16f && !getenv("MCRT_NO_LEAN");
+        c->fast_div = (bad == 0) && !c->knobs.no_fast_div;
+        c->fast_div_all = c->fast_div && c->p.tex_res > 1e-16f && !c->knobs.no_lean;
         c->verified_res = c->p.tex_res;
     }
     if (c->have_scene && (!c->mtab_valid || c->mtab_key[0] != c->c.axial_res_f || c->mtab_key[1] != c->p.frequency)) {
@@ -173,6 +195,7 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     mcrt_ctx *c = new (std::nothrow) mcrt_ctx();
     if (!c) return set_error(MCRT_ERR_NOMEM, "out of host memory");
     c->device = device;
+    c->knobs = read_knobs();
     if (prop.multiProcessorCount > 0) c->n_cu = (uint32_t)prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(MCRT_ERR_HIP, "hipStreamCreate failed"); }
     c->stream = c->own_stream;
@@ -181,8 +204,8 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     mcrt_default_params(&c->p);
     c->c = derive_consts(c->p);
     c->stream = c->own_stream;
-    if (hipMalloc(&c->d_stats, 128 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->d_stats, 0, 128 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc(&c->d_error, 4) != hipSuccess || hipMemset(c->d_error, 0, 4) != hipSuccess) {
+    if (hipMalloc(&c->d_stats, 128 * sizeof(unsigned long long)) != hipSuccess || hipMemsetAsync(c->d_stats, 0, 128 * sizeof(unsigned long long), c->stream) != hipSuccess ||
+        hipMalloc(&c->d_error, 4) != hipSuccess || hipMemsetAsync(c->d_error, 0, 4, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
         hipStreamDestroy(c->own_stream); delete c; return set_error(MCRT_ERR_HIP, "hipMalloc failed");
     }
     { int rc = prepare_tables(c); if (rc) { mcrt_destroy(c); return rc; } }
@@ -193,9 +216,9 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
 static void free_work_buffers(Work &w)
 {
     hipFree(w.d_st0); hipFree(w.d_st1); hipFree(w.d_st2); hipFree(w.d_ray0); hipFree(w.d_ray1); hipFree(w.d_key0); hipFree(w.d_key1);
-    hipFree(w.d_q); hipFree(w.d_counts); hipFree(w.d_seg_count); hipFree(w.d_cursors); w.d_cursors = nullptr; hipFree(w.d_segs); hipFree(w.d_mrec);
+    hipFree(w.d_q); hipFree(w.d_counts); hipFree(w.d_seg_count); hipFree(w.d_cursors); w.d_cursors = nullptr; hipFree(w.d_segs); hipFree(w.d_hits); hipFree(w.d_mrec);
     w.d_st0 = w.d_st1 = w.d_st2 = w.d_ray0 = w.d_ray1 = nullptr; w.d_key0 = w.d_key1 = nullptr; w.d_q = w.d_counts = w.d_seg_count = nullptr;
-    w.d_segs = nullptr; w.d_mrec = nullptr; w.paths = 0; w.depth = 0;
+    w.d_segs = nullptr; w.segs_cap = 0; w.d_hits = nullptr; w.hits_cap = 0; w.d_mrec = nullptr; w.paths = 0; w.depth = 0;
 }
 
 static void free_work(mcrt_ctx *c)
@@ -220,7 +243,7 @@ static int get_work(mcrt_ctx *c, size_t g, Work **out)
         // their workgroups must not queue behind k_march's (measured: k_shade took 0.4-0.7 ms instead of 0.1 ms when they did)
         int prio_low = 0, prio_high = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-        if (getenv("MCRT_NO_PRIORITY")) prio_low = 0;   // tuning knob
+        if (c->knobs.no_priority) prio_low = 0;   // tuning knob
         for (int i = 0; i < MCRT_SIDE_STREAMS; i++) { HIP_TRY(hipStreamCreateWithPriority(&w.side[i], hipStreamNonBlocking, prio_low)); HIP_TRY(hipEventCreateWithFlags(&w.ev_join[i], hipEventDisableTiming)); }
         for (int i = 0; i < MCRT_MAX_BOUNCES; i++) HIP_TRY(hipEventCreateWithFlags(&w.ev_bounce[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
@@ -260,7 +283,7 @@ static int check_device_error(mcrt_ctx *c)
 {
     uint32_t e = 0;
     HIP_TRY(hipMemcpy(&e, c->d_error, 4, hipMemcpyDeviceToHost));
-    if (e) { HIP_TRY(hipMemset(c->d_error, 0, 4)); return set_error(MCRT_ERR_LIMIT, "device error flag 0x%x: BVH traversal stack overflow", e); }
+    if (e) { HIP_TRY(hipMemsetAsync(c->d_error, 0, 4, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); return set_error(MCRT_ERR_LIMIT, "device error flag 0x%x: BVH traversal stack overflow", e); }
     return MCRT_OK;
 }
 extern "C" int mcrt_synchronize(mcrt_ctx *c) { CTX_TRY(c); HIP_TRY(hipStreamSynchronize(c->stream)); return check_device_error(c); }
@@ -551,19 +574,36 @@ static int check_ready(mcrt_ctx *c, uint32_t e0, uint32_t e1)
     return MCRT_OK;
 }
 
-static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne)
+// out: 0 = RF image only, 1 = + hit indices, 2 = + the segment table (64 B per path and bounce: only allocated when asked for)
+static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne, int out)
 {
     const size_t np = (size_t)ne * c->p.n_samples;
-    if (np <= w.paths && c->p.max_depth <= w.depth) return MCRT_OK;
-    HIP_TRY(hipDeviceSynchronize());
-    free_work_buffers(w);
     const uint32_t B = c->p.max_depth;
+    if (out >= 2 && w.segs_cap < np * B) {
+        HIP_TRY(hipDeviceSynchronize());
+        hipFree(w.d_segs); w.d_segs = nullptr; w.segs_cap = 0;
+        HIP_TRY(hipMalloc(&w.d_segs, sizeof(mcrt_segment) * np * B));
+        w.segs_cap = np * B;
+    }
+    if (out >= 1 && w.hits_cap < np * B) {
+        HIP_TRY(hipDeviceSynchronize());
+        hipFree(w.d_hits); w.d_hits = nullptr; w.hits_cap = 0;
+        HIP_TRY(hipMalloc(&w.d_hits, 4 * np * B));
+        w.hits_cap = np * B;
+    }
+    if (np <= w.paths && B <= w.depth) return MCRT_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    {   // (the optional tables survive a re-allocation of the rest when they are large enough)
+        mcrt_segment *sg = w.d_segs; const size_t sc = w.segs_cap; int32_t *ht = w.d_hits; const size_t hc = w.hits_cap;
+        w.d_segs = nullptr; w.d_hits = nullptr;
+        free_work_buffers(w);
+        w.d_segs = sg; w.segs_cap = sc; w.d_hits = ht; w.hits_cap = hc;
+    }
     HIP_TRY(hipMalloc(&w.d_st0, 32 * np)); HIP_TRY(hipMalloc(&w.d_st1, 32 * np)); HIP_TRY(hipMalloc(&w.d_st2, 32 * np));   // two halves: bounce parity
     HIP_TRY(hipMalloc(&w.d_ray0, 32 * np)); HIP_TRY(hipMalloc(&w.d_ray1, 32 * np)); HIP_TRY(hipMalloc(&w.d_key0, 8 * np)); HIP_TRY(hipMalloc(&w.d_key1, 8 * np));
     HIP_TRY(hipMalloc(&w.d_q, 8 * np)); HIP_TRY(hipMalloc(&w.d_seg_count, 4 * np));
     HIP_TRY(hipMalloc(&w.d_counts, 4 * (MCRT_MAX_BOUNCES + 1)));
     HIP_TRY(hipMalloc(&w.d_cursors, 4 * (size_t)MCRT_MAX_BOUNCES * MCRT_XCDS * MCRT_CURSOR_STRIDE));
-    HIP_TRY(hipMalloc(&w.d_segs, sizeof(mcrt_segment) * np * B));
     HIP_TRY(hipMalloc(&w.d_mrec, 48 * np * B));
     w.paths = np; w.depth = B;
     return MCRT_OK;
@@ -578,16 +618,15 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     a.acc = c->d_acc; a.flags = c->d_flags;                 // the frame block [n_frames][acc_ne][R]; this group owns columns e0-acc_e0 ...
     a.acc_stride = acc_ne; a.acc_off = e0 - acc_e0;
     a.st0 = w.d_st0; a.st1 = w.d_st1; a.st2 = w.d_st2; a.queue = w.d_q;
-    a.ray0 = w.d_ray0; a.ray1 = w.d_ray1; a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.cursors = w.d_cursors; a.segs = w.d_segs; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
+    a.ray0 = w.d_ray0; a.ray1 = w.d_ray1; a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.cursors = w.d_cursors; a.segs = w.d_segs; a.hits = w.d_hits; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
     a.stats = c->d_stats; a.error_flag = c->d_error; a.stamps = c->d_stats + 8;
     a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
     a.e_begin = e0; a.ne_frame = e1 - e0; a.ne = (e1 - e0) * n_frames;   // n_frames consecutive frame ids traced as one pass
-    a.ksplit_limit = MCRT_KSPLIT_DEFAULT;   // bounces with fewer rays than this are cut into pieces (see k_trace)
-    if (const char *e = getenv("MCRT_KSPLIT_LIMIT")) { long v = atol(e); if (v >= 0 && v <= MCRT_KSPLIT_MAX) a.ksplit_limit = (uint32_t)v; }   // tuning knob; 0 = off
+    a.ksplit_limit = c->knobs.ksplit_limit;   // bounces with fewer rays than this are cut into pieces (see k_trace)
     if (c->stats_on) a.ksplit_limit = 0;   // counting mode = one walk per ray, so the counts are those of a plain closest-hit walk
     for (int i = 0; i < 3; i++) { a.scene_lo[i] = c->scene_lo[i]; a.scene_hi[i] = c->scene_hi[i]; }
-    a.trace_blocks = c->n_cu * 5u;   // persistent k_trace: 5 waves/SIMD = 5 four-wave workgroups per CU (1280 on the MI355X's 256 CUs)
-    if (const char *e = getenv("MCRT_TRACE_BLOCKS")) { int v = atoi(e); if (v >= 1) a.trace_blocks = (uint32_t)v; }   // tuning knob
+    a.trace_blocks = c->knobs.trace_blocks ? c->knobs.trace_blocks : c->n_cu * 5u;   // persistent k_trace: 5 waves/SIMD = 5 four-wave workgroups per CU (1280 on the MI355X's 256 CUs)
+    a.march_blocks = c->knobs.march_blocks;
     a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n; a.tex_mask = (c->tex_n & (c->tex_n - 1u)) == 0u ? c->tex_n - 1u : 0u;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
     a.freq = c->p.frequency; a.eps = c->p.intensity_epsilon; a.I0 = c->p.initial_intensity; a.offs = c->p.ray_start_offset;
@@ -604,11 +643,7 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     a.max_travel = c->c.max_travel_us; a.sos_d = (double)c->p.speed_of_sound; a.inv_row_dt = 1.0 / c->c.row_dt_us;
 }
 
-static uint32_t side_streams()
-{
-    static const uint32_t n = [] { uint32_t v = MCRT_SIDE_STREAMS_DEFAULT; if (const char *e = getenv("MCRT_MARCH_STREAMS")) { int x = atoi(e); if (x >= 1 && x <= MCRT_SIDE_STREAMS) v = (uint32_t)x; } return v; }();   // tuning knob
-    return n;
-}
+static uint32_t side_streams(const mcrt_ctx *c) { return c->knobs.march_streams; }
 
 // one bounce of one group: k_trace + k_shade on the group's stream, k_march of the finished segments on its side stream.
 // With timing enabled every k_trace launch (the dominant kernel) is bracketed by HIP events on the stream it is launched on.
@@ -630,7 +665,7 @@ static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArg
     HIP_TRY(mcrt::launch_shade(a, b, c->stats_on, st));
     if (accumulate && overlap) {   // the segments of bounce b are final: accumulate them beside the next bounce's walk
         HIP_TRY(hipEventRecord(w.ev_bounce[b], st));
-        hipStream_t side = w.side[b % side_streams()];
+        hipStream_t side = w.side[b % side_streams(c)];
         HIP_TRY(hipStreamWaitEvent(side, w.ev_bounce[b], 0));
         HIP_TRY(mcrt::launch_march(a, b, c->stats_on, side));
     } else if (accumulate) {
@@ -642,21 +677,22 @@ static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArg
 // scene::cast_rays (scene.cpp:50-183) [+ the accumulation loop] for scan-lines [e0,e1), split into `groups` independent
 // pipelines whose kernels run concurrently.  Everything is ordered after what is already queued on the context's stream, and
 // the context's stream waits for all of it.
-static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, bool accumulate, uint32_t groups, bool want_segs)
+static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, bool accumulate, uint32_t groups, int out)
 {
     const uint32_t ne = e1 - e0;
     if (groups > ne) groups = ne;
     if (groups < 1) groups = 1;
     if (groups > 16) groups = 16;
-    const bool overlap = !getenv("MCRT_NO_OVERLAP");
+    const bool overlap = !c->knobs.no_overlap;
     std::vector<mcrt::FrameArgs> args(groups);
     std::vector<Work *> ws(groups);
     for (uint32_t g = 0; g < groups; g++) {
         int rc = get_work(c, g, &ws[g]); if (rc) return rc;
         const uint32_t b0 = e0 + (uint32_t)(((uint64_t)ne * g) / groups), b1 = e0 + (uint32_t)(((uint64_t)ne * (g + 1)) / groups);
-        rc = ensure_work(c, *ws[g], (b1 - b0) * n_frames); if (rc) return rc;
+        rc = ensure_work(c, *ws[g], (b1 - b0) * n_frames, out); if (rc) return rc;
         fill_args(c, *ws[g], args[g], frame, n_frames, b0, b1, e0, ne);
-        args[g].want_segs = want_segs ? 1u : 0u;
+        args[g].want_segs = out >= 2 ? 1u : 0u;
+        if (out < 1) args[g].hits = nullptr;
     }
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
     for (uint32_t g = 0; g < groups; g++) {
@@ -671,7 +707,7 @@ static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0
     for (uint32_t g = 0; g < groups; g++) {
         hipStream_t st = g == 0 ? c->stream : ws[g]->stream;
         if (accumulate && overlap) {
-            for (uint32_t i = 0; i < side_streams(); i++) {
+            for (uint32_t i = 0; i < side_streams(c); i++) {
                 HIP_TRY(hipEventRecord(ws[g]->ev_join[i], ws[g]->side[i]));
                 HIP_TRY(hipStreamWaitEvent(st, ws[g]->ev_join[i], 0));
             }
@@ -686,9 +722,7 @@ static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0
 
 static uint32_t frame_groups(const mcrt_ctx *c)
 {
-    uint32_t g = MCRT_GROUPS_DEFAULT;
-    if (const char *e = getenv("MCRT_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 16) g = (uint32_t)v; }   // tuning knob
-    return c->stats_on ? 1u : g;
+    return c->stats_on ? 1u : c->knobs.groups;
 }
 
 extern "C" int mcrt_trace_frames(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, float *rf_dev)
@@ -699,7 +733,7 @@ extern "C" int mcrt_trace_frames(mcrt_ctx *c, uint32_t frame, uint32_t n_frames,
     if (n_frames == 0 || n_frames > 64) return set_error(MCRT_ERR_LIMIT, "n_frames must be 1..64");
     const uint32_t lines = (e1 - e0) * n_frames;
     rc = ensure_acc(c, lines); if (rc) return rc;
-    rc = run_frame(c, frame, n_frames, e0, e1, true, frame_groups(c), false); if (rc) return rc;
+    rc = run_frame(c, frame, n_frames, e0, e1, true, frame_groups(c), 0); if (rc) return rc;
     HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, lines, c->p.n_rows, c->stream));
     c->acc_clean_ne = lines; c->acc_clean_rows = c->p.n_rows;
     return MCRT_OK;
@@ -710,26 +744,26 @@ extern "C" int mcrt_trace_frame(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32
     return mcrt_trace_frames(c, frame, 1, e0, e1, rf_dev);
 }
 
-// copies the segment table (work set 0) to the host: segs [ne][S][B], seg_count [ne][S], hits [ne][S][B] (= segment.tri, -2 beyond the path's end)
+// copies the per-path tables (work set 0) to the host: segs [ne][S][B], seg_count [ne][S], hits [ne][S][B] (= segment.tri, -2 beyond the path's end)
 static int copy_out(mcrt_ctx *c, uint32_t ne, int32_t *hits, mcrt_segment *segs, uint32_t *seg_count)
 {
     const size_t np = (size_t)ne * c->p.n_samples, B = c->p.max_depth;
     const Work &w = c->work[0];
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc = check_device_error(c); if (rc) return rc;
-    std::vector<mcrt_segment> tmp;
     std::vector<uint32_t> cnt;
-    if (!segs && hits) { tmp.resize(np * B); segs = tmp.data(); }
-    if (!seg_count && hits) { cnt.resize(np); seg_count = cnt.data(); }
+    if (!seg_count && (hits || segs)) { cnt.resize(np); seg_count = cnt.data(); }
     if (seg_count) HIP_TRY(hipMemcpy(seg_count, w.d_seg_count, np * 4, hipMemcpyDeviceToHost));
     if (segs) {
         HIP_TRY(hipMemcpy(segs, w.d_segs, np * B * sizeof(mcrt_segment), hipMemcpyDeviceToHost));
         for (size_t p = 0; p < np; p++)                         // slots beyond a path's end are unspecified on the device
             for (size_t b = seg_count[p]; b < B; b++) memset(&segs[p * B + b], 0, sizeof(mcrt_segment));
     }
-    if (hits)
+    if (hits) {
+        HIP_TRY(hipMemcpy(hits, w.d_hits, np * B * 4, hipMemcpyDeviceToHost));
         for (size_t p = 0; p < np; p++)
-            for (size_t b = 0; b < B; b++) hits[p * B + b] = b < seg_count[p] ? segs[p * B + b].tri : -2;
+            for (size_t b = seg_count[p]; b < B; b++) hits[p * B + b] = -2;
+    }
     return MCRT_OK;
 }
 
@@ -740,7 +774,7 @@ extern "C" int mcrt_trace_frame_debug(mcrt_ctx *c, uint32_t frame, uint32_t e0, 
     int rc = check_ready(c, e0, e1); if (rc) return rc;
     if (!rf_dev) return set_error(MCRT_ERR_INVALID, "null rf_dev");
     rc = ensure_acc(c, e1 - e0); if (rc) return rc;
-    rc = run_frame(c, frame, 1, e0, e1, true, 1, true); if (rc) return rc;   // one group: the segment table is contiguous
+    rc = run_frame(c, frame, 1, e0, e1, true, 1, segs ? 2 : 1); if (rc) return rc;   // one group: the per-path tables are contiguous
     HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, e1 - e0, c->p.n_rows, c->stream));
     c->acc_clean_ne = e1 - e0; c->acc_clean_rows = c->p.n_rows;
     return copy_out(c, e1 - e0, hits, segs, seg_count);
@@ -750,7 +784,7 @@ extern "C" int mcrt_cast_rays(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32_t
 {
     CTX_TRY(c);
     int rc = check_ready(c, e0, e1); if (rc) return rc;
-    rc = run_frame(c, frame, 1, e0, e1, false, 1, true); if (rc) return rc;
+    rc = run_frame(c, frame, 1, e0, e1, false, 1, segs ? 2 : 1); if (rc) return rc;
     return copy_out(c, e1 - e0, hits, segs, seg_count);
 }
 
@@ -874,7 +908,7 @@ extern "C" int mcrt_get_stats(mcrt_ctx *c, mcrt_stats *out, int reset)
     unsigned long long v[6];
     HIP_TRY(hipMemcpy(v, c->d_stats, sizeof v, hipMemcpyDeviceToHost));
     if (out) { out->queries = v[0]; out->nodes_visited = v[1]; out->tris_tested = v[2]; out->segments = v[3]; out->rf_steps = v[4]; out->hits = v[5]; }
-    if (reset) HIP_TRY(hipMemset(c->d_stats, 0, sizeof v));
+    if (reset) { HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof v, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     return MCRT_OK;
 }
 
@@ -884,7 +918,7 @@ extern "C" int mcrt_debug_stamps(mcrt_ctx *c, uint64_t out[80], int reset)
     CTX_TRY(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, c->d_stats + 8, 80 * 8, hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(c->d_stats + 8, 0, 80 * 8));
+    if (reset) { HIP_TRY(hipMemsetAsync(c->d_stats + 8, 0, 80 * 8, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     return MCRT_OK;
 }
 

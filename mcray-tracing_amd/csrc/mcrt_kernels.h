@@ -24,7 +24,8 @@ struct FrameArgs {
     const uint32_t *tri_slot;  // [T] triangle id -> position in the leaf-order triangle array
     uint32_t *counts;          // [MAX_BOUNCES+1] live rays per bounce
     uint32_t *cursors;         // [MAX_BOUNCES][MCRT_XCDS][MCRT_CURSOR_STRIDE] queue cursors of the persistent walk, one per XCD sub-queue
-    mcrt_segment *segs;        // [np][B]   written only when want_segs (mcrt_cast_rays / mcrt_trace_frame_debug)
+    mcrt_segment *segs;        // [np][B]   written only when want_segs (mcrt_cast_rays / mcrt_trace_frame_debug with a segment buffer)
+    int32_t *hits;             // [np][B]   triangle hit at the end of each segment (-1 none); null unless the caller asked for hit indices
     float4 *mrec;              // [B][np][3] what k_march needs of a segment: from,refl | delta,intensity | t_start(f64),steps,media
     const float4 *mtab;        // [M] per material, for k_march: mu0, mu1, sigma, per-step attenuation factor
     uint32_t *seg_count;       // [np]
@@ -34,7 +35,7 @@ struct FrameArgs {
     uint32_t *error_flag;      // device word, bit 0: traversal stack overflow
     unsigned long long *stamps; // [80] diagnostic build (-DMCRT_STAMP) only
     // sizes / parameters
-    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, acc_stride, acc_off, trace_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift;
+    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, acc_stride, acc_off, trace_blocks, march_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift;
     float scene_lo[3], scene_hi[3];   // bounds of the whole BVH
     float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs, tex_rcp, lean_bound;
     double axial_res_mm, time_step, row_dt, max_travel, sos_d, inv_row_dt;

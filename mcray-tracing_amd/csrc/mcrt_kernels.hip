@@ -801,6 +801,7 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
             sg.distance_traveled = seg_dist; sg.media = seg_media; sg.tri = seg_tri;
             a.segs[(size_t)pid * a.B + b] = sg;
         }
+        if (a.hits) a.hits[(size_t)pid * a.B + b] = seg_tri;
         a.seg_count[pid] = b + 1u;
         alive = alive && (b + 1u < a.B);
     }
@@ -1213,7 +1214,7 @@ hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
 hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st)
 {
     // chunks per scan-line: aim at ~4096 workgroups, at least 16 slots per wavefront
-    static const uint32_t target = [] { uint32_t v = 4096u; if (const char *e = getenv("MCRT_MARCH_BLOCKS")) { int x = atoi(e); if (x >= 1) v = (uint32_t)x; } return v; }();   // tuning knob
+    const uint32_t target = a.march_blocks ? a.march_blocks : 4096u;
     uint32_t chunks = a.ne >= target ? 1u : (target + a.ne - 1u) / a.ne;
     const uint32_t max_chunks = (a.S + 63u) / 64u;
     if (chunks > max_chunks) chunks = max_chunks;

@@ -176,6 +176,7 @@ __global__ void k_fit(const int2 *child, const int *parent_int, const int *paren
     while (p >= 0) {
         __threadfence();                                   // this thread's box (if any) is visible before it signs in
         if (atomicAdd(&arrivals[p], 1u) == 0u) return;     // first child to arrive: the sibling finishes the node
+        __threadfence();                                   // acquire side: the sibling's box, published before ITS arrival, is read after ours
         const int2 c = child[p];
         float4 l0, h0, l1, h1;
         if (c.x >= 0) { l0 = load_coherent(&ilo[c.x]); h0 = load_coherent(&ihi[c.x]); } else { const uint32_t t = vals[~c.x]; l0 = plo[t]; h0 = phi[t]; }
@@ -334,6 +335,7 @@ __global__ void k_refit_nodes(float4 *nodes, uint32_t n4, const float4 *rec, con
     for (;;) {
         __threadfence();                                       // what this thread wrote is visible before it signs in
         if (atomicAdd(&arrived[n], 1u) != inner[n]) return;     // not the last of (own thread + inner children) to arrive at n
+        __threadfence();                                       // acquire side: the children's boxes, published before THEIR arrivals, are read after ours
         float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
         for (int k = 0; k < 4; k++) {
             const float4 A = load_coherent(&nodes[8 * (size_t)n + 2 * k]), B = load_coherent(&nodes[8 * (size_t)n + 2 * k + 1]);

@@ -13,23 +13,30 @@ def shard_range(rank, world, n_elements):
 
 
 def gather_rf(rf_local, n_elements, n_rows, dist=None, group=None):
-    """rf_local: [ne_local][R] tensor (device of the backend).  Returns the full [E][R] image on every rank."""
+    """rf_local: this rank's scan-line block, [ne_local][R] for one frame or [F][ne_local][R] for the F frames of a pass
+    (tensor on the backend's device).  Returns the full image(s), [E][R] or [F][E][R], on every rank -- ONE collective
+    whatever F is.  The collective is enqueued on the CURRENT torch stream."""
     if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return rf_local
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "gloo" and rf_local.is_cuda:      # plumbing checks only: stage through the host
         return gather_rf(rf_local.cpu(), n_elements, n_rows, dist, group).to(rf_local.device)
+    batched = rf_local.dim() == 3
+    loc = rf_local if batched else rf_local.unsqueeze(0)            # [F][ne][R]
+    F = loc.shape[0]
     sizes = [shard_range(r, world, n_elements) for r in range(world)]
-    full = torch.empty((n_elements, n_rows), dtype=rf_local.dtype, device=rf_local.device)
+    ne_max = max(e - b for b, e in sizes)
     if n_elements % world == 0:
-        dist.all_gather_into_tensor(full, rf_local.contiguous(), group=group)
+        mine = loc.contiguous()
+    else:                                                           # ragged shards: pad to the largest block
+        mine = torch.zeros((F, ne_max, n_rows), dtype=loc.dtype, device=loc.device)
+        mine[:, : loc.shape[1]] = loc
+    flat = torch.empty((world * F, ne_max, n_rows), dtype=loc.dtype, device=loc.device)      # rank blocks concatenated along dim 0
+    dist.all_gather_into_tensor(flat, mine, group=group)
+    stacked = flat.view(world, F, ne_max, n_rows)
+    if n_elements % world == 0:
+        full = stacked.permute(1, 0, 2, 3).reshape(F, n_elements, n_rows)      # frame-major, rank blocks concatenated (a copy)
     else:
-        parts = [full[b:e] for b, e in sizes]
-        ne_max = max(e - b for b, e in sizes)
-        bufs = [torch.empty((ne_max, n_rows), dtype=rf_local.dtype, device=rf_local.device) for _ in range(world)]
-        mine = torch.zeros((ne_max, n_rows), dtype=rf_local.dtype, device=rf_local.device)
-        mine[: rf_local.shape[0]] = rf_local
-        dist.all_gather(bufs, mine, group=group)
-        for p, b in zip(parts, bufs):
-            p.copy_(b[: p.shape[0]])
-    return full
+        full = torch.cat([stacked[r, :, : e - b] for r, (b, e) in enumerate(sizes)], dim=1)
+    full = full.contiguous()
+    return full if batched else full[0]

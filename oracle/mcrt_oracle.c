@@ -864,11 +864,26 @@ void orc_trace_frame(const orc_scene *sc, const orc_params *p,
     const uint32_t ne = e_end - e_begin, S = p->n_samples, B = p->max_depth, R = p->n_rows;
     orc_stats total; memset(&total, 0, sizeof total);
     if (n_threads < 1) n_threads = 1;
+    /* Tasks = (scan-line, block of samples).  The reference-order float image adds a scan-line's echoes strictly in
+     * sample order (main.cpp:106-144), so it is only produced with one task per scan-line; the fixed-point image is an
+     * integer sum and may be cut into sample blocks, which is what keeps every core of a many-core host busy
+     * (block sums are merged with integer adds: the result does not depend on the cut). */
+    uint32_t chunks = 1;
+    if (!rf_ref && ne > 0 && (uint32_t)n_threads > ne / 2u) {
+        chunks = (4u * (uint32_t)n_threads + ne - 1u) / ne;
+        if (chunks > S) chunks = S;
+        if (chunks < 1u) chunks = 1u;
+    }
+    const uint32_t per = (S + chunks - 1u) / chunks;
+    const long long n_tasks = (long long)ne * chunks;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
 #endif
-    for (uint32_t ei = 0; ei < ne; ei++) {
+    for (long long task = 0; task < n_tasks; task++) {
         orc_stats st; memset(&st, 0, sizeof st);
+        const uint32_t ei = (uint32_t)(task / chunks), ck = (uint32_t)(task % chunks);
+        const uint32_t s0 = ck * per, s1 = (s0 + per < S) ? s0 + per : S;
+        if (s0 >= s1) continue;
         uint32_t e = e_begin + ei;
         v3 pos = V(el_pos[3 * e], el_pos[3 * e + 1], el_pos[3 * e + 2]);
         v3 dir = V(el_dir[3 * e], el_dir[3 * e + 1], el_dir[3 * e + 2]);
@@ -876,11 +891,29 @@ void orc_trace_frame(const orc_scene *sc, const orc_params *p,
         k.rf_ref = rf_ref; k.ref_cols = ne; k.ref_col = ei;
         k.rf_fix = rf_fix ? rf_fix + (size_t)ei * R : NULL;
         k.rf_flags = rf_flags ? rf_flags + (size_t)ei * R : NULL;
-        for (uint32_t s = 0; s < S; s++) {
+        int64_t *priv_fix = NULL; uint8_t *priv_flags = NULL;
+        if (chunks > 1u && rf_fix) {                    /* private bins of this block, merged below */
+            priv_fix = (int64_t *)calloc(R, sizeof(int64_t)); priv_flags = (uint8_t *)calloc(R, 1);
+            k.rf_fix = priv_fix; k.rf_flags = rf_flags ? priv_flags : NULL;
+        }
+        for (uint32_t s = s0; s < s1; s++) {
             size_t pi = (size_t)ei * S + s;
             trace_path(sc, p, &c, texture, pos, dir, frame_id, e, s, use_bvh,
                        hits ? hits + pi * B : NULL, segs ? segs + pi * B : NULL,
                        seg_count ? seg_count + pi : NULL, &k, &st);
+        }
+        if (priv_fix) {
+            int64_t *dst = rf_fix + (size_t)ei * R;
+            for (uint32_t r = 0; r < R; r++) {
+                if (priv_fix[r]) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+                    dst[r] += priv_fix[r];
+                }
+                if (rf_flags && priv_flags[r]) rf_flags[(size_t)ei * R + r] = 1;     /* (every writer stores the same value) */
+            }
+            free(priv_fix); free(priv_flags);
         }
 #ifdef _OPENMP
 #pragma omp critical

@@ -28,8 +28,13 @@ def _worker(rank, world, port, E, S, out_path):
     o = osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=2, e_begin=e0, e_end=e1, want_hits=False, want_ref=False)
     local = torch.from_numpy(np.ascontiguousarray(o["rf"].T))          # [ne][R], the device layout
     full = gather_rf(local, E, p.n_rows, dist)
+    # the F frames of a pass go through ONE collective (what bench.py does): frames 2 and 3 as [F][ne][R]
+    o3 = osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=3, e_begin=e0, e_end=e1, want_hits=False, want_ref=False)
+    both = gather_rf(torch.stack([local, torch.from_numpy(np.ascontiguousarray(o3["rf"].T))]), E, p.n_rows, dist)
+    assert both.shape == (2, E, p.n_rows) and torch.equal(both[0], full)
     if rank == 0:
         np.save(out_path, full.numpy())
+        np.save(out_path + ".f3.npy", both[1].numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,6 +55,8 @@ def test_two_rank_scanline_sharding_matches_single_process(tmp_path, orc, mcrt, 
     p = orc.default_params(n_elements=E, n_samples=S, tex_n=16)
     ref = osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=2, want_hits=False, want_ref=False)["rf"]   # [R][E]
     assert np.array_equal(got.T.view(np.uint32), ref.view(np.uint32))
+    ref3 = osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=3, want_hits=False, want_ref=False)["rf"]
+    assert np.array_equal(np.load(out + ".f3.npy").T.view(np.uint32), ref3.view(np.uint32))
     ax, lat = orc.psf()
     assert np.array_equal(orc.convolve(np.ascontiguousarray(got.T), ax, lat).view(np.uint32), orc.convolve(ref, ax, lat).view(np.uint32))
 

@@ -1,0 +1,175 @@
+"""GPU parity at the sizes BASELINE.json quotes (run on the MI355X box).
+
+Every configuration is traced on the GPU at FULL size and compared with the CPU oracle on the same seeded inputs:
+  headline  1 M random triangles, 128 scan-lines x 1024 rays        (the bench workload: `metric`)
+  C3        liver-like scene (225 280 triangles), 128 x 4096
+  C4        1 M random triangles, 256 x 8192
+  C5        liver-like scene, 512 x 16384, + PSF convolution
+(C1 and C2, the sphere configurations, are in test_gpu_parity.py.)  The oracle checks every scan-line where that takes it
+well under a minute on the box's host cores, else a seeded subset of scan-line blocks (its e_begin/e_end range) -- the
+GPU always traces the whole frame.  Bars: hit indices bit-exact; fixed-point RF image bit-exact; reference-order float
+image within 1e-4 both relative to the peak and element-wise (|d| <= 1e-4 |ref| + 1e-6 peak); BVH node / triangle
+visit counts equal to the oracle's walk of the same tree (they are the roofline's algorithmic bytes)."""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL_REF = 1e-4          # north_star: RF image within 1e-4 relative of the CPU reference path
+ATOL_FLOOR = 1e-6        # element-wise absolute floor, in units of the image peak
+
+
+def assert_rf(rf_gpu, o, cols=None):
+    """rf_gpu [R][E] against the oracle's contract image (bit-exact) and its reference-order float sum (1e-4)"""
+    want, ref = o["rf"], o["rf_ref"]
+    if cols is not None:
+        rf_gpu = rf_gpu[:, cols[0]:cols[1]]
+    assert np.array_equal(rf_gpu.view(np.uint32), want.view(np.uint32)), "fixed-point RF not bit-exact"
+    assert np.array_equal(np.isnan(rf_gpu), np.isnan(ref))
+    m = ~np.isnan(ref)
+    peak = np.abs(ref[m]).max()
+    d = np.abs(rf_gpu[m] - ref[m])
+    assert d.max() <= RTOL_REF * peak, "relative to the peak: %g" % (d.max() / peak)
+    assert np.all(d <= RTOL_REF * np.abs(ref[m]) + ATOL_FLOOR * peak), "element-wise: worst excess %g of the peak" % ((d - RTOL_REF * np.abs(ref[m])).max() / peak)
+    return float(d.max() / peak)
+
+
+def _setup(mcrt, orc, cfg, sd, E, S, tex, **kw):
+    tr = mcrt.Transducer(E, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
+    sim = mcrt.Simulator(sd, tr, n_samples=S, texture=tex, **kw)
+    nodes, btri, _ = sim.ctx.get_bvh()
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
+    osc.set_bvh4(sim.ctx.get_bvh4()[0])
+    return tr, sim, osc
+
+
+def _blocks(E, width, n, seed):
+    """n disjoint scan-line blocks of `width`, seeded; always includes the first and the last block of the frame"""
+    starts = list(range(0, E - width + 1, width))
+    rng = np.random.default_rng(seed)
+    pick = {0, len(starts) - 1}
+    while len(pick) < min(n, len(starts)):
+        pick.add(int(rng.integers(0, len(starts))))
+    return [(starts[i], starts[i] + width) for i in sorted(pick)]
+
+
+def _check_blocks(orc, osc, tr, tex, hits, rf, p, frame, blocks, threads):
+    worst = 0.0
+    for b0, b1 in blocks:
+        o = osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=frame, e_begin=b0, e_end=b1, use_bvh=2, n_threads=threads)
+        assert np.array_equal(hits[b0:b1], o["hits"]), "hit indices differ in scan-lines [%d,%d)" % (b0, b1)
+        worst = max(worst, assert_rf(rf, o, (b0, b1)))
+    return worst
+
+
+def _visit_counts(mcrt, orc, sim, osc, tr, tex, p_kw, frame, S, o_stats, threads):
+    """the counting build of the kernels against the oracle's walk (bounce 0 is walked once per scan-line on the GPU)"""
+    sim.ctx.enable_stats(True); sim.ctx.get_stats(reset=True)
+    sim.trace(frame); st = sim.ctx.get_stats()
+    sim.ctx.enable_stats(False)
+    p0 = orc.default_params(max_depth=1, **p_kw)
+    o0 = osc.trace_frame(p0, tr.pos, tr.dir, tex, frame_id=frame, use_bvh=2, n_threads=threads, want_hits=False, want_ref=False, want_fix=False)["stats"]
+    for k in ("queries", "nodes_visited", "tris_tested"):
+        assert o0[k] % S == 0
+        assert st[k] == o_stats[k] - o0[k] + o0[k] // S, k
+    for k in ("segments", "hits"):
+        assert st[k] == o_stats[k], k
+
+
+def test_headline_1m_triangles_128x1024(mcrt, orc, tex256):
+    """the workload `metric` is quoted on and bench.py times: every scan-line against the oracle"""
+    cfg, meshes = mcrt.synth.random_scene(1_000_000, 8, 12345)
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    E, S, frame = 128, 1024, 0
+    threads = os.cpu_count() or 8
+    tr, sim, osc = _setup(mcrt, orc, cfg, sd, E, S, tex256)
+    hits, _, _ = sim.ctx.trace_frame_debug(frame, sim.rf_dev)
+    rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    p_kw = dict(n_elements=E, n_samples=S)
+    p = orc.default_params(**p_kw)
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=threads)
+    assert np.array_equal(hits, o["hits"])
+    assert (hits >= 0).sum() > 2 * E * S                      # the soup is hit, several bounces deep
+    assert_rf(rf, o)
+    _visit_counts(mcrt, orc, sim, osc, tr, tex256, p_kw, frame, S, o["stats"], threads)
+    # the batched pass the bench times (frames in flight) reproduces the frame bit for bit
+    F = 4
+    dev = sim.ctx.alloc(F * E * sim.R * 4)
+    sim.ctx.trace_frames(0, F, dev)
+    batch = sim.ctx.d2h(dev, (F, E, sim.R))
+    assert np.array_equal(batch[0].T.view(np.uint32), o["rf"].view(np.uint32))
+    o3 = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=3, use_bvh=2, n_threads=threads, want_hits=False, want_ref=False)
+    assert np.array_equal(batch[3].T.view(np.uint32), o3["rf"].view(np.uint32))
+    sim.ctx.free(dev)
+    sim.close()
+
+
+def test_c3_liver_128x4096(mcrt, orc, tex256):
+    """BASELINE config 3 at the benchmarked size: liver_scene(5) = 225 280 triangles, 128 scan-lines x 4096 rays"""
+    cfg, meshes = mcrt.synth.liver_scene(5)
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    assert sd.n_tri == 225280
+    E, S, frame = 128, 4096, 2
+    threads = os.cpu_count() or 8
+    tr, sim, osc = _setup(mcrt, orc, cfg, sd, E, S, tex256)
+    hits, _, _ = sim.ctx.trace_frame_debug(frame, sim.rf_dev)
+    rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    p_kw = dict(n_elements=E, n_samples=S)
+    p = orc.default_params(**p_kw)
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=threads)
+    assert np.array_equal(hits, o["hits"])
+    assert (hits >= 0).sum() > E * S
+    assert_rf(rf, o)
+    _visit_counts(mcrt, orc, sim, osc, tr, tex256, p_kw, frame, S, o["stats"], threads)
+    sim.close()
+
+
+def test_c4_1m_triangles_256x8192(mcrt, orc, tex256):
+    """BASELINE config 4: 1 M random triangles, 256 scan-lines x 8192 rays (2.1 M paths) -- GPU traces the full frame, the
+    oracle checks six seeded blocks of 16 scan-lines (786 432 paths)"""
+    cfg, meshes = mcrt.synth.random_scene(1_000_000, 8, 12345)
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    E, S, frame = 256, 8192, 1
+    threads = os.cpu_count() or 8
+    tr, sim, osc = _setup(mcrt, orc, cfg, sd, E, S, tex256)
+    hits, _, _ = sim.ctx.trace_frame_debug(frame, sim.rf_dev)
+    rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    p = orc.default_params(n_elements=E, n_samples=S)
+    _check_blocks(orc, osc, tr, tex256, hits, rf, p, frame, _blocks(E, 16, 6, seed=4), threads)
+    # scan-line shards (what 2/4/8 GPUs would each trace) reproduce the full frame bit for bit
+    full = sim.ctx.d2h(sim.rf_dev, (E, sim.R))
+    for g in (1, 6):                                              # two of the eight shards
+        sim.ctx.trace_frame(frame, sim.rf_dev, g * 32, g * 32 + 32)
+        part = sim.ctx.d2h(sim.rf_dev, (32, sim.R))
+        assert np.array_equal(part.view(np.uint32), full[g * 32:g * 32 + 32].view(np.uint32))
+    sim.close()
+
+
+def test_c5_liver_512x16384_psf(mcrt, orc, tex256):
+    """BASELINE config 5: liver-like scene, 512 scan-lines x 16384 rays (8.4 M paths) + PSF convolution -- GPU traces and
+    convolves the full frame; the oracle checks four seeded blocks of 32 scan-lines, and the convolution of the block
+    interiors (the lateral pass reads 12 columns to the right, rfimage.h:113-118)"""
+    cfg, meshes = mcrt.synth.liver_scene(5)
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    E, S, frame = 512, 16384, 7
+    threads = os.cpu_count() or 8
+    tr, sim, osc = _setup(mcrt, orc, cfg, sd, E, S, tex256)
+    hits, _, _ = sim.ctx.trace_frame_debug(frame, sim.rf_dev)
+    rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    p = orc.default_params(n_elements=E, n_samples=S)
+    blocks = _blocks(E, 32, 4, seed=5)
+    _check_blocks(orc, osc, tr, tex256, hits, rf, p, frame, blocks, threads)
+    del hits
+    # PSF convolution of the whole frame on the GPU == the oracle's convolution of the GPU's (verified) raw image
+    sim.convolve()
+    rfc = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    oc = orc.convolve(rf, sim.psf.axial_kernel, sim.psf.lateral_kernel)
+    assert np.array_equal(rfc.view(np.uint32), oc.view(np.uint32))
+    # ... and, independently of the GPU's raw image, inside every oracle-checked block
+    for b0, b1 in blocks:
+        o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, e_begin=b0, e_end=b1, use_bvh=2, n_threads=threads, want_hits=False, want_ref=False)
+        ob = orc.convolve(o["rf"], sim.psf.axial_kernel, sim.psf.lateral_kernel)          # [R][32]: columns 6..18 of the block are complete
+        lo, hi = 6, (b1 - b0) - 13
+        assert np.array_equal(rfc[:, b0 + lo:b0 + hi].view(np.uint32), ob[:, lo:hi].view(np.uint32))
+    sim.close()

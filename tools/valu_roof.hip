@@ -1,0 +1,235 @@
+// valu_roof.hip -- calibrates the VALU ISSUE ceiling of the MI355X (gfx950) for the instruction classes the tracer's
+// kernels are made of, at 1 / 2 / 4 / 5 / 8 wavefronts per SIMD.  The roofline of bench.py prices k_trace against what
+// this tool measures (profiles/round2/valu_roof.json), not against an assumed cycles-per-instruction figure.
+//
+//   hipcc --offload-arch=gfx950 -O2 -o build/valu_roof tools/valu_roof.hip && build/valu_roof > valu_roof.json
+//   rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAVES ... -- build/valu_roof --quick
+//
+// Method.  Every wavefront runs ITER x 64 register-only instructions of one class (inline asm, nothing for the compiler
+// to fold), stamped with s_memtime (shader clock) and s_memrealtime (100 MHz) around the loop, and records which SIMD
+// it ran on (HW_REG_HW_ID, HW_REG_XCC_ID).  A launch holds exactly W workgroups of 4 wavefronts per compute unit (dynamic
+// LDS sized so that no more fit; the host checks the recorded placement), i.e. W wavefronts per SIMD.  Per SIMD:
+//   cycles/instr of one wave = (its end - its start) / its instructions
+//   SIMD IPC                 = instructions of all its wavefronts / (latest end - earliest start)
+// The medians over the SIMDs are reported.  "dependent" variants chain every instruction on the previous one's result.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+enum Kind { FMA_IND, FMA_DEP, PKMUL_IND, PKMUL_DEP, MIN3_IND, MIN3_DEP, DPP_IND, DPP_DEP, CMP_CND, INT_ADD, FMA64_IND, ADD64_DEP, MUL64_IND, WALK_MIX, VALU_SALU, N_KINDS };
+static const char *kind_name[N_KINDS] = { "v_fma_f32 independent", "v_fma_f32 dependent", "v_pk_mul_f32 independent", "v_pk_mul_f32 dependent",
+    "v_min3_f32 independent", "v_min3_f32 dependent", "v_mov_b32 dpp quad_perm independent", "v_mov_b32 dpp quad_perm dependent",
+    "v_cmp_lt_f32 + v_cndmask_b32 pairs", "v_add_u32 independent", "v_fma_f64 independent", "v_add_f64 dependent", "v_mul_f64 independent",
+    "BVH4 node-step mix (pk sub/mul, min/max/min3/max3, dpp, cmp, cndmask, integer)", "v_fma_f32 + s_add_u32 interleaved 1:1 (VALU count only)" };
+// VALU instructions per unrolled body (the loop runs `iters` bodies)
+static const int kind_body[N_KINDS] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 64 };
+
+struct Stamp { unsigned long long t0, t1, r0, r1; unsigned hw_id, xcc_id, pad0, pad1; };
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define REP4(x) x x x x
+#define REP8(x) x x x x x x x x
+#define REP16(x) REP4(REP4(x))
+#define REP64(x) REP8(REP8(x))
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_roof(Stamp *out, int iters, float seed)
+{
+    extern __shared__ char lds_[];
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float x = 1.0000001f, y = 1e-9f;
+    v2f p0 = { a0, a1 }, p1 = { a2, a3 }, p2 = { a4, a5 }, p3 = { a6, a7 }, px = { x, x };
+    double d0 = a0, d1 = a1, d2 = a2, d3 = a3, dx = 1.0000000001, dy = 1e-12;
+    unsigned u0 = threadIdx.x, u1 = u0 + 1, u2 = u0 + 2, u3 = u0 + 3;
+    unsigned s0 = 1;
+    asm volatile("" : "+v"(x), "+v"(y), "+v"(px), "+v"(dx), "+v"(dy));
+    __syncthreads();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; i++) {
+        if constexpr (KIND == FMA_IND) {
+            REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                              "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y));)
+        } else if constexpr (KIND == FMA_DEP) {
+            REP64(asm volatile("v_fma_f32 %0, %0, %1, %2\n" : "+v"(a0) : "v"(x), "v"(y));)
+        } else if constexpr (KIND == PKMUL_IND) {
+            REP16(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                               : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(px));)
+        } else if constexpr (KIND == PKMUL_DEP) {
+            REP64(asm volatile("v_pk_mul_f32 %0, %0, %1\n" : "+v"(p0) : "v"(px));)
+        } else if constexpr (KIND == MIN3_IND) {
+            REP8(asm volatile("v_min3_f32 %0, %0, %8, %9\n v_min3_f32 %1, %1, %8, %9\n v_min3_f32 %2, %2, %8, %9\n v_min3_f32 %3, %3, %8, %9\n"
+                              "v_min3_f32 %4, %4, %8, %9\n v_min3_f32 %5, %5, %8, %9\n v_min3_f32 %6, %6, %8, %9\n v_min3_f32 %7, %7, %8, %9\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y));)
+        } else if constexpr (KIND == MIN3_DEP) {
+            REP64(asm volatile("v_min3_f32 %0, %0, %1, %2\n" : "+v"(a0) : "v"(x), "v"(y));)
+        } else if constexpr (KIND == DPP_IND) {
+            REP8(asm volatile("v_mov_b32_dpp %0, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                              "v_mov_b32_dpp %2, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                              "v_mov_b32_dpp %4, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                              "v_mov_b32_dpp %6, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x));)
+        } else if constexpr (KIND == DPP_DEP) {
+            REP16(asm volatile("v_mov_b32_dpp %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %0, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                               "v_mov_b32_dpp %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %0, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                               : "+v"(a0), "+v"(a1));)
+        } else if constexpr (KIND == CMP_CND) {
+            REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %4\n v_cndmask_b32 %0, %0, %5, vcc\n v_cmp_lt_f32 vcc, %1, %4\n v_cndmask_b32 %1, %1, %5, vcc\n"
+                              "v_cmp_lt_f32 vcc, %2, %4\n v_cndmask_b32 %2, %2, %5, vcc\n v_cmp_lt_f32 vcc, %3, %4\n v_cndmask_b32 %3, %3, %5, vcc\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x), "v"(y) : "vcc");)
+        } else if constexpr (KIND == INT_ADD) {
+            REP16(asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4\n"
+                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(u0));)
+        } else if constexpr (KIND == FMA64_IND) {
+            REP16(asm volatile("v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5\n"
+                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(dx), "v"(dy));)
+        } else if constexpr (KIND == ADD64_DEP) {
+            REP64(asm volatile("v_add_f64 %0, %0, %1\n" : "+v"(d0) : "v"(dy));)
+        } else if constexpr (KIND == MUL64_IND) {
+            REP16(asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n"
+                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(dx));)
+        } else if constexpr (KIND == WALK_MIX) {
+            // the register-only part of one BVH4 node step of k_trace, in its dependency structure: 3 pk_add + 3 pk_mul (slab planes),
+            // 2 min + 2 max + max + max3 + min + min3 (interval), 2 cmp, and_or key build (3), 2 dpp + 2 min_u32 (ranking), 2 dpp + 2 or
+            // (hit mask), bcnt, and, cmp, cndmask, 2 dpp + 2 or (candidate), cmp, lshl, not/and, bcnt, add, lshl_add, cndmask x2, add: 48
+            asm volatile(
+                "v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n"
+                "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n"
+                "v_min_f32 %5, %15, %16\n v_min_f32 %6, %15, %13\n v_max_f32 %7, %15, %16\n v_max_f32 %8, %15, %13\n"
+                "v_max_f32 %9, %16, %13\n v_max3_f32 %5, %5, %6, %9\n v_min_f32 %9, %16, %14\n v_min3_f32 %7, %7, %8, %9\n"
+                "v_cmp_le_f32 vcc, %5, %7\n v_cmp_ne_u32 s[10:11], %10, %11\n"
+                "v_and_b32 %6, -4, %5\n v_or_b32 %6, %6, %10\n v_cndmask_b32 %6, -1, %6, vcc\n"
+                "v_mov_b32_dpp %8, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_min_u32 %8, %6, %8\n"
+                "v_mov_b32_dpp %9, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_min_u32 %8, %8, %9\n"
+                "v_cndmask_b32 %9, 0, %11, vcc\n v_mov_b32_dpp %12, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_or_b32 %9, %9, %12\n"
+                "v_mov_b32_dpp %12, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_or_b32 %9, %9, %12\n"
+                "v_bcnt_u32_b32 %12, %9, 0\n v_and_b32 %3, 3, %8\n v_cmp_eq_u32 vcc, %6, %8\n v_cndmask_b32 %10, 0, %10, vcc\n"
+                "v_mov_b32_dpp %3, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_or_b32 %10, %10, %3\n"
+                "v_mov_b32_dpp %3, %10 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_or_b32 %10, %10, %3\n"
+                "v_cmp_eq_u32 vcc, 0, %12\n v_lshlrev_b32 %3, %3, %11\n v_bfi_b32 %3, %3, 0, %9\n v_add_u32 %6, -1, %11\n v_and_b32 %6, %6, %3\n"
+                "v_bcnt_u32_b32 %6, %6, %12\n v_lshl_add_u32 %6, %6, 8, %11\n v_add_u32 %12, %12, %11\n"
+                "v_cndmask_b32 %10, %10, %11, vcc\n v_cndmask_b32 %11, %11, %12, vcc\n v_add_u32 %10, %10, %6\n v_or_b32 %11, 1, %11\n"
+                : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(a3), "+v"(px), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a4), "+v"(a5), "+v"(u0), "+v"(u1), "+v"(u2)
+                : "v"(x), "v"(y), "v"(a6), "v"(a7) : "vcc", "s10", "s11");
+        } else if constexpr (KIND == VALU_SALU) {
+            REP8(asm volatile("v_fma_f32 %0, %0, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %1, %1, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %2, %2, %9, %10\n s_add_u32 %8, %8, 1\n"
+                              "v_fma_f32 %3, %3, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %4, %4, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %5, %5, %9, %10\n s_add_u32 %8, %8, 1\n"
+                              "v_fma_f32 %6, %6, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %7, %7, %9, %10\n s_add_u32 %8, %8, 1\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0) : "v"(x), "v"(y) : "scc");)
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    unsigned hw = 0, xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if ((threadIdx.x & 63) == 0) {
+        Stamp s; s.t0 = t0; s.t1 = t1; s.r0 = r0; s.r1 = r1; s.hw_id = hw; s.xcc_id = xcc; s.pad0 = s0; s.pad1 = 0;
+        out[blockIdx.x * 4 + (threadIdx.x >> 6)] = s;
+    }
+    // keep every chain alive
+    const float keep = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + (float)(d0 + d1 + d2 + d3) + (float)(u0 + u1 + u2 + u3);
+    if (keep == 12345.678f) lds_[0] = 1;
+    if (keep == 12345.678f && lds_[threadIdx.x] == 77) out[0].t0 = 0;
+}
+
+struct Result { double cyc_per_instr_wave, simd_ipc, clock_ghz, span_ms; int simds, waves_min, waves_max; };
+
+template <int KIND>
+static Result run(int W, int iters, int n_cu, Stamp *d_out, std::vector<Stamp> &h)
+{
+    const int blocks = n_cu * W;
+    // exactly W workgroups fit a compute unit: 160 KiB of LDS / W each, minus a margin smaller than one more share
+    size_t lds = (size_t)(160 * 1024) / (size_t)W;
+    lds -= (W >= 8) ? 0 : lds / (size_t)(2 * (W + 1));      // W = 8 is also the wave-slot limit (32 waves per CU)
+    lds &= ~(size_t)1023;
+    CHECK(hipFuncSetAttribute((const void *)k_roof<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int rep = 0; rep < 2; rep++) {      // the second launch is the measured one (clocks settled)
+        hipLaunchKernelGGL(k_roof<KIND>, dim3(blocks), dim3(256), lds, 0, d_out, iters, 1.0f);
+        CHECK(hipGetLastError());
+        CHECK(hipDeviceSynchronize());
+    }
+    h.resize((size_t)blocks * 4);
+    CHECK(hipMemcpy(h.data(), d_out, h.size() * sizeof(Stamp), hipMemcpyDeviceToHost));
+    struct Agg { unsigned long long t0 = ~0ull, t1 = 0; int n = 0; double cpi = 0; };
+    std::map<unsigned long long, Agg> simd;
+    const double instr = (double)iters * kind_body[KIND];
+    std::vector<double> clocks;
+    unsigned long long rmin = ~0ull, rmax = 0;
+    for (const Stamp &s : h) {
+        // HW_ID (gfx9): wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13 (+ 2 more SE bits on larger parts: keep everything but the wave slot)
+        const unsigned long long key = ((unsigned long long)s.xcc_id << 32) | (s.hw_id & 0xfffffff0u & ~0x000000c0u & 0x00ffffffu & ~0x00ff0000u);
+        Agg &a = simd[key];
+        a.t0 = std::min(a.t0, s.t0); a.t1 = std::max(a.t1, s.t1); a.n++; a.cpi += (double)(s.t1 - s.t0) / instr;
+        clocks.push_back((double)(s.t1 - s.t0) / ((double)(s.r1 - s.r0) * 10.0) );   // cycles per ns = GHz (100 MHz real-time ticks)
+        rmin = std::min(rmin, s.r0); rmax = std::max(rmax, s.r1);
+    }
+    std::vector<double> cpi, ipc;
+    int wmin = 1 << 30, wmax = 0;
+    for (auto &kv : simd) {
+        const Agg &a = kv.second;
+        cpi.push_back(a.cpi / a.n);
+        ipc.push_back(a.n * instr / (double)(a.t1 - a.t0));
+        wmin = std::min(wmin, a.n); wmax = std::max(wmax, a.n);
+    }
+    auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    Result r;
+    r.cyc_per_instr_wave = med(cpi); r.simd_ipc = med(ipc); r.clock_ghz = med(clocks); r.simds = (int)simd.size(); r.waves_min = wmin; r.waves_max = wmax;
+    r.span_ms = (double)(rmax - rmin) * 1e-5;
+    return r;
+}
+
+template <int K>
+static void sweep(bool &first, const std::vector<int> &Ws, int iters, int n_cu, Stamp *d_out, std::vector<Stamp> &h)
+{
+    for (int W : Ws) {
+        const Result r = run<K>(W, iters, n_cu, d_out, h);
+        printf("%s\n  {\"class\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_instr_one_wave\": %.3f, \"simd_ipc\": %.4f, \"clock_ghz\": %.3f, "
+               "\"simds_seen\": %d, \"waves_per_simd_seen\": [%d, %d], \"launch_ms\": %.3f}",
+               first ? "" : ",", kind_name[K], W, r.cyc_per_instr_wave, r.simd_ipc, r.clock_ghz, r.simds, r.waves_min, r.waves_max, r.span_ms);
+        first = false;
+        fflush(stdout);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const bool quick = argc > 1 && !strcmp(argv[1], "--quick");
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int n_cu = prop.multiProcessorCount;
+    const int iters = quick ? 2048 : 8192;
+    Stamp *d_out = nullptr;
+    CHECK(hipMalloc(&d_out, sizeof(Stamp) * (size_t)n_cu * 8 * 4));
+    std::vector<Stamp> h;
+    const std::vector<int> Ws = quick ? std::vector<int>{ 1, 2, 5 } : std::vector<int>{ 1, 2, 4, 5, 8 };
+    printf("{\"device\": \"%s\", \"compute_units\": %d, \"simds\": %d, \"instructions_per_wave\": %d, \"results\": [", prop.gcnArchName, n_cu, n_cu * 4, iters * 64);
+    bool first = true;
+    sweep<FMA_IND>(first, Ws, iters, n_cu, d_out, h);
+    sweep<FMA_DEP>(first, Ws, iters, n_cu, d_out, h);
+    sweep<PKMUL_IND>(first, Ws, iters, n_cu, d_out, h);
+    sweep<PKMUL_DEP>(first, Ws, iters, n_cu, d_out, h);
+    sweep<MIN3_IND>(first, Ws, iters, n_cu, d_out, h);
+    sweep<MIN3_DEP>(first, Ws, iters, n_cu, d_out, h);
+    sweep<DPP_IND>(first, Ws, iters, n_cu, d_out, h);
+    sweep<DPP_DEP>(first, Ws, iters, n_cu, d_out, h);
+    sweep<CMP_CND>(first, Ws, iters, n_cu, d_out, h);
+    sweep<INT_ADD>(first, Ws, iters, n_cu, d_out, h);
+    sweep<FMA64_IND>(first, Ws, iters, n_cu, d_out, h);
+    sweep<ADD64_DEP>(first, Ws, iters, n_cu, d_out, h);
+    sweep<MUL64_IND>(first, Ws, iters, n_cu, d_out, h);
+    sweep<WALK_MIX>(first, Ws, iters, n_cu, d_out, h);
+    sweep<VALU_SALU>(first, Ws, iters, n_cu, d_out, h);
+    printf("\n]}\n");
+    (void)hipFree(d_out);
+    return 0;
+}
