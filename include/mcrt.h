@@ -109,11 +109,15 @@ int mcrt_device_count(void);
 
 int mcrt_create(int device, mcrt_ctx **out);
 int mcrt_destroy(mcrt_ctx *ctx);
-int mcrt_set_stream(mcrt_ctx *ctx, void *hip_stream);           /* NULL = the context's own stream */
+/* The stream every asynchronous entry point enqueues on.  NULL = the context's own (non-blocking) stream -- NOT the legacy
+ * default stream: to order the kernels with work on HIP's legacy stream pass hipStreamLegacy explicitly, and with a
+ * framework's stream (torch.cuda.Stream().cuda_stream) pass that handle. */
+int mcrt_set_stream(mcrt_ctx *ctx, void *hip_stream);
 int mcrt_synchronize(mcrt_ctx *ctx);
 
 int mcrt_default_params(mcrt_params *p);
 int mcrt_set_params(mcrt_ctx *ctx, const mcrt_params *p);
+int mcrt_get_params(mcrt_ctx *ctx, mcrt_params *out);           /* the parameters in effect */
 
 /* Which builder mcrt_upload_scene / mcrt_update_triangles use for the BVH that replaces the per-mesh
  * btBvhTriangleMeshShape of scene.cpp:306-309:
@@ -171,6 +175,10 @@ int mcrt_scan_convert(mcrt_ctx *ctx, const float *rf_dev, uint32_t n_elements, u
 
 /* device [E][R]  ->  host [R][E] row-major (the cv::Mat layout of rfimage.h:217); synchronous */
 int mcrt_export_rf(mcrt_ctx *ctx, const float *rf_dev, uint32_t n_elements, uint32_t n_rows, float *host_rows_by_cols);
+
+/* host [R][E] row-major (the cv::Mat layout)  ->  device [E][R]: the inverse of mcrt_export_rf, for callers that deposit
+ * echoes on the host (rf_image::add_echo, rfimage.h:33-40) and post-process on the GPU; synchronous */
+int mcrt_import_rf(mcrt_ctx *ctx, const float *host_rows_by_cols, uint32_t n_elements, uint32_t n_rows, float *rf_dev);
 
 /* device memory helpers for callers without their own allocator */
 int mcrt_alloc(mcrt_ctx *ctx, size_t bytes, void **dev);

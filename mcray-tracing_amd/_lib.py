@@ -56,7 +56,7 @@ assert NODE_DTYPE.itemsize == 64 and SEGMENT_DTYPE.itemsize == 64 and C.sizeof(B
 
 # every symbol include/mcrt.h declares (tests/test_abi.py checks the .so exports each one)
 SYMBOLS = ["mcrt_last_error", "mcrt_version", "mcrt_device_count", "mcrt_create", "mcrt_destroy", "mcrt_set_stream",
-           "mcrt_synchronize", "mcrt_default_params", "mcrt_set_params", "mcrt_set_bvh_builder", "mcrt_upload_scene", "mcrt_update_triangles", "mcrt_refit_triangles", "mcrt_upload_texture",
+           "mcrt_synchronize", "mcrt_default_params", "mcrt_set_params", "mcrt_get_params", "mcrt_import_rf", "mcrt_set_bvh_builder", "mcrt_upload_scene", "mcrt_update_triangles", "mcrt_refit_triangles", "mcrt_upload_texture",
            "mcrt_set_transducer", "mcrt_trace_frame", "mcrt_trace_frames", "mcrt_trace_frame_debug", "mcrt_cast_rays", "mcrt_convolve", "mcrt_convolve_frames",
            "mcrt_envelope", "mcrt_scan_convert", "mcrt_export_rf", "mcrt_alloc", "mcrt_free", "mcrt_memcpy_d2h",
            "mcrt_memcpy_h2d", "mcrt_enable_stats", "mcrt_get_stats", "mcrt_enable_timing", "mcrt_get_kernel_time",
@@ -86,7 +86,7 @@ def load_library():
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
     sig = {
         "mcrt_create": [i32, C.POINTER(vp)], "mcrt_destroy": [vp], "mcrt_set_stream": [vp, vp], "mcrt_synchronize": [vp],
-        "mcrt_default_params": [C.POINTER(Params)], "mcrt_set_params": [vp, C.POINTER(Params)],
+        "mcrt_default_params": [C.POINTER(Params)], "mcrt_set_params": [vp, C.POINTER(Params)], "mcrt_get_params": [vp, C.POINTER(Params)], "mcrt_import_rf": [vp, vp, u32, u32, vp],
         "mcrt_upload_scene": [vp, vp, vp, u32, vp, u32, vp, u32, u32, vp],
         "mcrt_upload_texture": [vp, vp, u32], "mcrt_set_transducer": [vp, vp, vp, u32],
         "mcrt_trace_frame": [vp, u32, u32, u32, vp], "mcrt_trace_frames": [vp, u32, u32, u32, u32, vp], "mcrt_trace_frame_debug": [vp, u32, u32, u32, vp, vp, vp, vp],

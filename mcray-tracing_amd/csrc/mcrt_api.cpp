@@ -303,6 +303,13 @@ extern "C" int mcrt_set_params(mcrt_ctx *c, const mcrt_params *p)
     return prepare_tables(c);
 }
 
+extern "C" int mcrt_get_params(mcrt_ctx *c, mcrt_params *out)
+{
+    if (!c || !out) return set_error(MCRT_ERR_INVALID, "null argument");
+    *out = c->p;
+    return MCRT_OK;
+}
+
 // builds the BVH over tri[n_tri][9] (host or device pointer) with the context's builder and installs it on the device
 static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
 {
@@ -873,6 +880,17 @@ extern "C" int mcrt_export_rf(mcrt_ctx *c, const float *rf_dev, uint32_t E, uint
     int rc = ensure_tmp(c, (size_t)E * R); if (rc) return rc;
     HIP_TRY(mcrt::launch_transpose(rf_dev, c->d_tmp, E, R, c->stream));
     HIP_TRY(hipMemcpyAsync(host, c->d_tmp, (size_t)E * R * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_import_rf(mcrt_ctx *c, const float *host, uint32_t E, uint32_t R, float *rf_dev)
+{
+    CTX_TRY(c);
+    if (!rf_dev || !host || E == 0 || R == 0) return set_error(MCRT_ERR_INVALID, "mcrt_import_rf: bad arguments");
+    int rc = ensure_tmp(c, (size_t)E * R); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_tmp, host, (size_t)E * R * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(mcrt::launch_transpose(c->d_tmp, rf_dev, R, E, c->stream));          // [R][E] -> [E][R]
     HIP_TRY(hipStreamSynchronize(c->stream));
     return MCRT_OK;
 }

@@ -29,13 +29,12 @@ int main(int argc, char **argv)
         const auto &t_dir = cfg.at("transducerAngles");
         // millimeter_t sep = amplitude.to<float>() * radius / elements (main.cpp:66): float * cm -> cm, then -> mm
         const double separation_mm = (((double)(float)transducer_amplitude * transducer_radius_cm) / (double)transducer_elements) * 10.0;
-        transducer_ transducer(transducer_frequency, transducer_radius_cm, separation_mm, { (float)t_pos[0], (float)t_pos[1], (float)t_pos[2] },
-                               { (float)t_dir[0], (float)t_dir[1], (float)t_dir[2] });
+        transducer_ transducer(transducer_frequency, transducer_radius_cm, separation_mm, vec3((float)t_pos[0], (float)t_pos[1], (float)t_pos[2]),
+                               std::array<float, 3>{ (float)t_dir[0], (float)t_dir[1], (float)t_dir[2] });
         auto dev = std::make_shared<device>(0);
         scene scene{ cfg, transducer, dev, samples };
         scene.step(1000.0f);
         rf_image_ rf_image{ dev, transducer_radius_cm * 10.0, transducer_amplitude };
-        std::cout << "rf_image: " << rf_image_::max_rows << ", " << transducer_elements << std::endl;
 
         const auto t0 = std::chrono::high_resolution_clock::now();
         for (int f = 0; f < frames; f++) {

@@ -6,7 +6,9 @@
 //   psf<ax,lat,elev,res>     psf.h:34-77
 //   scene                    scene.h:19-76, scene.cpp:16-48,185-247 (JSON keys, "Error while loading scene: ..." wrapping)
 //   rf_image<cols,us,um>     rfimage.h:20-219      (clear / convolve / envelope / postprocess; data lives on the GPU)
-//   ray_physics::segment     ray.h:28-36
+//   ray_physics::segment     ray.h:28-36           (vec3 stands in for btVector3; `media` is held BY VALUE: the reference's
+//                                                   `const material &` dangles by the time main.cpp:126 reads it)
+//   volume<size,res>         volume.h:19-61        (host copy of the texture the GPU samples)
 //
 // Units are plain doubles (the reference's units.h types are compile-time only); names say the unit.
 #pragma once
@@ -18,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <iostream>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -150,38 +153,73 @@ inline void load_obj_triangles(const std::string &path, std::vector<float> &tri9
     }
 }
 
-namespace ray_physics { using segment = mcrt_segment; }   // ray.h:28-36; `media` is the material index
+// the subset of btVector3 the reference's host code uses (main.cpp:72,117,120,131; scene.cpp:342-346)
+struct vec3 {
+    float v[3] = { 0, 0, 0 };
+    vec3() = default;
+    vec3(float x, float y, float z) : v{ x, y, z } {}
+    float x() const { return v[0]; } float y() const { return v[1]; } float z() const { return v[2]; }
+    vec3 operator+(const vec3 &o) const { return { v[0] + o.v[0], v[1] + o.v[1], v[2] + o.v[2] }; }
+    vec3 operator-(const vec3 &o) const { return { v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2] }; }
+    vec3 &operator+=(const vec3 &o) { v[0] += o.v[0]; v[1] += o.v[1]; v[2] += o.v[2]; return *this; }
+    float dot(const vec3 &o) const { return v[0] * o.v[0] + v[1] * o.v[1] + v[2] * o.v[2]; }
+    float length() const { return std::sqrt(dot(*this)); }
+    float distance(const vec3 &o) const { return (o - *this).length(); }
+};
+inline vec3 operator*(float s, const vec3 &a) { return { s * a.v[0], s * a.v[1], s * a.v[2] }; }
+inline vec3 operator*(const vec3 &a, float s) { return s * a; }
+
+namespace ray_physics {
+struct segment {   // ray.h:28-36
+    vec3 from, to, direction;
+    float reflected_intensity;   // reflected back to the transducer, at the end of the segment
+    float initial_intensity, attenuation;
+    double distance_traveled;    // [mm] traveled from the transducer to the beginning of the segment
+    material media;              // by value (see the header comment)
+    int32_t tri;                 // triangle hit at the end of the segment (-1 none): not in the reference, free with the GPU walk
+};
+}  // namespace ray_physics
 
 // ---------------------------------------------------------------- transducer<N> (transducer.h)
 template <size_t transducer_elements>
 class transducer {
 public:
-    struct transducer_element { std::array<float, 3> position, direction; };
+    struct transducer_element { vec3 position, direction; };
 
-    transducer(float frequency_mhz, double radius_cm, double element_separation_mm, const std::array<float, 3> &position, const std::array<float, 3> &angles_deg)
+    // transducer.h:24-62 (frequency MHz, radius cm, element separation mm, position in scene units, angles in degrees)
+    transducer(float frequency_mhz, double radius_cm, double element_separation_mm, const vec3 &position, const std::array<float, 3> &angles_deg)
         : frequency(frequency_mhz), position(position), angles(angles_deg), radius_cm(radius_cm), separation_mm(element_separation_mm)
     {
         if (!(element_separation_mm * transducer_elements < 3.14159 * radius_cm * 10.0))      // the assert of transducer.h:35
             throw std::invalid_argument("transducer: elements do not fit on the arc");
         update();
     }
-    void update()   // transducer.h:82-118
+    void update()   // transducer.h:82-118: the elements from the current position and angles
     {
         pos.resize(3 * transducer_elements); dir.resize(3 * transducer_elements);
-        check(mcrt_transducer_elements((uint32_t)transducer_elements, radius_cm, separation_mm, position.data(), angles.data(), pos.data(), dir.data()), "transducer");
+        check(mcrt_transducer_elements((uint32_t)transducer_elements, radius_cm, separation_mm, position.v, angles.data(), pos.data(), dir.data()), "transducer");
     }
-    transducer_element element(size_t i) const
+    transducer_element element(size_t i) const   // transducer.h:64-67 (std::array::at: throws when out of range)
     {
         if (i >= transducer_elements) throw std::out_of_range("transducer::element");
-        return { { pos[3 * i], pos[3 * i + 1], pos[3 * i + 2] }, { dir[3 * i], dir[3 * i + 1], dir[3 * i + 2] } };
+        return { vec3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]), vec3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]) };
     }
-    void setPosition(const std::array<float, 3> &p) { position = p; }
+    void print(bool direction) const   // transducer.h:69-80: "x,z" per element
+    {
+        for (size_t i = 0; i < transducer_elements; i++) {
+            const auto e = element(i);
+            const vec3 &v = direction ? e.direction : e.position;
+            std::cout << v.x() << "," << v.z() << std::endl;
+        }
+    }
+    void setPosition(const vec3 &p) { position = p; }
     void setAngles(const std::array<float, 3> &a) { angles = a; }
-    std::array<float, 3> getPosition() const { return position; }
+    vec3 getPosition() const { return position; }
     static constexpr size_t size() { return transducer_elements; }
 
     const float frequency;
-    std::array<float, 3> position, angles;
+    vec3 position, direction;
+    std::array<float, 3> angles;
     std::vector<float> pos, dir;          // [N][3] each, what mcrt_set_transducer takes
 private:
     const double radius_cm, separation_mm;
@@ -211,13 +249,47 @@ struct device {
     device(const device &) = delete; device &operator=(const device &) = delete;
     mcrt_ctx *ctx = nullptr;
 };
+// the reference's objects take no device argument: they share this process-wide one (GPU 0), created on first use
+inline std::shared_ptr<device> default_device()
+{
+    static std::weak_ptr<device> weak;
+    auto d = weak.lock();
+    if (!d) { d = std::make_shared<device>(0); weak = d; }
+    return d;
+}
+
+// ---------------------------------------------------------------- volume (volume.h): host copy of the tissue texture
+template <unsigned int size, unsigned int resolution_micrometers>
+class volume {
+public:
+    volume() : matrix((size_t)size * size * size * 2) { check(mcrt_generate_texture(matrix.data(), size), "mcrt_generate_texture"); }   // volume.h:19-35
+    constexpr float get_resolution_in_millis() const { return static_cast<float>(resolution_micrometers) / 1000.0f; }
+    // volume.h:46-61 (float -> unsigned of a negative coordinate wraps like x86-64: DESIGN.md, quirk 4)
+    float get_scattering(const float scattering_density, const float scattering_mu, const float scattering_sigma,
+                         const float x_millis, const float y_millis, const float z_millis) const
+    {
+        constexpr float resolution = resolution_micrometers / 1000.0f;
+        const unsigned int x = index(x_millis / resolution), y = index(y_millis / resolution), z = index(z_millis / resolution);
+        const float *voxel = &matrix[2 * (((size_t)x * size + y) * size + z)];     // { texture_noise, scattering_probability }
+        return voxel[1] >= scattering_density ? voxel[0] * scattering_sigma + scattering_mu : 0.0f;
+    }
+    const float *data() const { return matrix.data(); }
+private:
+    static unsigned int index(float q)
+    {
+        long long i = std::fabs(q) < 9.2233720368547758e18f ? (long long)q : (long long)0x8000000000000000ull;
+        return (unsigned int)i % size;
+    }
+    std::vector<float> matrix;
+};
 
 // ---------------------------------------------------------------- scene (scene.h / scene.cpp)
 class scene {
 public:
     // scene(json, transducer&): parse_config + upload (replaces create_empty_world/init/add_rigidbody_from_obj)
     template <size_t N>
-    scene(const json &config, transducer<N> &t, std::shared_ptr<device> dev, unsigned samples = 5, unsigned seed = 0x5EED) : dev(std::move(dev))
+    scene(const json &config, transducer<N> &t, std::shared_ptr<device> dev_ = nullptr, unsigned samples = 5, unsigned seed = 0x5EED)
+        : dev(dev_ ? std::move(dev_) : default_device())
     {
         try { parse_config(config); }
         catch (const std::exception &ex) { throw std::runtime_error{ "Error while loading scene: " + std::string{ ex.what() } }; }
@@ -232,13 +304,43 @@ public:
 
     template <size_t N> void set_transducer(const transducer<N> &t) { check(mcrt_set_transducer(dev->ctx, t.pos.data(), t.dir.data(), (uint32_t)N), "mcrt_set_transducer"); }
 
-    // cast_rays<sample_count, ray_count>(transducer): the segments of every (element, sample) path (scene.cpp:50-183)
-    std::vector<std::vector<std::vector<ray_physics::segment>>> cast_rays(uint32_t frame_id = 0)
+    // scene::cast_rays<sample_count, ray_count>(transducer) (scene.h:29-30, scene.cpp:50-183): the segments of every
+    // (element, sample) path, traced on the GPU.  The reference draws fresh random numbers on every call (random_device);
+    // here every call advances the frame id of the counter-based generator.
+    template <unsigned int sample_count, unsigned int ray_count, size_t N>
+    std::array<std::array<std::vector<ray_physics::segment>, sample_count>, ray_count> cast_rays(transducer<N> &t)
+    {
+        static_assert(ray_count == N, "one ray bundle per transducer element");
+        if (params.n_samples != sample_count || params.n_elements != ray_count) {
+            check(mcrt_get_params(dev->ctx, &params), "mcrt_get_params");
+            params.n_samples = sample_count; params.n_elements = ray_count;
+            check(mcrt_set_params(dev->ctx, &params), "mcrt_set_params");
+        }
+        set_transducer(t);
+        const size_t B = params.max_depth;
+        std::vector<mcrt_segment> flat((size_t)ray_count * sample_count * B); std::vector<uint32_t> cnt((size_t)ray_count * sample_count);
+        check(mcrt_cast_rays(dev->ctx, frame_id++, 0, ray_count, flat.data(), cnt.data(), nullptr), "mcrt_cast_rays");
+        std::array<std::array<std::vector<ray_physics::segment>, sample_count>, ray_count> out;
+        for (size_t e = 0; e < ray_count; e++)
+            for (size_t s = 0; s < sample_count; s++) {
+                const size_t p = e * sample_count + s;
+                auto &dst = out[e][s];
+                dst.reserve(cnt[p]);
+                for (uint32_t b = 0; b < cnt[p]; b++) {
+                    const mcrt_segment &g = flat[p * B + b];
+                    dst.push_back(ray_physics::segment{ vec3(g.from[0], g.from[1], g.from[2]), vec3(g.to[0], g.to[1], g.to[2]), vec3(g.dir[0], g.dir[1], g.dir[2]),
+                                                        g.reflected_intensity, g.initial_intensity, g.attenuation, g.distance_traveled, materials[(size_t)g.media], g.tri });
+                }
+            }
+        return out;
+    }
+    // the flat form of the same call, for a given frame id
+    std::vector<std::vector<std::vector<mcrt_segment>>> cast_rays(uint32_t frame)
     {
         const size_t E = params.n_elements, S = params.n_samples, B = params.max_depth;
         std::vector<mcrt_segment> flat(E * S * B); std::vector<uint32_t> cnt(E * S);
-        check(mcrt_cast_rays(dev->ctx, frame_id, 0, (uint32_t)E, flat.data(), cnt.data(), nullptr), "mcrt_cast_rays");
-        std::vector<std::vector<std::vector<ray_physics::segment>>> out(E, std::vector<std::vector<ray_physics::segment>>(S));
+        check(mcrt_cast_rays(dev->ctx, frame, 0, (uint32_t)E, flat.data(), cnt.data(), nullptr), "mcrt_cast_rays");
+        std::vector<std::vector<std::vector<mcrt_segment>>> out(E, std::vector<std::vector<mcrt_segment>>(S));
         for (size_t e = 0; e < E; e++)
             for (size_t s = 0; s < S; s++) {
                 const size_t p = e * S + s;
@@ -247,9 +349,11 @@ public:
         return out;
     }
     void step(float) {}   // scene.cpp:336-339: all bodies are static, nothing to integrate
+    double distance(const vec3 &from, const vec3 &to) const { return (double)(from.distance(to) * 10.0f); }   // [mm], scene.cpp:342-346
 
     std::shared_ptr<device> dev;
     mcrt_params params{};
+    uint32_t frame_id = 0;
     std::vector<std::string> material_names;
     std::vector<material> materials;
     std::vector<mesh> meshes;
@@ -308,29 +412,66 @@ private:
     }
 };
 
-// ---------------------------------------------------------------- rf_image (rfimage.h); the image lives on the GPU
+// ---------------------------------------------------------------- rf_image (rfimage.h)
+// Two ways to fill it, both the reference's semantics:
+//   trace(frame)            clear + cast_rays + the accumulation loop of main.cpp:102-144 fused on the GPU (the fast path)
+//   clear() / add_echo()    the reference's own host-side accumulation (rfimage.h:33-40,161-164) into a host image [max_rows][columns]
+// convolve / envelope / postprocess always run on the GPU: a host-accumulated image is uploaded first.
 template <unsigned int columns, unsigned int max_travel_time_us, unsigned int axial_resolution_um, unsigned int speed_of_sound = 1500>
 class rf_image {
 public:
     static constexpr unsigned int max_rows = (speed_of_sound * max_travel_time_us) / axial_resolution_um;   // rfimage.h:180
 
-    rf_image(std::shared_ptr<device> dev, double radius_mm, double angle_rad) : dev(std::move(dev)), radius_mm(radius_mm), angle(angle_rad)
+    rf_image(double radius_mm, double angle_rad, std::shared_ptr<device> dev_ = nullptr)
+        : dev(dev_ ? std::move(dev_) : default_device()), radius_mm(radius_mm), angle(angle_rad), host((size_t)columns * max_rows, 0.0f)
     {
+        std::cout << "rf_image: " << max_rows << ", " << columns << std::endl;          // rfimage.h:30
         check(mcrt_alloc(this->dev->ctx, sizeof(float) * columns * max_rows, (void **)&rf_dev), "mcrt_alloc");
         check(mcrt_alloc(this->dev->ctx, sizeof(float) * 400 * 500, (void **)&scan_dev), "mcrt_alloc");
     }
+    rf_image(std::shared_ptr<device> dev_, double radius_mm, double angle_rad) : rf_image(radius_mm, angle_rad, std::move(dev_)) {}
     ~rf_image() { mcrt_free(dev->ctx, rf_dev); mcrt_free(dev->ctx, scan_dev); }
+    rf_image(const rf_image &) = delete; rf_image &operator=(const rf_image &) = delete;
 
-    // clear() + cast_rays + the accumulation loop of main.cpp:102-144 in one call
-    void trace(uint32_t frame_id) { check(mcrt_trace_frame(dev->ctx, frame_id, 0, columns, rf_dev), "mcrt_trace_frame"); }
+    // rfimage.h:33-40: row = micros / (axial_resolution / speed_of_sound), integer micrometres over um/us
+    void add_echo(const unsigned int column, const float echo, const double micros_from_source)
+    {
+        to_host();
+        const double row = micros_from_source / ((double)axial_resolution_um / (double)speed_of_sound);
+        if (row < (double)max_rows) host[(size_t)(int)row * columns + column] += echo;
+    }
+    constexpr double get_dt() const { return (double)axial_resolution_um / (double)speed_of_sound; }                      // [us] rfimage.h:43-46
+    constexpr double micros_traveled(double microm_from_source) const { return microm_from_source / (double)speed_of_sound; }   // rfimage.h:48-51
+    void clear() { std::fill(host.begin(), host.end(), 0.0f); where = on_host; }                                       // rfimage.h:161-164
+    void print(size_t column) const                                                                                       // rfimage.h:166-173
+    {
+        const auto img = intensities();
+        for (size_t i = 0; i < max_rows; i++) std::cout << img[i * columns + column] << ", ";
+        std::cout << std::endl;
+    }
+
+    // clear() + cast_rays + the accumulation loop of main.cpp:102-144 in one call, on the GPU
+    void trace(uint32_t frame_id)
+    {
+        mcrt_params p; check(mcrt_get_params(dev->ctx, &p), "mcrt_get_params");
+        if (p.n_rows != max_rows || p.n_elements != columns) {       // the image's shape is the kernel's: rows from THIS image's template arguments
+            p.n_rows = max_rows; p.n_elements = columns; p.speed_of_sound = speed_of_sound;
+            check(mcrt_set_params(dev->ctx, &p), "mcrt_set_params");
+        }
+        check(mcrt_trace_frame(dev->ctx, frame_id, 0, columns, rf_dev), "mcrt_trace_frame");
+        where = on_device;
+    }
     template <typename psf_> void convolve(const psf_ &p)
     {
+        to_device();
         check(mcrt_convolve(dev->ctx, rf_dev, columns, max_rows, p.axial_kernel.data(), (uint32_t)p.get_axial_size(), p.lateral_kernel.data(), (uint32_t)p.get_lateral_size()), "mcrt_convolve");
     }
-    void envelope() { check(mcrt_envelope(dev->ctx, rf_dev, columns, max_rows), "mcrt_envelope"); }
-    void postprocess() { check(mcrt_scan_convert(dev->ctx, rf_dev, columns, max_rows, radius_mm, angle, scan_dev, 400, 500), "mcrt_scan_convert"); }
+    void envelope() { to_device(); check(mcrt_envelope(dev->ctx, rf_dev, columns, max_rows), "mcrt_envelope"); }
+    void postprocess() { to_device(); check(mcrt_scan_convert(dev->ctx, rf_dev, columns, max_rows, radius_mm, angle, scan_dev, 400, 500), "mcrt_scan_convert"); }
+    void show() const {}   // rfimage.h:150-158 opens an OpenCV window and blocks on a key: out of scope
     std::vector<float> intensities() const   // row-major [max_rows][columns], the cv::Mat of rfimage.h:217
     {
+        if (where == on_host) return host;
         std::vector<float> h((size_t)columns * max_rows);
         check(mcrt_export_rf(dev->ctx, rf_dev, columns, max_rows, h.data()), "mcrt_export_rf");
         return h;
@@ -350,7 +491,17 @@ public:
     }
     std::shared_ptr<device> dev;
 private:
+    void to_device()
+    {
+        if (where == on_host) { check(mcrt_import_rf(dev->ctx, host.data(), columns, max_rows, rf_dev), "mcrt_import_rf"); where = on_device; }
+    }
+    void to_host()
+    {
+        if (where == on_device) { check(mcrt_export_rf(dev->ctx, rf_dev, columns, max_rows, host.data()), "mcrt_export_rf"); where = on_host; }
+    }
     double radius_mm, angle;
+    std::vector<float> host;                     // [max_rows][columns]
+    enum { on_host, on_device } where = on_host;
     float *rf_dev = nullptr, *scan_dev = nullptr;
 };
 

@@ -55,3 +55,13 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.lower() or f in ("synth.py",) and "mcrt_oracle" not in txt, (dp, f)
+
+
+def test_reference_style_program_compiles_against_the_host_shim():
+    """host/reference_style_main.cpp uses the reference's class surface (volume, psf, rf_image::add_echo / clear /
+    micros_traveled / get_dt, scene::cast_rays<S,E>(transducer&), scene::distance, transducer::print/update): it must
+    compile and link against host/mcrt_host.hpp + libmcrt_hip.so (run on the GPU by tests/test_gpu_parity.py)"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "mcray-tracing_amd"), "reference_style_main", "mattausch_hip"])
+    assert os.path.exists(os.path.join(root, "mcray-tracing_amd", "reference_style_main"))

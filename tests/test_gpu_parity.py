@@ -569,3 +569,35 @@ def test_bench_line_contract_and_inline_parity():
     assert out["parity_check"]["rf_bit_exact"] is True and out["parity_check"]["scan_lines"] == 16
     assert out["gather_check"]["equal"]
     assert out["roofline"]["bound"] == "valu" and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["seconds"] >= 5.0
+
+
+def test_reference_style_program_on_the_host_shim(mcrt, orc, tex256, tmp_path):
+    """host/reference_style_main.cpp is written the way the reference's main.cpp is (volume, psf, rf_image::clear/add_echo/
+    micros_traveled, scene::cast_rays<5,512>(transducer), scene::distance, convolve/envelope/postprocess): its host-side
+    accumulation over the GPU-cast segments must agree with the fused GPU frame and with the oracle's reference-order image"""
+    import json, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "mcray-tracing_amd"), "reference_style_main"])
+    exe = os.path.join(root, "mcray-tracing_amd", "reference_style_main")
+    cfg, meshes = mcrt.synth.sphere_scene(3)
+    cfg["workingDirectory"] = str(tmp_path) + "/"
+    for f, (V, F) in meshes.items():
+        mcrt.scene_io.save_obj(str(tmp_path / f), V, F)
+    (tmp_path / "sphere.scene").write_text(json.dumps(cfg))
+    r = subprocess.run([exe, str(tmp_path / "sphere.scene"), str(tmp_path / "host.bin"), str(tmp_path / "fused.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rf_image: 465, 512" in r.stdout
+    host = np.fromfile(str(tmp_path / "host.bin"), np.float32).reshape(465, 512)
+    fused = np.fromfile(str(tmp_path / "fused.bin"), np.float32).reshape(465, 512)
+    sd = mcrt.scene_io.load_scene_file(str(tmp_path / "sphere.scene"))
+    tr = mcrt.Transducer(512, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
+    o = osc.trace_frame(orc.default_params(), tr.pos, tr.dir, tex256, frame_id=0, n_threads=8)
+    ax, lat = orc.psf()
+    assert np.array_equal(fused.view(np.uint32), orc.convolve(o["rf"], ax, lat).view(np.uint32))       # the fused path: bit-exact as ever
+    ref = orc.convolve(o["rf_ref"], ax, lat)                                                          # the reference's summation order
+    m = ~np.isnan(ref)
+    assert np.array_equal(np.isnan(host), np.isnan(ref)) and m.sum() > 0.9 * m.size
+    peak = np.abs(ref[m]).max()
+    assert peak > 0 and np.abs(host[m] - ref[m]).max() <= 1e-5 * peak          # (std::exp in the host loop vs the contract's expf: <= 1 ulp per step)
+    assert np.abs(host[m] - fused[m]).max() <= RTOL_REF * peak

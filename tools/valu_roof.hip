@@ -23,13 +23,16 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum Kind { FMA_IND, FMA_DEP, PKMUL_IND, PKMUL_DEP, MIN3_IND, MIN3_DEP, DPP_IND, DPP_DEP, CMP_CND, INT_ADD, FMA64_IND, ADD64_DEP, MUL64_IND, WALK_MIX, VALU_SALU, N_KINDS };
+enum Kind { FMA_IND, FMA_DEP, PKMUL_IND, PKMUL_DEP, MIN3_IND, MIN3_DEP, DPP_IND, DPP_DEP, CMP_CND, INT_ADD, FMA64_IND, ADD64_DEP, MUL64_IND, WALK_MIX, VALU_SALU, FETCH_AOS, FETCH_SPLIT, FETCH_LANE, N_KINDS };
 static const char *kind_name[N_KINDS] = { "v_fma_f32 independent", "v_fma_f32 dependent", "v_pk_mul_f32 independent", "v_pk_mul_f32 dependent",
     "v_min3_f32 independent", "v_min3_f32 dependent", "v_mov_b32 dpp quad_perm independent", "v_mov_b32 dpp quad_perm dependent",
     "v_cmp_lt_f32 + v_cndmask_b32 pairs", "v_add_u32 independent", "v_fma_f64 independent", "v_add_f64 dependent", "v_mul_f64 independent",
-    "BVH4 node-step mix (pk sub/mul, min/max/min3/max3, dpp, cmp, cndmask, integer)", "v_fma_f32 + s_add_u32 interleaved 1:1 (VALU count only)" };
+    "BVH4 node-step mix (pk sub/mul, min/max/min3/max3, dpp, cmp, cndmask, integer)", "v_fma_f32 + s_add_u32 interleaved 1:1 (VALU count only)",
+    "node fetch, quad reads one 128-B node, lane j bytes [32j,32j+32) as 2 x dwordx4 (k_trace round 1); counts wave-level loads",
+    "node fetch, quad reads one 128-B node, lane j bytes [16j,16j+16) and [64+16j,..) (half-line contiguous); counts wave-level loads",
+    "node fetch, every LANE reads its own 128-B node as 8 x dwordx4 (one lane per ray); counts wave-level loads" };
 // VALU instructions per unrolled body (the loop runs `iters` bodies)
-static const int kind_body[N_KINDS] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 64 };
+static const int kind_body[N_KINDS] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 64, 16, 16, 16 };
 
 struct Stamp { unsigned long long t0, t1, r0, r1; unsigned hw_id, xcc_id, pad0, pad1; };
 
@@ -41,7 +44,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define REP64(x) REP8(REP8(x))
 
 template <int KIND>
-__global__ void __launch_bounds__(256) k_roof(Stamp *out, int iters, float seed)
+__global__ void __launch_bounds__(256) k_roof(Stamp *out, int iters, float seed, const float4 *nodes, unsigned node_mask)
 {
     extern __shared__ char lds_[];
     float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
@@ -120,6 +123,22 @@ __global__ void __launch_bounds__(256) k_roof(Stamp *out, int iters, float seed)
                 "v_cndmask_b32 %10, %10, %11, vcc\n v_cndmask_b32 %11, %11, %12, vcc\n v_add_u32 %10, %10, %6\n v_or_b32 %11, 1, %11\n"
                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(a3), "+v"(px), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a4), "+v"(a5), "+v"(u0), "+v"(u1), "+v"(u2)
                 : "v"(x), "v"(y), "v"(a6), "v"(a7) : "vcc", "s10", "s11");
+        } else if constexpr (KIND == FETCH_AOS || KIND == FETCH_SPLIT || KIND == FETCH_LANE) {
+            // 16 wave-level dwordx4 loads in flight, addresses from a per-quad (or per-lane) hash: rays of a wavefront sit on different nodes
+            float4 r[16];
+            const unsigned who = (KIND == FETCH_LANE) ? threadIdx.x : (threadIdx.x >> 2), j = threadIdx.x & 3;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int step = (KIND == FETCH_LANE) ? (k >> 3) : (k >> 1);           // node visits per body: 2 (lane) or 8 (quad)
+                unsigned h = (who * 2654435761u) ^ ((unsigned)(i * 8 + step) * 2246822519u) ^ (blockIdx.x * 3266489917u);
+                h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+                const float4 *N = nodes + (size_t)(h & node_mask) * 8;
+                if (KIND == FETCH_AOS) r[k] = N[2 * j + (k & 1)];
+                else if (KIND == FETCH_SPLIT) r[k] = N[4 * (k & 1) + j];
+                else r[k] = N[k & 7];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) a0 += r[k].x + r[k].w;
         } else if constexpr (KIND == VALU_SALU) {
             REP8(asm volatile("v_fma_f32 %0, %0, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %1, %1, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %2, %2, %9, %10\n s_add_u32 %8, %8, 1\n"
                               "v_fma_f32 %3, %3, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %4, %4, %9, %10\n s_add_u32 %8, %8, 1\n v_fma_f32 %5, %5, %9, %10\n s_add_u32 %8, %8, 1\n"
@@ -145,8 +164,9 @@ __global__ void __launch_bounds__(256) k_roof(Stamp *out, int iters, float seed)
 struct Result { double cyc_per_instr_wave, simd_ipc, clock_ghz, span_ms; int simds, waves_min, waves_max; };
 
 template <int KIND>
-static Result run(int W, int iters, int n_cu, Stamp *d_out, std::vector<Stamp> &h)
+static Result run(int W, int iters, int n_cu, Stamp *d_out, std::vector<Stamp> &h, const float4 *d_nodes, unsigned node_mask)
 {
+    if (KIND >= FETCH_AOS) iters = iters / 8 > 64 ? iters / 8 : 64;
     const int blocks = n_cu * W;
     // exactly W workgroups fit a compute unit: 160 KiB of LDS / W each, minus a margin smaller than one more share
     size_t lds = (size_t)(160 * 1024) / (size_t)W;
@@ -154,7 +174,7 @@ static Result run(int W, int iters, int n_cu, Stamp *d_out, std::vector<Stamp> &
     lds &= ~(size_t)1023;
     CHECK(hipFuncSetAttribute((const void *)k_roof<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int rep = 0; rep < 2; rep++) {      // the second launch is the measured one (clocks settled)
-        hipLaunchKernelGGL(k_roof<KIND>, dim3(blocks), dim3(256), lds, 0, d_out, iters, 1.0f);
+        hipLaunchKernelGGL(k_roof<KIND>, dim3(blocks), dim3(256), lds, 0, d_out, iters, 1.0f, d_nodes, node_mask);
         CHECK(hipGetLastError());
         CHECK(hipDeviceSynchronize());
     }
@@ -189,13 +209,13 @@ static Result run(int W, int iters, int n_cu, Stamp *d_out, std::vector<Stamp> &
 }
 
 template <int K>
-static void sweep(bool &first, const std::vector<int> &Ws, int iters, int n_cu, Stamp *d_out, std::vector<Stamp> &h)
+static void sweep(bool &first, const std::vector<int> &Ws, int iters, int n_cu, Stamp *d_out, std::vector<Stamp> &h, const float4 *d_nodes = nullptr, unsigned node_mask = 0, const char *where = "")
 {
     for (int W : Ws) {
-        const Result r = run<K>(W, iters, n_cu, d_out, h);
-        printf("%s\n  {\"class\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_instr_one_wave\": %.3f, \"simd_ipc\": %.4f, \"clock_ghz\": %.3f, "
+        const Result r = run<K>(W, iters, n_cu, d_out, h, d_nodes, node_mask);
+        printf("%s\n  {\"class\": \"%s%s\", \"waves_per_simd\": %d, \"cycles_per_instr_one_wave\": %.3f, \"simd_ipc\": %.4f, \"clock_ghz\": %.3f, "
                "\"simds_seen\": %d, \"waves_per_simd_seen\": [%d, %d], \"launch_ms\": %.3f}",
-               first ? "" : ",", kind_name[K], W, r.cyc_per_instr_wave, r.simd_ipc, r.clock_ghz, r.simds, r.waves_min, r.waves_max, r.span_ms);
+               first ? "" : ",", kind_name[K], where, W, r.cyc_per_instr_wave, r.simd_ipc, r.clock_ghz, r.simds, r.waves_min, r.waves_max, r.span_ms);
         first = false;
         fflush(stdout);
     }
@@ -229,6 +249,21 @@ int main(int argc, char **argv)
     sweep<MUL64_IND>(first, Ws, iters, n_cu, d_out, h);
     sweep<WALK_MIX>(first, Ws, iters, n_cu, d_out, h);
     sweep<VALU_SALU>(first, Ws, iters, n_cu, d_out, h);
+    // node-fetch patterns on tables of three sizes: 16 KiB (vector L1), 2 MiB (one XCD's L2), 64 MiB (Infinity Cache: the size of the 1 M-triangle BVH)
+    {
+        const size_t max_nodes = (size_t)1 << 19;
+        float4 *d_nodes = nullptr;
+        CHECK(hipMalloc(&d_nodes, max_nodes * 128));
+        CHECK(hipMemset(d_nodes, 0, max_nodes * 128));
+        const unsigned masks[3] = { (1u << 7) - 1u, (1u << 14) - 1u, (1u << 19) - 1u };
+        const char *names[3] = { " [16 KiB table: L1]", " [2 MiB table: L2]", " [64 MiB table: Infinity Cache]" };
+        for (int t = 0; t < 3; t++) {
+            sweep<FETCH_AOS>(first, Ws, iters, n_cu, d_out, h, d_nodes, masks[t], names[t]);
+            sweep<FETCH_SPLIT>(first, Ws, iters, n_cu, d_out, h, d_nodes, masks[t], names[t]);
+            sweep<FETCH_LANE>(first, Ws, iters, n_cu, d_out, h, d_nodes, masks[t], names[t]);
+        }
+        (void)hipFree(d_nodes);
+    }
     printf("\n]}\n");
     (void)hipFree(d_out);
     return 0;
