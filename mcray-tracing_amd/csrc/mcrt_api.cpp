@@ -66,7 +66,7 @@ struct Work {
 // tuning knobs from the environment, read ONCE at mcrt_create (never on the frame path)
 struct Knobs {
     uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 4096;
-    bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false;
+    bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false, quad_walk = false;
 };
 static Knobs read_knobs()
 {
@@ -78,6 +78,7 @@ static Knobs read_knobs()
     if (const char *e = getenv("MCRT_MARCH_BLOCKS")) { int v = atoi(e); if (v >= 1) k.march_blocks = (uint32_t)v; }
     k.no_overlap = getenv("MCRT_NO_OVERLAP") != nullptr; k.no_priority = getenv("MCRT_NO_PRIORITY") != nullptr;
     k.no_fast_div = getenv("MCRT_NO_FAST_DIV") != nullptr; k.no_lean = getenv("MCRT_NO_LEAN") != nullptr;
+    k.quad_walk = getenv("MCRT_QUAD_WALK") != nullptr;       // the round-1 walk (four lanes per ray) instead of one lane per ray
     return k;
 }
 
@@ -94,6 +95,7 @@ struct mcrt_ctx {
     mcrt_bvh4 bvh4{};
     uint32_t *d_error = nullptr;
     float4 *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr;
+    float4 *d_nodes_soa = nullptr; int *d_stack_ovf = nullptr;   // lane-per-ray walk: child-transposed nodes, traversal-stack overflow
     uint4 *d_meshes = nullptr;
     uint32_t *d_tri_slot = nullptr;
     uint32_t n_mesh = 0, n_mat = 0, start_mat = 0, n_cu = 256;
@@ -253,8 +255,27 @@ static int get_work(mcrt_ctx *c, size_t g, Work **out)
     return MCRT_OK;
 }
 
+// the lane-per-ray walk's view of the tree: child-transposed nodes (rebuilt whenever d_nodes changes) and, for trees whose
+// worst-case traversal stack exceeds the LDS part, the overflow array
+static int refresh_soa(mcrt_ctx *c)
+{
+    hipFree(c->d_nodes_soa); c->d_nodes_soa = nullptr;
+    hipFree(c->d_stack_ovf); c->d_stack_ovf = nullptr;
+    if (c->knobs.quad_walk || c->bvh4.n_nodes == 0) return MCRT_OK;
+    HIP_TRY(hipMalloc(&c->d_nodes_soa, 128 * (size_t)c->bvh4.n_nodes));
+    HIP_TRY(mcrt::launch_nodes_soa(c->d_nodes, c->bvh4.n_nodes, c->d_nodes_soa, c->stream));
+    const uint32_t lds_part = mcrt::lane_stack_entries();
+    if (c->bvh4.max_stack > lds_part) {
+        const uint32_t blocks = c->knobs.trace_blocks ? c->knobs.trace_blocks : c->n_cu * 5u;
+        HIP_TRY(hipMalloc(&c->d_stack_ovf, 4 * (size_t)(c->bvh4.max_stack - lds_part) * blocks * 256));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MCRT_OK;
+}
+
 static void free_scene(mcrt_ctx *c)
 {
+    hipFree(c->d_nodes_soa); c->d_nodes_soa = nullptr; hipFree(c->d_stack_ovf); c->d_stack_ovf = nullptr;
     hipFree(c->d_nodes); hipFree(c->d_tris); hipFree(c->d_mats); hipFree(c->d_meshes); hipFree(c->d_tri_slot); c->d_tri_slot = nullptr;
     c->d_nodes = c->d_tris = c->d_mats = nullptr; c->d_meshes = nullptr;
     mcrt_free_bvh(&c->bvh);
@@ -431,6 +452,7 @@ extern "C" int mcrt_update_triangles(mcrt_ctx *c, const float *tri, uint32_t n_t
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_scene = false;                           // a failed rebuild leaves no scene
     int rc = index_triangles(c, tri, n_tri); if (rc) return rc;
+    rc = refresh_soa(c); if (rc) return rc;
     c->have_scene = true;
     return MCRT_OK;
 }
@@ -449,6 +471,7 @@ extern "C" int mcrt_refit_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tr
     float pad = 0.0f, lo[3], hi[3];
     if (!rc) rc = mcrt::bvh_refit(d_tri, n_tri, c->d_nodes, c->bvh4.n_nodes, c->d_tris, c->stream, &pad, lo, hi);
     hipFree(d_tri);
+    if (!rc) rc = refresh_soa(c);
     if (rc) { c->have_scene = false; return rc; }           // a failed refit leaves no scene
     c->bvh.pad_abs = pad;
     for (int i = 0; i < 3; i++) { c->scene_lo[i] = lo[i]; c->scene_hi[i] = hi[i]; }
@@ -477,6 +500,7 @@ extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *
     if (n_tri) {
         c->tri_mesh.assign(tri_mesh, tri_mesh + n_tri);
         int rc = index_triangles(c, tri, n_tri); if (rc) return rc;
+        rc = refresh_soa(c); if (rc) return rc;
     }
     HIP_TRY(hipMalloc(&c->d_mats, 32 * (size_t)n_mat));
     HIP_TRY(hipMemcpy(c->d_mats, mats, 32 * (size_t)n_mat, hipMemcpyHostToDevice));
@@ -620,7 +644,7 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne, int out)
 static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, uint32_t acc_e0, uint32_t acc_ne)
 {
     memset(&a, 0, sizeof a);
-    a.nodes = c->d_nodes; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
+    a.nodes = c->d_nodes; a.nodes_soa = c->d_nodes_soa; a.stack_ovf = c->d_stack_ovf; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
     a.el_pos = c->d_pos; a.el_dir = c->d_dir; a.row_thr = c->d_row_thr;
     a.acc = c->d_acc; a.flags = c->d_flags;                 // the frame block [n_frames][acc_ne][R]; this group owns columns e0-acc_e0 ...
     a.acc_stride = acc_ne; a.acc_off = e0 - acc_e0;

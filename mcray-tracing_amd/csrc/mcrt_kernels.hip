@@ -645,6 +645,277 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
     }
 }
 
+
+// =============================================================================================================
+// k_trace_lane -- the same closest-hit walk with ONE LANE per ray (64 rays per wavefront instead of 16).
+//
+// The quad walk above keeps 16 rays in flight per wavefront, two 16-byte loads each per node step: with five wavefronts per
+// SIMD a compute unit has 320 rays and 640 loads in flight, and the counters show its wavefronts parked on memory for more
+// than half of their life (SQ_WAIT_ANY 56 %) with the vector units at 41 % of their issue rate -- the walk is LATENCY-bound.
+// One lane per ray puts four times as many rays (and seven independent 16-byte loads per ray and step) behind every
+// wavefront, and spends fewer instructions per ray: no quad ranking exchanges, and the slab planes of two children at a time
+// go through the packed-f32 pipe (v_pk_add_f32 / v_pk_mul_f32).
+//
+// Nodes are read from a child-transposed copy of the BVH4 (k_nodes_soa): eight float4 per node,
+//     lo.x[4] | lo.y[4] | lo.z[4] | hi.x[4] | hi.y[4] | hi.z[4] | ref[4] | -
+// with unused slots stored as the point box at +infinity, which no slab test hits (so the walk needs no EMPTY test).
+// Per ray the arithmetic is the quad walk's, operation for operation: (plane - origin) * reciprocal, the same min/max
+// combination, the same nearest-child key (t_near bits with the slot number in the two low bits), the other hit children
+// stacked in slot order, and the same triangle test -- so hits AND visit counts equal the quad walk's and the oracle's.
+// Traversal stacks: MCRT_LANE_STACK entries per lane in LDS ([entry][thread], conflict-free); deeper entries (only reachable on
+// degenerate paths of deep trees) go to a global overflow array.
+// =============================================================================================================
+#ifndef MCRT_LANE_STACK
+#define MCRT_LANE_STACK 32
+#endif
+#ifndef MCRT_LANE_WAVES
+#define MCRT_LANE_WAVES 5            // waves per SIMD the register budget of k_trace_lane is set for
+#endif
+#ifndef MCRT_LANE_REFILL
+#define MCRT_LANE_REFILL 16          // fetch and set up new rays once this many of a wavefront's 64 lanes are without one
+#endif
+#ifndef MCRT_LANE_LEAF_BATCH
+#define MCRT_LANE_LEAF_BATCH 20      // leave the inner-node phase once this many lanes are parked on a leaf
+#endif
+#ifndef MCRT_LANE_FETCH
+#define MCRT_LANE_FETCH 64           // queue positions a wavefront claims per atomic
+#endif
+
+__global__ void k_nodes_soa(const float4 *in, uint32_t n_nodes, float4 *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    float lo[3][4], hi[3][4]; int ref[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float4 A = in[8 * (size_t)i + 2 * c], B = in[8 * (size_t)i + 2 * c + 1];
+        ref[c] = __float_as_int(B.z);
+        const bool empty = ref[c] == MCRT_BVH4_EMPTY;
+        lo[0][c] = empty ? INFINITY : A.x; lo[1][c] = empty ? INFINITY : A.y; lo[2][c] = empty ? INFINITY : A.z;
+        hi[0][c] = empty ? INFINITY : A.w; hi[1][c] = empty ? INFINITY : B.x; hi[2][c] = empty ? INFINITY : B.y;
+    }
+    float4 *o = out + 8 * (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { o[k] = make_float4(lo[k][0], lo[k][1], lo[k][2], lo[k][3]); o[3 + k] = make_float4(hi[k][0], hi[k][1], hi[k][2], hi[k][3]); }
+    o[6] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(ref[2]), __int_as_float(ref[3]));
+    o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// slab interval of one child from its six plane distances (the combination of slab_pairs, same instructions)
+MCRT_DEV bool slab_combine(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z, float tlow, float tcap, float &tmin_o)
+{
+    float lo3 = fminf(t0z, t1z), hi3 = fmaxf(t0z, t1z), tmin, tmax;
+    const float lo1 = fminf(t0x, t1x), lo2 = fminf(t0y, t1y), hi1 = fmaxf(t0x, t1x), hi2 = fmaxf(t0y, t1y);
+    asm("v_max_f32 %0, %1, %2" : "=v"(lo3) : "v"(lo3), "v"(tlow));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmin) : "v"(lo1), "v"(lo2), "v"(lo3));
+    asm("v_min_f32 %0, %1, %2" : "=v"(hi3) : "v"(hi3), "v"(tcap));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(hi1), "v"(hi2), "v"(hi3));
+    tmin_o = tmin;
+    return tmin <= tmax;
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a, uint32_t b)
+{
+    __shared__ int stack[MCRT_LANE_STACK * 256];      // [entry][thread]: entry sp of thread t at sp*256 + t -> conflict-free
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t n_rays = (b == 0u) ? a.ne : a.counts[b];
+    const uint32_t K = ksplit(n_rays, a.ksplit_limit);
+    const uint32_t n = n_rays * K;
+    const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
+    const uint32_t ray_stride = (b == 0u) ? a.S : 1u;
+    unsigned long long *keys = (b & 1u) ? a.key1 : a.key0;
+    unsigned long long st_nodes = 0, st_tris = 0, st_q = 0;
+    int *ovf = a.stack_ovf + ((size_t)blockIdx.x * 256 + tid);       // overflow entries of this lane: [entry - MCRT_LANE_STACK][grid thread]
+    const size_t ovf_stride = (size_t)gridDim.x * 256;
+
+    // work distribution: as in k_trace (one sub-queue and cursor per XCD, swept in order), one item per LANE
+    const uint32_t X = (n >= (uint32_t)MCRT_XCD_MIN_ITEMS) ? (uint32_t)MCRT_XCDS : 1u;
+    if (X == 1u && blockIdx.x * 256u >= n) return;
+    const uint32_t x_shift = (X == 1u) ? 0u : 3u;
+    uint32_t cur_x = blockIdx.x & (X - 1u), visited = 0;
+#define MCRT_SUB_LO(sq) ((uint32_t)(((unsigned long long)n * (sq)) >> x_shift))
+#define MCRT_SUB_STATIC(sq) (((gridDim.x - (sq) + X - 1u) >> x_shift) * 256u)
+    uint32_t *cursors = a.cursors + (size_t)b * MCRT_XCDS * MCRT_CURSOR_STRIDE;
+    uint32_t i = MCRT_SUB_LO(cur_x) + (blockIdx.x >> x_shift) * 256u + (uint32_t)tid;      // the first item of each lane is assigned statically
+    if (i >= MCRT_SUB_LO(cur_x + 1u)) i = 0xffffffffu;
+    uint32_t ray_id = 0;
+    bool exhausted = false, fresh = true;
+    f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1), inv = mk(1, 1, 1);
+    float t_lo = 0.0f;
+    Best best; best.frac = 1.0f; best.tri = -1;
+    constexpr int CUR_IDLE = (int)0x80000000;
+    int sp = 0, cur = CUR_IDLE;
+#define MCRT_ON_INNER(c) __builtin_amdgcn_sicmp((c), -1, 38)
+#define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)
+#define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)
+#define MCRT_POP() { if (sp > 0) { sp--; cur = (sp < MCRT_LANE_STACK) ? stack[sp * 256 + tid] : ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride]; } else cur = CUR_IDLE; }
+#define MCRT_PUSH(v) { if (sp < MCRT_LANE_STACK) stack[sp * 256 + tid] = (v); else ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride] = (v); sp++; }
+    uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
+    for (;;) {
+        // ---- finished rays report and idle lanes take new ones, once enough of them wait (the code runs for the whole wavefront) ----
+        const bool do_refill = __popcll(__ballot(cur == CUR_IDLE && !exhausted)) >= MCRT_LANE_REFILL || MCRT_WALKING(cur) == 0ull;
+        if (do_refill) {
+            if (cur == CUR_IDLE && !fresh && !exhausted) {
+                if (best.tri >= 0) {
+                    const unsigned long long word = ((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri;
+                    if (K == 1u) keys[ray_id] = word;
+                    else atomicMin(&keys[ray_id], word);
+                }
+                fresh = true; i = 0xffffffffu;
+            }
+            const bool need = fresh && !exhausted;
+            const unsigned long long dynm = __ballot(need && i == 0xffffffffu);
+            if (dynm) {
+                while (pool_next >= pool_end && !queue_empty) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&cursors[(size_t)cur_x * MCRT_CURSOR_STRIDE], (uint32_t)MCRT_LANE_FETCH);
+                    base = __shfl(base, 0, 64);
+                    const uint32_t hi = MCRT_SUB_LO(cur_x + 1u);
+                    const unsigned long long start = (unsigned long long)MCRT_SUB_LO(cur_x) + MCRT_SUB_STATIC(cur_x) + base;
+                    if (start < hi) { pool_next = (uint32_t)start; pool_end = min((uint32_t)start + (uint32_t)MCRT_LANE_FETCH, hi); }
+                    else if (++visited >= X) queue_empty = true;
+                    else cur_x = (cur_x + 1u) & (X - 1u);
+                }
+                if (need && i == 0xffffffffu) {
+                    const uint32_t mine = pool_next + (uint32_t)__popcll(dynm & ((1ull << lane) - 1ull));
+                    if (queue_empty) i = n;
+                    else if (mine < pool_end) i = mine;
+                }
+                const uint32_t taken = (uint32_t)__popcll(dynm);
+                pool_next = (pool_next + taken < pool_end) ? pool_next + taken : pool_end;
+            }
+            if (need && i != 0xffffffffu) {
+                if (i < n) {
+                    uint32_t piece = 0u;
+                    if (K == 1u) ray_id = i;
+                    else { piece = i / n_rays; ray_id = i - piece * n_rays; }
+                    const float4 r0 = rays[2 * (size_t)ray_id * ray_stride], r1 = rays[2 * (size_t)ray_id * ray_stride + 1];
+                    f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
+                    const f3 d = to - f2;
+                    inv = mk(r1.z, r1.w, 1.0f / d.z);
+                    t_lo = 0.0f;
+                    float t_hi = 1.0f;
+                    if (K > 1u) {
+                        float tin, tout;
+                        if (slab(mk(a.scene_lo[0], a.scene_lo[1], a.scene_lo[2]), mk(a.scene_hi[0], a.scene_hi[1], a.scene_hi[2]), f2, inv, 0.0f, 1.0f, tin, tout)) {
+                            const float w = tout - tin;
+                            if (piece > 0u) t_lo = tin + w * ((float)piece / (float)K);
+                            if (piece + 1u < K) t_hi = tin + w * ((float)(piece + 1u) / (float)K);
+                        } else if (piece > 0u) t_hi = 0.0f;
+                    }
+                    best.frac = t_hi; best.tri = -1;
+                    sp = 0; cur = (a.n_nodes != 0u && t_lo < t_hi) ? 0 : CUR_IDLE; fresh = false;
+                    if (STATS && piece == 0u) st_q++;
+                } else exhausted = true;
+            }
+        }
+        if (MCRT_WALKING(cur) == 0ull) { if (!__any(!exhausted)) break; else continue; }
+
+        // ---- phase 1: inner nodes, until enough lanes are parked on a leaf ----
+        const float tcap = fminf(1.0f, best.frac);               // best only changes in phase 2
+        const v2f oxx = (v2f){ f2.x, f2.x }, oyy = (v2f){ f2.y, f2.y }, ozz = (v2f){ f2.z, f2.z };
+        const v2f ixx = (v2f){ inv.x, inv.x }, iyy = (v2f){ inv.y, inv.y }, izz = (v2f){ inv.z, inv.z };
+        for (;;) {
+            const unsigned long long inner = MCRT_ON_INNER(cur);
+            if (inner == 0ull) break;
+            if (__popcll(MCRT_ON_LEAF(cur)) >= MCRT_LANE_LEAF_BATCH) break;
+            if (cur >= 0) {
+                const float4 *N = (const float4 *)((const char *)a.nodes_soa + ((uint32_t)cur << 7));
+                const float4 LX = N[0], LY = N[1], LZ = N[2], HX = N[3], HY = N[4], HZ = N[5], RF = N[6];
+                if (STATS) st_nodes++;
+                // six plane distances of the four children, two children per packed operation: (plane - origin) * reciprocal
+                const v2f t0x_a = ((v2f){ LX.x, LX.y } - oxx) * ixx, t0x_b = ((v2f){ LX.z, LX.w } - oxx) * ixx;
+                const v2f t0y_a = ((v2f){ LY.x, LY.y } - oyy) * iyy, t0y_b = ((v2f){ LY.z, LY.w } - oyy) * iyy;
+                const v2f t0z_a = ((v2f){ LZ.x, LZ.y } - ozz) * izz, t0z_b = ((v2f){ LZ.z, LZ.w } - ozz) * izz;
+                const v2f t1x_a = ((v2f){ HX.x, HX.y } - oxx) * ixx, t1x_b = ((v2f){ HX.z, HX.w } - oxx) * ixx;
+                const v2f t1y_a = ((v2f){ HY.x, HY.y } - oyy) * iyy, t1y_b = ((v2f){ HY.z, HY.w } - oyy) * iyy;
+                const v2f t1z_a = ((v2f){ HZ.x, HZ.y } - ozz) * izz, t1z_b = ((v2f){ HZ.z, HZ.w } - ozz) * izz;
+                float tn0, tn1, tn2, tn3;
+                const bool h0 = slab_combine(t0x_a.x, t0y_a.x, t0z_a.x, t1x_a.x, t1y_a.x, t1z_a.x, t_lo, tcap, tn0);
+                const bool h1 = slab_combine(t0x_a.y, t0y_a.y, t0z_a.y, t1x_a.y, t1y_a.y, t1z_a.y, t_lo, tcap, tn1);
+                const bool h2 = slab_combine(t0x_b.x, t0y_b.x, t0z_b.x, t1x_b.x, t1y_b.x, t1z_b.x, t_lo, tcap, tn2);
+                const bool h3 = slab_combine(t0x_b.y, t0y_b.y, t0z_b.y, t1x_b.y, t1y_b.y, t1z_b.y, t_lo, tcap, tn3);
+                // nearest hit child first (key unique per node: t_near bits with the slot number in the two low bits), the others
+                // are stacked in slot order -- exactly the quad walk's order
+                const uint32_t k0 = h0 ? ((__float_as_uint(tn0) & ~3u) | 0u) : 0xffffffffu, k1 = h1 ? ((__float_as_uint(tn1) & ~3u) | 1u) : 0xffffffffu;
+                const uint32_t k2 = h2 ? ((__float_as_uint(tn2) & ~3u) | 2u) : 0xffffffffu, k3 = h3 ? ((__float_as_uint(tn3) & ~3u) | 3u) : 0xffffffffu;
+                const uint32_t kmin = min(min(k0, k1), min(k2, k3));
+                int r0 = __float_as_int(RF.x), r1 = __float_as_int(RF.y), r2 = __float_as_int(RF.z), r3 = __float_as_int(RF.w);
+                asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));      // (the child references are fetched WITH the boxes, not after the tests in a second round trip)
+                if (kmin == 0xffffffffu) { MCRT_POP() }
+                else {
+                    const bool p0 = h0 && k0 != kmin, p1 = h1 && k1 != kmin, p2 = h2 && k2 != kmin, p3 = h3 && k3 != kmin;
+                    if (__builtin_expect(__any(sp + 3 > MCRT_LANE_STACK), 0)) {       // (some lane may leave the LDS part: the general form)
+                        if (p0) MCRT_PUSH(r0)
+                        if (p1) MCRT_PUSH(r1)
+                        if (p2) MCRT_PUSH(r2)
+                        if (p3) MCRT_PUSH(r3)
+                    } else {
+                        int *top = &stack[sp * 256 + tid];
+                        const int s1 = p0 ? 256 : 0, s2 = s1 + (p1 ? 256 : 0), s3 = s2 + (p2 ? 256 : 0);
+                        if (p0) top[0] = r0;
+                        if (p1) top[s1] = r1;
+                        if (p2) top[s2] = r2;
+                        if (p3) top[s3] = r3;
+                        sp += (s3 >> 8) + (p3 ? 1 : 0);
+                    }
+                    const uint32_t jn = kmin & 3u;
+                    cur = jn == 0u ? r0 : jn == 1u ? r1 : jn == 2u ? r2 : r3;
+                }
+            }
+        }
+        // ---- phase 2: the parked leaves; the triangle test of the contract (btTriangleRaycastCallback::processTriangle behind
+        // the padded-bounds rule), one lane per ray, same expressions as the quad walk's shared test ----
+        if ((uint32_t)cur > 0x80000000u) {
+            const uint32_t v = (uint32_t)~cur;
+            const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; k++) {
+                const float4 *T = (const float4 *)((const char *)a.tris + (first + k) * 96u);
+                const float4 P = T[0];
+                const f3 nrm = xyz(P);
+                const float da = dot(nrm, f2) - P.w;
+                const float db = dot(nrm, to) - P.w;
+                if (da * db >= 0.0f) continue;
+                const float4 PL = T[1], PH = T[2];
+                const int id = __float_as_int(PL.w);
+                const float proj = da - db;
+                const float frac = da / proj;
+                if (!(frac < best.frac || (frac == best.frac && id < best.tri)) || !(frac >= t_lo)) continue;
+                float tmin, tmax;
+                const RayPairs rp = ray_pairs(f2, inv);
+                if (!(slab_pairs((v2f){ PL.x, PL.y }, (v2f){ PL.z, PH.x }, (v2f){ PH.y, PH.z }, rp, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax)) continue;
+                const float4 V0 = T[3], V1 = T[4], V2 = T[5];
+                const float edge_tol = V0.w;
+                const float s = 1.0f - frac;
+                const f3 p = mk(s * f2.x + frac * to.x, s * f2.y + frac * to.y, s * f2.z + frac * to.z);
+                const f3 p0 = xyz(V0) - p, p1 = xyz(V1) - p, p2 = xyz(V2) - p;
+                if (!(dot(cross(p0, p1), nrm) >= edge_tol)) continue;
+                if (!(dot(cross(p1, p2), nrm) >= edge_tol)) continue;
+                if (!(dot(cross(p2, p0), nrm) >= edge_tol)) continue;
+                best.frac = frac; best.tri = id;
+            }
+            if (STATS) st_tris += cnt;
+            MCRT_POP()
+        }
+    }
+#undef MCRT_SUB_LO
+#undef MCRT_SUB_STATIC
+#undef MCRT_ON_INNER
+#undef MCRT_ON_LEAF
+#undef MCRT_WALKING
+#undef MCRT_POP
+#undef MCRT_PUSH
+    if (STATS) {
+        unsigned long long v[3] = { st_q, st_nodes, st_tris };
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            long long x = wave_sum_i64((long long)v[k]);
+            if (lane == 0 && x) atomicAdd(&a.stats[k], (unsigned long long)x);
+        }
+    }
+}
+
 // ---- interface interaction (scene.cpp:122-165, ray.cpp:11-97): one lane per live ray ----
 template <bool STATS>
 __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, uint32_t b)
@@ -1188,8 +1459,25 @@ hipError_t launch_init(const FrameArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
+hipError_t launch_nodes_soa(const float4 *nodes, uint32_t n_nodes, float4 *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_nodes_soa, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, nodes, n_nodes, out);
+    return hipGetLastError();
+}
+
+uint32_t lane_stack_entries() { return MCRT_LANE_STACK; }
+
 hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st)
 {
+    if (a.nodes_soa) {          // one lane per ray
+        uint32_t np = (b == 0u) ? a.ne : a.ne * a.S;
+        if (np < a.ksplit_limit) np = a.ksplit_limit;
+        const uint32_t blocks = (np + 255u) / 256u;
+        const dim3 grid(blocks < a.trace_blocks ? blocks : a.trace_blocks), blk(256);
+        if (stats) hipLaunchKernelGGL((k_trace_lane<true>), grid, blk, 0, st, a, b);
+        else hipLaunchKernelGGL((k_trace_lane<false>), grid, blk, 0, st, a, b);
+        return hipGetLastError();
+    }
     // persistent over the bounce's queue: at most trace_blocks workgroups (the rest of the queue is fetched dynamically);
     // the live-ray count is only known on the device, surplus blocks read it and leave
     uint32_t np = (b == 0u) ? a.ne : a.ne * a.S;
