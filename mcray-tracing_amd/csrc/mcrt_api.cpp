@@ -67,6 +67,8 @@ struct Work {
 struct Knobs {
     uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 4096;
     bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false, quad_walk = false;
+    int pipeline = 0;                          // 0 = by pass size, 1 = wavefront (a launch per stage and bounce), 2 = fused path kernel
+    uint32_t fused_groups = 2, fused_max_paths = 1u << 20;
 };
 static Knobs read_knobs()
 {
@@ -78,7 +80,10 @@ static Knobs read_knobs()
     if (const char *e = getenv("MCRT_MARCH_BLOCKS")) { int v = atoi(e); if (v >= 1) k.march_blocks = (uint32_t)v; }
     k.no_overlap = getenv("MCRT_NO_OVERLAP") != nullptr; k.no_priority = getenv("MCRT_NO_PRIORITY") != nullptr;
     k.no_fast_div = getenv("MCRT_NO_FAST_DIV") != nullptr; k.no_lean = getenv("MCRT_NO_LEAN") != nullptr;
-    k.quad_walk = getenv("MCRT_QUAD_WALK") != nullptr;       // the round-1 walk (four lanes per ray) instead of one lane per ray
+    k.quad_walk = getenv("MCRT_QUAD_WALK") != nullptr;
+    if (const char *e = getenv("MCRT_PIPELINE")) { if (!strcmp(e, "wavefront")) k.pipeline = 1; else if (!strcmp(e, "fused")) k.pipeline = 2; }
+    if (const char *e = getenv("MCRT_FUSED_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 16) k.fused_groups = (uint32_t)v; }
+    if (const char *e = getenv("MCRT_FUSED_MAX")) { long v = atol(e); if (v >= 0) k.fused_max_paths = (uint32_t)v; }       // the round-1 walk (four lanes per ray) instead of one lane per ray
     return k;
 }
 
@@ -676,21 +681,15 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
 
 static uint32_t side_streams(const mcrt_ctx *c) { return c->knobs.march_streams; }
 
+static int timing_events(mcrt_ctx *c, hipEvent_t *e0, hipEvent_t *e1);
+
 // one bounce of one group: k_trace + k_shade on the group's stream, k_march of the finished segments on its side stream.
 // With timing enabled every k_trace launch (the dominant kernel) is bracketed by HIP events on the stream it is launched on.
 static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArgs &a, uint32_t b, bool accumulate, bool overlap)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->timing_on) {
-        if (c->ev_used == c->ev.size()) {
-            if (c->ev.size() >= 65536) return set_error(MCRT_ERR_LIMIT, "timing buffer full: call mcrt_get_kernel_time(reset=1)");
-            hipEvent_t x, y;
-            HIP_TRY(hipEventCreate(&x)); HIP_TRY(hipEventCreate(&y));
-            c->ev.emplace_back(x, y);
-        }
-        e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; c->ev_used++;
-        HIP_TRY(hipEventRecord(e0, st));
-    }
+    { int rc = timing_events(c, &e0, &e1); if (rc) return rc; }
+    if (e0) HIP_TRY(hipEventRecord(e0, st));
     HIP_TRY(mcrt::launch_trace(a, b, c->stats_on, st));
     if (c->timing_on) HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(mcrt::launch_shade(a, b, c->stats_on, st));
@@ -708,9 +707,39 @@ static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArg
 // scene::cast_rays (scene.cpp:50-183) [+ the accumulation loop] for scan-lines [e0,e1), split into `groups` independent
 // pipelines whose kernels run concurrently.  Everything is ordered after what is already queued on the context's stream, and
 // the context's stream waits for all of it.
+// Which pipeline traces a pass of `paths` sample paths: small passes (one frame at a time: the reference's own frame loop)
+// take the fused path kernel -- five launches per scan-line group instead of thirty-one, one drain instead of ten; big passes the
+// wavefront pipeline, whose interface physics runs in full wavefronts and whose accumulation overlaps the next bounce's walk.
+static bool use_fused(const mcrt_ctx *c, size_t paths)
+{
+    if (!c->d_nodes_soa) return false;                     // (the fused kernel walks the child-transposed nodes)
+    if (c->knobs.pipeline == 1) return false;
+    if (c->knobs.pipeline == 2) return true;
+    return paths <= (size_t)c->knobs.fused_max_paths;
+}
+
+static int timing_events(mcrt_ctx *c, hipEvent_t *e0, hipEvent_t *e1)
+{
+    *e0 = *e1 = nullptr;
+    if (!c->timing_on) return MCRT_OK;
+    if (c->ev_used == c->ev.size()) {
+        if (c->ev.size() >= 65536) return set_error(MCRT_ERR_LIMIT, "timing buffer full: call mcrt_get_kernel_time(reset=1)");
+        hipEvent_t x, y;
+        HIP_TRY(hipEventCreate(&x)); HIP_TRY(hipEventCreate(&y));
+        c->ev.emplace_back(x, y);
+    }
+    *e0 = c->ev[c->ev_used].first; *e1 = c->ev[c->ev_used].second; c->ev_used++;
+    return MCRT_OK;
+}
+
+// scene::cast_rays (scene.cpp:50-183) [+ the accumulation loop] for scan-lines [e0,e1), split into `groups` independent
+// scan-line blocks.  Everything is ordered after what is already queued on the context's stream, and the context's stream
+// waits for all of it.
 static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, bool accumulate, uint32_t groups, int out)
 {
     const uint32_t ne = e1 - e0;
+    const bool fused = use_fused(c, (size_t)ne * n_frames * c->p.n_samples);
+    if (fused && out == 0 && !c->stats_on && groups == 1 && accumulate) groups = c->knobs.fused_groups;   // march of block g beside the paths of block g+1
     if (groups > ne) groups = ne;
     if (groups < 1) groups = 1;
     if (groups > 16) groups = 16;
@@ -724,6 +753,33 @@ static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0
         fill_args(c, *ws[g], args[g], frame, n_frames, b0, b1, e0, ne);
         args[g].want_segs = out >= 2 ? 1u : 0u;
         if (out < 1) args[g].hits = nullptr;
+    }
+    if (fused) {
+        // k_init -> shared bounce-0 walk -> k_paths (all bounces of every path) on the context's stream, block after block;
+        // each block's accumulation (ONE k_march over all its bounces) on its low-priority side stream beside the next block's paths
+        for (uint32_t g = 0; g < groups; g++) {
+            hipStream_t st = c->stream;
+            HIP_TRY(mcrt::launch_init(args[g], st));
+            HIP_TRY(mcrt::launch_trace(args[g], 0u, c->stats_on, st));
+            hipEvent_t t0, t1;
+            { int rc = timing_events(c, &t0, &t1); if (rc) return rc; }
+            if (t0) HIP_TRY(hipEventRecord(t0, st));
+            HIP_TRY(mcrt::launch_paths(args[g], c->stats_on, st));
+            if (t1) HIP_TRY(hipEventRecord(t1, st));
+            if (accumulate && overlap) {
+                HIP_TRY(hipEventRecord(ws[g]->ev_bounce[0], st));
+                HIP_TRY(hipStreamWaitEvent(ws[g]->side[0], ws[g]->ev_bounce[0], 0));
+                HIP_TRY(mcrt::launch_march(args[g], mcrt::MCRT_ALL_BOUNCES, c->stats_on, ws[g]->side[0]));
+            } else if (accumulate) {
+                HIP_TRY(mcrt::launch_march(args[g], mcrt::MCRT_ALL_BOUNCES, c->stats_on, st));
+            }
+        }
+        if (accumulate && overlap)
+            for (uint32_t g = 0; g < groups; g++) {
+                HIP_TRY(hipEventRecord(ws[g]->ev_join[0], ws[g]->side[0]));
+                HIP_TRY(hipStreamWaitEvent(c->stream, ws[g]->ev_join[0], 0));
+            }
+        return MCRT_OK;
     }
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
     for (uint32_t g = 0; g < groups; g++) {

@@ -43,6 +43,8 @@ struct FrameArgs {
     double axial_res_mm, time_step, row_dt, max_travel, sos_d, inv_row_dt;
 };
 
+constexpr uint32_t MCRT_ALL_BOUNCES = 0xffffffffu;   // launch_march: accumulate the segments of every bounce in one launch
+
 struct ConvTaps { float ax[16]; float lat[32]; uint32_t n_ax, n_lat; };
 
 hipError_t launch_init(const FrameArgs &a, hipStream_t st);
@@ -50,6 +52,7 @@ hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
 hipError_t launch_nodes_soa(const float4 *nodes, uint32_t n_nodes, float4 *out, hipStream_t st);
 uint32_t lane_stack_entries();
 hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
+hipError_t launch_paths(const FrameArgs &a, bool stats, hipStream_t st);
 hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
 hipError_t launch_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t ne, uint32_t R, hipStream_t st);
 hipError_t launch_convolve(float *img, float *tmp, uint32_t n_img, uint32_t E, uint32_t R, const ConvTaps &taps, hipStream_t st);

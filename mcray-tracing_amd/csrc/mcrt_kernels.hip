@@ -916,38 +916,20 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
     }
 }
 
-// ---- interface interaction (scene.cpp:122-165, ray.cpp:11-97): one lane per live ray ----
+// ---- interface interaction (scene.cpp:122-165, ray.cpp:11-97) of ONE path at bounce b, given its ray and the closest-hit
+// word of the walk: thickness draw, travel, hit_boundary, the segment's records, the continuing ray's state.  Returns whether
+// the path goes on.  Shared by the wavefront pipeline (k_shade) and the fused path kernel (k_paths): one body, one arithmetic.
+struct PathState { f3 from, dir; float intensity; int media, outside; double dist_mm; };
+
 template <bool STATS>
-__global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, uint32_t b)
+MCRT_DEV bool shade_path(const FrameArgs &a, uint32_t b, uint32_t pid, PathState &ps, f3 f2, f3 to, unsigned long long key, bool &reflected,
+                         unsigned long long &st_seg, unsigned long long &st_hits)
 {
-    const uint32_t n = a.counts[b];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x * blockDim.x >= n) return;
-    const int lane = threadIdx.x & 63;
-    // two queue buffers, ping-pong by bounce parity (like the path state)
-    const uint32_t *q_in = a.queue + (size_t)(b & 1u) * a.ne * a.S;
-    uint32_t *q_out = a.queue + (size_t)((b + 1u) & 1u) * a.ne * a.S;
-    const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
-    float4 *rays_out = (b & 1u) ? a.ray0 : a.ray1;
-    const bool valid = i < n;
-    bool alive = false, reflected = false;
-    uint32_t pid = 0;
-    f3 from = mk(0, 0, 0), dir = mk(0, 0, 1);
-    float intensity = 0.0f; int media = 0, outside = OUT_NONE; double dist_mm = 0.0;
-    unsigned long long st_seg = 0, st_hits = 0;
-    if (valid) {
-        pid = q_in[i];
-        // path state lives in queue order (ping-pong halves by bounce parity), so a wavefront reads and writes it coalesced
-        const size_t sin = (size_t)(b & 1u) * a.ne * a.S + i;
-        const float4 s0 = a.st0[sin], s1 = a.st1[sin], s2 = a.st2[sin];
-        from = mk(s0.x, s0.y, s0.z); intensity = s0.w;
-        dir = mk(s1.x, s1.y, s1.z); media = __float_as_int(s1.w);
-        dist_mm = __hiloint2double(__float_as_int(s2.y), __float_as_int(s2.x));
-        outside = __float_as_int(s2.z);
-        const float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
-        const f3 f2 = mk(r0.x, r0.y, r0.z), to = mk(r0.w, r1.x, r1.y);
-        const size_t hi = (b == 0u) ? (size_t)(i / a.S) : (size_t)i;            // bounce 0: one walk per queued scan-line (see k_trace, k_init)
-        const unsigned long long key = ((b & 1u) ? a.key1 : a.key0)[hi];
+    bool alive = false;
+    f3 from = ps.from, dir = ps.dir;
+    float intensity = ps.intensity; int media = ps.media, outside = ps.outside; double dist_mm = ps.dist_mm;
+    reflected = false;
+    {
         Hit best; best.frac = __uint_as_float((uint32_t)(key >> 32)); best.tri = (int)(uint32_t)key; best.da = 0.0f; best.mesh = 0; best.n = mk(0, 0, 0);
         if (best.tri >= 0) {
             // plane normal, mesh and the origin-side value of the winning triangle, as the walk's test evaluated them
@@ -1076,6 +1058,270 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
         a.seg_count[pid] = b + 1u;
         alive = alive && (b + 1u < a.B);
     }
+    ps.from = from; ps.dir = dir; ps.intensity = intensity; ps.media = media; ps.outside = outside; ps.dist_mm = dist_mm;
+    return alive;
+}
+
+
+// =============================================================================================================
+// k_paths -- the FUSED path kernel: every lane owns one sample path and carries it through ALL its bounces (walk, interface
+// physics, next ray) in one persistent launch, so a frame costs five launches (k_init, the shared bounce-0 walk, k_paths,
+// k_march over all bounces, k_finalize) instead of thirty-one, and drains once instead of once per bounce.  This is what one
+// frame at a time wants (the reference's own frame loop, main.cpp:92-152, is one frame at a time); big passes keep the
+// wavefront pipeline, whose interface physics runs in full wavefronts.
+//
+// The walk is k_trace_lane's (same node test, same order, same triangle test: hits and visit counts are identical); the
+// physics is shade_path(), the body k_shade runs.  A wavefront alternates between three kinds of work, each run for all the
+// lanes that need it at once: inner-node steps, parked leaves, and the interface physics of lanes whose walk has ended
+// (fp64-heavy, a few thousand instructions: it waits until MCRT_PATHS_SHADE_BATCH lanes need it, or nothing else is left).
+// Path state lives in st0..st2 at the path's queue position between its bounces, so the walk keeps its registers.
+// =============================================================================================================
+#ifndef MCRT_PATHS_SHADE_BATCH
+#define MCRT_PATHS_SHADE_BATCH 24
+#endif
+#ifndef MCRT_PATHS_REFILL
+#define MCRT_PATHS_REFILL 16
+#endif
+template <bool STATS>
+__global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_paths(FrameArgs a)
+{
+    __shared__ int stack[MCRT_LANE_STACK * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t n = a.ne * a.S;                               // paths = positions of the bounce-0 queue (scan-line-major, see k_init)
+    unsigned long long st_nodes = 0, st_tris = 0, st_q = 0, st_seg = 0, st_hits = 0;
+    int *ovf = a.stack_ovf + ((size_t)blockIdx.x * 256 + tid);
+    const size_t ovf_stride = (size_t)gridDim.x * 256;
+    const uint32_t X = (n >= (uint32_t)MCRT_XCD_MIN_ITEMS) ? (uint32_t)MCRT_XCDS : 1u;
+    if (X == 1u && blockIdx.x * 256u >= n) return;
+    const uint32_t x_shift = (X == 1u) ? 0u : 3u;
+    uint32_t cur_x = blockIdx.x & (X - 1u), visited = 0;
+#define MCRT_SUB_LO(sq) ((uint32_t)(((unsigned long long)n * (sq)) >> x_shift))
+#define MCRT_SUB_STATIC(sq) (((gridDim.x - (sq) + X - 1u) >> x_shift) * 256u)
+    uint32_t *cursors = a.cursors + (size_t)1 * MCRT_XCDS * MCRT_CURSOR_STRIDE;     // (slot 0 belongs to the bounce-0 walk)
+    uint32_t i = MCRT_SUB_LO(cur_x) + (blockIdx.x >> x_shift) * 256u + (uint32_t)tid;
+    if (i >= MCRT_SUB_LO(cur_x + 1u)) i = 0xffffffffu;
+    uint32_t pos = 0, pid = 0, bounce = 0;
+    bool exhausted = false, has_path = false, pend = false;      // pend: the walk of `bounce` has ended, the physics is due
+    f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1), inv = mk(1, 1, 1);
+    Best best; best.frac = 1.0f; best.tri = -1;
+    constexpr int CUR_IDLE = (int)0x80000000;
+    int sp = 0, cur = CUR_IDLE;
+#define MCRT_ON_INNER(c) __builtin_amdgcn_sicmp((c), -1, 38)
+#define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)
+#define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)
+#define MCRT_POP() { if (sp > 0) { sp--; cur = (sp < MCRT_LANE_STACK) ? stack[sp * 256 + tid] : ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride]; } else { cur = CUR_IDLE; pend = true; } }
+#define MCRT_PUSH(v) { if (sp < MCRT_LANE_STACK) stack[sp * 256 + tid] = (v); else ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride] = (v); sp++; }
+    uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;
+    for (;;) {
+        const unsigned long long walking = MCRT_WALKING(cur);
+        const unsigned long long pending = __ballot(pend);
+        // ---- lanes without a path take the next queue positions ----
+        if (__popcll(__ballot(!has_path && !exhausted)) >= MCRT_PATHS_REFILL || (walking == 0ull && pending == 0ull)) {
+            const bool need = !has_path && !exhausted;
+            const unsigned long long dynm = __ballot(need && i == 0xffffffffu);
+            if (dynm) {
+                while (pool_next >= pool_end && !queue_empty) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&cursors[(size_t)cur_x * MCRT_CURSOR_STRIDE], (uint32_t)MCRT_LANE_FETCH);
+                    base = __shfl(base, 0, 64);
+                    const uint32_t hi = MCRT_SUB_LO(cur_x + 1u);
+                    const unsigned long long start = (unsigned long long)MCRT_SUB_LO(cur_x) + MCRT_SUB_STATIC(cur_x) + base;
+                    if (start < hi) { pool_next = (uint32_t)start; pool_end = min((uint32_t)start + (uint32_t)MCRT_LANE_FETCH, hi); }
+                    else if (++visited >= X) queue_empty = true;
+                    else cur_x = (cur_x + 1u) & (X - 1u);
+                }
+                if (need && i == 0xffffffffu) {
+                    const uint32_t mine = pool_next + (uint32_t)__popcll(dynm & ((1ull << lane) - 1ull));
+                    if (queue_empty) i = n;
+                    else if (mine < pool_end) i = mine;
+                }
+                const uint32_t taken = (uint32_t)__popcll(dynm);
+                pool_next = (pool_next + taken < pool_end) ? pool_next + taken : pool_end;
+            }
+            if (need && i != 0xffffffffu) {
+                if (i < n) {
+                    // bounce 0: every sample of a scan-line starts as a copy of first_ray (scene.cpp:83-101), walked ONCE per scan-line
+                    // by the launch before this one; the path starts with that result in hand
+                    pos = i; pid = a.queue[pos]; bounce = 0u;
+                    const float4 r0 = a.ray0[2 * (size_t)pos], r1 = a.ray0[2 * (size_t)pos + 1];
+                    f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
+                    const unsigned long long key = a.key0[pos / a.S];
+                    best.frac = __uint_as_float((uint32_t)(key >> 32)); best.tri = (int)(uint32_t)key;
+                    has_path = true; pend = true; cur = CUR_IDLE; i = 0xffffffffu;
+                } else exhausted = true;
+            }
+        }
+        // ---- interface physics of the lanes whose walk has ended ----
+        const unsigned long long pending2 = __ballot(pend);
+        if (pending2 != 0ull && (__popcll(pending2) >= MCRT_PATHS_SHADE_BATCH || MCRT_WALKING(cur) == 0ull)) {
+            if (pend) {
+                PathState ps;
+                const float4 s0 = a.st0[pos], s1 = a.st1[pos], s2 = a.st2[pos];
+                ps.from = mk(s0.x, s0.y, s0.z); ps.intensity = s0.w;
+                ps.dir = mk(s1.x, s1.y, s1.z); ps.media = __float_as_int(s1.w);
+                ps.dist_mm = __hiloint2double(__float_as_int(s2.y), __float_as_int(s2.x));
+                ps.outside = __float_as_int(s2.z);
+                const unsigned long long key = ((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri;
+                bool reflected;
+                const bool alive = shade_path<STATS>(a, bounce, pid, ps, f2, to, key, reflected, st_seg, st_hits);
+                pend = false;
+                if (alive) {
+                    bounce++;
+                    a.st0[pos] = make_float4(ps.from.x, ps.from.y, ps.from.z, ps.intensity);
+                    a.st1[pos] = make_float4(ps.dir.x, ps.dir.y, ps.dir.z, __int_as_float(ps.media));
+                    a.st2[pos] = make_float4(__int_as_float(__double2loint(ps.dist_mm)), __int_as_float(__double2hiint(ps.dist_mm)), __int_as_float(ps.outside), 0.0f);
+                    const Ray r = make_ray(ps.from, ps.dir, ps.intensity, a.mats[2 * ps.media].y, a);
+                    f2 = r.f2; to = r.to;
+                    inv = mk(1.0f / (r.to.x - r.f2.x), 1.0f / (r.to.y - r.f2.y), 1.0f / (r.to.z - r.f2.z));
+                    best.frac = 1.0f; best.tri = -1;
+                    sp = 0;
+                    if (a.n_nodes != 0u) cur = 0; else { cur = CUR_IDLE; pend = true; }      // (no geometry: an immediate miss)
+                    if (STATS) st_q++;
+                } else has_path = false;
+            }
+        }
+        if (MCRT_WALKING(cur) == 0ull) {
+            if (__any(pend)) continue;
+            if (!__any(has_path || !exhausted)) break;
+            continue;
+        }
+
+        // ---- inner nodes, until enough lanes are parked on a leaf or wait for their physics ----
+        const float tcap = fminf(1.0f, best.frac);
+        const v2f oxx = (v2f){ f2.x, f2.x }, oyy = (v2f){ f2.y, f2.y }, ozz = (v2f){ f2.z, f2.z };
+        const v2f ixx = (v2f){ inv.x, inv.x }, iyy = (v2f){ inv.y, inv.y }, izz = (v2f){ inv.z, inv.z };
+        for (;;) {
+            const unsigned long long inner = MCRT_ON_INNER(cur);
+            if (inner == 0ull) break;
+            if (__popcll(MCRT_ON_LEAF(cur)) >= MCRT_LANE_LEAF_BATCH) break;
+            if (__popcll(__ballot(pend)) >= 2 * MCRT_PATHS_SHADE_BATCH) break;
+            if (cur >= 0) {
+                const float4 *N = (const float4 *)((const char *)a.nodes_soa + ((uint32_t)cur << 7));
+                const float4 LX = N[0], LY = N[1], LZ = N[2], HX = N[3], HY = N[4], HZ = N[5], RF = N[6];
+                if (STATS) st_nodes++;
+                const v2f t0x_a = ((v2f){ LX.x, LX.y } - oxx) * ixx, t0x_b = ((v2f){ LX.z, LX.w } - oxx) * ixx;
+                const v2f t0y_a = ((v2f){ LY.x, LY.y } - oyy) * iyy, t0y_b = ((v2f){ LY.z, LY.w } - oyy) * iyy;
+                const v2f t0z_a = ((v2f){ LZ.x, LZ.y } - ozz) * izz, t0z_b = ((v2f){ LZ.z, LZ.w } - ozz) * izz;
+                const v2f t1x_a = ((v2f){ HX.x, HX.y } - oxx) * ixx, t1x_b = ((v2f){ HX.z, HX.w } - oxx) * ixx;
+                const v2f t1y_a = ((v2f){ HY.x, HY.y } - oyy) * iyy, t1y_b = ((v2f){ HY.z, HY.w } - oyy) * iyy;
+                const v2f t1z_a = ((v2f){ HZ.x, HZ.y } - ozz) * izz, t1z_b = ((v2f){ HZ.z, HZ.w } - ozz) * izz;
+                float tn0, tn1, tn2, tn3;
+                const bool h0 = slab_combine(t0x_a.x, t0y_a.x, t0z_a.x, t1x_a.x, t1y_a.x, t1z_a.x, 0.0f, tcap, tn0);
+                const bool h1 = slab_combine(t0x_a.y, t0y_a.y, t0z_a.y, t1x_a.y, t1y_a.y, t1z_a.y, 0.0f, tcap, tn1);
+                const bool h2 = slab_combine(t0x_b.x, t0y_b.x, t0z_b.x, t1x_b.x, t1y_b.x, t1z_b.x, 0.0f, tcap, tn2);
+                const bool h3 = slab_combine(t0x_b.y, t0y_b.y, t0z_b.y, t1x_b.y, t1y_b.y, t1z_b.y, 0.0f, tcap, tn3);
+                const uint32_t k0 = h0 ? ((__float_as_uint(tn0) & ~3u) | 0u) : 0xffffffffu, k1 = h1 ? ((__float_as_uint(tn1) & ~3u) | 1u) : 0xffffffffu;
+                const uint32_t k2 = h2 ? ((__float_as_uint(tn2) & ~3u) | 2u) : 0xffffffffu, k3 = h3 ? ((__float_as_uint(tn3) & ~3u) | 3u) : 0xffffffffu;
+                const uint32_t kmin = min(min(k0, k1), min(k2, k3));
+                int r0 = __float_as_int(RF.x), r1 = __float_as_int(RF.y), r2 = __float_as_int(RF.z), r3 = __float_as_int(RF.w);
+                asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+                if (kmin == 0xffffffffu) { MCRT_POP() }
+                else {
+                    const bool p0 = h0 && k0 != kmin, p1 = h1 && k1 != kmin, p2 = h2 && k2 != kmin, p3 = h3 && k3 != kmin;
+                    if (__builtin_expect(__any(sp + 3 > MCRT_LANE_STACK), 0)) {
+                        if (p0) MCRT_PUSH(r0)
+                        if (p1) MCRT_PUSH(r1)
+                        if (p2) MCRT_PUSH(r2)
+                        if (p3) MCRT_PUSH(r3)
+                    } else {
+                        int *top = &stack[sp * 256 + tid];
+                        const int s1 = p0 ? 256 : 0, s2 = s1 + (p1 ? 256 : 0), s3 = s2 + (p2 ? 256 : 0);
+                        if (p0) top[0] = r0;
+                        if (p1) top[s1] = r1;
+                        if (p2) top[s2] = r2;
+                        if (p3) top[s3] = r3;
+                        sp += (s3 >> 8) + (p3 ? 1 : 0);
+                    }
+                    const uint32_t jn = kmin & 3u;
+                    cur = jn == 0u ? r0 : jn == 1u ? r1 : jn == 2u ? r2 : r3;
+                }
+            }
+        }
+        // ---- the parked leaves (the contract's triangle test, as in k_trace_lane) ----
+        if ((uint32_t)cur > 0x80000000u) {
+            const uint32_t v = (uint32_t)~cur;
+            const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; k++) {
+                const float4 *T = (const float4 *)((const char *)a.tris + (first + k) * 96u);
+                const float4 P = T[0];
+                const f3 nrm = xyz(P);
+                const float da = dot(nrm, f2) - P.w;
+                const float db = dot(nrm, to) - P.w;
+                if (da * db >= 0.0f) continue;
+                const float4 PL = T[1], PH = T[2];
+                const int id = __float_as_int(PL.w);
+                const float proj = da - db;
+                const float frac = da / proj;
+                if (!(frac < best.frac || (frac == best.frac && id < best.tri)) || !(frac >= 0.0f)) continue;
+                float tmin, tmax;
+                const RayPairs rp = ray_pairs(f2, inv);
+                if (!(slab_pairs((v2f){ PL.x, PL.y }, (v2f){ PL.z, PH.x }, (v2f){ PH.y, PH.z }, rp, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax)) continue;
+                const float4 V0 = T[3], V1 = T[4], V2 = T[5];
+                const float edge_tol = V0.w;
+                const float s = 1.0f - frac;
+                const f3 p = mk(s * f2.x + frac * to.x, s * f2.y + frac * to.y, s * f2.z + frac * to.z);
+                const f3 p0 = xyz(V0) - p, p1 = xyz(V1) - p, p2 = xyz(V2) - p;
+                if (!(dot(cross(p0, p1), nrm) >= edge_tol)) continue;
+                if (!(dot(cross(p1, p2), nrm) >= edge_tol)) continue;
+                if (!(dot(cross(p2, p0), nrm) >= edge_tol)) continue;
+                best.frac = frac; best.tri = id;
+            }
+            if (STATS) st_tris += cnt;
+            MCRT_POP()
+        }
+    }
+#undef MCRT_SUB_LO
+#undef MCRT_SUB_STATIC
+#undef MCRT_ON_INNER
+#undef MCRT_ON_LEAF
+#undef MCRT_WALKING
+#undef MCRT_POP
+#undef MCRT_PUSH
+    if (STATS) {
+        unsigned long long v[5] = { st_q, st_nodes, st_tris, st_seg, st_hits };
+        const int slot[5] = { 0, 1, 2, 3, 5 };
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            long long x = wave_sum_i64((long long)v[k]);
+            if (lane == 0 && x) atomicAdd(&a.stats[slot[k]], (unsigned long long)x);
+        }
+    }
+}
+
+// ---- interface interaction of a bounce's live rays (wavefront pipeline): one lane per ray ----
+template <bool STATS>
+__global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, uint32_t b)
+{
+    const uint32_t n = a.counts[b];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= n) return;
+    const int lane = threadIdx.x & 63;
+    // two queue buffers, ping-pong by bounce parity (like the path state)
+    const uint32_t *q_in = a.queue + (size_t)(b & 1u) * a.ne * a.S;
+    uint32_t *q_out = a.queue + (size_t)((b + 1u) & 1u) * a.ne * a.S;
+    const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
+    float4 *rays_out = (b & 1u) ? a.ray0 : a.ray1;
+    const bool valid = i < n;
+    bool alive = false, reflected = false;
+    uint32_t pid = 0;
+    PathState ps; ps.from = mk(0, 0, 0); ps.dir = mk(0, 0, 1); ps.intensity = 0.0f; ps.media = 0; ps.outside = OUT_NONE; ps.dist_mm = 0.0;
+    unsigned long long st_seg = 0, st_hits = 0;
+    if (valid) {
+        pid = q_in[i];
+        // path state lives in queue order (ping-pong halves by bounce parity), so a wavefront reads and writes it coalesced
+        const size_t sin = (size_t)(b & 1u) * a.ne * a.S + i;
+        const float4 s0 = a.st0[sin], s1 = a.st1[sin], s2 = a.st2[sin];
+        ps.from = mk(s0.x, s0.y, s0.z); ps.intensity = s0.w;
+        ps.dir = mk(s1.x, s1.y, s1.z); ps.media = __float_as_int(s1.w);
+        ps.dist_mm = __hiloint2double(__float_as_int(s2.y), __float_as_int(s2.x));
+        ps.outside = __float_as_int(s2.z);
+        const float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
+        const f3 f2 = mk(r0.x, r0.y, r0.z), to = mk(r0.w, r1.x, r1.y);
+        const size_t hi = (b == 0u) ? (size_t)(i / a.S) : (size_t)i;            // bounce 0: one walk per queued scan-line (see k_trace, k_init)
+        const unsigned long long key = ((b & 1u) ? a.key1 : a.key0)[hi];
+        alive = shade_path<STATS>(a, b, pid, ps, f2, to, key, reflected, st_seg, st_hits);
+    }
+    const f3 from = ps.from, dir = ps.dir; const float intensity = ps.intensity; const int media = ps.media, outside = ps.outside; const double dist_mm = ps.dist_mm;
 
     // survivors -> next bounce's queue (ballot + prefix; ONE atomic per workgroup: tens of thousands of returning atomics on the
     // single counter would serialise in L2 and bound the kernel).  Inside a wavefront's block the reflected rays
@@ -1166,6 +1412,27 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     uint32_t sidx = 0, steps = 0;
     bool more = false;
     int row_guess = 0;
+    // b == MCRT_ALL_BOUNCES: the launch accumulates EVERY bounce's segments; a group then walks its path's segments one after
+    // the other (seg_b = the one in progress, seg_n = how many the path has) before it takes the next slot
+    const bool all_b = b == MCRT_ALL_BOUNCES;
+    uint32_t seg_b = all_b ? 0u : b, seg_n = 0; size_t seg_pid = 0;
+#define MCRT_LOAD_SEGMENT() { \
+        const float4 *mr = a.mrec + 3 * ((size_t)seg_b * a.ne * a.S + seg_pid); \
+        const float4 g0 = mr[0], g1 = mr[1], g2 = mr[2]; \
+        const float4 mt = a.mtab[__float_as_int(g2.w)]; \
+        point = mk(g0.x, g0.y, g0.z); seg_refl = g0.w; \
+        delta = mk(g1.x, g1.y, g1.z); inten = g1.w; \
+        t_start = __hiloint2double(__float_as_int(g2.y), __float_as_int(g2.x)); \
+        steps = __float_as_uint(g2.z); \
+        m_mu = mt.x; m_dens = mt.y; m_sigma = mt.z; k_att = mt.w; \
+        t = t_start; sidx = (uint32_t)j; \
+        /* scattering is exactly +0 for every voxel when mu0 == sigma == 0 (finite texture): the adds are no-ops */ \
+        const bool silent = a.tex_finite && m_mu == 0.0f && m_sigma == 0.0f; \
+        more = !silent && steps > 0u && t < a.max_travel; \
+        _Pragma("unroll") for (int u = 1; u < G; u++) if (j >= u) MCRT_ADVANCE() \
+        /* first guess of this lane's RF row; afterwards each own step lies G steps (a little over G rows) further */ \
+        row_guess = (t >= 0.0 && t < thr_end) ? (int)(t * a.inv_row_dt) : 0; \
+        busy = true; }
 #define MCRT_ADVANCE() { point = point + delta; t = t + a.time_step; inten *= k_att; }
 #ifdef MCRT_STAMP
     unsigned long long mc_iter = 0, mc_step_it = 0, mc_step_quads = 0, mc_fin_it = 0, mc_refill = 0;
@@ -1187,6 +1454,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
                     rf_add(bins, lflags, row_of(te, thr, R, a.inv_row_dt, thr_end), seg_refl / (float)a.S);
                 }
                 busy = false;
+                if (all_b && seg_b + 1u < seg_n) { seg_b++; MCRT_LOAD_SEGMENT() }      // the path's next segment
             }
             while (cursor < s_end) {
                 const unsigned long long want = __ballot(!busy && j == 0);
@@ -1196,26 +1464,10 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
 #endif
                 const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~(G - 1))) - 1ull));
                 if (!busy && mine < s_end) {
-                    const size_t pid = pid0 + mine;
-                    if (b < a.seg_count[pid]) {
-                        const float4 *mr = a.mrec + 3 * ((size_t)b * a.ne * a.S + pid);
-                        const float4 g0 = mr[0], g1 = mr[1], g2 = mr[2];
-                        const float4 mt = a.mtab[__float_as_int(g2.w)];
-                        point = mk(g0.x, g0.y, g0.z); seg_refl = g0.w;
-                        delta = mk(g1.x, g1.y, g1.z); inten = g1.w;
-                        t_start = __hiloint2double(__float_as_int(g2.y), __float_as_int(g2.x));
-                        steps = __float_as_uint(g2.z);
-                        m_mu = mt.x; m_dens = mt.y; m_sigma = mt.z; k_att = mt.w;
-                        t = t_start; sidx = (uint32_t)j;
-                        // scattering is exactly +0 for every voxel when mu0 == sigma == 0 (finite texture): the adds are no-ops
-                        const bool silent = a.tex_finite && m_mu == 0.0f && m_sigma == 0.0f;
-                        more = !silent && steps > 0u && t < a.max_travel;
-#pragma unroll
-                        for (int u = 1; u < G; u++) if (j >= u) MCRT_ADVANCE()
-                        // first guess of this lane's RF row; afterwards each own step lies G steps (a little over G rows) further
-                        row_guess = (t >= 0.0 && t < thr_end) ? (int)(t * a.inv_row_dt) : 0;
-                        busy = true;
-                    }
+                    seg_pid = pid0 + mine;
+                    seg_n = a.seg_count[seg_pid];
+                    seg_b = all_b ? 0u : b;
+                    if (seg_b < seg_n) MCRT_LOAD_SEGMENT()
                 }
                 const uint32_t nw = (uint32_t)__popcll(want);
                 cursor = (cursor + nw < s_end) ? cursor + nw : s_end;
@@ -1258,6 +1510,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
         }
     }
 #undef MCRT_ADVANCE
+#undef MCRT_LOAD_SEGMENT
 #ifdef MCRT_STAMP
     if (lane == 0) { atomicAdd(&a.stamps[9], mc_iter); atomicAdd(&a.stamps[10], mc_step_it); atomicAdd(&a.stamps[11], mc_step_quads); atomicAdd(&a.stamps[12], mc_fin_it); atomicAdd(&a.stamps[13], mc_refill); atomicAdd(&a.stamps[14], 1ull); }
 #endif
@@ -1486,6 +1739,16 @@ hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
     const dim3 grid(blocks < a.trace_blocks ? blocks : a.trace_blocks), blk(256);
     if (stats) hipLaunchKernelGGL((k_trace<true>), grid, blk, 0, st, a, b);
     else hipLaunchKernelGGL((k_trace<false>), grid, blk, 0, st, a, b);
+    return hipGetLastError();
+}
+
+// the fused path kernel: bounce 0's shared walk must have run (launch_trace(a, 0, ...)); needs a.nodes_soa
+hipError_t launch_paths(const FrameArgs &a, bool stats, hipStream_t st)
+{
+    const uint32_t np = a.ne * a.S, blocks = (np + 255u) / 256u;
+    const dim3 grid(blocks < a.trace_blocks ? blocks : a.trace_blocks), blk(256);
+    if (stats) hipLaunchKernelGGL((k_paths<true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_paths<false>), grid, blk, 0, st, a);
     return hipGetLastError();
 }
 

