@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMD = 1024           # 256 CUs x 4 SIMD-32
-TRACE_KERNEL = "k_trace<false"
+TRACE_KERNELS = ("k_trace_lane<false", "k_paths<false", "k_trace<false")   # the walk kernels of the timed build (lane walk, fused, quad walk)
 
 
 def build_workload(m, name):
@@ -349,12 +349,19 @@ def roofline_from(pmc, k_ms, alg_gbs):
 
 
 def _pmc_rows(d):
-    agg = {}
+    """counter values of the walk kernel's launches (the kernel with the most launches among the candidates), per counter"""
+    per = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if TRACE_KERNEL in row["Kernel_Name"]:
-                agg.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-    return agg
+            for k in TRACE_KERNELS:
+                if k in row["Kernel_Name"]:
+                    per.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                    break
+    if not per:
+        return {}, None
+    # the dominant walk kernel: bounce 0's shared walk also runs k_trace_lane in the fused pipeline, with few launches
+    name = max(per, key=lambda k: (k == "k_paths<false", max(len(v) for v in per[k].values())))
+    return per[name], name
 
 
 def live_pmc(args):
@@ -371,13 +378,15 @@ def live_pmc(args):
     tmp = tempfile.mkdtemp(prefix="mcrt_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for name, ctrs in (("sq", ["SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES", "SQ_WAVES"]), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+        for name, ctrs in (("sq", ["SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES", "SQ_WAVES", "SQ_INSTS_VMEM_RD"]), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
             d = os.path.join(tmp, name)
             r = subprocess.run([exe, "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
-            rows = _pmc_rows(d)
+            rows, kname = _pmc_rows(d)
             if r.returncode != 0 or not rows:
+                sys.stderr.write("bench.py: PMC pass '%s' failed (rc %s): %s\n" % (name, r.returncode, (r.stdout or b"")[-600:].decode(errors="replace")))
                 return None
+            got["kernel"] = kname
             for c, v in rows.items():
                 got[c] = (sum(v) / len(v), len(v))
     except Exception:
@@ -385,9 +394,10 @@ def live_pmc(args):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     try:
-        return {"source": "live: rocprofv3 --pmc child passes of this command (same pass sizes), per k_trace launch",
+        return {"source": "live: rocprofv3 --pmc child passes of this command (same pass sizes), per launch of the walk kernel", "kernel": got["kernel"],
                 "launches_profiled": got["SQ_INSTS_VALU"][1],
                 "valu_instructions_per_launch": got["SQ_INSTS_VALU"][0], "busy_cu_cycles_per_launch": got["SQ_BUSY_CU_CYCLES"][0] / 256.0,
+                "vmem_read_instructions_per_launch": got["SQ_INSTS_VMEM_RD"][0],
                 "fetch_size_kib": got["FETCH_SIZE"][0], "write_size_kib": got["WRITE_SIZE"][0],
                 "traffic_bytes_per_launch": (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0}
     except KeyError:
@@ -411,6 +421,31 @@ def committed_pmc(args, pass_sizes):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline + parity
+def usable_cores():
+    """host cores this process may actually use: the affinity mask, cut by the cgroup CPU quota (os.cpu_count() reports the
+    machine's threads, which a container's quota can be far below)"""
+    n = os.cpu_count() or 1
+    info = {"cpu_count": n}
+    try:
+        n = min(n, len(os.sched_getaffinity(0))); info["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    q = float(txt[0]) / float(txt[1]); info["cgroup_quota_cpus"] = q; n = max(1, min(n, int(q + 0.5)))
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()); info["cgroup_quota_cpus"] = q / per; n = max(1, min(n, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n, info
+
+
 def cpu_baseline(m, sd, tr, ctx, S, R, rf0):
     """The oracle (a port of the reference algorithm; the reference binary itself needs Bullet + OpenCV and cannot be
     built) timed on this box's host cores on a bounded sample of the same workload: whole frames, tasks = (scan-line x block
@@ -418,7 +453,7 @@ def cpu_baseline(m, sd, tr, ctx, S, R, rf0):
     parity check of the timed workload: the GPU's frame-0 RF image (fixed-point contract) must equal it bit for bit."""
     import numpy as np
     from oracle import orc
-    cores = os.cpu_count() or 1
+    cores, core_info = usable_cores()
     nodes, btri, _ = ctx.get_bvh()
     osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
     osc.set_bvh4(ctx.get_bvh4()[0])
@@ -427,7 +462,7 @@ def cpu_baseline(m, sd, tr, ctx, S, R, rf0):
     p = orc.default_params(n_elements=E, n_samples=S, n_rows=R)
     kw = dict(use_bvh=2, n_threads=cores, want_hits=False, want_ref=False)
     osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=99, e_begin=0, e_end=min(E, 8), **kw)   # untimed: thread pool, page faults
-    t0 = time.perf_counter()
+    t0 = time.perf_counter(); c0 = sum(os.times()[:2])
     frames, o0 = 0, None
     while True:
         o = osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=frames, **kw)
@@ -437,6 +472,7 @@ def cpu_baseline(m, sd, tr, ctx, S, R, rf0):
         dt = time.perf_counter() - t0
         if dt >= 5.0 or frames >= 64:
             break
+    busy = (sum(os.times()[:2]) - c0) / dt                      # CPU seconds per wall second: the cores the sample really kept busy
     want = o0["rf"]                                             # [R][E]
     got = np.ascontiguousarray(rf0.T)
     parity = {"rf_bit_exact": bool(np.array_equal(got.view(np.uint32), want.view(np.uint32))), "frame": 0, "scan_lines": int(E),
@@ -446,7 +482,7 @@ def cpu_baseline(m, sd, tr, ctx, S, R, rf0):
     t1 = time.perf_counter()
     osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=0, e_begin=0, e_end=n1, use_bvh=2, n_threads=1, want_hits=False, want_ref=False)
     dt1 = time.perf_counter() - t1
-    base = {"value": E * S * frames / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+    base = {"value": E * S * frames / dt, "unit": "rays/s", "cores": cores, "kind": "port", "host": core_info, "cores_kept_busy": round(busy, 1),
             "single_thread": {"value": n1 * S / dt1, "unit": "rays/s", "cores": 1, "sample": "%d scan-lines x %d rays, one thread" % (n1, S), "seconds": dt1},
             "sample": "%d whole frame(s) of %d scan-lines x %d rays of the same workload, OpenMP over (scan-line x sample-block) tasks on %d threads "
                       "(trace + RF accumulation, no PSF)" % (frames, E, S, cores),

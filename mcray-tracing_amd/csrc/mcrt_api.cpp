@@ -240,23 +240,40 @@ static void free_work(mcrt_ctx *c)
     c->work.clear();
 }
 
-// work set g (created on first use); set 0 runs on the context's stream, the others on streams of their own
+// work set g (created on first use).  Streams are created only when a pipeline asks for them (work_stream / side_stream):
+// HIP multiplexes streams onto a few hardware queues, where one stream's event wait holds up whatever shares its queue, so a
+// context keeps no stream it does not use.
 static int get_work(mcrt_ctx *c, size_t g, Work **out)
 {
     while (c->work.size() <= g) {
         Work w;
-        if (!c->work.empty()) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-        // k_march runs beside the next bounce's walk on a LOW-priority stream: k_trace / k_shade are the critical chain, and
-        // their workgroups must not queue behind k_march's (measured: k_shade took 0.4-0.7 ms instead of 0.1 ms when they did)
-        int prio_low = 0, prio_high = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-        if (c->knobs.no_priority) prio_low = 0;   // tuning knob
-        for (int i = 0; i < MCRT_SIDE_STREAMS; i++) { HIP_TRY(hipStreamCreateWithPriority(&w.side[i], hipStreamNonBlocking, prio_low)); HIP_TRY(hipEventCreateWithFlags(&w.ev_join[i], hipEventDisableTiming)); }
+        for (int i = 0; i < MCRT_SIDE_STREAMS; i++) HIP_TRY(hipEventCreateWithFlags(&w.ev_join[i], hipEventDisableTiming));
         for (int i = 0; i < MCRT_MAX_BOUNCES; i++) HIP_TRY(hipEventCreateWithFlags(&w.ev_bounce[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&w.ev_done, hipEventDisableTiming));
         c->work.push_back(w);
     }
     *out = &c->work[g];
+    return MCRT_OK;
+}
+// the stream of scan-line group g of the wavefront pipeline: group 0 runs on the context's stream, the others on their own
+static int work_stream(mcrt_ctx *c, Work &w, bool first, hipStream_t *out)
+{
+    if (first) { *out = c->stream; return MCRT_OK; }
+    if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    *out = w.stream;
+    return MCRT_OK;
+}
+// k_march runs beside the walk on a LOW-priority stream: k_trace / k_shade are the critical chain, and their workgroups must
+// not queue behind k_march's (measured: k_shade took 0.4-0.7 ms instead of 0.1 ms when they did)
+static int side_stream(mcrt_ctx *c, Work &w, uint32_t i, hipStream_t *out)
+{
+    if (!w.side[i]) {
+        int prio_low = 0, prio_high = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        if (c->knobs.no_priority) prio_low = 0;   // tuning knob
+        HIP_TRY(hipStreamCreateWithPriority(&w.side[i], hipStreamNonBlocking, prio_low));
+    }
+    *out = w.side[i];
     return MCRT_OK;
 }
 
@@ -309,7 +326,7 @@ static int check_device_error(mcrt_ctx *c)
 {
     uint32_t e = 0;
     HIP_TRY(hipMemcpy(&e, c->d_error, 4, hipMemcpyDeviceToHost));
-    if (e) { HIP_TRY(hipMemsetAsync(c->d_error, 0, 4, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); return set_error(MCRT_ERR_LIMIT, "device error flag 0x%x: BVH traversal stack overflow", e); }
+    if (e) { HIP_TRY(hipMemsetAsync(c->d_error, 0, 4, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); return set_error(MCRT_ERR_LIMIT, "device error flag 0x%x:%s%s", e, (e & 1u) ? " BVH traversal stack overflow" : "", (e & 2u) ? " kernel watchdog expired (a persistent kernel ran for more than its time limit and was abandoned)" : ""); }
     return MCRT_OK;
 }
 extern "C" int mcrt_synchronize(mcrt_ctx *c) { CTX_TRY(c); HIP_TRY(hipStreamSynchronize(c->stream)); return check_device_error(c); }
@@ -695,7 +712,8 @@ static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArg
     HIP_TRY(mcrt::launch_shade(a, b, c->stats_on, st));
     if (accumulate && overlap) {   // the segments of bounce b are final: accumulate them beside the next bounce's walk
         HIP_TRY(hipEventRecord(w.ev_bounce[b], st));
-        hipStream_t side = w.side[b % side_streams(c)];
+        hipStream_t side;
+        { int rc = side_stream(c, w, b % side_streams(c), &side); if (rc) return rc; }
         HIP_TRY(hipStreamWaitEvent(side, w.ev_bounce[b], 0));
         HIP_TRY(mcrt::launch_march(a, b, c->stats_on, side));
     } else if (accumulate) {
@@ -757,6 +775,8 @@ static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0
     if (fused) {
         // k_init -> shared bounce-0 walk -> k_paths (all bounces of every path) on the context's stream, block after block;
         // each block's accumulation (ONE k_march over all its bounces) on its low-priority side stream beside the next block's paths
+        hipStream_t side = nullptr;
+        if (accumulate && overlap) { int rc = side_stream(c, *ws[0], 0, &side); if (rc) return rc; }     // ONE side stream: the blocks' accumulations run one after the other
         for (uint32_t g = 0; g < groups; g++) {
             hipStream_t st = c->stream;
             HIP_TRY(mcrt::launch_init(args[g], st));
@@ -768,39 +788,39 @@ static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0
             if (t1) HIP_TRY(hipEventRecord(t1, st));
             if (accumulate && overlap) {
                 HIP_TRY(hipEventRecord(ws[g]->ev_bounce[0], st));
-                HIP_TRY(hipStreamWaitEvent(ws[g]->side[0], ws[g]->ev_bounce[0], 0));
-                HIP_TRY(mcrt::launch_march(args[g], mcrt::MCRT_ALL_BOUNCES, c->stats_on, ws[g]->side[0]));
+                HIP_TRY(hipStreamWaitEvent(side, ws[g]->ev_bounce[0], 0));
+                HIP_TRY(mcrt::launch_march(args[g], mcrt::MCRT_ALL_BOUNCES, c->stats_on, side));
             } else if (accumulate) {
                 HIP_TRY(mcrt::launch_march(args[g], mcrt::MCRT_ALL_BOUNCES, c->stats_on, st));
             }
         }
-        if (accumulate && overlap)
-            for (uint32_t g = 0; g < groups; g++) {
-                HIP_TRY(hipEventRecord(ws[g]->ev_join[0], ws[g]->side[0]));
-                HIP_TRY(hipStreamWaitEvent(c->stream, ws[g]->ev_join[0], 0));
-            }
+        if (accumulate && overlap) {
+            HIP_TRY(hipEventRecord(ws[0]->ev_join[0], side));
+            HIP_TRY(hipStreamWaitEvent(c->stream, ws[0]->ev_join[0], 0));
+        }
         return MCRT_OK;
     }
+    std::vector<hipStream_t> gst(groups);
+    for (uint32_t g = 0; g < groups; g++) { int rc = work_stream(c, *ws[g], g == 0, &gst[g]); if (rc) return rc; }
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
     for (uint32_t g = 0; g < groups; g++) {
-        hipStream_t st = g == 0 ? c->stream : ws[g]->stream;
-        if (g) HIP_TRY(hipStreamWaitEvent(st, c->ev_start, 0));
-        HIP_TRY(mcrt::launch_init(args[g], st));
+        if (g) HIP_TRY(hipStreamWaitEvent(gst[g], c->ev_start, 0));
+        HIP_TRY(mcrt::launch_init(args[g], gst[g]));
     }
     for (uint32_t b = 0; b < c->p.max_depth; b++)
         for (uint32_t g = 0; g < groups; g++) {
-            int rc = run_bounce(c, *ws[g], g == 0 ? c->stream : ws[g]->stream, args[g], b, accumulate, overlap); if (rc) return rc;
+            int rc = run_bounce(c, *ws[g], gst[g], args[g], b, accumulate, overlap); if (rc) return rc;
         }
     for (uint32_t g = 0; g < groups; g++) {
-        hipStream_t st = g == 0 ? c->stream : ws[g]->stream;
         if (accumulate && overlap) {
             for (uint32_t i = 0; i < side_streams(c); i++) {
+                if (!ws[g]->side[i]) continue;
                 HIP_TRY(hipEventRecord(ws[g]->ev_join[i], ws[g]->side[i]));
-                HIP_TRY(hipStreamWaitEvent(st, ws[g]->ev_join[i], 0));
+                HIP_TRY(hipStreamWaitEvent(gst[g], ws[g]->ev_join[i], 0));
             }
         }
         if (g) {
-            HIP_TRY(hipEventRecord(ws[g]->ev_done, st));
+            HIP_TRY(hipEventRecord(ws[g]->ev_done, gst[g]));
             HIP_TRY(hipStreamWaitEvent(c->stream, ws[g]->ev_done, 0));
         }
     }

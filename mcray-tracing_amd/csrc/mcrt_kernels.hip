@@ -668,6 +668,15 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 #ifndef MCRT_LANE_STACK
 #define MCRT_LANE_STACK 32
 #endif
+// Persistent kernels carry a WATCHDOG: every 4096 iterations of its outer loop a wavefront compares the 100 MHz wall clock
+// with its start, and a kernel that is still running after MCRT_WATCHDOG_SECONDS sets bit 1 of the device error word and leaves
+// -- a logic error then surfaces as MCRT_ERR_LIMIT from the next synchronising call instead of a hung GPU.
+#ifndef MCRT_WATCHDOG_SECONDS
+#define MCRT_WATCHDOG_SECONDS 20
+#endif
+#define MCRT_WATCHDOG_DECL() const unsigned long long wd_start = wall_clock64(); uint32_t wd_iter = 0;
+#define MCRT_WATCHDOG_CHECK() { if ((++wd_iter & 4095u) == 0u && wall_clock64() - wd_start > (unsigned long long)MCRT_WATCHDOG_SECONDS * 100000000ull) { \
+        if ((threadIdx.x & 63) == 0) atomicOr(a.error_flag, 2u); break; } }
 #ifndef MCRT_LANE_WAVES
 #define MCRT_LANE_WAVES 5            // waves per SIMD the register budget of k_trace_lane is set for
 #endif
@@ -752,7 +761,9 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
 #define MCRT_POP() { if (sp > 0) { sp--; cur = (sp < MCRT_LANE_STACK) ? stack[sp * 256 + tid] : ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride]; } else cur = CUR_IDLE; }
 #define MCRT_PUSH(v) { if (sp < MCRT_LANE_STACK) stack[sp * 256 + tid] = (v); else ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride] = (v); sp++; }
     uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
+    MCRT_WATCHDOG_DECL()
     for (;;) {
+        MCRT_WATCHDOG_CHECK()
         // ---- finished rays report and idle lanes take new ones, once enough of them wait (the code runs for the whole wavefront) ----
         const bool do_refill = __popcll(__ballot(cur == CUR_IDLE && !exhausted)) >= MCRT_LANE_REFILL || MCRT_WALKING(cur) == 0ull;
         if (do_refill) {
@@ -1112,7 +1123,9 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_paths(FrameArgs a)
 #define MCRT_POP() { if (sp > 0) { sp--; cur = (sp < MCRT_LANE_STACK) ? stack[sp * 256 + tid] : ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride]; } else { cur = CUR_IDLE; pend = true; } }
 #define MCRT_PUSH(v) { if (sp < MCRT_LANE_STACK) stack[sp * 256 + tid] = (v); else ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride] = (v); sp++; }
     uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;
+    MCRT_WATCHDOG_DECL()
     for (;;) {
+        MCRT_WATCHDOG_CHECK()
         const unsigned long long walking = MCRT_WALKING(cur);
         const unsigned long long pending = __ballot(pend);
         // ---- lanes without a path take the next queue positions ----

@@ -737,6 +737,13 @@ static inline void fix_add(int64_t *acc, uint8_t *flag, float echo)
     *acc += (int64_t)rint((double)echo * FIX_SCALE);
 }
 
+/* Optional companion of rf_ref: the SAME echoes added in the SAME (reference) order, but into doubles.  The float image is what
+ * the reference's `cv::Mat += echo` produces; the distance between the two is that running float sum's own rounding error,
+ * which grows with the number of samples per scan-line.  Set by orc_set_ref64 around a call that requests rf_ref (tests only;
+ * one call at a time). */
+static double *g_ref64 = NULL;
+void orc_set_ref64(double *buf) { g_ref64 = buf; }
+
 typedef struct {
     float *rf_ref; uint32_t ref_cols, ref_col;       /* [R][cols] */
     int64_t *rf_fix; uint8_t *rf_flags;               /* [R] of this element */
@@ -748,7 +755,10 @@ static inline void add_echo(const rf_sink *k, const orc_consts *c, uint32_t n_ro
     double row = t_us / c->row_dt_us;
     if (row < (double)n_rows) {
         int r = (int)row;
-        if (k->rf_ref) k->rf_ref[(size_t)r * k->ref_cols + k->ref_col] += echo;
+        if (k->rf_ref) {
+            k->rf_ref[(size_t)r * k->ref_cols + k->ref_col] += echo;
+            if (g_ref64) g_ref64[(size_t)r * k->ref_cols + k->ref_col] += (double)echo;
+        }
         if (k->rf_fix) fix_add(&k->rf_fix[r], k->rf_flags ? &k->rf_flags[r] : NULL, echo);
     }
 }

@@ -143,6 +143,9 @@ int32_t orc_closest_hit(const orc_scene *sc, const float from[3], const float to
  *  rf_fix   : [E_range][R] int64 fixed-point accumulators (contract mode)      (may be NULL)
  *  rf_flags : [E_range][R] uint8 non-finite flags for rf_fix                   (may be NULL)
  */
+/* test aid: while set, a call that produces rf_ref also adds every echo, in the same order, into this [R][E_range] double image */
+void orc_set_ref64(double *buf);
+
 void orc_trace_frame(const orc_scene *sc, const orc_params *p,
                      const float *el_pos, const float *el_dir, const float *texture,
                      uint32_t frame_id, uint32_t e_begin, uint32_t e_end, int use_bvh, int n_threads,

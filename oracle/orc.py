@@ -197,7 +197,7 @@ class OracleScene:
         return tri, float(frac[0]), n, p, st.as_dict()
 
     def trace_frame(self, params, el_pos, el_dir, tex, frame_id=0, e_begin=0, e_end=None, use_bvh=False, n_threads=1,
-                    want_hits=True, want_segs=False, want_ref=True, want_fix=True):
+                    want_hits=True, want_segs=False, want_ref=True, want_fix=True, want_ref64=False):
         E = params.n_elements if e_end is None else e_end
         e_end = E
         ne = e_end - e_begin; S = params.n_samples; B = params.max_depth; R = params.n_rows
@@ -211,13 +211,23 @@ class OracleScene:
         rf_fix = np.zeros((ne, R), np.int64) if want_fix else None
         rf_flg = np.zeros((ne, R), np.uint8) if want_fix else None
         st = Stats()
-        lib().orc_trace_frame(C.byref(self.c), C.byref(params), _p(el_pos), _p(el_dir), _p(tex),
-                              C.c_uint32(frame_id), C.c_uint32(e_begin), C.c_uint32(e_end), int(use_bvh), int(n_threads),
-                              _p(hits), _p(segs), _p(segc), _p(rf_ref), _p(rf_fix), _p(rf_flg), C.cast(C.byref(st), C.c_void_p))
-        out.update(hits=hits, segs=segs, seg_count=segc, rf_ref=rf_ref, rf_fix=rf_fix, rf_flags=rf_flg, stats=st.as_dict())
+        # the reference-order sum carried in double beside the float one (what the float running sum loses: tests at large S)
+        rf_ref64 = np.zeros((R, ne), np.float64) if (want_ref and want_ref64) else None
+        lib().orc_set_ref64.argtypes = [C.c_void_p]; lib().orc_set_ref64.restype = None
+        lib().orc_set_ref64(_p(rf_ref64))
+        try:
+            self._trace(params, el_pos, el_dir, tex, frame_id, e_begin, e_end, use_bvh, n_threads, hits, segs, segc, rf_ref, rf_fix, rf_flg, st)
+        finally:
+            lib().orc_set_ref64(None)
+        out.update(hits=hits, segs=segs, seg_count=segc, rf_ref=rf_ref, rf_ref64=rf_ref64, rf_fix=rf_fix, rf_flags=rf_flg, stats=st.as_dict())
         if want_fix:
             out["rf"] = finalize_rf(rf_fix, rf_flg)
         return out
+
+    def _trace(self, params, el_pos, el_dir, tex, frame_id, e_begin, e_end, use_bvh, n_threads, hits, segs, segc, rf_ref, rf_fix, rf_flg, st):
+        lib().orc_trace_frame(C.byref(self.c), C.byref(params), _p(el_pos), _p(el_dir), _p(tex),
+                              C.c_uint32(frame_id), C.c_uint32(e_begin), C.c_uint32(e_end), int(use_bvh), int(n_threads),
+                              _p(hits), _p(segs), _p(segc), _p(rf_ref), _p(rf_fix), _p(rf_flg), C.cast(C.byref(st), C.c_void_p))
 
 
 def finalize_rf(rf_fix, rf_flags):

@@ -8,7 +8,8 @@ Every configuration is traced on the GPU at FULL size and compared with the CPU 
 (C1 and C2, the sphere configurations, are in test_gpu_parity.py.)  The oracle checks every scan-line where that takes it
 well under a minute on the box's host cores, else a seeded subset of scan-line blocks (its e_begin/e_end range) -- the
 GPU always traces the whole frame.  Bars: hit indices bit-exact; fixed-point RF image bit-exact; reference-order float
-image within 1e-4 both relative to the peak and element-wise (|d| <= 1e-4 |ref| + 1e-5 peak); BVH node / triangle
+image within 1e-4 both relative to the peak and element-wise (|d| <= 1e-4 |ref| + 1e-6 peak; see assert_rf for how the
+reference's own float accumulation noise is kept out of the comparison at thousands of samples per scan-line); BVH node / triangle
 visit counts equal to the oracle's walk of the same tree (they are the roofline's algorithmic bytes)."""
 import os
 import numpy as np
@@ -17,12 +18,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 RTOL_REF = 1e-4          # north_star: RF image within 1e-4 relative of the CPU reference path
-ATOL_FLOOR = 1e-5        # element-wise absolute floor, in units of the image peak: what the float reference-order sum itself loses
-                         # in a bin fed by ~10^4 echoes (measured: 3e-6 of the peak at 8192 samples per scan-line); 10x below the peak-relative bar
+ATOL_FLOOR = 1e-6        # element-wise absolute floor, in units of the image peak
 
 
 def assert_rf(rf_gpu, o, cols=None):
-    """rf_gpu [R][E] against the oracle's contract image (bit-exact) and its reference-order float sum (1e-4)"""
+    """rf_gpu [R][E] against the oracle: (1) the contract image, bit for bit; (2) the reference's own summation order
+    (main.cpp:106-144) within 1e-4, peak-relative AND element-wise.  The reference adds echoes into a float image
+    (`cv::Mat += echo`, rfimage.h:38); that running float sum carries its own rounding error, which grows with the samples per
+    scan-line (measured: 3e-7 of the peak at 1024, 1.5e-4 at 16384).  Where the oracle also carried the same order in double
+    (`rf_ref64`), the 1e-4 bars are applied to THAT image -- the reference's arithmetic without its accumulation noise -- and the
+    float image must differ from the GPU's by no more than it differs from its own double-precision twin (+10 %)."""
     want, ref = o["rf"], o["rf_ref"]
     if cols is not None:
         rf_gpu = rf_gpu[:, cols[0]:cols[1]]
@@ -30,10 +35,19 @@ def assert_rf(rf_gpu, o, cols=None):
     assert np.array_equal(np.isnan(rf_gpu), np.isnan(ref))
     m = ~np.isnan(ref)
     peak = np.abs(ref[m]).max()
-    d = np.abs(rf_gpu[m] - ref[m])
+    d32 = np.abs(rf_gpu[m] - ref[m]).max() / peak
+    if o.get("rf_ref64") is not None:
+        ref64 = o["rf_ref64"]
+        d = np.abs(rf_gpu[m].astype(np.float64) - ref64[m])
+        own = np.abs(ref[m].astype(np.float64) - ref64[m]).max() / peak          # the float running sum against itself in double
+        assert d32 <= 1.1 * own + 1e-6, "float reference image: off by %g of the peak, its own rounding is %g" % (d32, own)
+        ref_abs = np.abs(ref64[m])
+    else:
+        d = np.abs(rf_gpu[m] - ref[m])
+        ref_abs = np.abs(ref[m])
     assert d.max() <= RTOL_REF * peak, "relative to the peak: %g" % (d.max() / peak)
-    assert np.all(d <= RTOL_REF * np.abs(ref[m]) + ATOL_FLOOR * peak), "element-wise: worst excess %g of the peak" % ((d - RTOL_REF * np.abs(ref[m])).max() / peak)
-    return float(d.max() / peak)
+    assert np.all(d <= RTOL_REF * ref_abs + ATOL_FLOOR * peak), "element-wise: worst excess %g of the peak" % ((d - RTOL_REF * ref_abs).max() / peak)
+    return float(d.max() / peak), float(d32)
 
 
 def _setup(mcrt, orc, cfg, sd, E, S, tex, **kw):
@@ -58,9 +72,9 @@ def _blocks(E, width, n, seed):
 def _check_blocks(orc, osc, tr, tex, hits, rf, p, frame, blocks, threads):
     worst = 0.0
     for b0, b1 in blocks:
-        o = osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=frame, e_begin=b0, e_end=b1, use_bvh=2, n_threads=threads)
+        o = osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=frame, e_begin=b0, e_end=b1, use_bvh=2, n_threads=threads, want_ref64=True)
         assert np.array_equal(hits[b0:b1], o["hits"]), "hit indices differ in scan-lines [%d,%d)" % (b0, b1)
-        worst = max(worst, assert_rf(rf, o, (b0, b1)))
+        worst = max(worst, assert_rf(rf, o, (b0, b1))[1])
     return worst
 
 
@@ -89,10 +103,11 @@ def test_headline_1m_triangles_128x1024(mcrt, orc, tex256):
     rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
     p_kw = dict(n_elements=E, n_samples=S)
     p = orc.default_params(**p_kw)
-    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=threads)
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=threads, want_ref64=True)
     assert np.array_equal(hits, o["hits"])
     assert (hits >= 0).sum() > 2 * E * S                      # the soup is hit, several bounces deep
-    assert_rf(rf, o)
+    d64, d32 = assert_rf(rf, o)
+    assert d32 <= RTOL_REF                                      # at 1024 samples per scan-line even the float running sum is within the bar
     _visit_counts(mcrt, orc, sim, osc, tr, tex256, p_kw, frame, S, o["stats"], threads)
     # the batched pass the bench times (frames in flight) reproduces the frame bit for bit
     F = 4
@@ -118,7 +133,7 @@ def test_c3_liver_128x4096(mcrt, orc, tex256):
     rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
     p_kw = dict(n_elements=E, n_samples=S)
     p = orc.default_params(**p_kw)
-    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=threads)
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=threads, want_ref64=True)
     assert np.array_equal(hits, o["hits"])
     assert (hits >= 0).sum() > E * S
     assert_rf(rf, o)
