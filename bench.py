@@ -470,7 +470,7 @@ def cpu_baseline(m, sd, tr, ctx, S, R, rf0):
             o0 = o
         frames += 1
         dt = time.perf_counter() - t0
-        if dt >= 5.0 or frames >= 64:
+        if dt >= 5.0 or frames >= 100000:
             break
     busy = (sum(os.times()[:2]) - c0) / dt                      # CPU seconds per wall second: the cores the sample really kept busy
     want = o0["rf"]                                             # [R][E]

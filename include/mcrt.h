@@ -215,7 +215,7 @@ int mcrt_transducer_elements(uint32_t n_elements, double radius_cm, double separ
 
 /* contract-math probe used by the parity tests: evaluates op over n inputs ON THE GPU.
  * op: 0 log_d, 1 exp_d, 2 sin_d, 3 cos_d, 4 sqrt_d, 5 div_d(x,y), 6 logf, 7 expf, 8 powf(x,y),
- *     9 sqrtf, 10 divf(x,y), 11 pow_d(x,y), 12/13 low 31 bits / remaining bits of the fixed-point echo rint(x*2^52).  x,y,out are host double arrays (float ops use the
+ *     9 sqrtf, 10 divf(x,y), 11 pow_d(x,y), 12/13 low 31 bits / remaining bits of the fixed-point echo rint(x*2^40).  x,y,out are host double arrays (float ops use the
  * value converted to float). */
 int mcrt_debug_math(mcrt_ctx *ctx, int op, const double *x, const double *y, double *out, uint32_t n);
 int mcrt_debug_philox(mcrt_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

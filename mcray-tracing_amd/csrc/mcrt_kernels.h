@@ -31,7 +31,7 @@ struct FrameArgs {
     float4 *mrec;              // [B][np][3] what k_march needs of a segment: from,refl | delta,intensity | t_start(f64),steps,media
     const float4 *mtab;        // [M] per material, for k_march: mu0, mu1, sigma, per-step attenuation factor
     uint32_t *seg_count;       // [np]
-    long long *acc;            // [ne][R] fixed-point RF accumulators (2^-52 units)
+    long long *acc;            // [ne][R] fixed-point RF accumulators (2^-40 units)
     uint32_t *flags;           // [ne][(R+31)/32] non-finite flags
     unsigned long long *stats; // [6]
     uint32_t *error_flag;      // device word, bit 0: traversal stack overflow

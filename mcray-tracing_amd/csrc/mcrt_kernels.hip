@@ -265,34 +265,22 @@ MCRT_DEV uint32_t vox_cell_lean(f3 p, const FrameArgs &a)
 }
 MCRT_DEV float abs_sum(f3 p) { return (fabsf(p.x) + fabsf(p.y)) + fabsf(p.z); }   // >= every |coordinate|; NaN/inf propagate
 
-// one echo into the scan-line's fixed-point LDS bins (2^-52 units; integer adds commute, so the image does not depend
+// one echo into the scan-line's fixed-point LDS bins (2^-40 units; integer adds commute, so the image does not depend
 // on the order lanes, waves or workgroups arrive in)
-// rint(echo * 2^52) for |echo| < 1024, built from the float's bits (exactly what the double multiply + rint gives: the product
-// is exact, so only echoes below 2^-29 need rounding at all -- round-to-nearest-even on the dropped mantissa bits)
-MCRT_DEV long long fix52(float echo)
+// rint(echo * 2^40) for |echo| < 1024 (so |echo * 2^40| < 2^50), round to nearest even -- in TWO floating-point instructions: the
+// product echo * 2^40 is exact in double, and adding 1.5 * 2^52 to it rounds the sum to an integer (ulp = 1 in [2^52, 2^53))
+// whose low mantissa bits ARE that integer, offset by 2^51; one fma does both, an integer subtract removes the offset.
+MCRT_DEV long long fix40(float echo)
 {
-    const uint32_t u = __float_as_uint(echo);
-    const int e = (int)((u >> 23) & 255u);
-    const uint32_t m = (u & 0x7fffffu) | (e ? 0x800000u : 0u);
-    const int sh = (e ? e : 1) - 98;                       // echo = m * 2^(e-150)  ->  echo * 2^52 = m * 2^(e-98)
-    long long v;
-    if (sh >= 0) v = (long long)((unsigned long long)m << sh);
-    else {
-        const int r = -sh;
-        if (r > 25) v = 0;
-        else {
-            const uint32_t q = m >> r, rem = m & ((1u << r) - 1u), half = 1u << (r - 1);
-            v = (long long)(q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u));
-        }
-    }
-    return (u >> 31) ? -v : v;
+    const double x = fma((double)echo, 0x1p40, 0x1.8p52);
+    return (long long)__double_as_longlong(x) - (long long)__double_as_longlong(0x1.8p52);
 }
 
 MCRT_DEV void rf_add(long long *bins, uint32_t *lflags, int row, float echo)
 {
     if (row < 0) return;
     if (!(fabsf(echo) < 1024.0f)) { atomicOr(&lflags[row >> 5], 1u << (row & 31)); return; }
-    const long long v = fix52(echo);
+    const long long v = fix40(echo);
     if (v != 0) atomicAdd((unsigned long long *)&bins[row], (unsigned long long)v);
 }
 
@@ -661,7 +649,7 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 // with unused slots stored as the point box at +infinity, which no slab test hits (so the walk needs no EMPTY test).
 // Per ray the arithmetic is the quad walk's, operation for operation: (plane - origin) * reciprocal, the same min/max
 // combination, the same nearest-child key (t_near bits with the slot number in the two low bits), the other hit children
-// stacked in slot order, and the same triangle test -- so hits AND visit counts equal the quad walk's and the oracle's.
+// stacked in slot order, and the same triangle test -- so hits AND visit counts equal the quad walk's, visit for visit.
 // Traversal stacks: MCRT_LANE_STACK entries per lane in LDS ([entry][thread], conflict-free); deeper entries (only reachable on
 // degenerate paths of deep trees) go to a global overflow array.
 // =============================================================================================================
@@ -1550,7 +1538,7 @@ __global__ void k_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t 
     const uint32_t nf = (R + 31u) >> 5;
     const bool bad = (flags[(size_t)e * nf + (r >> 5)] >> (r & 31)) & 1u;
     const long long v = acc[i];
-    rf[i] = bad ? __uint_as_float(0x7fc00000u) : (float)((double)v * 0x1p-52);
+    rf[i] = bad ? __uint_as_float(0x7fc00000u) : (float)((double)v * 0x1p-40);
     acc[i] = 0;
 }
 __global__ void k_clear_flags(uint32_t *flags, size_t n)
@@ -1667,8 +1655,8 @@ __global__ void k_math_probe(int op, const double *x, const double *y, double *o
     case 9: r = (double)sqrtf((float)a); break;
     case 10: r = (double)((float)a / (float)b); break;
     case 11: r = det_pow_pos(a, b); break;
-    case 12: r = (double)(fix52((float)a) & 0x7fffffffll); break;          // low 31 bits of the fixed-point echo
-    case 13: r = (double)(fix52((float)a) >> 31); break;                    // the rest (arithmetic shift)
+    case 12: r = (double)(fix40((float)a) & 0x7fffffffll); break;          // low 31 bits of the fixed-point echo
+    case 13: r = (double)(fix40((float)a) >> 31); break;                    // the rest (arithmetic shift)
     default: break;
     }
     out[i] = r;

@@ -730,7 +730,7 @@ static inline uint32_t steps_from(double q)
     return (uint32_t)(int64_t)q;
 }
 
-#define FIX_SCALE 4503599627370496.0   /* 2^52 */
+#define FIX_SCALE 1099511627776.0   /* 2^40: |echo| < 1024 keeps every term below 2^50 */
 static inline void fix_add(int64_t *acc, uint8_t *flag, float echo)
 {
     if (!(fabsf(echo) < 1024.0f)) { if (flag) *flag = 1; return; }
@@ -941,7 +941,7 @@ void orc_finalize_rf(const int64_t *rf_fix, const uint8_t *rf_flags, uint32_t n_
     for (uint32_t e = 0; e < n_elem; e++)
         for (uint32_t r = 0; r < n_rows; r++) {
             size_t i = (size_t)e * n_rows + r;
-            float v = (rf_flags && rf_flags[i]) ? u2f(0x7fc00000u) : (float)((double)rf_fix[i] * 0x1p-52);
+            float v = (rf_flags && rf_flags[i]) ? u2f(0x7fc00000u) : (float)((double)rf_fix[i] * 0x1p-40);
             out[(size_t)r * n_elem + e] = v;
         }
 }

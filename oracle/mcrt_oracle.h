@@ -152,7 +152,7 @@ void orc_trace_frame(const orc_scene *sc, const orc_params *p,
                      int32_t *hits, orc_segment *segs, uint32_t *seg_count,
                      float *rf_ref, int64_t *rf_fix, uint8_t *rf_flags, orc_stats *st);
 
-/* contract finalisation: float = flag ? NaN : (float)((double)acc * 2^-52); out [R][E] row-major */
+/* contract finalisation: float = flag ? NaN : (float)((double)acc * 2^-40); out [R][E] row-major */
 void orc_finalize_rf(const int64_t *rf_fix, const uint8_t *rf_flags, uint32_t n_elem, uint32_t n_rows, float *out_rows_by_cols);
 
 /* rfimage.h:93-123 on a row-major [R][E] image, in place (tmp = scratch of same size) */

@@ -75,12 +75,12 @@ def test_contract_math_on_gpu(mcrt, orc):
     g = ctx.debug_math(8, xb, yb)
     ref = np.array([orc.lib().orc_powf(a_, b_) for a_, b_ in zip(xb.tolist(), yb.tolist())], np.float64)
     assert np.array_equal(np.isnan(g), np.isnan(ref)) and np.array_equal(g[~np.isnan(g)], ref[~np.isnan(ref)])
-    # fixed-point echo conversion (integer construction in the kernel) == rint(echo * 2^52), incl. the sub-2^-29 rounding path
-    ech = np.concatenate([rng.normal(size=n) * 10.0 ** rng.uniform(-14, 2, n), (rng.uniform(-1, 1, n) * 2.0 ** -52 * rng.integers(1, 1 << 24, n)),
-                          [0.0, -0.0, 2.0 ** -53, 3 * 2.0 ** -54, 2.0 ** -29, 1023.99994, 1e-45, -1e-45]]).astype(np.float32)
+    # fixed-point echo conversion (one fma + an integer subtract in the kernel) == rint(echo * 2^40), incl. ties and sub-unit echoes
+    ech = np.concatenate([rng.normal(size=n) * 10.0 ** rng.uniform(-14, 2, n), (rng.uniform(-1, 1, n) * 2.0 ** -40 * rng.integers(1, 1 << 24, n)),
+                          [0.0, -0.0, 2.0 ** -41, 3 * 2.0 ** -42, 5 * 2.0 ** -42, -2.0 ** -41, 2.0 ** -17, 1023.99994, -1023.99994, 1e-45, -1e-45]]).astype(np.float32)
     ech = ech[np.abs(ech) < 1024]
     lo = ctx.debug_math(12, ech.astype(np.float64)).astype(np.int64); hi = ctx.debug_math(13, ech.astype(np.float64)).astype(np.int64)
-    ref = np.rint(ech.astype(np.float64) * 2.0 ** 52).astype(np.int64)
+    ref = np.rint(ech.astype(np.float64) * 2.0 ** 40).astype(np.int64)
     assert np.array_equal((hi << 31) | lo, ref)
     # philox
     for ctr, key in [([0, 0, 0, 0], [0, 0]), ([0xffffffff] * 4, [0xffffffff] * 2), ([1, 2, 3, 4], [5, 6])]:
@@ -438,10 +438,17 @@ def test_large_passes_use_the_per_xcd_queues(mcrt, orc, sphere, tex256):
 
 
 @pytest.mark.parametrize("case", range(16))
-def test_randomised_configurations(mcrt, orc, case):
+def test_randomised_configurations(mcrt, orc, case, monkeypatch):
     """a sweep over shapes and parameters nobody picked by hand: odd element / sample / row counts, depths 1..16, both builders,
     textures of several sizes, TIR sanitising on and off, frequency, seed, frames in flight -- hits and RF bit for bit"""
     rng = np.random.default_rng(1000 + case)
+    # every fourth case through the fused path kernel, one through the round-1 quad walk (the library reads its knobs at mcrt_create)
+    for k in ("MCRT_PIPELINE", "MCRT_QUAD_WALK"):
+        monkeypatch.delenv(k, raising=False)
+    if case % 4 == 3:
+        monkeypatch.setenv("MCRT_PIPELINE", "fused")
+    if case == 6:
+        monkeypatch.setenv("MCRT_QUAD_WALK", "1")
     if case % 3 == 0:
         cfg, meshes = mcrt.synth.random_scene(int(rng.integers(2000, 30000)), 8, seed=int(rng.integers(1, 1000)))
     elif case % 3 == 1:

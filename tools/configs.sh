@@ -2,7 +2,7 @@
 # the BASELINE.json configurations on ONE GPU (C1..C5), one line each
 mkdir -p gpurun_out/configs
 run() { name=$1; shift
-  timeout 600 python bench.py --no-cpu-baseline --no-latency-leg "$@" > gpurun_out/configs/$name.log 2>&1
+  timeout 600 python bench.py --no-cpu-baseline --no-latency-leg --no-pmc "$@" > gpurun_out/configs/$name.log 2>&1
   python3 - "$name" <<'PY'
 import json,sys
 n=sys.argv[1]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # instruction counts only (two --pmc passes) for the kernels of one bench run: quick before/after check of a kernel change
 out=gpurun_out/pmcq_$1; mkdir -p $out; export TMPDIR=/tmp
-B="python3 bench.py --steps 32 --warmup 32 --no-cpu-baseline --no-latency-leg ${BENCH_ARGS}"
+B="python3 bench.py --steps 32 --warmup 32 --no-cpu-baseline --no-latency-leg --no-pmc ${BENCH_ARGS}"
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $out/q1 -- $B > $out/q1.log 2>&1
 python3 - $out <<'PY'
 import csv, glob, sys, collections

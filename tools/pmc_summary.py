@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 output dirs (kernel stats + PMC passes) of tools/pmc.sh into one JSON + text table."""
 import csv, glob, json, os, sys, collections
-KERNEL = os.environ.get("PMC_KERNEL", "k_trace<false>")   # substring of the kernel the counters are reported for
+KERNEL = os.environ.get("PMC_KERNEL", "k_trace_lane<false>")   # substring of the kernel the counters are reported for
 out = sys.argv[1]
 res = {"kernel_stats": [], "pmc": {}}
 for f in glob.glob(out + "/stats/*/*kernel_stats.csv"):
