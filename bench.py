@@ -214,9 +214,11 @@ def main():
     pipe.run_steps(0, K); pipe.sync()
     st = ctx.get_stats(reset=True)
     ctx.enable_stats(False)
-    # Algorithmic bytes (adapted to the 128-B BVH4 nodes).  The dominant kernel is k_trace, launched once per
-    # bounce and pass: per closest-hit query nodes*128 B + triangles*48 B + the 32-B ray read and 32-B hit record written.
-    trace_bytes_frame = (st["nodes_visited"] * 128 + st["tris_tested"] * 48 + st["queries"] * 64) / K
+    # Algorithmic bytes (adapted to the BVH4 nodes the walk reads: 64 B with half-float boxes for the lane-per-ray
+    # walk, 128 B for the quad walk).  The dominant kernel is the walk, launched once per bounce and pass: per closest-hit query
+    # nodes*64 B + triangles*48 B + the 32-B ray read and 32-B hit record written.
+    node_bytes = 128 if os.environ.get("MCRT_QUAD_WALK") else 64
+    trace_bytes_frame = (st["nodes_visited"] * node_bytes + st["tris_tested"] * 48 + st["queries"] * 64) / K
     # the rest of the frame, for the record: 64-B segment written + read, 8-B texture gather per RF step, RF block + bins
     other_bytes_frame = (st["segments"] * 128 + st["rf_steps"] * 8) / K + E_local * R * (4 + 8)
 
@@ -269,7 +271,7 @@ def main():
                        "overlap_gather_psf_with_next_trace": not args.no_overlap, "bvh_builder": args.bvh, "bvh_build_s": round(t_bvh, 3)},
         }
         roof = {"kernel": "k_trace", "kernel_ms": k_ms, "launches": k_n, "launches_per_frame": launches_per_frame,
-                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps_cache_served": alg_gbs,
+                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps_cache_served": alg_gbs, "node_bytes": node_bytes,
                 "trace_bytes_per_frame": trace_bytes_frame, "other_stage_bytes_per_frame": other_bytes_frame,
                 "per_frame": {k: v / K for k, v in st.items()}}
         pmc = None

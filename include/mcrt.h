@@ -201,6 +201,10 @@ void mcrt_free_bvh(mcrt_bvh *bvh);
 int mcrt_get_bvh(mcrt_ctx *ctx, mcrt_bvh *out /* borrowed pointers, valid until next upload */);
 int mcrt_build_bvh4(const mcrt_bvh *bvh2, mcrt_bvh4 *out);
 void mcrt_free_bvh4(mcrt_bvh4 *bvh4);
+/* The BVH4 as the closest-hit walk reads it (borrowed; valid until the next upload / update / refit).  The default
+ * lane-per-ray walk stores node boxes as half floats rounded outwards (64-byte nodes: the walk is bound by the number of
+ * 16-byte pieces it fetches); the boxes returned here are those decoded values, so a CPU walk of this tree visits exactly the
+ * nodes the GPU walk visits.  Hits never depend on the node boxes (closest hit). */
 int mcrt_get_bvh4(mcrt_ctx *ctx, mcrt_bvh4 *out /* borrowed */);
 /* the exact row look-up table used instead of the per-echo double division (see DESIGN.md "RF rows"):
  * thr[r] = smallest double t with fl(t / row_dt) >= r, r = 0..n_rows */

@@ -100,7 +100,8 @@ struct mcrt_ctx {
     mcrt_bvh4 bvh4{};
     uint32_t *d_error = nullptr;
     float4 *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr;
-    float4 *d_nodes_soa = nullptr; int *d_stack_ovf = nullptr;   // lane-per-ray walk: child-transposed nodes, traversal-stack overflow
+    mcrt_bvh4_node *walked_nodes = nullptr; bool walked_stale = true;   // host copy of the tree as the lane walk sees it (mcrt_get_bvh4)
+    uint4 *d_nodes_walk = nullptr; int *d_stack_ovf = nullptr;   // lane-per-ray walk: child-transposed nodes, traversal-stack overflow
     uint4 *d_meshes = nullptr;
     uint32_t *d_tri_slot = nullptr;
     uint32_t n_mesh = 0, n_mat = 0, start_mat = 0, n_cu = 256;
@@ -281,11 +282,12 @@ static int side_stream(mcrt_ctx *c, Work &w, uint32_t i, hipStream_t *out)
 // worst-case traversal stack exceeds the LDS part, the overflow array
 static int refresh_soa(mcrt_ctx *c)
 {
-    hipFree(c->d_nodes_soa); c->d_nodes_soa = nullptr;
+    c->walked_stale = true;
+    hipFree(c->d_nodes_walk); c->d_nodes_walk = nullptr;
     hipFree(c->d_stack_ovf); c->d_stack_ovf = nullptr;
     if (c->knobs.quad_walk || c->bvh4.n_nodes == 0) return MCRT_OK;
-    HIP_TRY(hipMalloc(&c->d_nodes_soa, 128 * (size_t)c->bvh4.n_nodes));
-    HIP_TRY(mcrt::launch_nodes_soa(c->d_nodes, c->bvh4.n_nodes, c->d_nodes_soa, c->stream));
+    HIP_TRY(hipMalloc(&c->d_nodes_walk, 64 * (size_t)c->bvh4.n_nodes));
+    HIP_TRY(mcrt::launch_nodes_walk(c->d_nodes, c->bvh4.n_nodes, c->d_nodes_walk, c->stream));
     const uint32_t lds_part = mcrt::lane_stack_entries();
     if (c->bvh4.max_stack > lds_part) {
         const uint32_t blocks = c->knobs.trace_blocks ? c->knobs.trace_blocks : c->n_cu * 5u;
@@ -297,7 +299,8 @@ static int refresh_soa(mcrt_ctx *c)
 
 static void free_scene(mcrt_ctx *c)
 {
-    hipFree(c->d_nodes_soa); c->d_nodes_soa = nullptr; hipFree(c->d_stack_ovf); c->d_stack_ovf = nullptr;
+    free(c->walked_nodes); c->walked_nodes = nullptr; c->walked_stale = true;
+    hipFree(c->d_nodes_walk); c->d_nodes_walk = nullptr; hipFree(c->d_stack_ovf); c->d_stack_ovf = nullptr;
     hipFree(c->d_nodes); hipFree(c->d_tris); hipFree(c->d_mats); hipFree(c->d_meshes); hipFree(c->d_tri_slot); c->d_tri_slot = nullptr;
     c->d_nodes = c->d_tris = c->d_mats = nullptr; c->d_meshes = nullptr;
     mcrt_free_bvh(&c->bvh);
@@ -312,6 +315,7 @@ extern "C" int mcrt_destroy(mcrt_ctx *c)
     hipDeviceSynchronize();
     free_scene(c);
     free_work(c);
+    free(c->walked_nodes); c->walked_nodes = nullptr;
     hipFree(c->d_tex); hipFree(c->d_pos); hipFree(c->d_dir); hipFree(c->d_acc); hipFree(c->d_flags); hipFree(c->d_tmp);
     hipFree(c->d_map_col); hipFree(c->d_map_row); hipFree(c->d_stats); hipFree(c->d_row_thr); hipFree(c->d_error); hipFree(c->d_mtab);
     for (auto &e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -547,6 +551,26 @@ extern "C" int mcrt_get_bvh4(mcrt_ctx *c, mcrt_bvh4 *out)
 {
     if (!c || !out) return set_error(MCRT_ERR_INVALID, "null argument");
     if (!c->have_scene) return set_error(MCRT_ERR_INVALID, "no scene uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->d_nodes_walk) {
+        // the tree AS WALKED: the lane-per-ray walk reads half-float boxes rounded outwards; decoded back into the builders' layout
+        if (c->walked_stale || !c->walked_nodes) {
+            const size_t bytes = sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes;
+            float4 *d_tmp = nullptr;
+            HIP_TRY(hipMalloc(&d_tmp, bytes));
+            hipError_t e = mcrt::launch_nodes_walk_decode(c->d_nodes_walk, c->bvh4.n_nodes, d_tmp, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            free(c->walked_nodes);
+            c->walked_nodes = (mcrt_bvh4_node *)malloc(bytes);
+            if (e == hipSuccess && c->walked_nodes) e = hipMemcpy(c->walked_nodes, d_tmp, bytes, hipMemcpyDeviceToHost);
+            hipFree(d_tmp);
+            if (!c->walked_nodes) return set_error(MCRT_ERR_NOMEM, "out of memory");
+            if (e != hipSuccess) return set_error(MCRT_ERR_HIP, "mcrt_get_bvh4: %s", hipGetErrorString(e));
+            c->walked_stale = false;
+        }
+        out->n_nodes = c->bvh4.n_nodes; out->max_stack = c->bvh4.max_stack; out->nodes = c->walked_nodes;
+        return MCRT_OK;
+    }
     { int rc = download_bvh(c); if (rc) return rc; }
     *out = c->bvh4;
     return MCRT_OK;
@@ -666,7 +690,7 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne, int out)
 static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, uint32_t acc_e0, uint32_t acc_ne)
 {
     memset(&a, 0, sizeof a);
-    a.nodes = c->d_nodes; a.nodes_soa = c->d_nodes_soa; a.stack_ovf = c->d_stack_ovf; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
+    a.nodes = c->d_nodes; a.nodes_walk = c->d_nodes_walk; a.stack_ovf = c->d_stack_ovf; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
     a.el_pos = c->d_pos; a.el_dir = c->d_dir; a.row_thr = c->d_row_thr;
     a.acc = c->d_acc; a.flags = c->d_flags;                 // the frame block [n_frames][acc_ne][R]; this group owns columns e0-acc_e0 ...
     a.acc_stride = acc_ne; a.acc_off = e0 - acc_e0;
@@ -733,7 +757,7 @@ static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArg
 // natural base for a queue-fed persistent design).
 static bool use_fused(const mcrt_ctx *c, size_t paths)
 {
-    if (!c->d_nodes_soa) return false;                     // (the fused kernel walks the child-transposed nodes)
+    if (!c->d_nodes_walk) return false;                     // (the fused kernel walks the child-transposed nodes)
     if (c->knobs.pipeline == 1) return false;
     if (c->knobs.pipeline == 2) return true;
     return paths <= (size_t)c->knobs.fused_max_paths;

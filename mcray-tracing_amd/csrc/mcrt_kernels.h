@@ -9,7 +9,7 @@ namespace mcrt {
 struct FrameArgs {
     // scene (HBM-resident, read-only)
     const float4 *nodes;       // [n_nodes][8]  128-B BVH4 nodes (4 x 32-B child records)
-    const float4 *nodes_soa;   // [n_nodes][8]  the same nodes transposed per child (lo.x[4] | lo.y[4] | ... | ref[4] | -) for the lane-per-ray walk; null = quad walk
+    const uint4 *nodes_walk;   // [n_nodes][4]  the lane-per-ray walk's 64-byte nodes: child-transposed half-float boxes (rounded outwards) + refs; null = quad walk
     int *stack_ovf;            // [max_stack - MCRT_LANE_STACK][trace_blocks * 256] traversal-stack entries beyond the LDS part (lane-per-ray walk)
     const float4 *tris;        // [T][6]        96-B triangle records, leaf order: n|dist, padded lo|id, padded hi|mesh, v0, v1, v2
     const uint4 *meshes;       // [n_mesh]      mat_inside, mat_outside, vascular, -
@@ -49,7 +49,8 @@ struct ConvTaps { float ax[16]; float lat[32]; uint32_t n_ax, n_lat; };
 
 hipError_t launch_init(const FrameArgs &a, hipStream_t st);
 hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
-hipError_t launch_nodes_soa(const float4 *nodes, uint32_t n_nodes, float4 *out, hipStream_t st);
+hipError_t launch_nodes_walk(const float4 *nodes, uint32_t n_nodes, uint4 *out, hipStream_t st);
+hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 *out, hipStream_t st);
 uint32_t lane_stack_entries();
 hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
 hipError_t launch_paths(const FrameArgs &a, bool stats, hipStream_t st);

@@ -11,6 +11,7 @@
 // Everything is scalar fp32/fp64 VALU + integer work; there is no dense contraction, hence no MFMA.
 // Arithmetic follows the parity contract expression by expression (compiled -ffp-contract=off).
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include "../../include/mcrt.h"
 #include "mcrt_internal.h"
@@ -644,9 +645,15 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 // wavefront, and spends fewer instructions per ray: no quad ranking exchanges, and the slab planes of two children at a time
 // go through the packed-f32 pipe (v_pk_add_f32 / v_pk_mul_f32).
 //
-// Nodes are read from a child-transposed copy of the BVH4 (k_nodes_soa): eight float4 per node,
-//     lo.x[4] | lo.y[4] | lo.z[4] | hi.x[4] | hi.y[4] | hi.z[4] | ref[4] | -
-// with unused slots stored as the point box at +infinity, which no slab test hits (so the walk needs no EMPTY test).
+// Nodes are read from a COMPACT copy of the BVH4 (k_nodes_walk): 64 bytes per node instead of 128 -- the walk is bound by the
+// vector memory pipe (tools/fetch_roof.hip: a scattered 16-byte-per-lane load costs the compute unit's TCP ~0.75 lanes per
+// clock, whatever the cache level), so what counts is the number of 16-byte pieces a lane fetches per node: four
+//     lo.x[4] lo.y[4] | lo.z[4] hi.x[4] | hi.y[4] hi.z[4] | ref[4]          (boxes as IEEE half floats, child-transposed)
+// instead of seven.  The halves are rounded OUTWARDS (lo down, hi up), so every stored box contains the builder's box: node
+// boxes only ever cull, and the contract's closest hit does not depend on them as long as they contain their triangles'
+// padded bounds -- hits stay bit-identical, the walk visits ~2.5 % more nodes (measured on the 1 M-triangle
+// scene).  Unused slots are stored as the point box at +infinity, which no slab test hits (so the walk needs no EMPTY test).
+// mcrt_get_bvh4 hands out the tree AS WALKED (the decoded boxes), so a CPU walk of it counts exactly this walk's visits.
 // Per ray the arithmetic is the quad walk's, operation for operation: (plane - origin) * reciprocal, the same min/max
 // combination, the same nearest-child key (t_near bits with the slot number in the two low bits), the other hit children
 // stacked in slot order, and the same triangle test -- so hits AND visit counts equal the quad walk's, visit for visit.
@@ -678,24 +685,77 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 #define MCRT_LANE_FETCH 64           // queue positions a wavefront claims per atomic
 #endif
 
-__global__ void k_nodes_soa(const float4 *in, uint32_t n_nodes, float4 *out)
+// float -> half, rounded towards -infinity / +infinity (integer steps on the half's bit pattern from the nearest-even conversion)
+MCRT_DEV uint32_t half_towards(float x, bool up)
+{
+    __half h = __float2half_rn(x);
+    uint32_t b = (uint32_t)__half_as_ushort(h);
+    const float back = __half2float(h);
+    if (x != x) return 0x7e00u;                                  // NaN stays NaN (never produced by the builders)
+    if (up ? (back < x) : (back > x)) {                          // the nearest half lies on the wrong side: one step towards the target
+        const bool neg = (b & 0x8000u) != 0u;
+        if ((b & 0x7fffu) == 0u) b = up ? 0x0001u : 0x8001u;     // +-0 -> the smallest subnormal of the right sign
+        else if (neg == up) b -= 1u;                             // magnitude shrinks: negative going up, positive going down
+        else b += 1u;                                            // magnitude grows (0x7bff + 1 = 0x7c00 = infinity: still an outward bound)
+    }
+    return b & 0xffffu;
+}
+MCRT_DEV float half_bits_to_float(uint32_t b) { return __half2float(__ushort_as_half((unsigned short)b)); }
+
+// the walk's 64-byte nodes from the builders' 128-byte ones
+__global__ void k_nodes_walk(const float4 *in, uint32_t n_nodes, uint4 *out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
-    float lo[3][4], hi[3][4]; int ref[4];
+    uint32_t lo[3][4], hi[3][4]; int ref[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const float4 A = in[8 * (size_t)i + 2 * c], B = in[8 * (size_t)i + 2 * c + 1];
         ref[c] = __float_as_int(B.z);
         const bool empty = ref[c] == MCRT_BVH4_EMPTY;
-        lo[0][c] = empty ? INFINITY : A.x; lo[1][c] = empty ? INFINITY : A.y; lo[2][c] = empty ? INFINITY : A.z;
-        hi[0][c] = empty ? INFINITY : A.w; hi[1][c] = empty ? INFINITY : B.x; hi[2][c] = empty ? INFINITY : B.y;
-    }
-    float4 *o = out + 8 * (size_t)i;
+        const float l[3] = { A.x, A.y, A.z }, h[3] = { A.w, B.x, B.y };
 #pragma unroll
-    for (int k = 0; k < 3; k++) { o[k] = make_float4(lo[k][0], lo[k][1], lo[k][2], lo[k][3]); o[3 + k] = make_float4(hi[k][0], hi[k][1], hi[k][2], hi[k][3]); }
-    o[6] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(ref[2]), __int_as_float(ref[3]));
-    o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int k = 0; k < 3; k++) { lo[k][c] = empty ? 0x7c00u : half_towards(l[k], false); hi[k][c] = empty ? 0x7c00u : half_towards(h[k], true); }
+    }
+    uint4 *o = out + 4 * (size_t)i;
+#define MCRT_PACK4(v) (v)[0] | ((v)[1] << 16), (v)[2] | ((v)[3] << 16)
+    o[0] = make_uint4(MCRT_PACK4(lo[0]), MCRT_PACK4(lo[1]));
+    o[1] = make_uint4(MCRT_PACK4(lo[2]), MCRT_PACK4(hi[0]));
+    o[2] = make_uint4(MCRT_PACK4(hi[1]), MCRT_PACK4(hi[2]));
+    o[3] = make_uint4((uint32_t)ref[0], (uint32_t)ref[1], (uint32_t)ref[2], (uint32_t)ref[3]);
+#undef MCRT_PACK4
+}
+// ... and back: the tree as the walk sees it, in the builders' layout (for mcrt_get_bvh4)
+__global__ void k_nodes_walk_decode(const uint4 *in, uint32_t n_nodes, float4 *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint4 q0 = in[4 * (size_t)i], q1 = in[4 * (size_t)i + 1], q2 = in[4 * (size_t)i + 2], q3 = in[4 * (size_t)i + 3];
+    const uint32_t w[12] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w };      // lo.x lo.y lo.z hi.x hi.y hi.z, two words each
+    const uint32_t ref[4] = { q3.x, q3.y, q3.z, q3.w };
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float v[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) v[k] = half_bits_to_float((w[2 * k + (c >> 1)] >> ((c & 1) * 16)) & 0xffffu);
+        const bool empty = (int)ref[c] == MCRT_BVH4_EMPTY;
+        if (empty) { v[0] = v[1] = v[2] = INFINITY; v[3] = v[4] = v[5] = -INFINITY; }                 // the builders' own form of an unused slot
+        out[8 * (size_t)i + 2 * c] = make_float4(v[0], v[1], v[2], v[3]);
+        out[8 * (size_t)i + 2 * c + 1] = make_float4(v[4], v[5], __int_as_float((int)ref[c]), 0.0f);
+    }
+}
+
+// the four children's plane distances from a packed pair of half-float words: (plane - origin) * reciprocal, two children per
+// packed operation
+struct Planes4 { v2f a, b; };
+MCRT_DEV Planes4 planes4(uint32_t w01, uint32_t w23, v2f o, v2f inv)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 p01 = __builtin_bit_cast(h2, w01), p23 = __builtin_bit_cast(h2, w23);
+    Planes4 r;
+    r.a = ((v2f){ (float)p01.x, (float)p01.y } - o) * inv;
+    r.b = ((v2f){ (float)p23.x, (float)p23.y } - o) * inv;
+    return r;
 }
 
 // slab interval of one child from its six plane distances (the combination of slab_pairs, same instructions)
@@ -820,16 +880,14 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
             if (inner == 0ull) break;
             if (__popcll(MCRT_ON_LEAF(cur)) >= MCRT_LANE_LEAF_BATCH) break;
             if (cur >= 0) {
-                const float4 *N = (const float4 *)((const char *)a.nodes_soa + ((uint32_t)cur << 7));
-                const float4 LX = N[0], LY = N[1], LZ = N[2], HX = N[3], HY = N[4], HZ = N[5], RF = N[6];
+                const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
+                const uint4 Q0 = N[0], Q1 = N[1], Q2 = N[2], RF = N[3];
                 if (STATS) st_nodes++;
-                // six plane distances of the four children, two children per packed operation: (plane - origin) * reciprocal
-                const v2f t0x_a = ((v2f){ LX.x, LX.y } - oxx) * ixx, t0x_b = ((v2f){ LX.z, LX.w } - oxx) * ixx;
-                const v2f t0y_a = ((v2f){ LY.x, LY.y } - oyy) * iyy, t0y_b = ((v2f){ LY.z, LY.w } - oyy) * iyy;
-                const v2f t0z_a = ((v2f){ LZ.x, LZ.y } - ozz) * izz, t0z_b = ((v2f){ LZ.z, LZ.w } - ozz) * izz;
-                const v2f t1x_a = ((v2f){ HX.x, HX.y } - oxx) * ixx, t1x_b = ((v2f){ HX.z, HX.w } - oxx) * ixx;
-                const v2f t1y_a = ((v2f){ HY.x, HY.y } - oyy) * iyy, t1y_b = ((v2f){ HY.z, HY.w } - oyy) * iyy;
-                const v2f t1z_a = ((v2f){ HZ.x, HZ.y } - ozz) * izz, t1z_b = ((v2f){ HZ.z, HZ.w } - ozz) * izz;
+                // six plane distances of the four children (halves -> floats, then (plane - origin) * reciprocal, two children per packed operation)
+                const Planes4 X0 = planes4(Q0.x, Q0.y, oxx, ixx), Y0 = planes4(Q0.z, Q0.w, oyy, iyy), Z0 = planes4(Q1.x, Q1.y, ozz, izz);
+                const Planes4 X1 = planes4(Q1.z, Q1.w, oxx, ixx), Y1 = planes4(Q2.x, Q2.y, oyy, iyy), Z1 = planes4(Q2.z, Q2.w, ozz, izz);
+                const v2f t0x_a = X0.a, t0x_b = X0.b, t0y_a = Y0.a, t0y_b = Y0.b, t0z_a = Z0.a, t0z_b = Z0.b;
+                const v2f t1x_a = X1.a, t1x_b = X1.b, t1y_a = Y1.a, t1y_b = Y1.b, t1z_a = Z1.a, t1z_b = Z1.b;
                 float tn0, tn1, tn2, tn3;
                 const bool h0 = slab_combine(t0x_a.x, t0y_a.x, t0z_a.x, t1x_a.x, t1y_a.x, t1z_a.x, t_lo, tcap, tn0);
                 const bool h1 = slab_combine(t0x_a.y, t0y_a.y, t0z_a.y, t1x_a.y, t1y_a.y, t1z_a.y, t_lo, tcap, tn1);
@@ -840,7 +898,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                 const uint32_t k0 = h0 ? ((__float_as_uint(tn0) & ~3u) | 0u) : 0xffffffffu, k1 = h1 ? ((__float_as_uint(tn1) & ~3u) | 1u) : 0xffffffffu;
                 const uint32_t k2 = h2 ? ((__float_as_uint(tn2) & ~3u) | 2u) : 0xffffffffu, k3 = h3 ? ((__float_as_uint(tn3) & ~3u) | 3u) : 0xffffffffu;
                 const uint32_t kmin = min(min(k0, k1), min(k2, k3));
-                int r0 = __float_as_int(RF.x), r1 = __float_as_int(RF.y), r2 = __float_as_int(RF.z), r3 = __float_as_int(RF.w);
+                int r0 = (int)RF.x, r1 = (int)RF.y, r2 = (int)RF.z, r3 = (int)RF.w;
                 asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));      // (the child references are fetched WITH the boxes, not after the tests in a second round trip)
                 if (kmin == 0xffffffffu) { MCRT_POP() }
                 else {
@@ -1197,15 +1255,14 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_paths(FrameArgs a)
             if (__popcll(MCRT_ON_LEAF(cur)) >= MCRT_LANE_LEAF_BATCH) break;
             if (__popcll(__ballot(pend)) >= 2 * MCRT_PATHS_SHADE_BATCH) break;
             if (cur >= 0) {
-                const float4 *N = (const float4 *)((const char *)a.nodes_soa + ((uint32_t)cur << 7));
-                const float4 LX = N[0], LY = N[1], LZ = N[2], HX = N[3], HY = N[4], HZ = N[5], RF = N[6];
+                const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
+                const uint4 Q0 = N[0], Q1 = N[1], Q2 = N[2], RF = N[3];
                 if (STATS) st_nodes++;
-                const v2f t0x_a = ((v2f){ LX.x, LX.y } - oxx) * ixx, t0x_b = ((v2f){ LX.z, LX.w } - oxx) * ixx;
-                const v2f t0y_a = ((v2f){ LY.x, LY.y } - oyy) * iyy, t0y_b = ((v2f){ LY.z, LY.w } - oyy) * iyy;
-                const v2f t0z_a = ((v2f){ LZ.x, LZ.y } - ozz) * izz, t0z_b = ((v2f){ LZ.z, LZ.w } - ozz) * izz;
-                const v2f t1x_a = ((v2f){ HX.x, HX.y } - oxx) * ixx, t1x_b = ((v2f){ HX.z, HX.w } - oxx) * ixx;
-                const v2f t1y_a = ((v2f){ HY.x, HY.y } - oyy) * iyy, t1y_b = ((v2f){ HY.z, HY.w } - oyy) * iyy;
-                const v2f t1z_a = ((v2f){ HZ.x, HZ.y } - ozz) * izz, t1z_b = ((v2f){ HZ.z, HZ.w } - ozz) * izz;
+                // six plane distances of the four children (halves -> floats, then (plane - origin) * reciprocal, two children per packed operation)
+                const Planes4 X0 = planes4(Q0.x, Q0.y, oxx, ixx), Y0 = planes4(Q0.z, Q0.w, oyy, iyy), Z0 = planes4(Q1.x, Q1.y, ozz, izz);
+                const Planes4 X1 = planes4(Q1.z, Q1.w, oxx, ixx), Y1 = planes4(Q2.x, Q2.y, oyy, iyy), Z1 = planes4(Q2.z, Q2.w, ozz, izz);
+                const v2f t0x_a = X0.a, t0x_b = X0.b, t0y_a = Y0.a, t0y_b = Y0.b, t0z_a = Z0.a, t0z_b = Z0.b;
+                const v2f t1x_a = X1.a, t1x_b = X1.b, t1y_a = Y1.a, t1y_b = Y1.b, t1z_a = Z1.a, t1z_b = Z1.b;
                 float tn0, tn1, tn2, tn3;
                 const bool h0 = slab_combine(t0x_a.x, t0y_a.x, t0z_a.x, t1x_a.x, t1y_a.x, t1z_a.x, 0.0f, tcap, tn0);
                 const bool h1 = slab_combine(t0x_a.y, t0y_a.y, t0z_a.y, t1x_a.y, t1y_a.y, t1z_a.y, 0.0f, tcap, tn1);
@@ -1214,7 +1271,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_paths(FrameArgs a)
                 const uint32_t k0 = h0 ? ((__float_as_uint(tn0) & ~3u) | 0u) : 0xffffffffu, k1 = h1 ? ((__float_as_uint(tn1) & ~3u) | 1u) : 0xffffffffu;
                 const uint32_t k2 = h2 ? ((__float_as_uint(tn2) & ~3u) | 2u) : 0xffffffffu, k3 = h3 ? ((__float_as_uint(tn3) & ~3u) | 3u) : 0xffffffffu;
                 const uint32_t kmin = min(min(k0, k1), min(k2, k3));
-                int r0 = __float_as_int(RF.x), r1 = __float_as_int(RF.y), r2 = __float_as_int(RF.z), r3 = __float_as_int(RF.w);
+                int r0 = (int)RF.x, r1 = (int)RF.y, r2 = (int)RF.z, r3 = (int)RF.w;
                 asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
                 if (kmin == 0xffffffffu) { MCRT_POP() }
                 else {
@@ -1713,9 +1770,14 @@ hipError_t launch_init(const FrameArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_nodes_soa(const float4 *nodes, uint32_t n_nodes, float4 *out, hipStream_t st)
+hipError_t launch_nodes_walk(const float4 *nodes, uint32_t n_nodes, uint4 *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_nodes_soa, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, nodes, n_nodes, out);
+    hipLaunchKernelGGL(k_nodes_walk, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, nodes, n_nodes, out);
+    return hipGetLastError();
+}
+hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_nodes_walk_decode, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, walk, n_nodes, out);
     return hipGetLastError();
 }
 
@@ -1723,7 +1785,7 @@ uint32_t lane_stack_entries() { return MCRT_LANE_STACK; }
 
 hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st)
 {
-    if (a.nodes_soa) {          // one lane per ray
+    if (a.nodes_walk) {          // one lane per ray
         uint32_t np = (b == 0u) ? a.ne : a.ne * a.S;
         if (np < a.ksplit_limit) np = a.ksplit_limit;
         const uint32_t blocks = (np + 255u) / 256u;
@@ -1743,7 +1805,7 @@ hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
     return hipGetLastError();
 }
 
-// the fused path kernel: bounce 0's shared walk must have run (launch_trace(a, 0, ...)); needs a.nodes_soa
+// the fused path kernel: bounce 0's shared walk must have run (launch_trace(a, 0, ...)); needs a.nodes_walk
 hipError_t launch_paths(const FrameArgs &a, bool stats, hipStream_t st)
 {
     const uint32_t np = a.ne * a.S, blocks = (np + 255u) / 256u;

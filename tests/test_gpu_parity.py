@@ -642,11 +642,10 @@ def test_pipelines_and_walks_agree(mcrt, orc, tex256, monkeypatch):
         sim.ctx.trace_frames(frame - 1, 3, dev)                   # a 3-frame pass through the same pipeline: its middle frame is `frame`
         batch = sim.ctx.d2h(dev, (3, E, sim.R))
         sim.ctx.free(dev)
-        if name == "fused":
-            nodes, btri, _ = sim.ctx.get_bvh()
-            nodes4 = sim.ctx.get_bvh4()[0]
+        nodes, btri, _ = sim.ctx.get_bvh()
+        nodes4 = sim.ctx.get_bvh4()[0]                            # the tree as THIS walk reads it (half-float boxes for the lane walk)
         sim.close()
-        got[name] = (hits, segs.tobytes(), cnt, rf, st, batch[1].T.copy())
+        got[name] = (hits, segs.tobytes(), cnt, rf, st, batch[1].T.copy(), nodes4)
     for k in ("MCRT_PIPELINE", "MCRT_QUAD_WALK"):
         monkeypatch.delenv(k, raising=False)
     a = got["fused"]
@@ -654,16 +653,21 @@ def test_pipelines_and_walks_agree(mcrt, orc, tex256, monkeypatch):
         b = got[name]
         assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2]), name
         assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)), name
-        assert {k: v for k, v in a[4].items() if k != "rf_steps"} == {k: v for k, v in b[4].items() if k != "rf_steps"}, name
+    # the two pipelines of the lane walk read the same nodes: same visit counts; the quad walk reads the builders' float boxes
+    assert {k: v for k, v in a[4].items() if k != "rf_steps"} == {k: v for k, v in got["wavefront_lane"][4].items() if k != "rf_steps"}
+    assert np.array_equal(a[6], got["wavefront_lane"][6]) and not np.array_equal(a[6], got["wavefront_quad"][6])
+    assert got["wavefront_quad"][4]["nodes_visited"] <= a[4]["nodes_visited"] <= 1.1 * got["wavefront_quad"][4]["nodes_visited"]
     for name, g in got.items():
         assert np.array_equal(g[5].view(np.uint32), g[3].view(np.uint32)), name
-    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
-    osc.set_bvh4(nodes4)
     p = orc.default_params(n_elements=E, n_samples=S)
-    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=16)
-    assert np.array_equal(a[0], o["hits"])
-    _assert_rf(a[3], o)
     p0 = orc.default_params(n_elements=E, n_samples=S, max_depth=1)
-    o0 = osc.trace_frame(p0, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=16, want_ref=False, want_fix=False)["stats"]
-    for k in ("queries", "nodes_visited", "tris_tested"):
-        assert a[4][k] == o["stats"][k] - o0[k] + o0[k] // S, k
+    for name in ("fused", "wavefront_quad"):                      # each walk's counts against the oracle walking the tree that walk reads
+        g = got[name]
+        osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
+        osc.set_bvh4(g[6])
+        o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=16)
+        assert np.array_equal(g[0], o["hits"]), name
+        _assert_rf(g[3], o)
+        o0 = osc.trace_frame(p0, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=16, want_ref=False, want_fix=False)["stats"]
+        for k in ("queries", "nodes_visited", "tris_tested"):
+            assert g[4][k] == o["stats"][k] - o0[k] + o0[k] // S, (name, k)
