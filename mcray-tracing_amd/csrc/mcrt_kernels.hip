@@ -698,7 +698,13 @@ MCRT_DEV uint32_t half_towards(float x, bool up)
         else if (neg == up) b -= 1u;                             // magnitude shrinks: negative going up, positive going down
         else b += 1u;                                            // magnitude grows (0x7bff + 1 = 0x7c00 = infinity: still an outward bound)
     }
-    return b & 0xffffu;
+    b &= 0xffffu;
+    // no subnormal halves (the walk's arithmetic then never depends on a denormal mode): snap outwards to 0 or +-2^-14
+    if ((b & 0x7c00u) == 0u && (b & 0x03ffu) != 0u) {
+        const bool neg = (b & 0x8000u) != 0u;
+        b = up ? (neg ? 0x8000u : 0x0400u) : (neg ? 0x8400u : 0x0000u);
+    }
+    return b;
 }
 MCRT_DEV float half_bits_to_float(uint32_t b) { return __half2float(__ushort_as_half((unsigned short)b)); }
 
@@ -753,8 +759,22 @@ MCRT_DEV Planes4 planes4(uint32_t w01, uint32_t w23, v2f o, v2f inv)
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const h2 p01 = __builtin_bit_cast(h2, w01), p23 = __builtin_bit_cast(h2, w23);
     Planes4 r;
+#ifdef MCRT_NO_FMA_MIX
     r.a = ((v2f){ (float)p01.x, (float)p01.y } - o) * inv;
     r.b = ((v2f){ (float)p23.x, (float)p23.y } - o) * inv;
+#else
+    // plane - origin as fma(plane, 1, -origin): the product is exact, so this IS the IEEE subtraction -- and the mixed-precision
+    // fma (v_fma_mix_f32) reads the half operand directly (op_sel picks the half of the word), which saves the 24 conversions
+    const float mo = -o.x;
+    float a0, a1, b0, b1;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(a0) : "v"(w01), "v"(mo));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(a1) : "v"(w01), "v"(mo));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(b0) : "v"(w23), "v"(mo));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(b1) : "v"(w23), "v"(mo));
+    (void)p01; (void)p23;
+    r.a = (v2f){ a0, a1 } * inv;
+    r.b = (v2f){ b0, b1 } * inv;
+#endif
     return r;
 }
 
