@@ -791,6 +791,19 @@ MCRT_DEV bool slab_combine(float t0x, float t0y, float t0z, float t1x, float t1y
     return tmin <= tmax;
 }
 
+// position of the r-th (0-based) set bit of a 64-bit mask (r < popcount): binary search on popcounts
+MCRT_DEV int nth_set_bit(unsigned long long m, uint32_t r)
+{
+    int base = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const unsigned long long low = m & ((1ull << w) - 1ull);
+        const uint32_t c = (uint32_t)__popcll(low);
+        if (r >= c) { r -= c; m >>= w; base += w; } else m = low;
+    }
+    return base;
+}
+
 template <bool STATS>
 __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a, uint32_t b)
 {
@@ -822,26 +835,29 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
     float t_lo = 0.0f;
     Best best; best.frac = 1.0f; best.tri = -1;
     constexpr int CUR_IDLE = (int)0x80000000;
-    int sp = 0, cur = CUR_IDLE;
+    int sp = 0, sb = 0, cur = CUR_IDLE;          // the lane's stack entries live in [sb, sp): sb moves up when the bottom entry is given away (see below)
+    bool shared = false;                         // another lane of the wavefront works on a subtree of this lane's ray: results meet in the ray's word
 #define MCRT_ON_INNER(c) __builtin_amdgcn_sicmp((c), -1, 38)
 #define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)
 #define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)
-#define MCRT_POP() { if (sp > 0) { sp--; cur = (sp < MCRT_LANE_STACK) ? stack[sp * 256 + tid] : ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride]; } else cur = CUR_IDLE; }
+#define MCRT_POP() { if (sp > sb) { sp--; cur = (sp < MCRT_LANE_STACK) ? stack[sp * 256 + tid] : ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride]; } else cur = CUR_IDLE; }
 #define MCRT_PUSH(v) { if (sp < MCRT_LANE_STACK) stack[sp * 256 + tid] = (v); else ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride] = (v); sp++; }
     uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
     MCRT_WATCHDOG_DECL()
     for (;;) {
         MCRT_WATCHDOG_CHECK()
         // ---- finished rays report and idle lanes take new ones, once enough of them wait (the code runs for the whole wavefront) ----
-        const bool do_refill = __popcll(__ballot(cur == CUR_IDLE && !exhausted)) >= MCRT_LANE_REFILL || MCRT_WALKING(cur) == 0ull;
+        // (once the queue has run dry, finished lanes report at once: they are the helpers of the donation step below)
+        const bool do_refill = __popcll(__ballot(cur == CUR_IDLE && !exhausted)) >= MCRT_LANE_REFILL || MCRT_WALKING(cur) == 0ull ||
+                               (queue_empty && __any(cur == CUR_IDLE && !fresh));
         if (do_refill) {
-            if (cur == CUR_IDLE && !fresh && !exhausted) {
+            if (cur == CUR_IDLE && !fresh) {
                 if (best.tri >= 0) {
                     const unsigned long long word = ((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri;
-                    if (K == 1u) keys[ray_id] = word;
+                    if (K == 1u && !shared) keys[ray_id] = word;         // the only walker of this ray: a plain store
                     else atomicMin(&keys[ray_id], word);
                 }
-                fresh = true; i = 0xffffffffu;
+                fresh = true; shared = false; i = 0xffffffffu;
             }
             const bool need = fresh && !exhausted;
             const unsigned long long dynm = __ballot(need && i == 0xffffffffu);
@@ -884,12 +900,45 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                         } else if (piece > 0u) t_hi = 0.0f;
                     }
                     best.frac = t_hi; best.tri = -1;
-                    sp = 0; cur = (a.n_nodes != 0u && t_lo < t_hi) ? 0 : CUR_IDLE; fresh = false;
+                    sp = 0; sb = 0; shared = false; cur = (a.n_nodes != 0u && t_lo < t_hi) ? 0 : CUR_IDLE; fresh = false;
                     if (STATS && piece == 0u) st_q++;
                 } else exhausted = true;
             }
         }
         if (MCRT_WALKING(cur) == 0ull) { if (!__any(!exhausted)) break; else continue; }
+
+        // ---- the END of a launch (and one frame at a time, where a bounce has fewer rays than the GPU has lanes): the queue is
+        // empty, lanes run out of rays while a few long walks go on.  Idle lanes then TAKE OVER SUBTREES: the k-th idle lane adopts
+        // the bottom stack entry (the farthest, usually largest pending subtree) of the k-th lane that has one, with a copy of its
+        // ray and its current closest fraction, walks it on its own stack, and reports through the ray's closest-hit word, whose
+        // atomicMin is exactly the contract's (smaller fraction, then smaller triangle id) rule -- the answer is the single walk's.
+        // A launch then ends after its wavefronts' remaining WORK, not after their longest walk.  (Not in the counting build, whose
+        // visit counts are those of one walk per ray.)
+        if (!STATS && queue_empty) {
+            const bool thief = cur == CUR_IDLE && fresh;
+            const bool donor = cur != CUR_IDLE && sp > sb && sb < MCRT_LANE_STACK;
+            const unsigned long long tm = __ballot(thief), dm = __ballot(donor);
+            if (tm != 0ull && dm != 0ull) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t pairs = (uint32_t)min(__popcll(tm), __popcll(dm));
+                const uint32_t trank = (uint32_t)__popcll(tm & below), drank = (uint32_t)__popcll(dm & below);
+                const bool take = thief && trank < pairs, give = donor && drank < pairs;
+                const int src = take ? nth_set_bit(dm, trank) : lane;
+                const int d_sb = __shfl(sb, src, 64);
+                const float c0 = __shfl(f2.x, src, 64), c1 = __shfl(f2.y, src, 64), c2 = __shfl(f2.z, src, 64);
+                const float c3 = __shfl(to.x, src, 64), c4 = __shfl(to.y, src, 64), c5 = __shfl(to.z, src, 64);
+                const float c6 = __shfl(inv.x, src, 64), c7 = __shfl(inv.y, src, 64), c8 = __shfl(inv.z, src, 64);
+                const float c9 = __shfl(t_lo, src, 64), c10 = __shfl(best.frac, src, 64);
+                const uint32_t c11 = (uint32_t)__shfl((int)ray_id, src, 64);
+                if (take) {
+                    cur = stack[d_sb * 256 + (tid & ~63) + src];        // the donor's bottom entry (same wavefront, read before the donor moves on)
+                    f2 = mk(c0, c1, c2); to = mk(c3, c4, c5); inv = mk(c6, c7, c8); t_lo = c9;
+                    best.frac = c10; best.tri = -1; ray_id = c11;
+                    sp = 0; sb = 0; fresh = false; shared = true;
+                }
+                if (give) { sb++; shared = true; }
+            }
+        }
 
         // ---- phase 1: inner nodes, until enough lanes are parked on a leaf ----
         const float tcap = fminf(1.0f, best.frac);               // best only changes in phase 2
