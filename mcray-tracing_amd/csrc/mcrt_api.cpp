@@ -718,6 +718,11 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     }
     a.axial_res_mm = c->c.axial_res_mm; a.time_step = c->c.time_step_us; a.row_dt = c->c.row_dt_us;
     a.max_travel = c->c.max_travel_us; a.sos_d = (double)c->p.speed_of_sound; a.inv_row_dt = 1.0 / c->c.row_dt_us;
+    {   // k_march's one-read row stepper needs a time step slightly longer than a row (true whenever the axial resolution is not a
+        // whole number of micrometres); 4 = the largest lane stride G
+        const double ratio = c->c.time_step_us / c->c.row_dt_us - 1.0;
+        a.row_fast = (ratio > 1e-7 && ratio < 1.0 / 8.0) ? 1u : 0u;
+    }
 }
 
 static uint32_t side_streams(const mcrt_ctx *c) { return c->knobs.march_streams; }

@@ -837,6 +837,8 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
     constexpr int CUR_IDLE = (int)0x80000000;
     int sp = 0, sb = 0, cur = CUR_IDLE;          // the lane's stack entries live in [sb, sp): sb moves up when the bottom entry is given away (see below)
     bool shared = false;                         // another lane of the wavefront works on a subtree of this lane's ray: results meet in the ray's word
+    bool helper = false;                         // this lane walks an adopted subtree: it starts from the owner's closest fraction WITHOUT the owner's
+                                                 // triangle, so a triangle at exactly that fraction is a candidate (the word's atomicMin applies the id rule)
 #define MCRT_ON_INNER(c) __builtin_amdgcn_sicmp((c), -1, 38)
 #define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)
 #define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)
@@ -857,7 +859,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                     if (K == 1u && !shared) keys[ray_id] = word;         // the only walker of this ray: a plain store
                     else atomicMin(&keys[ray_id], word);
                 }
-                fresh = true; shared = false; i = 0xffffffffu;
+                fresh = true; shared = false; helper = false; i = 0xffffffffu;
             }
             const bool need = fresh && !exhausted;
             const unsigned long long dynm = __ballot(need && i == 0xffffffffu);
@@ -900,7 +902,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                         } else if (piece > 0u) t_hi = 0.0f;
                     }
                     best.frac = t_hi; best.tri = -1;
-                    sp = 0; sb = 0; shared = false; cur = (a.n_nodes != 0u && t_lo < t_hi) ? 0 : CUR_IDLE; fresh = false;
+                    sp = 0; sb = 0; shared = false; helper = false; cur = (a.n_nodes != 0u && t_lo < t_hi) ? 0 : CUR_IDLE; fresh = false;
                     if (STATS && piece == 0u) st_q++;
                 } else exhausted = true;
             }
@@ -930,11 +932,13 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                 const float c6 = __shfl(inv.x, src, 64), c7 = __shfl(inv.y, src, 64), c8 = __shfl(inv.z, src, 64);
                 const float c9 = __shfl(t_lo, src, 64), c10 = __shfl(best.frac, src, 64);
                 const uint32_t c11 = (uint32_t)__shfl((int)ray_id, src, 64);
+                const int c12 = __shfl(best.tri, src, 64);
                 if (take) {
                     cur = stack[d_sb * 256 + (tid & ~63) + src];        // the donor's bottom entry (same wavefront, read before the donor moves on)
                     f2 = mk(c0, c1, c2); to = mk(c3, c4, c5); inv = mk(c6, c7, c8); t_lo = c9;
                     best.frac = c10; best.tri = -1; ray_id = c11;
                     sp = 0; sb = 0; fresh = false; shared = true;
+                    helper = c12 >= 0;                                   // (an owner without a find so far passes on the ray's own bound, which stays exclusive)
                 }
                 if (give) { sb++; shared = true; }
             }
@@ -1007,7 +1011,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                 const int id = __float_as_int(PL.w);
                 const float proj = da - db;
                 const float frac = da / proj;
-                if (!(frac < best.frac || (frac == best.frac && id < best.tri)) || !(frac >= t_lo)) continue;
+                if (!(frac < best.frac || (frac == best.frac && (id < best.tri || (helper && best.tri < 0)))) || !(frac >= t_lo)) continue;
                 float tmin, tmax;
                 const RayPairs rp = ray_pairs(f2, inv);
                 if (!(slab_pairs((v2f){ PL.x, PL.y }, (v2f){ PL.z, PH.x }, (v2f){ PH.y, PH.z }, rp, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax)) continue;
@@ -1512,7 +1516,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     for (uint32_t r = tid; r < R; r += nthr) bins[r] = 0;
     for (uint32_t r = tid; r < nf; r += nthr) lflags[r] = 0u;
     for (uint32_t r = tid; r <= R; r += nthr) thr[r] = a.row_thr[r];
-    __syncthreads();
+    __shared__ uint32_t pool_cursor;         // next unclaimed slot of the WORKGROUP's range: its four wavefronts draw from one pool
 
     // XCD-aware numbering: workgroup w runs on XCD w % 8; give every XCD a CONTIGUOUS range of scan-lines, so that the texture
     // cells its segments touch (neighbouring scan-lines cross the same tissue) are shared in ITS L2
@@ -1521,13 +1525,18 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     // ... and within it the F frames of a scan-line one after the other (they cross exactly the same tissue)
     const uint32_t F = a.ne / a.ne_frame, ol = bid / chunks, chunk = bid % chunks;
     const uint32_t line = (ol % F) * a.ne_frame + ol / F;
-    // this wavefront's slot range: the line's S slots are cut into chunks*4 contiguous pieces
-    const uint32_t per = (a.S + chunks * 4u - 1u) / (chunks * 4u);
-    const uint32_t s_begin = min(a.S, (chunk * 4u + (uint32_t)wv) * per), s_end = min(a.S, s_begin + per);
+    // the workgroup's slot range: the line's S slots are cut into `chunks` contiguous pieces; its wavefronts share the piece as ONE
+    // task pool (a wavefront-private quarter left each wavefront alone with the tail of its own 8 slots per group: the lanes
+    // were busy 65 % of the time)
+    const uint32_t per = (a.S + chunks - 1u) / chunks;
+    const uint32_t s_begin = min(a.S, chunk * per), s_end = min(a.S, s_begin + per);
     const size_t pid0 = (size_t)line * a.S;
     unsigned long long st_steps = 0;
+    if (tid == 0) pool_cursor = s_begin;
+    __syncthreads();
+    (void)wv;
 
-    uint32_t cursor = s_begin;                               // wave-uniform: next unclaimed slot
+    bool pool_empty = false;                                 // wave-uniform: the pool has been seen empty
     const double thr_end = a.row_thr[R];
     bool busy = false;
     // A GROUP of G lanes (a DPP quad, or half of one) owns a segment.  Lane j of the group carries the segment's running
@@ -1539,6 +1548,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     uint32_t sidx = 0, steps = 0;
     bool more = false;
     int row_guess = 0;
+    bool row_ok = false;      // row_guess - G is the exact row of this lane's previous step (see the row stepper below)
     // b == MCRT_ALL_BOUNCES: the launch accumulates EVERY bounce's segments; a group then walks its path's segments one after
     // the other (seg_b = the one in progress, seg_n = how many the path has) before it takes the next slot
     const bool all_b = b == MCRT_ALL_BOUNCES;
@@ -1558,7 +1568,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
         more = !silent && steps > 0u && t < a.max_travel; \
         _Pragma("unroll") for (int u = 1; u < G; u++) if (j >= u) MCRT_ADVANCE() \
         /* first guess of this lane's RF row; afterwards each own step lies G steps (a little over G rows) further */ \
-        row_guess = (t >= 0.0 && t < thr_end) ? (int)(t * a.inv_row_dt) : 0; \
+        row_guess = (t >= 0.0 && t < thr_end) ? (int)(t * a.inv_row_dt) : 0; row_ok = false; \
         busy = true; }
 #define MCRT_ADVANCE() { point = point + delta; t = t + a.time_step; inten *= k_att; }
 #ifdef MCRT_STAMP
@@ -1583,12 +1593,17 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
                 busy = false;
                 if (all_b && seg_b + 1u < seg_n) { seg_b++; MCRT_LOAD_SEGMENT() }      // the path's next segment
             }
-            while (cursor < s_end) {
+            while (!pool_empty) {
                 const unsigned long long want = __ballot(!busy && j == 0);
-                if (__popcll(want) < REFILL) break;
+                const uint32_t nw = (uint32_t)__popcll(want);
+                if (nw < (uint32_t)REFILL) break;
 #ifdef MCRT_STAMP
                 mc_refill++;
 #endif
+                uint32_t cursor = 0;
+                if (lane == 0) cursor = atomicAdd(&pool_cursor, nw);                  // (LDS atomic: one per refill of a wavefront)
+                cursor = (uint32_t)__shfl((int)cursor, 0, 64);
+                if (cursor >= s_end) { pool_empty = true; break; }
                 const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~(G - 1))) - 1ull));
                 if (!busy && mine < s_end) {
                     seg_pid = pid0 + mine;
@@ -1596,11 +1611,9 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
                     seg_b = all_b ? 0u : b;
                     if (seg_b < seg_n) MCRT_LOAD_SEGMENT()
                 }
-                const uint32_t nw = (uint32_t)__popcll(want);
-                cursor = (cursor + nw < s_end) ? cursor + nw : s_end;
             }
         }
-        if (!__any(busy)) { if (cursor >= s_end) break; else continue; }
+        if (!__any(busy)) { if (pool_empty) break; else continue; }
 
         // ---- G*H steps of every running segment ----
         if (busy && more) {
@@ -1628,8 +1641,19 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
             for (int h = 0; h < H; h++) {
                 if (myv[h]) {
                     const float scattering = vox[h].y >= m_dens ? vox[h].x * m_sigma + m_mu : 0.0f;
-                    const int row = row_near(myt[h], row_guess, thr, R, a.inv_row_dt, thr_end);
+                    // The RF row of this step.  A lane's consecutive steps lie G time steps apart, and a time step is a little
+                    // longer than a row (the row pitch uses the axial resolution truncated to whole micrometres, rfimage.h:35,178):
+                    // with row_fast (checked on the host: 1e-7 < time_step / row_dt - 1 < 1 / (2 G)) the row advances by exactly G
+                    // or G + 1 -- far beyond what the rounding of the running double sum could blur -- so ONE threshold read decides
+                    // it.  The first step of a segment, and every step when row_fast does not hold, go through the general search.
+                    int row;
+                    if (a.row_fast && row_ok) {
+                        int r = row_guess;
+                        if (r < (int)R && myt[h] >= thr[r + 1]) r++;          // (thr[R] is the end of the image)
+                        row = r < (int)R ? r : -1;
+                    } else row = row_near(myt[h], row_guess, thr, R, a.inv_row_dt, thr_end);
                     rf_add(bins, lflags, row, myin[h] * scattering);
+                    row_ok = row >= 0;
                     row_guess = (row >= 0 ? row : row_guess) + G;
                     if (STATS) st_steps++;
                 }
