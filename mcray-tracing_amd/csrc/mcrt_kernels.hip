@@ -1528,13 +1528,22 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     // the workgroup's slot range: the line's S slots are cut into `chunks` contiguous pieces; its wavefronts share the piece as ONE
     // task pool (a wavefront-private quarter left each wavefront alone with the tail of its own 8 slots per group: the lanes
     // were busy 65 % of the time)
+#ifdef MCRT_MARCH_BLOCK_POOL
     const uint32_t per = (a.S + chunks - 1u) / chunks;
     const uint32_t s_begin = min(a.S, chunk * per), s_end = min(a.S, s_begin + per);
+    if (tid == 0) pool_cursor = s_begin;
+    (void)wv;
+#else
+    // (measured: one pool per workgroup -- an LDS cursor shared by its four wavefronts -- costs more scalar work than the better
+    //  balance returns: 891 vs 829 us per launch; each wavefront keeps a contiguous quarter of the workgroup's slots)
+    const uint32_t per = (a.S + chunks * 4u - 1u) / (chunks * 4u);
+    const uint32_t s_begin = min(a.S, (chunk * 4u + (uint32_t)wv) * per), s_end = min(a.S, s_begin + per);
+    uint32_t wave_cursor = s_begin;
+    (void)pool_cursor;
+#endif
     const size_t pid0 = (size_t)line * a.S;
     unsigned long long st_steps = 0;
-    if (tid == 0) pool_cursor = s_begin;
     __syncthreads();
-    (void)wv;
 
     bool pool_empty = false;                                 // wave-uniform: the pool has been seen empty
     const double thr_end = a.row_thr[R];
@@ -1600,9 +1609,14 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
 #ifdef MCRT_STAMP
                 mc_refill++;
 #endif
+#ifdef MCRT_MARCH_BLOCK_POOL
                 uint32_t cursor = 0;
                 if (lane == 0) cursor = atomicAdd(&pool_cursor, nw);                  // (LDS atomic: one per refill of a wavefront)
                 cursor = (uint32_t)__shfl((int)cursor, 0, 64);
+#else
+                const uint32_t cursor = wave_cursor;
+                wave_cursor += nw;
+#endif
                 if (cursor >= s_end) { pool_empty = true; break; }
                 const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~(G - 1))) - 1ull));
                 if (!busy && mine < s_end) {
@@ -1647,11 +1661,14 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
                     // or G + 1 -- far beyond what the rounding of the running double sum could blur -- so ONE threshold read decides
                     // it.  The first step of a segment, and every step when row_fast does not hold, go through the general search.
                     int row;
+#ifndef MCRT_MARCH_NO_ROW_FAST
                     if (a.row_fast && row_ok) {
                         int r = row_guess;
                         if (r < (int)R && myt[h] >= thr[r + 1]) r++;          // (thr[R] is the end of the image)
                         row = r < (int)R ? r : -1;
-                    } else row = row_near(myt[h], row_guess, thr, R, a.inv_row_dt, thr_end);
+                    } else
+#endif
+                        row = row_near(myt[h], row_guess, thr, R, a.inv_row_dt, thr_end);
                     rf_add(bins, lflags, row, myin[h] * scattering);
                     row_ok = row >= 0;
                     row_guess = (row >= 0 ? row : row_guess) + G;
@@ -1927,7 +1944,9 @@ hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1u) chunks = 1u;
     const dim3 grid(a.ne * chunks), blk(256);
-    const size_t lds = march_lds_bytes(a.R);
+    // (march_lds_pad: extra LDS per workgroup = fewer resident k_march workgroups per CU, so that the critical chain's kernels --
+    //  k_shade, the next k_trace -- find free registers when they are launched beside a running k_march; tuning knob)
+    const size_t lds = march_lds_bytes(a.R) + a.march_lds_pad;
     // lanes per segment: pairs give the higher throughput when there is plenty of work (515 vs 524 us per launch with 16 frames in
     // flight), quads the shorter iterations that matter when one frame at a time is traced (2.19 vs 2.37 ms per frame)
     const bool pairs = (size_t)a.ne * a.S >= (size_t)MCRT_MARCH_PAIRS_FROM;
