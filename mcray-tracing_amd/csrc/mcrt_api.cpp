@@ -68,7 +68,7 @@ struct Knobs {
     uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 4096;
     bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false, quad_walk = false;
     int pipeline = 1;                          // 1 = wavefront (a launch per stage and bounce: the default), 2 = fused path kernel, 0 = fused for passes of at most fused_max_paths
-    uint32_t fused_groups = 1, fused_max_paths = 1u << 20, march_lds_pad = 0;
+    uint32_t fused_groups = 1, fused_max_paths = 1u << 20;
 };
 static Knobs read_knobs()
 {
@@ -83,7 +83,6 @@ static Knobs read_knobs()
     k.quad_walk = getenv("MCRT_QUAD_WALK") != nullptr;
     if (const char *e = getenv("MCRT_PIPELINE")) { if (!strcmp(e, "wavefront")) k.pipeline = 1; else if (!strcmp(e, "fused")) k.pipeline = 2; else if (!strcmp(e, "auto")) k.pipeline = 0; }
     if (const char *e = getenv("MCRT_FUSED_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 16) k.fused_groups = (uint32_t)v; }
-    if (const char *e = getenv("MCRT_MARCH_LDS_PAD")) { int v = atoi(e); if (v >= 0 && v <= 60000) k.march_lds_pad = (uint32_t)v; }
     if (const char *e = getenv("MCRT_FUSED_MAX")) { long v = atol(e); if (v >= 0) k.fused_max_paths = (uint32_t)v; }       // the round-1 walk (four lanes per ray) instead of one lane per ray
     return k;
 }
@@ -704,7 +703,7 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     if (c->stats_on) a.ksplit_limit = 0;   // counting mode = one walk per ray, so the counts are those of a plain closest-hit walk
     for (int i = 0; i < 3; i++) { a.scene_lo[i] = c->scene_lo[i]; a.scene_hi[i] = c->scene_hi[i]; }
     a.trace_blocks = c->knobs.trace_blocks ? c->knobs.trace_blocks : c->n_cu * 5u;   // persistent k_trace: 5 waves/SIMD = 5 four-wave workgroups per CU (1280 on the MI355X's 256 CUs)
-    a.march_blocks = c->knobs.march_blocks; a.march_lds_pad = c->knobs.march_lds_pad;
+    a.march_blocks = c->knobs.march_blocks;
     a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n; a.tex_mask = (c->tex_n & (c->tex_n - 1u)) == 0u ? c->tex_n - 1u : 0u;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
     a.freq = c->p.frequency; a.eps = c->p.intensity_epsilon; a.I0 = c->p.initial_intensity; a.offs = c->p.ray_start_offset;
@@ -719,11 +718,6 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     }
     a.axial_res_mm = c->c.axial_res_mm; a.time_step = c->c.time_step_us; a.row_dt = c->c.row_dt_us;
     a.max_travel = c->c.max_travel_us; a.sos_d = (double)c->p.speed_of_sound; a.inv_row_dt = 1.0 / c->c.row_dt_us;
-    {   // k_march's one-read row stepper needs a time step slightly longer than a row (true whenever the axial resolution is not a
-        // whole number of micrometres); 4 = the largest lane stride G
-        const double ratio = c->c.time_step_us / c->c.row_dt_us - 1.0;
-        a.row_fast = (ratio > 1e-7 && ratio < 1.0 / 8.0) ? 1u : 0u;
-    }
 }
 
 static uint32_t side_streams(const mcrt_ctx *c) { return c->knobs.march_streams; }

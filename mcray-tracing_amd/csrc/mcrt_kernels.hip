@@ -1499,6 +1499,10 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
 // segment; a group that has finished (or found a dead path's empty slot) takes the next slot, so short, long and missing
 // segments do not wait for each other.  Eight consecutive steps per iteration, lane j of the group owns steps j, j+G, ...
 // (that many texture gathers per lane in flight).
+// Tried on top of this and measured slower (MI355X, 32 frames per pass, per launch alone): one task pool per workgroup instead of
+// a quarter of its slots per wavefront (an LDS cursor: 891 vs 829 us -- the extra scalar work outweighs the better balance); a
+// one-read row stepper for steps after a segment's first (the row advances by G or G + 1: no gain, the two threshold reads were
+// never the cost); fewer resident workgroups per CU so that k_shade / the next k_trace find registers at once (LDS padding: no gain).
 template <bool STATS, int G>
 __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t chunks)
 {
@@ -1516,7 +1520,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     for (uint32_t r = tid; r < R; r += nthr) bins[r] = 0;
     for (uint32_t r = tid; r < nf; r += nthr) lflags[r] = 0u;
     for (uint32_t r = tid; r <= R; r += nthr) thr[r] = a.row_thr[r];
-    __shared__ uint32_t pool_cursor;         // next unclaimed slot of the WORKGROUP's range: its four wavefronts draw from one pool
+    __syncthreads();
 
     // XCD-aware numbering: workgroup w runs on XCD w % 8; give every XCD a CONTIGUOUS range of scan-lines, so that the texture
     // cells its segments touch (neighbouring scan-lines cross the same tissue) are shared in ITS L2
@@ -1525,27 +1529,13 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     // ... and within it the F frames of a scan-line one after the other (they cross exactly the same tissue)
     const uint32_t F = a.ne / a.ne_frame, ol = bid / chunks, chunk = bid % chunks;
     const uint32_t line = (ol % F) * a.ne_frame + ol / F;
-    // the workgroup's slot range: the line's S slots are cut into `chunks` contiguous pieces; its wavefronts share the piece as ONE
-    // task pool (a wavefront-private quarter left each wavefront alone with the tail of its own 8 slots per group: the lanes
-    // were busy 65 % of the time)
-#ifdef MCRT_MARCH_BLOCK_POOL
-    const uint32_t per = (a.S + chunks - 1u) / chunks;
-    const uint32_t s_begin = min(a.S, chunk * per), s_end = min(a.S, s_begin + per);
-    if (tid == 0) pool_cursor = s_begin;
-    (void)wv;
-#else
-    // (measured: one pool per workgroup -- an LDS cursor shared by its four wavefronts -- costs more scalar work than the better
-    //  balance returns: 891 vs 829 us per launch; each wavefront keeps a contiguous quarter of the workgroup's slots)
+    // this wavefront's slot range: the line's S slots are cut into chunks*4 contiguous pieces
     const uint32_t per = (a.S + chunks * 4u - 1u) / (chunks * 4u);
     const uint32_t s_begin = min(a.S, (chunk * 4u + (uint32_t)wv) * per), s_end = min(a.S, s_begin + per);
-    uint32_t wave_cursor = s_begin;
-    (void)pool_cursor;
-#endif
     const size_t pid0 = (size_t)line * a.S;
     unsigned long long st_steps = 0;
-    __syncthreads();
 
-    bool pool_empty = false;                                 // wave-uniform: the pool has been seen empty
+    uint32_t cursor = s_begin;                               // wave-uniform: next unclaimed slot
     const double thr_end = a.row_thr[R];
     bool busy = false;
     // A GROUP of G lanes (a DPP quad, or half of one) owns a segment.  Lane j of the group carries the segment's running
@@ -1557,7 +1547,6 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     uint32_t sidx = 0, steps = 0;
     bool more = false;
     int row_guess = 0;
-    bool row_ok = false;      // row_guess - G is the exact row of this lane's previous step (see the row stepper below)
     // b == MCRT_ALL_BOUNCES: the launch accumulates EVERY bounce's segments; a group then walks its path's segments one after
     // the other (seg_b = the one in progress, seg_n = how many the path has) before it takes the next slot
     const bool all_b = b == MCRT_ALL_BOUNCES;
@@ -1577,7 +1566,7 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
         more = !silent && steps > 0u && t < a.max_travel; \
         _Pragma("unroll") for (int u = 1; u < G; u++) if (j >= u) MCRT_ADVANCE() \
         /* first guess of this lane's RF row; afterwards each own step lies G steps (a little over G rows) further */ \
-        row_guess = (t >= 0.0 && t < thr_end) ? (int)(t * a.inv_row_dt) : 0; row_ok = false; \
+        row_guess = (t >= 0.0 && t < thr_end) ? (int)(t * a.inv_row_dt) : 0; \
         busy = true; }
 #define MCRT_ADVANCE() { point = point + delta; t = t + a.time_step; inten *= k_att; }
 #ifdef MCRT_STAMP
@@ -1602,22 +1591,12 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
                 busy = false;
                 if (all_b && seg_b + 1u < seg_n) { seg_b++; MCRT_LOAD_SEGMENT() }      // the path's next segment
             }
-            while (!pool_empty) {
+            while (cursor < s_end) {
                 const unsigned long long want = __ballot(!busy && j == 0);
-                const uint32_t nw = (uint32_t)__popcll(want);
-                if (nw < (uint32_t)REFILL) break;
+                if (__popcll(want) < REFILL) break;
 #ifdef MCRT_STAMP
                 mc_refill++;
 #endif
-#ifdef MCRT_MARCH_BLOCK_POOL
-                uint32_t cursor = 0;
-                if (lane == 0) cursor = atomicAdd(&pool_cursor, nw);                  // (LDS atomic: one per refill of a wavefront)
-                cursor = (uint32_t)__shfl((int)cursor, 0, 64);
-#else
-                const uint32_t cursor = wave_cursor;
-                wave_cursor += nw;
-#endif
-                if (cursor >= s_end) { pool_empty = true; break; }
                 const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~(G - 1))) - 1ull));
                 if (!busy && mine < s_end) {
                     seg_pid = pid0 + mine;
@@ -1625,9 +1604,11 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
                     seg_b = all_b ? 0u : b;
                     if (seg_b < seg_n) MCRT_LOAD_SEGMENT()
                 }
+                const uint32_t nw = (uint32_t)__popcll(want);
+                cursor = (cursor + nw < s_end) ? cursor + nw : s_end;
             }
         }
-        if (!__any(busy)) { if (pool_empty) break; else continue; }
+        if (!__any(busy)) { if (cursor >= s_end) break; else continue; }
 
         // ---- G*H steps of every running segment ----
         if (busy && more) {
@@ -1655,22 +1636,8 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
             for (int h = 0; h < H; h++) {
                 if (myv[h]) {
                     const float scattering = vox[h].y >= m_dens ? vox[h].x * m_sigma + m_mu : 0.0f;
-                    // The RF row of this step.  A lane's consecutive steps lie G time steps apart, and a time step is a little
-                    // longer than a row (the row pitch uses the axial resolution truncated to whole micrometres, rfimage.h:35,178):
-                    // with row_fast (checked on the host: 1e-7 < time_step / row_dt - 1 < 1 / (2 G)) the row advances by exactly G
-                    // or G + 1 -- far beyond what the rounding of the running double sum could blur -- so ONE threshold read decides
-                    // it.  The first step of a segment, and every step when row_fast does not hold, go through the general search.
-                    int row;
-#ifndef MCRT_MARCH_NO_ROW_FAST
-                    if (a.row_fast && row_ok) {
-                        int r = row_guess;
-                        if (r < (int)R && myt[h] >= thr[r + 1]) r++;          // (thr[R] is the end of the image)
-                        row = r < (int)R ? r : -1;
-                    } else
-#endif
-                        row = row_near(myt[h], row_guess, thr, R, a.inv_row_dt, thr_end);
+                    const int row = row_near(myt[h], row_guess, thr, R, a.inv_row_dt, thr_end);
                     rf_add(bins, lflags, row, myin[h] * scattering);
-                    row_ok = row >= 0;
                     row_guess = (row >= 0 ? row : row_guess) + G;
                     if (STATS) st_steps++;
                 }
@@ -1944,9 +1911,7 @@ hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1u) chunks = 1u;
     const dim3 grid(a.ne * chunks), blk(256);
-    // (march_lds_pad: extra LDS per workgroup = fewer resident k_march workgroups per CU, so that the critical chain's kernels --
-    //  k_shade, the next k_trace -- find free registers when they are launched beside a running k_march; tuning knob)
-    const size_t lds = march_lds_bytes(a.R) + a.march_lds_pad;
+    const size_t lds = march_lds_bytes(a.R);
     // lanes per segment: pairs give the higher throughput when there is plenty of work (515 vs 524 us per launch with 16 frames in
     // flight), quads the shorter iterations that matter when one frame at a time is traced (2.19 vs 2.37 ms per frame)
     const bool pairs = (size_t)a.ne * a.S >= (size_t)MCRT_MARCH_PAIRS_FROM;

@@ -8,7 +8,7 @@ import json,sys
 n=sys.argv[1]
 try:
     d=json.loads([x for x in open('gpurun_out/configs/%s.log'%n) if x.startswith('{')][-1]); r=d['roofline']
-    print("%-4s %-62s %.3e rays/s %8.2f ms/frame  k_trace %.0f GB/s (%.2f)" % (n, d['config']['workload'][:62], d['value'], d['ms_per_step'], r['achieved'], r['frac']))
+    print("%-4s %-62s %.3e rays/s %8.2f ms/frame  walk %.0f GB/s algorithmic, cache-served (%.2f of the HBM figure)" % (n, d['config']['workload'][:62], d['value'], d['ms_per_step'], r['algorithmic_GBps_cache_served'], r['algorithmic_GBps_cache_served'] / 8000.0))
 except Exception as e:
     print(n,'FAILED',e, open('gpurun_out/configs/%s.log'%n).read()[-300:])
 PY
