@@ -681,6 +681,10 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 #ifndef MCRT_LANE_LEAF_BATCH
 #define MCRT_LANE_LEAF_BATCH 20      // leave the inner-node phase once this many lanes are parked on a leaf
 #endif
+#ifndef MCRT_LEAF_PREFETCH
+#define MCRT_LEAF_PREFETCH 2         // pieces of a triangle record fetched ahead of the tests that need them: 0 = none, 1 = plane + padded bounds, 2 = all six
+                                     // (measured per leaf phase: 5833 / 4597 / 4153 cycles; frame 0.512 / 0.506 / 0.505 ms)
+#endif
 #ifndef MCRT_LANE_FETCH
 #define MCRT_LANE_FETCH 64           // queue positions a wavefront claims per atomic
 #endif
@@ -845,6 +849,15 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
 #define MCRT_POP() { if (sp > sb) { sp--; cur = (sp < MCRT_LANE_STACK) ? stack[sp * 256 + tid] : ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride]; } else cur = CUR_IDLE; }
 #define MCRT_PUSH(v) { if (sp < MCRT_LANE_STACK) stack[sp * 256 + tid] = (v); else ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride] = (v); sp++; }
     uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
+#ifdef MCRT_STAMP
+    // diagnostic build: cycles and lane counts per phase, summed over wavefronts (tools/stamps.py)
+    unsigned long long sc_refill = 0, sc_p1 = 0, sc_p2 = 0, sc_n1 = 0, sc_n2 = 0, sc_outer = 0, sc_t0 = __builtin_readcyclecounter(), sc_act1 = 0, sc_act2 = 0, sc_park1 = 0, sc_idle1 = 0, sc_adopt = 0;
+    const unsigned long long wc_start = wall_clock64();
+    if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 0], ~wc_start);
+#define LSTAMP(var) { const unsigned long long t_ = __builtin_readcyclecounter(); var += t_ - sc_t0; sc_t0 = t_; }
+#else
+#define LSTAMP(var)
+#endif
     MCRT_WATCHDOG_DECL()
     for (;;) {
         MCRT_WATCHDOG_CHECK()
@@ -873,6 +886,9 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                     if (start < hi) { pool_next = (uint32_t)start; pool_end = min((uint32_t)start + (uint32_t)MCRT_LANE_FETCH, hi); }
                     else if (++visited >= X) queue_empty = true;
                     else cur_x = (cur_x + 1u) & (X - 1u);
+#ifdef MCRT_STAMP
+                    if (queue_empty && lane == 0) atomicMax(&a.stamps[16 + 4 * b + 1], ~(unsigned long long)wall_clock64());
+#endif
                 }
                 if (need && i == 0xffffffffu) {
                     const uint32_t mine = pool_next + (uint32_t)__popcll(dynm & ((1ull << lane) - 1ull));
@@ -941,8 +957,12 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                     helper = c12 >= 0;                                   // (an owner without a find so far passes on the ray's own bound, which stays exclusive)
                 }
                 if (give) { sb++; shared = true; }
+#ifdef MCRT_STAMP
+                sc_adopt += pairs;
+#endif
             }
         }
+        LSTAMP(sc_refill)
 
         // ---- phase 1: inner nodes, until enough lanes are parked on a leaf ----
         const float tcap = fminf(1.0f, best.frac);               // best only changes in phase 2
@@ -952,6 +972,9 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
             const unsigned long long inner = MCRT_ON_INNER(cur);
             if (inner == 0ull) break;
             if (__popcll(MCRT_ON_LEAF(cur)) >= MCRT_LANE_LEAF_BATCH) break;
+#ifdef MCRT_STAMP
+            sc_n1++; sc_act1 += __popcll(inner); sc_park1 += __popcll(MCRT_ON_LEAF(cur)); sc_idle1 += 64 - __popcll(MCRT_WALKING(cur));
+#endif
             if (cur >= 0) {
                 const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
                 const uint4 Q0 = N[0], Q1 = N[1], Q2 = N[2], RF = N[3];
@@ -995,6 +1018,10 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                 }
             }
         }
+        LSTAMP(sc_p1)
+#ifdef MCRT_STAMP
+        { const unsigned long long lm = MCRT_ON_LEAF(cur); if (lm) { sc_n2++; sc_act2 += __popcll(lm); } sc_outer++; }
+#endif
         // ---- phase 2: the parked leaves; the triangle test of the contract (btTriangleRaycastCallback::processTriangle behind
         // the padded-bounds rule), one lane per ray, same expressions as the quad walk's shared test ----
         if ((uint32_t)cur > 0x80000000u) {
@@ -1002,12 +1029,25 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
             const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
             for (uint32_t k = 0; k < cnt; k++) {
                 const float4 *T = (const float4 *)((const char *)a.tris + (first + k) * 96u);
+#if MCRT_LEAF_PREFETCH >= 1
+                // the record's pieces are fetched TOGETHER, not stage by stage behind the early exits: a leaf phase then costs one
+                // memory round trip instead of three (the pieces of a rejected triangle are wasted loads; the walk has TCP headroom)
+                float4 P = T[0], PL = T[1], PH = T[2];
+                asm volatile("" : "+v"(PL.x), "+v"(PL.y), "+v"(PL.z), "+v"(PL.w), "+v"(PH.x), "+v"(PH.y), "+v"(PH.z));
+#if MCRT_LEAF_PREFETCH >= 2
+                float4 V0 = T[3], V1 = T[4], V2 = T[5];
+                asm volatile("" : "+v"(V0.x), "+v"(V0.y), "+v"(V0.z), "+v"(V0.w), "+v"(V1.x), "+v"(V1.y), "+v"(V1.z), "+v"(V2.x), "+v"(V2.y), "+v"(V2.z));
+#endif
+#else
                 const float4 P = T[0];
+#endif
                 const f3 nrm = xyz(P);
                 const float da = dot(nrm, f2) - P.w;
                 const float db = dot(nrm, to) - P.w;
                 if (da * db >= 0.0f) continue;
+#if MCRT_LEAF_PREFETCH < 1
                 const float4 PL = T[1], PH = T[2];
+#endif
                 const int id = __float_as_int(PL.w);
                 const float proj = da - db;
                 const float frac = da / proj;
@@ -1015,7 +1055,9 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                 float tmin, tmax;
                 const RayPairs rp = ray_pairs(f2, inv);
                 if (!(slab_pairs((v2f){ PL.x, PL.y }, (v2f){ PL.z, PH.x }, (v2f){ PH.y, PH.z }, rp, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax)) continue;
+#if MCRT_LEAF_PREFETCH < 2
                 const float4 V0 = T[3], V1 = T[4], V2 = T[5];
+#endif
                 const float edge_tol = V0.w;
                 const float s = 1.0f - frac;
                 const f3 p = mk(s * f2.x + frac * to.x, s * f2.y + frac * to.y, s * f2.z + frac * to.z);
@@ -1028,7 +1070,18 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
             if (STATS) st_tris += cnt;
             MCRT_POP()
         }
+        LSTAMP(sc_p2)
     }
+#ifdef MCRT_STAMP
+    if (lane == 0) {
+        atomicAdd(&a.stamps[0], sc_refill); atomicAdd(&a.stamps[1], sc_p1); atomicAdd(&a.stamps[2], sc_p2); atomicAdd(&a.stamps[3], sc_n1);
+        atomicAdd(&a.stamps[4], sc_n2); atomicAdd(&a.stamps[5], sc_outer); atomicAdd(&a.stamps[6], sc_act1); atomicAdd(&a.stamps[7], sc_act2); atomicAdd(&a.stamps[8], 1ull);
+        atomicAdd(&a.stamps[56], sc_park1); atomicAdd(&a.stamps[57], sc_idle1); atomicAdd(&a.stamps[58], sc_adopt);
+        const unsigned long long wc_end = wall_clock64();
+        atomicMax(&a.stamps[16 + 4 * b + 2], wc_end); atomicAdd(&a.stamps[16 + 4 * b + 3], wc_end - wc_start);
+    }
+#endif
+#undef LSTAMP
 #undef MCRT_SUB_LO
 #undef MCRT_SUB_STATIC
 #undef MCRT_ON_INNER
@@ -1502,7 +1555,9 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
 // Tried on top of this and measured slower (MI355X, 32 frames per pass, per launch alone): one task pool per workgroup instead of
 // a quarter of its slots per wavefront (an LDS cursor: 891 vs 829 us -- the extra scalar work outweighs the better balance); a
 // one-read row stepper for steps after a segment's first (the row advances by G or G + 1: no gain, the two threshold reads were
-// never the cost); fewer resident workgroups per CU so that k_shade / the next k_trace find registers at once (LDS padding: no gain).
+// never the cost); fewer resident workgroups per CU so that k_shade / the next k_trace find registers at once (LDS padding: no gain);
+// one wavefront per scan-line, four lines and four bin arrays per workgroup (a pool of S slots per wavefront instead of S/4: the GPU is
+// then a quarter as finely cut and the heaviest lines set the pace -- 1714 vs 827 us).
 template <bool STATS, int G>
 __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t chunks)
 {

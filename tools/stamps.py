@@ -31,7 +31,10 @@ print("cycles per phase-1 iteration %.0f (avg active lanes %.1f/64); per phase-2
 print("per wave: %.0f cycles, %.1f node iterations, %.1f leaf iterations" % (tot / v[8], v[3] / v[8], v[4] / v[8]))
 print("k_march: %d waves, loop iterations %.1f per wave; step iterations %.1f per wave with %.2f of 16 quads active; iterations with a finishing quad %.1f; refill rounds %.1f"
       % (v[14], v[9] / max(v[14], 1), v[10] / max(v[14], 1), v[11] / max(v[10], 1), v[12] / max(v[14], 1), v[13] / max(v[14], 1)))
-print("node visits %d, of them after a pop (previous node had no hit child) %d, of those again without a hit child %d" % (v[56], v[57], v[58]))
+if os.environ.get("MCRT_QUAD_WALK"):
+    print("node visits %d, of them after a pop (previous node had no hit child) %d, of those again without a hit child %d" % (v[56], v[57], v[58]))
+else:
+    print("lane walk, per node-step iteration: %.1f lanes stepping, %.1f parked on a leaf, %.1f without a walk; subtrees adopted %d" % (v[6] / max(v[3], 1), v[56] / max(v[3], 1), v[57] / max(v[3], 1), v[58]))
 M = (1 << 64) - 1
 print("bounce   launch us   queue empty at us (share of launch)   mean wave lifetime us")
 for b in range(10):
