@@ -795,6 +795,114 @@ MCRT_DEV bool slab_combine(float t0x, float t0y, float t0z, float t1x, float t1y
     return tmin <= tmax;
 }
 
+// ---- the lane-per-ray walk's two steps, shared by k_trace_lane and k_paths ------------------------------------------------
+// A lane's traversal stack: entries [sb, sp), entry e of thread t at lds[e * 256 + t] while e < MCRT_LANE_STACK, beyond that in the
+// global overflow array (only reachable on degenerate paths of deep trees).
+struct LaneStack { int *lds; int *ovf; size_t ovf_stride; int tid; };
+constexpr int CUR_IDLE = (int)0x80000000;      // walk state: cur >= 0 inner node, cur < 0 ~(leaf descriptor), CUR_IDLE = no walk in progress
+MCRT_DEV void lane_pop(const LaneStack &S, int &cur, int &sp, int sb)
+{
+    if (sp > sb) { sp--; cur = (sp < MCRT_LANE_STACK) ? S.lds[sp * 256 + S.tid] : S.ovf[(size_t)(sp - MCRT_LANE_STACK) * S.ovf_stride]; }
+    else cur = CUR_IDLE;
+}
+MCRT_DEV void lane_push(const LaneStack &S, int &sp, int v)
+{
+    if (sp < MCRT_LANE_STACK) S.lds[sp * 256 + S.tid] = v; else S.ovf[(size_t)(sp - MCRT_LANE_STACK) * S.ovf_stride] = v;
+    sp++;
+}
+struct LaneRay { v2f oxx, oyy, ozz, ixx, iyy, izz; };     // origin and reciprocal direction, each component twice (packed operands)
+
+// one inner node: the four children's slab tests, the nearest hit child next, the other hit children stacked in slot order
+MCRT_DEV void lane_node_step(const FrameArgs &a, const LaneStack &S, const LaneRay &r, float t_lo, float tcap, int &cur, int &sp, int sb)
+{
+    const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
+    const uint4 Q0 = N[0], Q1 = N[1], Q2 = N[2], RF = N[3];
+    // six plane distances of the four children (halves -> floats, then (plane - origin) * reciprocal, two children per packed operation)
+    const Planes4 X0 = planes4(Q0.x, Q0.y, r.oxx, r.ixx), Y0 = planes4(Q0.z, Q0.w, r.oyy, r.iyy), Z0 = planes4(Q1.x, Q1.y, r.ozz, r.izz);
+    const Planes4 X1 = planes4(Q1.z, Q1.w, r.oxx, r.ixx), Y1 = planes4(Q2.x, Q2.y, r.oyy, r.iyy), Z1 = planes4(Q2.z, Q2.w, r.ozz, r.izz);
+    float tn0, tn1, tn2, tn3;
+    const bool h0 = slab_combine(X0.a.x, Y0.a.x, Z0.a.x, X1.a.x, Y1.a.x, Z1.a.x, t_lo, tcap, tn0);
+    const bool h1 = slab_combine(X0.a.y, Y0.a.y, Z0.a.y, X1.a.y, Y1.a.y, Z1.a.y, t_lo, tcap, tn1);
+    const bool h2 = slab_combine(X0.b.x, Y0.b.x, Z0.b.x, X1.b.x, Y1.b.x, Z1.b.x, t_lo, tcap, tn2);
+    const bool h3 = slab_combine(X0.b.y, Y0.b.y, Z0.b.y, X1.b.y, Y1.b.y, Z1.b.y, t_lo, tcap, tn3);
+    // nearest hit child first (key unique per node: t_near bits with the slot number in the two low bits), the others are
+    // stacked in slot order -- exactly the quad walk's order
+    const uint32_t k0 = h0 ? ((__float_as_uint(tn0) & ~3u) | 0u) : 0xffffffffu, k1 = h1 ? ((__float_as_uint(tn1) & ~3u) | 1u) : 0xffffffffu;
+    const uint32_t k2 = h2 ? ((__float_as_uint(tn2) & ~3u) | 2u) : 0xffffffffu, k3 = h3 ? ((__float_as_uint(tn3) & ~3u) | 3u) : 0xffffffffu;
+    const uint32_t kmin = min(min(k0, k1), min(k2, k3));
+    int r0 = (int)RF.x, r1 = (int)RF.y, r2 = (int)RF.z, r3 = (int)RF.w;
+    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));      // (the child references are fetched WITH the boxes, not after the tests in a second round trip)
+    if (kmin == 0xffffffffu) { lane_pop(S, cur, sp, sb); return; }
+    const bool p0 = h0 && k0 != kmin, p1 = h1 && k1 != kmin, p2 = h2 && k2 != kmin, p3 = h3 && k3 != kmin;
+    if (__builtin_expect(__any(sp + 3 > MCRT_LANE_STACK), 0)) {       // (some lane may leave the LDS part: the general form)
+        if (p0) lane_push(S, sp, r0);
+        if (p1) lane_push(S, sp, r1);
+        if (p2) lane_push(S, sp, r2);
+        if (p3) lane_push(S, sp, r3);
+    } else {
+        int *top = &S.lds[sp * 256 + S.tid];
+        const int s1 = p0 ? 256 : 0, s2 = s1 + (p1 ? 256 : 0), s3 = s2 + (p2 ? 256 : 0);
+        if (p0) top[0] = r0;
+        if (p1) top[s1] = r1;
+        if (p2) top[s2] = r2;
+        if (p3) top[s3] = r3;
+        sp += (s3 >> 8) + (p3 ? 1 : 0);
+    }
+    const uint32_t jn = kmin & 3u;
+    cur = jn == 0u ? r0 : jn == 1u ? r1 : jn == 2u ? r2 : r3;
+}
+
+// one leaf: the contract's triangle test (btTriangleRaycastCallback::processTriangle behind the padded-bounds rule) on each of its
+// triangles, then the next stack entry.  helper: the lane walks an adopted subtree (see k_trace_lane): a triangle at exactly the
+// owner's closest fraction is a candidate.  Returns the number of triangles of the leaf.
+MCRT_DEV uint32_t lane_leaf_test(const FrameArgs &a, const LaneStack &S, f3 f2, f3 to, f3 inv, float t_lo, bool helper, Best &best, int &cur, int &sp, int sb)
+{
+    const uint32_t v = (uint32_t)~cur;
+    const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+    for (uint32_t k = 0; k < cnt; k++) {
+        const float4 *T = (const float4 *)((const char *)a.tris + (first + k) * 96u);
+#if MCRT_LEAF_PREFETCH >= 1
+        // the record's pieces are fetched TOGETHER, not stage by stage behind the early exits: a leaf phase then costs one
+        // memory round trip instead of three (the pieces of a rejected triangle are wasted loads; the walk has TCP headroom)
+        float4 P = T[0], PL = T[1], PH = T[2];
+        asm volatile("" : "+v"(PL.x), "+v"(PL.y), "+v"(PL.z), "+v"(PL.w), "+v"(PH.x), "+v"(PH.y), "+v"(PH.z));
+#if MCRT_LEAF_PREFETCH >= 2
+        float4 V0 = T[3], V1 = T[4], V2 = T[5];
+        asm volatile("" : "+v"(V0.x), "+v"(V0.y), "+v"(V0.z), "+v"(V0.w), "+v"(V1.x), "+v"(V1.y), "+v"(V1.z), "+v"(V2.x), "+v"(V2.y), "+v"(V2.z));
+#endif
+#else
+        const float4 P = T[0];
+#endif
+        const f3 nrm = xyz(P);
+        const float da = dot(nrm, f2) - P.w;
+        const float db = dot(nrm, to) - P.w;
+        if (da * db >= 0.0f) continue;
+#if MCRT_LEAF_PREFETCH < 1
+        const float4 PL = T[1], PH = T[2];
+#endif
+        const int id = __float_as_int(PL.w);
+        const float proj = da - db;
+        const float frac = da / proj;
+        if (!(frac < best.frac || (frac == best.frac && (id < best.tri || (helper && best.tri < 0)))) || !(frac >= t_lo)) continue;
+        float tmin, tmax;
+        const RayPairs rp = ray_pairs(f2, inv);
+        if (!(slab_pairs((v2f){ PL.x, PL.y }, (v2f){ PL.z, PH.x }, (v2f){ PH.y, PH.z }, rp, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax)) continue;
+#if MCRT_LEAF_PREFETCH < 2
+        const float4 V0 = T[3], V1 = T[4], V2 = T[5];
+#endif
+        const float edge_tol = V0.w;
+        const float s = 1.0f - frac;
+        const f3 p = mk(s * f2.x + frac * to.x, s * f2.y + frac * to.y, s * f2.z + frac * to.z);
+        const f3 p0 = xyz(V0) - p, p1 = xyz(V1) - p, p2 = xyz(V2) - p;
+        if (!(dot(cross(p0, p1), nrm) >= edge_tol)) continue;
+        if (!(dot(cross(p1, p2), nrm) >= edge_tol)) continue;
+        if (!(dot(cross(p2, p0), nrm) >= edge_tol)) continue;
+        best.frac = frac; best.tri = id;
+    }
+    lane_pop(S, cur, sp, sb);
+    return cnt;
+}
+
 // position of the r-th (0-based) set bit of a 64-bit mask (r < popcount): binary search on popcounts
 MCRT_DEV int nth_set_bit(unsigned long long m, uint32_t r)
 {
@@ -820,8 +928,8 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
     const uint32_t ray_stride = (b == 0u) ? a.S : 1u;
     unsigned long long *keys = (b & 1u) ? a.key1 : a.key0;
     unsigned long long st_nodes = 0, st_tris = 0, st_q = 0;
-    int *ovf = a.stack_ovf + ((size_t)blockIdx.x * 256 + tid);       // overflow entries of this lane: [entry - MCRT_LANE_STACK][grid thread]
-    const size_t ovf_stride = (size_t)gridDim.x * 256;
+    // (overflow entries of this lane: [entry - MCRT_LANE_STACK][grid thread])
+    const LaneStack S = { stack, a.stack_ovf + ((size_t)blockIdx.x * 256 + tid), (size_t)gridDim.x * 256, tid };
 
     // work distribution: as in k_trace (one sub-queue and cursor per XCD, swept in order), one item per LANE
     const uint32_t X = (n >= (uint32_t)MCRT_XCD_MIN_ITEMS) ? (uint32_t)MCRT_XCDS : 1u;
@@ -838,7 +946,6 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
     f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1), inv = mk(1, 1, 1);
     float t_lo = 0.0f;
     Best best; best.frac = 1.0f; best.tri = -1;
-    constexpr int CUR_IDLE = (int)0x80000000;
     int sp = 0, sb = 0, cur = CUR_IDLE;          // the lane's stack entries live in [sb, sp): sb moves up when the bottom entry is given away (see below)
     bool shared = false;                         // another lane of the wavefront works on a subtree of this lane's ray: results meet in the ray's word
     bool helper = false;                         // this lane walks an adopted subtree: it starts from the owner's closest fraction WITHOUT the owner's
@@ -846,8 +953,6 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
 #define MCRT_ON_INNER(c) __builtin_amdgcn_sicmp((c), -1, 38)
 #define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)
 #define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)
-#define MCRT_POP() { if (sp > sb) { sp--; cur = (sp < MCRT_LANE_STACK) ? stack[sp * 256 + tid] : ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride]; } else cur = CUR_IDLE; }
-#define MCRT_PUSH(v) { if (sp < MCRT_LANE_STACK) stack[sp * 256 + tid] = (v); else ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride] = (v); sp++; }
     uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
 #ifdef MCRT_STAMP
     // diagnostic build: cycles and lane counts per phase, summed over wavefronts (tools/stamps.py)
@@ -966,8 +1071,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
 
         // ---- phase 1: inner nodes, until enough lanes are parked on a leaf ----
         const float tcap = fminf(1.0f, best.frac);               // best only changes in phase 2
-        const v2f oxx = (v2f){ f2.x, f2.x }, oyy = (v2f){ f2.y, f2.y }, ozz = (v2f){ f2.z, f2.z };
-        const v2f ixx = (v2f){ inv.x, inv.x }, iyy = (v2f){ inv.y, inv.y }, izz = (v2f){ inv.z, inv.z };
+        const LaneRay lr = { (v2f){ f2.x, f2.x }, (v2f){ f2.y, f2.y }, (v2f){ f2.z, f2.z }, (v2f){ inv.x, inv.x }, (v2f){ inv.y, inv.y }, (v2f){ inv.z, inv.z } };
         for (;;) {
             const unsigned long long inner = MCRT_ON_INNER(cur);
             if (inner == 0ull) break;
@@ -976,46 +1080,8 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
             sc_n1++; sc_act1 += __popcll(inner); sc_park1 += __popcll(MCRT_ON_LEAF(cur)); sc_idle1 += 64 - __popcll(MCRT_WALKING(cur));
 #endif
             if (cur >= 0) {
-                const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
-                const uint4 Q0 = N[0], Q1 = N[1], Q2 = N[2], RF = N[3];
                 if (STATS) st_nodes++;
-                // six plane distances of the four children (halves -> floats, then (plane - origin) * reciprocal, two children per packed operation)
-                const Planes4 X0 = planes4(Q0.x, Q0.y, oxx, ixx), Y0 = planes4(Q0.z, Q0.w, oyy, iyy), Z0 = planes4(Q1.x, Q1.y, ozz, izz);
-                const Planes4 X1 = planes4(Q1.z, Q1.w, oxx, ixx), Y1 = planes4(Q2.x, Q2.y, oyy, iyy), Z1 = planes4(Q2.z, Q2.w, ozz, izz);
-                const v2f t0x_a = X0.a, t0x_b = X0.b, t0y_a = Y0.a, t0y_b = Y0.b, t0z_a = Z0.a, t0z_b = Z0.b;
-                const v2f t1x_a = X1.a, t1x_b = X1.b, t1y_a = Y1.a, t1y_b = Y1.b, t1z_a = Z1.a, t1z_b = Z1.b;
-                float tn0, tn1, tn2, tn3;
-                const bool h0 = slab_combine(t0x_a.x, t0y_a.x, t0z_a.x, t1x_a.x, t1y_a.x, t1z_a.x, t_lo, tcap, tn0);
-                const bool h1 = slab_combine(t0x_a.y, t0y_a.y, t0z_a.y, t1x_a.y, t1y_a.y, t1z_a.y, t_lo, tcap, tn1);
-                const bool h2 = slab_combine(t0x_b.x, t0y_b.x, t0z_b.x, t1x_b.x, t1y_b.x, t1z_b.x, t_lo, tcap, tn2);
-                const bool h3 = slab_combine(t0x_b.y, t0y_b.y, t0z_b.y, t1x_b.y, t1y_b.y, t1z_b.y, t_lo, tcap, tn3);
-                // nearest hit child first (key unique per node: t_near bits with the slot number in the two low bits), the others
-                // are stacked in slot order -- exactly the quad walk's order
-                const uint32_t k0 = h0 ? ((__float_as_uint(tn0) & ~3u) | 0u) : 0xffffffffu, k1 = h1 ? ((__float_as_uint(tn1) & ~3u) | 1u) : 0xffffffffu;
-                const uint32_t k2 = h2 ? ((__float_as_uint(tn2) & ~3u) | 2u) : 0xffffffffu, k3 = h3 ? ((__float_as_uint(tn3) & ~3u) | 3u) : 0xffffffffu;
-                const uint32_t kmin = min(min(k0, k1), min(k2, k3));
-                int r0 = (int)RF.x, r1 = (int)RF.y, r2 = (int)RF.z, r3 = (int)RF.w;
-                asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));      // (the child references are fetched WITH the boxes, not after the tests in a second round trip)
-                if (kmin == 0xffffffffu) { MCRT_POP() }
-                else {
-                    const bool p0 = h0 && k0 != kmin, p1 = h1 && k1 != kmin, p2 = h2 && k2 != kmin, p3 = h3 && k3 != kmin;
-                    if (__builtin_expect(__any(sp + 3 > MCRT_LANE_STACK), 0)) {       // (some lane may leave the LDS part: the general form)
-                        if (p0) MCRT_PUSH(r0)
-                        if (p1) MCRT_PUSH(r1)
-                        if (p2) MCRT_PUSH(r2)
-                        if (p3) MCRT_PUSH(r3)
-                    } else {
-                        int *top = &stack[sp * 256 + tid];
-                        const int s1 = p0 ? 256 : 0, s2 = s1 + (p1 ? 256 : 0), s3 = s2 + (p2 ? 256 : 0);
-                        if (p0) top[0] = r0;
-                        if (p1) top[s1] = r1;
-                        if (p2) top[s2] = r2;
-                        if (p3) top[s3] = r3;
-                        sp += (s3 >> 8) + (p3 ? 1 : 0);
-                    }
-                    const uint32_t jn = kmin & 3u;
-                    cur = jn == 0u ? r0 : jn == 1u ? r1 : jn == 2u ? r2 : r3;
-                }
+                lane_node_step(a, S, lr, t_lo, tcap, cur, sp, sb);
             }
         }
         LSTAMP(sc_p1)
@@ -1025,50 +1091,8 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
         // ---- phase 2: the parked leaves; the triangle test of the contract (btTriangleRaycastCallback::processTriangle behind
         // the padded-bounds rule), one lane per ray, same expressions as the quad walk's shared test ----
         if ((uint32_t)cur > 0x80000000u) {
-            const uint32_t v = (uint32_t)~cur;
-            const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; k++) {
-                const float4 *T = (const float4 *)((const char *)a.tris + (first + k) * 96u);
-#if MCRT_LEAF_PREFETCH >= 1
-                // the record's pieces are fetched TOGETHER, not stage by stage behind the early exits: a leaf phase then costs one
-                // memory round trip instead of three (the pieces of a rejected triangle are wasted loads; the walk has TCP headroom)
-                float4 P = T[0], PL = T[1], PH = T[2];
-                asm volatile("" : "+v"(PL.x), "+v"(PL.y), "+v"(PL.z), "+v"(PL.w), "+v"(PH.x), "+v"(PH.y), "+v"(PH.z));
-#if MCRT_LEAF_PREFETCH >= 2
-                float4 V0 = T[3], V1 = T[4], V2 = T[5];
-                asm volatile("" : "+v"(V0.x), "+v"(V0.y), "+v"(V0.z), "+v"(V0.w), "+v"(V1.x), "+v"(V1.y), "+v"(V1.z), "+v"(V2.x), "+v"(V2.y), "+v"(V2.z));
-#endif
-#else
-                const float4 P = T[0];
-#endif
-                const f3 nrm = xyz(P);
-                const float da = dot(nrm, f2) - P.w;
-                const float db = dot(nrm, to) - P.w;
-                if (da * db >= 0.0f) continue;
-#if MCRT_LEAF_PREFETCH < 1
-                const float4 PL = T[1], PH = T[2];
-#endif
-                const int id = __float_as_int(PL.w);
-                const float proj = da - db;
-                const float frac = da / proj;
-                if (!(frac < best.frac || (frac == best.frac && (id < best.tri || (helper && best.tri < 0)))) || !(frac >= t_lo)) continue;
-                float tmin, tmax;
-                const RayPairs rp = ray_pairs(f2, inv);
-                if (!(slab_pairs((v2f){ PL.x, PL.y }, (v2f){ PL.z, PH.x }, (v2f){ PH.y, PH.z }, rp, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax)) continue;
-#if MCRT_LEAF_PREFETCH < 2
-                const float4 V0 = T[3], V1 = T[4], V2 = T[5];
-#endif
-                const float edge_tol = V0.w;
-                const float s = 1.0f - frac;
-                const f3 p = mk(s * f2.x + frac * to.x, s * f2.y + frac * to.y, s * f2.z + frac * to.z);
-                const f3 p0 = xyz(V0) - p, p1 = xyz(V1) - p, p2 = xyz(V2) - p;
-                if (!(dot(cross(p0, p1), nrm) >= edge_tol)) continue;
-                if (!(dot(cross(p1, p2), nrm) >= edge_tol)) continue;
-                if (!(dot(cross(p2, p0), nrm) >= edge_tol)) continue;
-                best.frac = frac; best.tri = id;
-            }
+            const uint32_t cnt = lane_leaf_test(a, S, f2, to, inv, t_lo, helper, best, cur, sp, sb);
             if (STATS) st_tris += cnt;
-            MCRT_POP()
         }
         LSTAMP(sc_p2)
     }
@@ -1087,8 +1111,6 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
 #undef MCRT_ON_INNER
 #undef MCRT_ON_LEAF
 #undef MCRT_WALKING
-#undef MCRT_POP
-#undef MCRT_PUSH
     if (STATS) {
         unsigned long long v[3] = { st_q, st_nodes, st_tris };
 #pragma unroll
@@ -1272,8 +1294,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_paths(FrameArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t n = a.ne * a.S;                               // paths = positions of the bounce-0 queue (scan-line-major, see k_init)
     unsigned long long st_nodes = 0, st_tris = 0, st_q = 0, st_seg = 0, st_hits = 0;
-    int *ovf = a.stack_ovf + ((size_t)blockIdx.x * 256 + tid);
-    const size_t ovf_stride = (size_t)gridDim.x * 256;
+    const LaneStack S = { stack, a.stack_ovf + ((size_t)blockIdx.x * 256 + tid), (size_t)gridDim.x * 256, tid };
     const uint32_t X = (n >= (uint32_t)MCRT_XCD_MIN_ITEMS) ? (uint32_t)MCRT_XCDS : 1u;
     if (X == 1u && blockIdx.x * 256u >= n) return;
     const uint32_t x_shift = (X == 1u) ? 0u : 3u;
@@ -1287,13 +1308,10 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_paths(FrameArgs a)
     bool exhausted = false, has_path = false, pend = false;      // pend: the walk of `bounce` has ended, the physics is due
     f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1), inv = mk(1, 1, 1);
     Best best; best.frac = 1.0f; best.tri = -1;
-    constexpr int CUR_IDLE = (int)0x80000000;
     int sp = 0, cur = CUR_IDLE;
 #define MCRT_ON_INNER(c) __builtin_amdgcn_sicmp((c), -1, 38)
 #define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)
 #define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)
-#define MCRT_POP() { if (sp > 0) { sp--; cur = (sp < MCRT_LANE_STACK) ? stack[sp * 256 + tid] : ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride]; } else { cur = CUR_IDLE; pend = true; } }
-#define MCRT_PUSH(v) { if (sp < MCRT_LANE_STACK) stack[sp * 256 + tid] = (v); else ovf[(size_t)(sp - MCRT_LANE_STACK) * ovf_stride] = (v); sp++; }
     uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;
     MCRT_WATCHDOG_DECL()
     for (;;) {
@@ -1373,85 +1391,23 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_paths(FrameArgs a)
 
         // ---- inner nodes, until enough lanes are parked on a leaf or wait for their physics ----
         const float tcap = fminf(1.0f, best.frac);
-        const v2f oxx = (v2f){ f2.x, f2.x }, oyy = (v2f){ f2.y, f2.y }, ozz = (v2f){ f2.z, f2.z };
-        const v2f ixx = (v2f){ inv.x, inv.x }, iyy = (v2f){ inv.y, inv.y }, izz = (v2f){ inv.z, inv.z };
+        const LaneRay lr = { (v2f){ f2.x, f2.x }, (v2f){ f2.y, f2.y }, (v2f){ f2.z, f2.z }, (v2f){ inv.x, inv.x }, (v2f){ inv.y, inv.y }, (v2f){ inv.z, inv.z } };
         for (;;) {
             const unsigned long long inner = MCRT_ON_INNER(cur);
             if (inner == 0ull) break;
             if (__popcll(MCRT_ON_LEAF(cur)) >= MCRT_LANE_LEAF_BATCH) break;
             if (__popcll(__ballot(pend)) >= 2 * MCRT_PATHS_SHADE_BATCH) break;
             if (cur >= 0) {
-                const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
-                const uint4 Q0 = N[0], Q1 = N[1], Q2 = N[2], RF = N[3];
                 if (STATS) st_nodes++;
-                // six plane distances of the four children (halves -> floats, then (plane - origin) * reciprocal, two children per packed operation)
-                const Planes4 X0 = planes4(Q0.x, Q0.y, oxx, ixx), Y0 = planes4(Q0.z, Q0.w, oyy, iyy), Z0 = planes4(Q1.x, Q1.y, ozz, izz);
-                const Planes4 X1 = planes4(Q1.z, Q1.w, oxx, ixx), Y1 = planes4(Q2.x, Q2.y, oyy, iyy), Z1 = planes4(Q2.z, Q2.w, ozz, izz);
-                const v2f t0x_a = X0.a, t0x_b = X0.b, t0y_a = Y0.a, t0y_b = Y0.b, t0z_a = Z0.a, t0z_b = Z0.b;
-                const v2f t1x_a = X1.a, t1x_b = X1.b, t1y_a = Y1.a, t1y_b = Y1.b, t1z_a = Z1.a, t1z_b = Z1.b;
-                float tn0, tn1, tn2, tn3;
-                const bool h0 = slab_combine(t0x_a.x, t0y_a.x, t0z_a.x, t1x_a.x, t1y_a.x, t1z_a.x, 0.0f, tcap, tn0);
-                const bool h1 = slab_combine(t0x_a.y, t0y_a.y, t0z_a.y, t1x_a.y, t1y_a.y, t1z_a.y, 0.0f, tcap, tn1);
-                const bool h2 = slab_combine(t0x_b.x, t0y_b.x, t0z_b.x, t1x_b.x, t1y_b.x, t1z_b.x, 0.0f, tcap, tn2);
-                const bool h3 = slab_combine(t0x_b.y, t0y_b.y, t0z_b.y, t1x_b.y, t1y_b.y, t1z_b.y, 0.0f, tcap, tn3);
-                const uint32_t k0 = h0 ? ((__float_as_uint(tn0) & ~3u) | 0u) : 0xffffffffu, k1 = h1 ? ((__float_as_uint(tn1) & ~3u) | 1u) : 0xffffffffu;
-                const uint32_t k2 = h2 ? ((__float_as_uint(tn2) & ~3u) | 2u) : 0xffffffffu, k3 = h3 ? ((__float_as_uint(tn3) & ~3u) | 3u) : 0xffffffffu;
-                const uint32_t kmin = min(min(k0, k1), min(k2, k3));
-                int r0 = (int)RF.x, r1 = (int)RF.y, r2 = (int)RF.z, r3 = (int)RF.w;
-                asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
-                if (kmin == 0xffffffffu) { MCRT_POP() }
-                else {
-                    const bool p0 = h0 && k0 != kmin, p1 = h1 && k1 != kmin, p2 = h2 && k2 != kmin, p3 = h3 && k3 != kmin;
-                    if (__builtin_expect(__any(sp + 3 > MCRT_LANE_STACK), 0)) {
-                        if (p0) MCRT_PUSH(r0)
-                        if (p1) MCRT_PUSH(r1)
-                        if (p2) MCRT_PUSH(r2)
-                        if (p3) MCRT_PUSH(r3)
-                    } else {
-                        int *top = &stack[sp * 256 + tid];
-                        const int s1 = p0 ? 256 : 0, s2 = s1 + (p1 ? 256 : 0), s3 = s2 + (p2 ? 256 : 0);
-                        if (p0) top[0] = r0;
-                        if (p1) top[s1] = r1;
-                        if (p2) top[s2] = r2;
-                        if (p3) top[s3] = r3;
-                        sp += (s3 >> 8) + (p3 ? 1 : 0);
-                    }
-                    const uint32_t jn = kmin & 3u;
-                    cur = jn == 0u ? r0 : jn == 1u ? r1 : jn == 2u ? r2 : r3;
-                }
+                lane_node_step(a, S, lr, 0.0f, tcap, cur, sp, 0);
+                if (cur == CUR_IDLE) pend = true;                 // the walk has ended: the physics is due
             }
         }
         // ---- the parked leaves (the contract's triangle test, as in k_trace_lane) ----
         if ((uint32_t)cur > 0x80000000u) {
-            const uint32_t v = (uint32_t)~cur;
-            const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; k++) {
-                const float4 *T = (const float4 *)((const char *)a.tris + (first + k) * 96u);
-                const float4 P = T[0];
-                const f3 nrm = xyz(P);
-                const float da = dot(nrm, f2) - P.w;
-                const float db = dot(nrm, to) - P.w;
-                if (da * db >= 0.0f) continue;
-                const float4 PL = T[1], PH = T[2];
-                const int id = __float_as_int(PL.w);
-                const float proj = da - db;
-                const float frac = da / proj;
-                if (!(frac < best.frac || (frac == best.frac && id < best.tri)) || !(frac >= 0.0f)) continue;
-                float tmin, tmax;
-                const RayPairs rp = ray_pairs(f2, inv);
-                if (!(slab_pairs((v2f){ PL.x, PL.y }, (v2f){ PL.z, PH.x }, (v2f){ PH.y, PH.z }, rp, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax)) continue;
-                const float4 V0 = T[3], V1 = T[4], V2 = T[5];
-                const float edge_tol = V0.w;
-                const float s = 1.0f - frac;
-                const f3 p = mk(s * f2.x + frac * to.x, s * f2.y + frac * to.y, s * f2.z + frac * to.z);
-                const f3 p0 = xyz(V0) - p, p1 = xyz(V1) - p, p2 = xyz(V2) - p;
-                if (!(dot(cross(p0, p1), nrm) >= edge_tol)) continue;
-                if (!(dot(cross(p1, p2), nrm) >= edge_tol)) continue;
-                if (!(dot(cross(p2, p0), nrm) >= edge_tol)) continue;
-                best.frac = frac; best.tri = id;
-            }
+            const uint32_t cnt = lane_leaf_test(a, S, f2, to, inv, 0.0f, false, best, cur, sp, 0);
             if (STATS) st_tris += cnt;
-            MCRT_POP()
+            if (cur == CUR_IDLE) pend = true;
         }
     }
 #undef MCRT_SUB_LO
@@ -1459,8 +1415,6 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_paths(FrameArgs a)
 #undef MCRT_ON_INNER
 #undef MCRT_ON_LEAF
 #undef MCRT_WALKING
-#undef MCRT_POP
-#undef MCRT_PUSH
     if (STATS) {
         unsigned long long v[5] = { st_q, st_nodes, st_tris, st_seg, st_hits };
         const int slot[5] = { 0, 1, 2, 3, 5 };
