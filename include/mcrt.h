@@ -223,10 +223,11 @@ int mcrt_transducer_elements(uint32_t n_elements, double radius_cm, double separ
  * value converted to float). */
 int mcrt_debug_math(mcrt_ctx *ctx, int op, const double *x, const double *y, double *out, uint32_t n);
 int mcrt_debug_philox(mcrt_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-/* diagnostic builds of the library (-DMCRT_STAMP) only: out[0..15] per-phase cycle sums of k_trace, out[16+4b..] the launch
- * timeline of bounce b (100 MHz clock: ~earliest wave start, ~earliest empty queue, latest wave end, summed wave lifetimes;
- * the first two stored complemented); all zero otherwise */
-int mcrt_debug_stamps(mcrt_ctx *ctx, uint64_t out[80], int reset);
+/* diagnostic builds of the library (-DMCRT_STAMP, or -DMCRT_STAMP_LITE for the timeline alone) only: out[0..15] per-phase cycle
+ * sums of k_trace, out[16+4b..] the launch timeline of bounce b (100 MHz clock: ~earliest wave start, ~earliest empty queue,
+ * latest wave end, summed wave lifetimes; the first two stored complemented), out[60..119] per-bounce wavefront counts, start
+ * times, longest lifetime and node-step iterations (tools/stamps.py decodes them); all zero otherwise */
+int mcrt_debug_stamps(mcrt_ctx *ctx, uint64_t out[120], int reset);
 
 #ifdef __cplusplus
 }

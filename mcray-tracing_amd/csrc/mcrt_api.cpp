@@ -1057,13 +1057,13 @@ extern "C" int mcrt_get_stats(mcrt_ctx *c, mcrt_stats *out, int reset)
     return MCRT_OK;
 }
 
-// diagnostic builds (-DMCRT_STAMP): per-phase cycle sums of k_trace [0,16) and its per-bounce launch timeline [16,80); zeros otherwise
-extern "C" int mcrt_debug_stamps(mcrt_ctx *c, uint64_t out[80], int reset)
+// diagnostic builds (-DMCRT_STAMP): per-phase cycle sums of k_trace [0,16) and its per-bounce launch timeline [16,120) (the timeline alone: -DMCRT_STAMP_LITE); zeros otherwise
+extern "C" int mcrt_debug_stamps(mcrt_ctx *c, uint64_t out[120], int reset)
 {
     CTX_TRY(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out, c->d_stats + 8, 80 * 8, hipMemcpyDeviceToHost));
-    if (reset) { HIP_TRY(hipMemsetAsync(c->d_stats + 8, 0, 80 * 8, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+    HIP_TRY(hipMemcpy(out, c->d_stats + 8, 120 * 8, hipMemcpyDeviceToHost));
+    if (reset) { HIP_TRY(hipMemsetAsync(c->d_stats + 8, 0, 120 * 8, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     return MCRT_OK;
 }
 

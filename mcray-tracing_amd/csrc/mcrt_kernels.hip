@@ -681,6 +681,12 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 #ifndef MCRT_LANE_LEAF_BATCH
 #define MCRT_LANE_LEAF_BATCH 20      // leave the inner-node phase once this many lanes are parked on a leaf
 #endif
+#ifndef MCRT_LANE_POLL
+#define MCRT_LANE_POLL 1             // walkers of one ray exchange their closest hit through the ray's word (k_trace_lane)
+#endif
+#ifndef MCRT_LANE_ADOPT_STEPS
+#define MCRT_LANE_ADOPT_STEPS 4      // while idle lanes wait for a subtree, the inner-node phase returns to the hand-over after this many steps
+#endif
 #ifndef MCRT_LEAF_PREFETCH
 #define MCRT_LEAF_PREFETCH 2         // pieces of a triangle record fetched ahead of the tests that need them: 0 = none, 1 = plane + padded bounds, 2 = all six
                                      // (measured per leaf phase: 5833 / 4597 / 4153 cycles; frame 0.512 / 0.506 / 0.505 ms)
@@ -954,14 +960,18 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
 #define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)
 #define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)
     uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
+    unsigned long long poll_old = 0; uint32_t poll_ray = 0; bool poll_pending = false;      // (see the end of the loop)
 #ifdef MCRT_STAMP
     // diagnostic build: cycles and lane counts per phase, summed over wavefronts (tools/stamps.py)
     unsigned long long sc_refill = 0, sc_p1 = 0, sc_p2 = 0, sc_n1 = 0, sc_n2 = 0, sc_outer = 0, sc_t0 = __builtin_readcyclecounter(), sc_act1 = 0, sc_act2 = 0, sc_park1 = 0, sc_idle1 = 0, sc_adopt = 0;
-    const unsigned long long wc_start = wall_clock64();
-    if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 0], ~wc_start);
 #define LSTAMP(var) { const unsigned long long t_ = __builtin_readcyclecounter(); var += t_ - sc_t0; sc_t0 = t_; }
 #else
 #define LSTAMP(var)
+#endif
+#if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
+    // timeline only (a handful of atomics per wavefront: usable on the production schedule)
+    const unsigned long long wc_start = wall_clock64(); unsigned long long wc_empty = 0, wc_steps = 0;
+    if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 0], ~wc_start);
 #endif
     MCRT_WATCHDOG_DECL()
     for (;;) {
@@ -991,8 +1001,8 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                     if (start < hi) { pool_next = (uint32_t)start; pool_end = min((uint32_t)start + (uint32_t)MCRT_LANE_FETCH, hi); }
                     else if (++visited >= X) queue_empty = true;
                     else cur_x = (cur_x + 1u) & (X - 1u);
-#ifdef MCRT_STAMP
-                    if (queue_empty && lane == 0) atomicMax(&a.stamps[16 + 4 * b + 1], ~(unsigned long long)wall_clock64());
+#if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
+                    if (queue_empty) { wc_empty = wall_clock64(); if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 1], ~wc_empty); }
 #endif
                 }
                 if (need && i == 0xffffffffu) {
@@ -1053,13 +1063,14 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                 const float c6 = __shfl(inv.x, src, 64), c7 = __shfl(inv.y, src, 64), c8 = __shfl(inv.z, src, 64);
                 const float c9 = __shfl(t_lo, src, 64), c10 = __shfl(best.frac, src, 64);
                 const uint32_t c11 = (uint32_t)__shfl((int)ray_id, src, 64);
-                const int c12 = __shfl(best.tri, src, 64);
+                const int c12 = __shfl(best.tri, src, 64), c13 = __shfl((int)helper, src, 64);
                 if (take) {
                     cur = stack[d_sb * 256 + (tid & ~63) + src];        // the donor's bottom entry (same wavefront, read before the donor moves on)
                     f2 = mk(c0, c1, c2); to = mk(c3, c4, c5); inv = mk(c6, c7, c8); t_lo = c9;
                     best.frac = c10; best.tri = -1; ray_id = c11;
                     sp = 0; sb = 0; fresh = false; shared = true;
-                    helper = c12 >= 0;                                   // (an owner without a find so far passes on the ray's own bound, which stays exclusive)
+                    helper = c12 >= 0 || c13 != 0;                       // (an owner without a find so far passes on the ray's own bound, which stays exclusive;
+                                                                         // a lane that is itself a helper passes its owner's fraction on)
                 }
                 if (give) { sb++; shared = true; }
 #ifdef MCRT_STAMP
@@ -1071,11 +1082,17 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
 
         // ---- phase 1: inner nodes, until enough lanes are parked on a leaf ----
         const float tcap = fminf(1.0f, best.frac);               // best only changes in phase 2
+        const bool thieves_wait = !STATS && queue_empty && __any(cur == CUR_IDLE && fresh);     // (then phase 1 is cut short: see MCRT_LANE_ADOPT_STEPS)
+        int steps_left = MCRT_LANE_ADOPT_STEPS;
         const LaneRay lr = { (v2f){ f2.x, f2.x }, (v2f){ f2.y, f2.y }, (v2f){ f2.z, f2.z }, (v2f){ inv.x, inv.x }, (v2f){ inv.y, inv.y }, (v2f){ inv.z, inv.z } };
         for (;;) {
             const unsigned long long inner = MCRT_ON_INNER(cur);
             if (inner == 0ull) break;
             if (__popcll(MCRT_ON_LEAF(cur)) >= MCRT_LANE_LEAF_BATCH) break;
+            if (thieves_wait && --steps_left < 0) break;
+#if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
+            wc_steps++;
+#endif
 #ifdef MCRT_STAMP
             sc_n1++; sc_act1 += __popcll(inner); sc_park1 += __popcll(MCRT_ON_LEAF(cur)); sc_idle1 += 64 - __popcll(MCRT_WALKING(cur));
 #endif
@@ -1095,14 +1112,40 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
             if (STATS) st_tris += cnt;
         }
         LSTAMP(sc_p2)
+
+        // ---- walkers of ONE ray (the pieces of a cut ray, an owner and the lanes that took over its subtrees) meet in the ray's
+        // closest-hit word: each publishes its find there and takes the smallest word back as its own closest hit, so a subtree or
+        // piece behind another walker's hit is left as the single walk would leave it.  The word only ever holds real finds, and the
+        // smallest of them is the answer, so cutting by it cannot cut the answer.  The returned word is looked at ONE round later
+        // (its latency is then behind the node fetches of the round in between).
+        if (!STATS && MCRT_LANE_POLL && (K > 1u || queue_empty)) {
+            if (poll_pending) {
+                poll_pending = false;
+                const unsigned long long mine = ((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri;   // (no find: id 0xffffffff)
+                if (poll_ray == ray_id && cur != CUR_IDLE && poll_old < mine) {
+                    best.frac = __uint_as_float((uint32_t)(poll_old >> 32)); best.tri = (int)(uint32_t)poll_old; helper = false;
+                }
+            }
+            if ((shared || K > 1u) && cur != CUR_IDLE) {
+                const unsigned long long word = (best.tri >= 0) ? (((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri) : ~0ull;
+                poll_old = atomicMin(&keys[ray_id], word); poll_ray = ray_id; poll_pending = true;
+            }
+        }
     }
 #ifdef MCRT_STAMP
     if (lane == 0) {
         atomicAdd(&a.stamps[0], sc_refill); atomicAdd(&a.stamps[1], sc_p1); atomicAdd(&a.stamps[2], sc_p2); atomicAdd(&a.stamps[3], sc_n1);
         atomicAdd(&a.stamps[4], sc_n2); atomicAdd(&a.stamps[5], sc_outer); atomicAdd(&a.stamps[6], sc_act1); atomicAdd(&a.stamps[7], sc_act2); atomicAdd(&a.stamps[8], 1ull);
         atomicAdd(&a.stamps[56], sc_park1); atomicAdd(&a.stamps[57], sc_idle1); atomicAdd(&a.stamps[58], sc_adopt);
+    }
+#endif
+#if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
+    if (lane == 0 && b < 10u) {
         const unsigned long long wc_end = wall_clock64();
         atomicMax(&a.stamps[16 + 4 * b + 2], wc_end); atomicAdd(&a.stamps[16 + 4 * b + 3], wc_end - wc_start);
+        atomicAdd(&a.stamps[60 + 2 * b], wc_empty ? wc_end - wc_empty : 0ull); atomicAdd(&a.stamps[61 + 2 * b], 1ull);   // time after the queue ran dry; wavefronts
+        atomicAdd(&a.stamps[80 + b], wc_start); atomicMax(&a.stamps[90 + b], wc_end - wc_start);                          // start times (sum); longest life
+        atomicAdd(&a.stamps[100 + b], wc_steps); atomicMax(&a.stamps[110 + b], wc_steps);                                  // node-step iterations: sum, most
     }
 #endif
 #undef LSTAMP

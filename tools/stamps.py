@@ -14,7 +14,7 @@ tr = m.Transducer(128, position=cfg["transducerPosition"], angles_deg=cfg["trans
 sim = m.Simulator(sd, tr, n_samples=rays)
 ctx = sim.ctx
 rf = torch.empty((F, 128, sim.R), dtype=torch.float32, device="cuda")
-out = (C.c_uint64 * 80)()
+out = (C.c_uint64 * 120)()
 for f in range(3):
     ctx.trace_frames(f * F, F, rf, 0, 128)
 ctx.synchronize()
@@ -23,27 +23,33 @@ ctx.trace_frames(100, F, rf, 0, 128)          # ONE pass: the timeline slots hol
 ctx.synchronize()
 ctx.L.mcrt_debug_stamps(ctx.h, out, 1)
 v = [int(x) for x in out]
-names = ["refill cyc", "phase1 cyc", "phase2 cyc", "phase1 iters", "phase2 iters", "outer iters", "active lanes p1 (sum)", "active lanes p2 (sum)", "waves"]
-for n, x in zip(names, v): print("%-24s %16d" % (n, x))
-tot = v[0] + v[1] + v[2]
-print("shares: refill %.1f%%  phase1 %.1f%%  phase2 %.1f%%" % (100 * v[0] / tot, 100 * v[1] / tot, 100 * v[2] / tot))
-print("cycles per phase-1 iteration %.0f (avg active lanes %.1f/64); per phase-2 iteration %.0f (avg parked lanes %.1f/64)" % (v[1] / max(v[3], 1), v[6] / max(v[3], 1), v[2] / max(v[4], 1), v[7] / max(v[4], 1)))
-print("per wave: %.0f cycles, %.1f node iterations, %.1f leaf iterations" % (tot / v[8], v[3] / v[8], v[4] / v[8]))
-print("k_march: %d waves, loop iterations %.1f per wave; step iterations %.1f per wave with %.2f of 16 quads active; iterations with a finishing quad %.1f; refill rounds %.1f"
-      % (v[14], v[9] / max(v[14], 1), v[10] / max(v[14], 1), v[11] / max(v[10], 1), v[12] / max(v[14], 1), v[13] / max(v[14], 1)))
-if os.environ.get("MCRT_QUAD_WALK"):
-    print("node visits %d, of them after a pop (previous node had no hit child) %d, of those again without a hit child %d" % (v[56], v[57], v[58]))
-else:
-    print("lane walk, per node-step iteration: %.1f lanes stepping, %.1f parked on a leaf, %.1f without a walk; subtrees adopted %d" % (v[6] / max(v[3], 1), v[56] / max(v[3], 1), v[57] / max(v[3], 1), v[58]))
+if v[8]:      # (a -DMCRT_STAMP_LITE build carries only the timeline)
+    names = ["refill cyc", "phase1 cyc", "phase2 cyc", "phase1 iters", "phase2 iters", "outer iters", "active lanes p1 (sum)", "active lanes p2 (sum)", "waves"]
+    for n, x in zip(names, v): print("%-24s %16d" % (n, x))
+    tot = v[0] + v[1] + v[2]
+    print("shares: refill %.1f%%  phase1 %.1f%%  phase2 %.1f%%" % (100 * v[0] / tot, 100 * v[1] / tot, 100 * v[2] / tot))
+    print("cycles per phase-1 iteration %.0f (avg active lanes %.1f/64); per phase-2 iteration %.0f (avg parked lanes %.1f/64)" % (v[1] / max(v[3], 1), v[6] / max(v[3], 1), v[2] / max(v[4], 1), v[7] / max(v[4], 1)))
+    print("per wave: %.0f cycles, %.1f node iterations, %.1f leaf iterations" % (tot / v[8], v[3] / v[8], v[4] / v[8]))
+    print("k_march: %d waves, loop iterations %.1f per wave; step iterations %.1f per wave with %.2f of 16 quads active; iterations with a finishing quad %.1f; refill rounds %.1f"
+          % (v[14], v[9] / max(v[14], 1), v[10] / max(v[14], 1), v[11] / max(v[10], 1), v[12] / max(v[14], 1), v[13] / max(v[14], 1)))
+    if os.environ.get("MCRT_QUAD_WALK"):
+        print("node visits %d, of them after a pop (previous node had no hit child) %d, of those again without a hit child %d" % (v[56], v[57], v[58]))
+    else:
+        print("lane walk, per node-step iteration: %.1f lanes stepping, %.1f parked on a leaf, %.1f without a walk; subtrees adopted %d" % (v[6] / max(v[3], 1), v[56] / max(v[3], 1), v[57] / max(v[3], 1), v[58]))
 M = (1 << 64) - 1
-print("bounce   launch us   queue empty at us (share of launch)   mean wave lifetime us")
+lane = not os.environ.get("MCRT_QUAD_WALK")
+print("bounce   launch us   queue empty at us (share of launch)   wavefronts   mean wave lifetime us   mean time after the queue ran dry us | mean start us  longest life us | node-step iterations per wave: mean, most")
 for b in range(10):
     s0, s1, e, life = v[16 + 4 * b: 20 + 4 * b]
     if e == 0: continue
     start, empty = M - s0, (M - s1) if s1 else None
     dur = (e - start) / 100.0
     em = (empty - start) / 100.0 if empty is not None else float("nan")
-    print("%4d   %10.1f   %10.1f (%.0f%%)   %10.1f" % (b, dur, em, 100 * em / dur if dur else 0, life / 100.0 / 5120))
+    waves = v[61 + 2 * b] if lane else 5120
+    print("%4d   %10.1f   %10.1f (%.0f%%)   %8d   %10.1f   %10.1f" % (b, dur, em, 100 * em / dur if dur else 0, waves, life / 100.0 / max(waves, 1), (v[60 + 2 * b] / 100.0 / max(waves, 1)) if lane else float("nan")), end="")
+    if lane and waves: print("   | %8.1f %10.1f | %8.1f %8d" % ((v[80 + b] / waves - start) / 100.0, v[90 + b] / 100.0, v[100 + b] / waves, v[110 + b]))
+    else: print()
+if lane: sys.exit(0)
 h = v[60:77]
 tot_h = sum(h) or 1
 print("node visits per walk (bounces >= 1), log2 bins: share of walks / share of visits (bin midpoint estimate)")
