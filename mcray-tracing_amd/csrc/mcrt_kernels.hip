@@ -684,6 +684,12 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 #ifndef MCRT_LANE_POLL
 #define MCRT_LANE_POLL 1             // walkers of one ray exchange their closest hit through the ray's word (k_trace_lane)
 #endif
+#ifndef MCRT_MARCH_WAVES
+#define MCRT_MARCH_WAVES 6           // waves per SIMD the register budget of k_march is set for (7: 14 spilled registers, 789 vs 750 us per launch; 5: 777)
+#endif
+#ifndef MCRT_MARCH_TILE
+#define MCRT_MARCH_TILE 256          // slots a wavefront of k_march sorts by segment length at a time (a multiple of 64, at most 256: one byte per slot)
+#endif
 #ifndef MCRT_LANE_ADOPT_STEPS
 #define MCRT_LANE_ADOPT_STEPS 4      // while idle lanes wait for a subtree, the inner-node phase returns to the hand-over after this many steps
 #endif
@@ -1556,7 +1562,7 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
 // one wavefront per scan-line, four lines and four bin arrays per workgroup (a pool of S slots per wavefront instead of S/4: the GPU is
 // then a quarter as finely cut and the heaviest lines set the pace -- 1714 vs 827 us).
 template <bool STATS, int G>
-__global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t chunks)
+__global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, uint32_t b, uint32_t chunks)
 {
     constexpr int H = 8 / G;                 // RF steps per lane and iteration: a group does G*H = 8 consecutive steps
 #ifndef MCRT_MARCH_REFILL_DIV
@@ -1569,6 +1575,8 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     long long *bins = (long long *)smem;
     uint32_t *lflags = (uint32_t *)(bins + ((R + 1u) & ~1u));
     double *thr = (double *)(lflags + ((nf + 3u) & ~3u));
+    uint32_t *sort_cnt = (uint32_t *)(thr + ((R + 2u) & ~1u)) + wv * 64;                   // this wavefront's 64 length classes ...
+    unsigned char *sort_list = (unsigned char *)((uint32_t *)(thr + ((R + 2u) & ~1u)) + 4 * 64) + wv * MCRT_MARCH_TILE;   // ... and its tile's slots, longest first
     for (uint32_t r = tid; r < R; r += nthr) bins[r] = 0;
     for (uint32_t r = tid; r < nf; r += nthr) lflags[r] = 0u;
     for (uint32_t r = tid; r <= R; r += nthr) thr[r] = a.row_thr[r];
@@ -1587,7 +1595,12 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
     const size_t pid0 = (size_t)line * a.S;
     unsigned long long st_steps = 0;
 
-    uint32_t cursor = s_begin;                               // wave-uniform: next unclaimed slot
+    // The wavefront takes its slots in TILES of MCRT_MARCH_TILE, and the segments of a tile LONGEST FIRST (counting sort by the
+    // number of 8-step iterations a segment needs, dead paths' slots left out): groups that start together then finish together,
+    // so the hand-out code below -- which the whole wavefront executes -- runs for many groups at once and seldom, and the lanes
+    // of a wavefront step in lockstep.  (RF bins are integer sums: the order is free.)
+    uint32_t tile0 = s_begin, list_base = s_begin, list_n = 0, list_pos = 0;      // wave-uniform: first slot of the next tile; of the tile in hand: first slot, live segments, the next one to hand out
+    bool tiles_left = s_begin < s_end;
     const double thr_end = a.row_thr[R];
     bool busy = false;
     // A GROUP of G lanes (a DPP quad, or half of one) owns a segment.  Lane j of the group carries the segment's running
@@ -1643,24 +1656,64 @@ __global__ void __launch_bounds__(256) k_march(FrameArgs a, uint32_t b, uint32_t
                 busy = false;
                 if (all_b && seg_b + 1u < seg_n) { seg_b++; MCRT_LOAD_SEGMENT() }      // the path's next segment
             }
-            while (cursor < s_end) {
+            while (list_pos < list_n || tiles_left) {
+                if (list_pos >= list_n) {
+                    // ---- the next tile: classes 0 (longest) .. 63, a slot's class from its segment's step count ----
+                    const uint32_t t1 = min(s_end, tile0 + (uint32_t)MCRT_MARCH_TILE);
+                    sort_cnt[lane] = 0u;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    // (the class of a slot is worked out twice -- once to count, once to place -- rather than kept in registers)
+                    auto slot_class = [&](uint32_t slot) -> uint32_t {
+                        if (slot >= t1) return 0xffffffffu;
+                        const uint32_t sn = a.seg_count[pid0 + slot], sb0 = all_b ? 0u : b;
+                        if (sb0 >= sn) return 0xffffffffu;
+                        uint32_t its = 0u;
+                        if (!all_b) {
+                            const float4 g2 = a.mrec[3 * ((size_t)sb0 * a.ne * a.S + pid0 + slot) + 2];
+                            const float4 mt = a.mtab[__float_as_int(g2.w)];
+                            const bool silent = a.tex_finite && mt.x == 0.0f && mt.z == 0.0f;
+                            its = silent ? 0u : (__float_as_uint(g2.z) + 7u) >> 3;
+                        }
+                        return 63u - (its < 63u ? its : 63u);
+                    };
+                    for (int k = 0; k < MCRT_MARCH_TILE / 64; k++) {
+                        const uint32_t c = slot_class(tile0 + (uint32_t)(k * 64 + lane));
+                        if (c != 0xffffffffu) atomicAdd(&sort_cnt[c], 1u);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    const uint32_t mine_cnt = sort_cnt[lane];
+                    uint32_t incl = mine_cnt;                                    // inclusive prefix sum over the 64 classes
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    sort_cnt[lane] = incl - mine_cnt;                            // now the class's next free position in the list
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    for (int k = 0; k < MCRT_MARCH_TILE / 64; k++) {
+                        const uint32_t c = slot_class(tile0 + (uint32_t)(k * 64 + lane));
+                        if (c != 0xffffffffu) sort_list[atomicAdd(&sort_cnt[c], 1u)] = (unsigned char)(k * 64 + lane);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    list_n = (uint32_t)__shfl((int)incl, 63, 64); list_pos = 0u;
+                    list_base = tile0; tile0 = t1; tiles_left = t1 < s_end;
+                    continue;
+                }
                 const unsigned long long want = __ballot(!busy && j == 0);
                 if (__popcll(want) < REFILL) break;
 #ifdef MCRT_STAMP
                 mc_refill++;
 #endif
-                const uint32_t mine = cursor + (uint32_t)__popcll(want & ((1ull << (lane & ~(G - 1))) - 1ull));
-                if (!busy && mine < s_end) {
-                    seg_pid = pid0 + mine;
+                const uint32_t mine = list_pos + (uint32_t)__popcll(want & ((1ull << (lane & ~(G - 1))) - 1ull));
+                if (!busy && mine < list_n) {
+                    seg_pid = pid0 + list_base + (uint32_t)sort_list[mine];
                     seg_n = a.seg_count[seg_pid];
                     seg_b = all_b ? 0u : b;
                     if (seg_b < seg_n) MCRT_LOAD_SEGMENT()
                 }
                 const uint32_t nw = (uint32_t)__popcll(want);
-                cursor = (cursor + nw < s_end) ? cursor + nw : s_end;
+                list_pos = (list_pos + nw < list_n) ? list_pos + nw : list_n;
             }
         }
-        if (!__any(busy)) { if (cursor >= s_end) break; else continue; }
+        if (!__any(busy)) { if (list_pos >= list_n && !tiles_left) break; else continue; }
 
         // ---- G*H steps of every running segment ----
         if (busy && more) {
@@ -1889,7 +1942,7 @@ __global__ void k_philox_probe(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c
 size_t march_lds_bytes(uint32_t R)
 {
     const size_t bins = (size_t)((R + 1u) & ~1u) * 8, flg = (size_t)((((R + 31u) >> 5) + 3u) & ~3u) * 4, thr = (size_t)((R + 2u) & ~1u) * 8;
-    return bins + flg + thr;
+    return bins + flg + thr + 4 * (64 * 4 + MCRT_MARCH_TILE);        // + per wavefront: 64 length-class counters, one tile of slot numbers
 }
 
 hipError_t launch_init(const FrameArgs &a, hipStream_t st)
