@@ -226,8 +226,8 @@ int mcrt_debug_philox(mcrt_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2
 /* diagnostic builds of the library (-DMCRT_STAMP, or -DMCRT_STAMP_LITE for the timeline alone) only: out[0..15] per-phase cycle
  * sums of k_trace, out[16+4b..] the launch timeline of bounce b (100 MHz clock: ~earliest wave start, ~earliest empty queue,
  * latest wave end, summed wave lifetimes; the first two stored complemented), out[60..119] per-bounce wavefront counts, start
- * times, longest lifetime and node-step iterations (tools/stamps.py decodes them); all zero otherwise */
-int mcrt_debug_stamps(mcrt_ctx *ctx, uint64_t out[120], int reset);
+ * times, longest lifetime and node-step iterations, out[120..129] cycle sums of k_march's sections (tools/stamps.py decodes them); all zero otherwise */
+int mcrt_debug_stamps(mcrt_ctx *ctx, uint64_t out[200], int reset);
 
 #ifdef __cplusplus
 }

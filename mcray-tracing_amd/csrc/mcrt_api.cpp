@@ -212,7 +212,7 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     mcrt_default_params(&c->p);
     c->c = derive_consts(c->p);
     c->stream = c->own_stream;
-    if (hipMalloc(&c->d_stats, 128 * sizeof(unsigned long long)) != hipSuccess || hipMemsetAsync(c->d_stats, 0, 128 * sizeof(unsigned long long), c->stream) != hipSuccess ||
+    if (hipMalloc(&c->d_stats, 256 * sizeof(unsigned long long)) != hipSuccess || hipMemsetAsync(c->d_stats, 0, 256 * sizeof(unsigned long long), c->stream) != hipSuccess ||
         hipMalloc(&c->d_error, 4) != hipSuccess || hipMemsetAsync(c->d_error, 0, 4, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
         hipStreamDestroy(c->own_stream); delete c; return set_error(MCRT_ERR_HIP, "hipMalloc failed");
     }
@@ -1057,13 +1057,13 @@ extern "C" int mcrt_get_stats(mcrt_ctx *c, mcrt_stats *out, int reset)
     return MCRT_OK;
 }
 
-// diagnostic builds (-DMCRT_STAMP): per-phase cycle sums of k_trace [0,16) and its per-bounce launch timeline [16,120) (the timeline alone: -DMCRT_STAMP_LITE); zeros otherwise
-extern "C" int mcrt_debug_stamps(mcrt_ctx *c, uint64_t out[120], int reset)
+// diagnostic builds (-DMCRT_STAMP): per-phase cycle sums of k_trace [0,16) and its per-bounce launch timeline [16,120), k_march's sections [120,130) (the timeline alone: -DMCRT_STAMP_LITE); zeros otherwise
+extern "C" int mcrt_debug_stamps(mcrt_ctx *c, uint64_t out[200], int reset)
 {
     CTX_TRY(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out, c->d_stats + 8, 120 * 8, hipMemcpyDeviceToHost));
-    if (reset) { HIP_TRY(hipMemsetAsync(c->d_stats + 8, 0, 120 * 8, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+    HIP_TRY(hipMemcpy(out, c->d_stats + 8, 200 * 8, hipMemcpyDeviceToHost));
+    if (reset) { HIP_TRY(hipMemsetAsync(c->d_stats + 8, 0, 200 * 8, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     return MCRT_OK;
 }
 

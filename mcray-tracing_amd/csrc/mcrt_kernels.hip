@@ -221,7 +221,9 @@ MCRT_DEV int row_of(double t, const double *thr, uint32_t R, double inv_dt, doub
     return r;
 }
 
-// the same row when a good guess is at hand (k_march: the row of the lane's previous step + 4): two threshold reads confirm it
+// the same row when a good guess is at hand: two threshold reads confirm it.  (k_march's guess is t * inv_dt itself, which misses
+// only by a rounding: a guess from the lane's previous row + its stride misses whenever the row advances by one more than the
+// stride -- every tenth step or so, i.e. in EVERY step of a wavefront some lane would take the search below, for all 64.)
 MCRT_DEV int row_near(double t, int guess, const double *thr, uint32_t R, double inv_dt, double thr_end)
 {
     const int r = guess < 0 ? 0 : (guess > (int)R - 1 ? (int)R - 1 : guess);
@@ -686,6 +688,9 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 #endif
 #ifndef MCRT_MARCH_WAVES
 #define MCRT_MARCH_WAVES 6           // waves per SIMD the register budget of k_march is set for (7: 14 spilled registers, 789 vs 750 us per launch; 5: 777)
+#endif
+#ifndef MCRT_MARCH_ROW_EST
+#define MCRT_MARCH_ROW_EST 1         // k_march: a step's RF row is guessed from its time (see row_near), not from the lane's previous row
 #endif
 #ifndef MCRT_MARCH_TILE
 #define MCRT_MARCH_TILE 256          // slots a wavefront of k_march sorts by segment length at a time (a multiple of 64, at most 256: one byte per slot)
@@ -1561,6 +1566,12 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
 // never the cost); fewer resident workgroups per CU so that k_shade / the next k_trace find registers at once (LDS padding: no gain);
 // one wavefront per scan-line, four lines and four bin arrays per workgroup (a pool of S slots per wavefront instead of S/4: the GPU is
 // then a quarter as finely cut and the heaviest lines set the pace -- 1714 vs 827 us).
+// With the sorted tiles (750 us): the steps' echoes as straight-line code (row confirmed by two reads, zero adds into a spare bin, the
+// rest left to a general path entered when any lane needs it) -- the loop issues two scalar instructions for three vector ones, but
+// the straight line keeps four echoes and rows alive: 20 spilled registers at 6 waves/SIMD (1255 us), 784 us at 5; the zero adds
+// all meet in one LDS word (869 / 757 us).  Taking parts of the step out (wrong images, timing only): no gathers 693, no row
+// search 679, no adds 707, none of the three 570 us, no loop at all 8 us (cycle stamps of the full kernel: hand-out 17 %, advance 4 %, voxel + gathers 27 %,
+// rows and bins with the wait for the gathers 51 %).
 template <bool STATS, int G>
 __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, uint32_t b, uint32_t chunks)
 {
@@ -1636,6 +1647,10 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
 #define MCRT_ADVANCE() { point = point + delta; t = t + a.time_step; inten *= k_att; }
 #ifdef MCRT_STAMP
     unsigned long long mc_iter = 0, mc_step_it = 0, mc_step_quads = 0, mc_fin_it = 0, mc_refill = 0;
+    unsigned long long mt_hand = 0, mt_adv = 0, mt_vox = 0, mt_acc = 0, mt_t0 = __builtin_readcyclecounter(); const unsigned long long mt_begin = mt_t0;
+#define MSTAMP(var) { const unsigned long long t_ = __builtin_readcyclecounter(); var += t_ - mt_t0; mt_t0 = t_; }
+#else
+#define MSTAMP(var)
 #endif
     for (;;) {
 #ifdef MCRT_STAMP
@@ -1713,6 +1728,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
                 list_pos = (list_pos + nw < list_n) ? list_pos + nw : list_n;
             }
         }
+        MSTAMP(mt_hand)
         if (!__any(busy)) { if (list_pos >= list_n && !tiles_left) break; else continue; }
 
         // ---- G*H steps of every running segment ----
@@ -1729,6 +1745,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
             }
             // the quad goes on while its base step (lane 0's) passes the loop test
             more = dpp_i<G == 4 ? QP_BCAST(0) : 0xA0>((sidx < steps && t < a.max_travel) ? 1 : 0) != 0;   // (0xA0: quad_perm [0,0,2,2])
+            MSTAMP(mt_adv)
             float2 vox[H];
             if (reach < a.lean_bound) {
 #pragma unroll
@@ -1737,21 +1754,24 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
 #pragma unroll
                 for (int h = 0; h < H; h++) vox[h] = myv[h] ? a.tex[vox_cell(myp[h], a)] : make_float2(0.0f, 0.0f);
             }
+            MSTAMP(mt_vox)
 #pragma unroll
             for (int h = 0; h < H; h++) {
                 if (myv[h]) {
                     const float scattering = vox[h].y >= m_dens ? vox[h].x * m_sigma + m_mu : 0.0f;
-                    const int row = row_near(myt[h], row_guess, thr, R, a.inv_row_dt, thr_end);
+                    const int row = row_near(myt[h], MCRT_MARCH_ROW_EST ? (int)(myt[h] * a.inv_row_dt) : row_guess, thr, R, a.inv_row_dt, thr_end);
                     rf_add(bins, lflags, row, myin[h] * scattering);
-                    row_guess = (row >= 0 ? row : row_guess) + G;
+                    if (!MCRT_MARCH_ROW_EST) row_guess = (row >= 0 ? row : row_guess) + G;
                     if (STATS) st_steps++;
                 }
             }
         }
+        MSTAMP(mt_acc)
     }
 #undef MCRT_ADVANCE
 #undef MCRT_LOAD_SEGMENT
 #ifdef MCRT_STAMP
+    if (lane == 0) { atomicAdd(&a.stamps[120], mt_hand); atomicAdd(&a.stamps[121], mt_adv); atomicAdd(&a.stamps[122], mt_vox); atomicAdd(&a.stamps[123], mt_acc); atomicAdd(&a.stamps[124], __builtin_readcyclecounter() - mt_begin); }
     if (lane == 0) { atomicAdd(&a.stamps[9], mc_iter); atomicAdd(&a.stamps[10], mc_step_it); atomicAdd(&a.stamps[11], mc_step_quads); atomicAdd(&a.stamps[12], mc_fin_it); atomicAdd(&a.stamps[13], mc_refill); atomicAdd(&a.stamps[14], 1ull); }
 #endif
     if (STATS) {

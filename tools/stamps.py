@@ -14,7 +14,7 @@ tr = m.Transducer(128, position=cfg["transducerPosition"], angles_deg=cfg["trans
 sim = m.Simulator(sd, tr, n_samples=rays)
 ctx = sim.ctx
 rf = torch.empty((F, 128, sim.R), dtype=torch.float32, device="cuda")
-out = (C.c_uint64 * 120)()
+out = (C.c_uint64 * 200)()
 for f in range(3):
     ctx.trace_frames(f * F, F, rf, 0, 128)
 ctx.synchronize()
@@ -32,6 +32,7 @@ if v[8]:      # (a -DMCRT_STAMP_LITE build carries only the timeline)
     print("per wave: %.0f cycles, %.1f node iterations, %.1f leaf iterations" % (tot / v[8], v[3] / v[8], v[4] / v[8]))
     print("k_march: %d waves, loop iterations %.1f per wave; step iterations %.1f per wave with %.2f of 16 quads active; iterations with a finishing quad %.1f; refill rounds %.1f"
           % (v[14], v[9] / max(v[14], 1), v[10] / max(v[14], 1), v[11] / max(v[10], 1), v[12] / max(v[14], 1), v[13] / max(v[14], 1)))
+    if v[124]: print("k_march cycle shares: hand-out and finished segments %.1f%%, advance %.1f%%, voxel + gathers %.1f%%, rows and bins %.1f%% (of the loop's %.0f cycles per wavefront)" % tuple([100.0 * v[120 + k] / v[124] for k in range(4)] + [v[124] / max(v[14], 1)]))
     if os.environ.get("MCRT_QUAD_WALK"):
         print("node visits %d, of them after a pop (previous node had no hit child) %d, of those again without a hit child %d" % (v[56], v[57], v[58]))
     else:
