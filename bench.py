@@ -65,15 +65,15 @@ def build_workload(m, name):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--workload", default="random1m")
     ap.add_argument("--scanlines", type=int, default=128, help="scan-lines per GPU (weak scaling)")
     ap.add_argument("--scanlines-total", type=int, default=0, help="scan-lines of the whole frame, sharded over the GPUs (strong scaling); overrides --scanlines")
     ap.add_argument("--rays", type=int, default=1024, help="sample paths per scan-line")
     ap.add_argument("--rows", type=int, default=465)
     ap.add_argument("--tex-n", type=int, default=256, help="texture edge in voxels (256 = the reference; smaller only for cache experiments)")
-    ap.add_argument("--frames-in-flight", type=int, default=32,
+    ap.add_argument("--frames-in-flight", type=int, default=128,
                     help="frames traced per pass (mcrt_trace_frames): a step is still ONE frame, but every kernel launch then carries the "
                          "rays of this many consecutive frames (1 = strict one-frame-at-a-time latency mode)")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="BVH builder: host binned SAH (default) or the device LBVH")
@@ -196,13 +196,14 @@ def main():
     ctx.upload_texture(None, args.tex_n)
     ctx.set_transducer(tr.pos, tr.dir)
     psf = m.Psf(freq=tr.frequency)
-    F = max(1, min(args.frames_in_flight, 64))
+    F = max(1, min(args.frames_in_flight, 256))
     K, W = args.steps, args.warmup
     pipe = Pipeline(torch, dist, ctx, psf, rank, world, E, e0, e1, R, F, args.backend, not args.no_overlap)
 
     if args.pmc_child:
-        # the process the PMC passes profile: the same warm-up and ONE K-step region, same pass sizes, nothing else
-        pipe.run_steps(1000, max(W, 1)); pipe.sync()
+        # the process the PMC passes profile: TWO K-step regions (the first as warm-up), so that every profiled launch has a pass
+        # size of the timed region -- the per-launch averages are then those of the launches the live kernel time is taken over
+        pipe.run_steps(1000, K); pipe.sync()
         pipe.run_steps(0, K); pipe.sync()
         ctx.close()
         return
