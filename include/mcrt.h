@@ -150,7 +150,9 @@ int mcrt_set_transducer(mcrt_ctx *ctx, const float *pos /*[E][3]*/, const float 
 int mcrt_trace_frame(mcrt_ctx *ctx, uint32_t frame_id, uint32_t e_begin, uint32_t e_end, float *rf_dev);
 /* n_frames consecutive frames (ids frame_id .. frame_id+n_frames-1, same scene and probe pose) traced as ONE pass: every
  * stage of the pipeline then runs over n_frames times the rays, which is what fills the GPU when a single frame is small.
- * rf_dev: device float [n_frames][(e_end-e_begin)][R].  Each image is bit-identical to the one mcrt_trace_frame produces. */
+ * rf_dev: device float [n_frames][(e_end-e_begin)][R].  Each image is bit-identical to the one mcrt_trace_frame produces.
+ * Limits (MCRT_ERR_LIMIT beyond them): n_frames <= 1024 and n_frames x scan-lines x samples <= 2^27 paths per pass (a path takes
+ * about 700 bytes of work buffers). */
 int mcrt_trace_frames(mcrt_ctx *ctx, uint32_t frame_id, uint32_t n_frames, uint32_t e_begin, uint32_t e_end, float *rf_dev);
 /* same, and additionally returns per-path data to HOST buffers (any may be NULL); synchronous.
  * hits [ne][S][B] int32 (-1 miss, -2 not cast); segs [ne][S][B]; seg_count [ne][S]. */

@@ -279,6 +279,23 @@ def test_error_paths(mcrt):
     ctx.close()
 
 
+def test_pass_size_limits(mcrt, sphere, tex256):
+    """mcrt_trace_frames: up to 1024 frames and 2^27 paths per pass, refused beyond with MCRT_ERR_LIMIT (not an allocation failure)"""
+    cfg, sd = sphere
+    tr, sim = _sim(mcrt, cfg, sd, 16, 64, texture=tex256)
+    dev = sim.ctx.alloc(4096)
+    with pytest.raises(mcrt.McrtError, match="n_frames must be 1..1024"):
+        sim.ctx.trace_frames(0, 1025, dev)
+    with pytest.raises(mcrt.McrtError, match="n_frames must be 1..1024"):
+        sim.ctx.trace_frames(0, 0, dev)
+    sim.ctx.free(dev); sim.close()
+    tr, sim = _sim(mcrt, cfg, sd, 512, 16384, texture=tex256)
+    dev = sim.ctx.alloc(4096)
+    with pytest.raises(mcrt.McrtError, match="more than 2\\^27 paths"):
+        sim.ctx.trace_frames(0, 17, dev)            # 17 x 512 x 16384 > 2^27 (checked before anything is allocated or written)
+    sim.ctx.free(dev); sim.close()
+
+
 def test_cpp_host_cli_matches_oracle(mcrt, orc, tex256, tmp_path):
     """the C++ host mirror (host/mcrt_host.hpp: JSON scene file, OBJ meshes, transducer<512>, psf, rf_image) driven by the
     mattausch_hip CLI with the reference's launch shape (512 x 5) against the oracle: trace + convolve + envelope"""
@@ -435,6 +452,40 @@ def test_large_passes_use_the_per_xcd_queues(mcrt, orc, sphere, tex256):
     assert np.array_equal(batch[2].T.view(np.uint32), o22["rf"].view(np.uint32))
     sim.ctx.free(dev)
     sim.close()
+
+
+@pytest.mark.parametrize("shape", [(48, 40), (128, 1024)])
+def test_duplicated_triangles_every_hit_is_a_tie(mcrt, orc, tex256, shape):
+    """the closest-hit rule's tie-break (same fraction -> smaller triangle id) when EVERY hit is a tie: the scene's triangles are
+    uploaded twice, so each hit has a twin with id + T at exactly the same fraction.  One frame at a time the walk runs in its
+    end-of-launch mode from the start (rays cut into pieces, idle lanes taking over subtrees of walking lanes, and of lanes that
+    themselves walk a taken-over subtree): whichever lane finds whichever twin first, the answer must be the smaller id -- hit
+    indices bit for bit against the oracle (brute force on the small shape, BVH on the large one).  (The twins mostly share a
+    leaf; the tie that crosses two hand-overs -- a lane that took over a subtree handing part of it on before its own first find
+    -- is the vertex hit of scan-line 327 in test_reference_shape_512x5_and_tir_flag, which caught exactly that in round 2.)"""
+    E, S = shape
+    cfg, meshes = mcrt.synth.sphere_scene(3)
+    sd0 = mcrt.scene_io.build_scene(cfg, meshes)
+    T = sd0.n_tri
+    sd = mcrt.scene_io.SceneData(np.concatenate([sd0.tri, sd0.tri]), np.concatenate([sd0.tri_mesh, sd0.tri_mesh]), sd0.meshes, sd0.materials,
+                                 sd0.material_names, sd0.start_mat, sd0.spacing, sd0.config)
+    for builder in ("sah", "lbvh"):
+        tr = mcrt.Transducer(E, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
+        sim = mcrt.Simulator(sd, tr, n_samples=S, texture=tex256, bvh_builder=builder)
+        hits, _, _ = sim.ctx.trace_frame_debug(5, sim.rf_dev)
+        rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+        osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
+        use_bvh = 0
+        if E * S > 4096:
+            nodes4, _ = sim.ctx.get_bvh4(); _, btri, _ = sim.ctx.get_bvh()
+            osc.set_bvh4(nodes4, btri); use_bvh = 2
+        p = orc.default_params(n_elements=E, n_samples=S)
+        o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=5, use_bvh=use_bvh, n_threads=16, want_ref=False)
+        assert (o["hits"] >= 0).sum() > E * S // 2
+        assert o["hits"].max() < T, "the oracle itself must pick the smaller twin"
+        assert np.array_equal(hits, o["hits"]), builder
+        assert np.array_equal(rf.view(np.uint32), o["rf"].view(np.uint32)), builder
+        sim.close()
 
 
 @pytest.mark.parametrize("case", range(16))
