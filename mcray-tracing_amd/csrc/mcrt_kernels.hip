@@ -689,6 +689,9 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 #ifndef MCRT_MARCH_WAVES
 #define MCRT_MARCH_WAVES 6           // waves per SIMD the register budget of k_march is set for (7: 14 spilled registers, 789 vs 750 us per launch; 5: 777)
 #endif
+#ifndef MCRT_LANE_SIGN_SELECT
+#define MCRT_LANE_SIGN_SELECT 1      // lane_node_step: near / far planes picked by the sign of the reciprocal direction
+#endif
 #ifndef MCRT_MARCH_ROW_EST
 #define MCRT_MARCH_ROW_EST 1         // k_march: a step's RF row is guessed from its time (see row_near), not from the lane's previous row
 #endif
@@ -827,7 +830,19 @@ MCRT_DEV void lane_push(const LaneStack &S, int &sp, int v)
     if (sp < MCRT_LANE_STACK) S.lds[sp * 256 + S.tid] = v; else S.ovf[(size_t)(sp - MCRT_LANE_STACK) * S.ovf_stride] = v;
     sp++;
 }
-struct LaneRay { v2f oxx, oyy, ozz, ixx, iyy, izz; };     // origin and reciprocal direction, each component twice (packed operands)
+struct LaneRay { v2f oxx, oyy, ozz, ixx, iyy, izz; bool nx, ny, nz; };     // origin and reciprocal direction, each component twice (packed operands); reciprocal negative?
+
+// slab interval of one child from the distances of its three NEAR and three FAR planes
+MCRT_DEV bool slab_near_far(float nx, float ny, float nz, float fx, float fy, float fz, float tlow, float tcap, float &tmin_o)
+{
+    float tmin, tmax;
+    asm("v_max_f32 %0, %1, %2" : "=v"(nz) : "v"(nz), "v"(tlow));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmin) : "v"(nx), "v"(ny), "v"(nz));
+    asm("v_min_f32 %0, %1, %2" : "=v"(fz) : "v"(fz), "v"(tcap));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(fx), "v"(fy), "v"(fz));
+    tmin_o = tmin;
+    return tmin <= tmax;
+}
 
 // one inner node: the four children's slab tests, the nearest hit child next, the other hit children stacked in slot order
 MCRT_DEV void lane_node_step(const FrameArgs &a, const LaneStack &S, const LaneRay &r, float t_lo, float tcap, int &cur, int &sp, int sb)
@@ -835,6 +850,21 @@ MCRT_DEV void lane_node_step(const FrameArgs &a, const LaneStack &S, const LaneR
     const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
     const uint4 Q0 = N[0], Q1 = N[1], Q2 = N[2], RF = N[3];
     // six plane distances of the four children (halves -> floats, then (plane - origin) * reciprocal, two children per packed operation)
+#if MCRT_LANE_SIGN_SELECT
+    // Which plane of a slab the ray meets first follows from the SIGN of the reciprocal direction (low plane for a positive one):
+    // the packed words of the near and far planes are picked per axis (12 selects) instead of ordering the 24 distances afterwards
+    // (24 min / max).  With low <= high and monotone rounding the picked distances ARE the minimum and maximum whenever both are
+    // numbers; where one is not (origin exactly on a plane the ray runs parallel to) the interval comes out wider, never narrower --
+    // a node may be entered that min/max would have skipped, the triangle tests (unchanged) decide as before.
+    const Planes4 XN = planes4(r.nx ? Q1.z : Q0.x, r.nx ? Q1.w : Q0.y, r.oxx, r.ixx), XF = planes4(r.nx ? Q0.x : Q1.z, r.nx ? Q0.y : Q1.w, r.oxx, r.ixx);
+    const Planes4 YN = planes4(r.ny ? Q2.x : Q0.z, r.ny ? Q2.y : Q0.w, r.oyy, r.iyy), YF = planes4(r.ny ? Q0.z : Q2.x, r.ny ? Q0.w : Q2.y, r.oyy, r.iyy);
+    const Planes4 ZN = planes4(r.nz ? Q2.z : Q1.x, r.nz ? Q2.w : Q1.y, r.ozz, r.izz), ZF = planes4(r.nz ? Q1.x : Q2.z, r.nz ? Q1.y : Q2.w, r.ozz, r.izz);
+    float tn0, tn1, tn2, tn3;
+    const bool h0 = slab_near_far(XN.a.x, YN.a.x, ZN.a.x, XF.a.x, YF.a.x, ZF.a.x, t_lo, tcap, tn0);
+    const bool h1 = slab_near_far(XN.a.y, YN.a.y, ZN.a.y, XF.a.y, YF.a.y, ZF.a.y, t_lo, tcap, tn1);
+    const bool h2 = slab_near_far(XN.b.x, YN.b.x, ZN.b.x, XF.b.x, YF.b.x, ZF.b.x, t_lo, tcap, tn2);
+    const bool h3 = slab_near_far(XN.b.y, YN.b.y, ZN.b.y, XF.b.y, YF.b.y, ZF.b.y, t_lo, tcap, tn3);
+#else
     const Planes4 X0 = planes4(Q0.x, Q0.y, r.oxx, r.ixx), Y0 = planes4(Q0.z, Q0.w, r.oyy, r.iyy), Z0 = planes4(Q1.x, Q1.y, r.ozz, r.izz);
     const Planes4 X1 = planes4(Q1.z, Q1.w, r.oxx, r.ixx), Y1 = planes4(Q2.x, Q2.y, r.oyy, r.iyy), Z1 = planes4(Q2.z, Q2.w, r.ozz, r.izz);
     float tn0, tn1, tn2, tn3;
@@ -842,6 +872,7 @@ MCRT_DEV void lane_node_step(const FrameArgs &a, const LaneStack &S, const LaneR
     const bool h1 = slab_combine(X0.a.y, Y0.a.y, Z0.a.y, X1.a.y, Y1.a.y, Z1.a.y, t_lo, tcap, tn1);
     const bool h2 = slab_combine(X0.b.x, Y0.b.x, Z0.b.x, X1.b.x, Y1.b.x, Z1.b.x, t_lo, tcap, tn2);
     const bool h3 = slab_combine(X0.b.y, Y0.b.y, Z0.b.y, X1.b.y, Y1.b.y, Z1.b.y, t_lo, tcap, tn3);
+#endif
     // nearest hit child first (key unique per node: t_near bits with the slot number in the two low bits), the others are
     // stacked in slot order -- exactly the quad walk's order
     const uint32_t k0 = h0 ? ((__float_as_uint(tn0) & ~3u) | 0u) : 0xffffffffu, k1 = h1 ? ((__float_as_uint(tn1) & ~3u) | 1u) : 0xffffffffu;
@@ -1095,7 +1126,8 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
         const float tcap = fminf(1.0f, best.frac);               // best only changes in phase 2
         const bool thieves_wait = !STATS && queue_empty && __any(cur == CUR_IDLE && fresh);     // (then phase 1 is cut short: see MCRT_LANE_ADOPT_STEPS)
         int steps_left = MCRT_LANE_ADOPT_STEPS;
-        const LaneRay lr = { (v2f){ f2.x, f2.x }, (v2f){ f2.y, f2.y }, (v2f){ f2.z, f2.z }, (v2f){ inv.x, inv.x }, (v2f){ inv.y, inv.y }, (v2f){ inv.z, inv.z } };
+        const LaneRay lr = { (v2f){ f2.x, f2.x }, (v2f){ f2.y, f2.y }, (v2f){ f2.z, f2.z }, (v2f){ inv.x, inv.x }, (v2f){ inv.y, inv.y }, (v2f){ inv.z, inv.z },
+                             inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f };
         for (;;) {
             const unsigned long long inner = MCRT_ON_INNER(cur);
             if (inner == 0ull) break;
@@ -1445,7 +1477,8 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_paths(FrameArgs a)
 
         // ---- inner nodes, until enough lanes are parked on a leaf or wait for their physics ----
         const float tcap = fminf(1.0f, best.frac);
-        const LaneRay lr = { (v2f){ f2.x, f2.x }, (v2f){ f2.y, f2.y }, (v2f){ f2.z, f2.z }, (v2f){ inv.x, inv.x }, (v2f){ inv.y, inv.y }, (v2f){ inv.z, inv.z } };
+        const LaneRay lr = { (v2f){ f2.x, f2.x }, (v2f){ f2.y, f2.y }, (v2f){ f2.z, f2.z }, (v2f){ inv.x, inv.x }, (v2f){ inv.y, inv.y }, (v2f){ inv.z, inv.z },
+                             inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f };
         for (;;) {
             const unsigned long long inner = MCRT_ON_INNER(cur);
             if (inner == 0ull) break;
@@ -1720,8 +1753,8 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
                 const uint32_t mine = list_pos + (uint32_t)__popcll(want & ((1ull << (lane & ~(G - 1))) - 1ull));
                 if (!busy && mine < list_n) {
                     seg_pid = pid0 + list_base + (uint32_t)sort_list[mine];
-                    seg_n = a.seg_count[seg_pid];
                     seg_b = all_b ? 0u : b;
+                    seg_n = all_b ? a.seg_count[seg_pid] : b + 1u;           // (the list holds live slots only: no need to ask again)
                     if (seg_b < seg_n) MCRT_LOAD_SEGMENT()
                 }
                 const uint32_t nw = (uint32_t)__popcll(want);

@@ -378,6 +378,22 @@ static inline int slab(const float lo[3], const float hi[3], v3 o, v3 inv, float
     return tmin <= tmax;
 }
 
+/* the same interval for a NODE of the flattened BVH4 (walk_bvh4, which mirrors the GPU walk's visit order so that node and
+ * triangle counts can be compared): the near and far plane of each slab are picked by the sign of the reciprocal direction
+ * instead of ordering the two distances.  Identical to slab() whenever both distances are numbers (lo <= hi, monotone rounding);
+ * where one is not (origin exactly on a plane the ray runs parallel to) fmaxf / fminf drop it and the interval is the wider one.
+ * Node tests only steer the walk: the answer is decided by tri_test, which keeps slab(). */
+static inline int slab_node(const float lo[3], const float hi[3], v3 o, v3 inv, float tcap, float *tmin_o)
+{
+    float nx = ((inv.x < 0.0f ? hi[0] : lo[0]) - o.x) * inv.x, fx = ((inv.x < 0.0f ? lo[0] : hi[0]) - o.x) * inv.x;
+    float ny = ((inv.y < 0.0f ? hi[1] : lo[1]) - o.y) * inv.y, fy = ((inv.y < 0.0f ? lo[1] : hi[1]) - o.y) * inv.y;
+    float nz = ((inv.z < 0.0f ? hi[2] : lo[2]) - o.z) * inv.z, fz = ((inv.z < 0.0f ? lo[2] : hi[2]) - o.z) * inv.z;
+    float tmin = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+    float tmax = fminf(fminf(fx, fy), fminf(fz, tcap));
+    *tmin_o = tmin;
+    return tmin <= tmax;
+}
+
 /* btTriangleRaycastCallback::processTriangle restated (Bullet, not under /root/reference), preceded by the
  * triangle's own bounds test.  Rules of the contract that make the answer independent of visiting order:
  *   - a hit counts only if its fraction lies inside the ray's overlap with the triangle's padded bounds
@@ -479,8 +495,8 @@ static void walk_bvh4(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stat
             uint32_t key[4]; int32_t ref[4]; int nh = 0;
             float tcap = fminf(1.0f, best->frac);
             for (int k = 0; k < 4; k++) {
-                float hi[3] = { N[k].hix, N[k].hiy, N[k].hiz }, tn, tx;
-                int h = slab(N[k].lo, hi, from, inv, tcap, &tn, &tx) && N[k].ref != ORC_BVH4_EMPTY;
+                float hi[3] = { N[k].hix, N[k].hiy, N[k].hiz }, tn;
+                int h = slab_node(N[k].lo, hi, from, inv, tcap, &tn) && N[k].ref != ORC_BVH4_EMPTY;
                 key[k] = h ? ((f2u(tn) & ~3u) | (uint32_t)k) : 0xffffffffu; ref[k] = N[k].ref; nh += h;   /* t_near >= 0: bits order like the value */
             }
             if (nh > 0) {
