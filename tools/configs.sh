@@ -13,8 +13,8 @@ except Exception as e:
     print(n,'FAILED',e, open('gpurun_out/configs/%s.log'%n).read()[-300:])
 PY
 }
-run C1 --workload sphere --scanlines 32 --rays 64 --steps 64 --warmup 16
-run C2 --workload sphere --scanlines 128 --rays 1024 --rows 512 --steps 32 --warmup 16
-run C3 --workload liver --scanlines 128 --rays 4096 --steps 16 --warmup 4 --frames-in-flight 4
-run C4 --workload random1m --scanlines 256 --rays 8192 --steps 4 --warmup 1 --frames-in-flight 1
-run C5 --workload liver --scanlines 512 --rays 16384 --steps 2 --warmup 1 --frames-in-flight 1
+run C1 --workload sphere --scanlines 32 --rays 64 --steps 256 --warmup 256
+run C2 --workload sphere --scanlines 128 --rays 1024 --rows 512 --steps 128 --warmup 128
+run C3 --workload liver --scanlines 128 --rays 4096 --steps 32 --warmup 16 --frames-in-flight 16
+run C4 --workload random1m --scanlines 256 --rays 8192 --steps 8 --warmup 4 --frames-in-flight 4
+run C5 --workload liver --scanlines 512 --rays 16384 --steps 4 --warmup 2 --frames-in-flight 2

@@ -17,6 +17,7 @@ def last_json(path):
 
 # ---- bench lines
 bench = last_json(os.path.join(src, "bench.json"))
+FIF = int(bench["config"]["frames_in_flight"])
 drv = last_json(os.path.join(src, "bench_driver_cmd.json"))
 json.dump(bench, open(os.path.join(dst, "bench_unprofiled.json"), "w"), indent=1)
 json.dump(drv, open(os.path.join(dst, "bench_driver_cmd.json"), "w"), indent=1)
@@ -41,9 +42,9 @@ for kernel, name in (("k_trace_lane<false", "pmc_k_trace_lane.json"), ("k_march<
     d = json.load(open(os.path.join(out, "pmc_" + tag, "summary.json")))
     p = {k: v["avg_per_launch"] for k, v in d["pmc"].items()}
     cu = p["SQ_BUSY_CU_CYCLES"] / 256
-    der = {"note": "per launch, averaged over the launches of a bench.py run (32 frames per pass); separate --pmc passes; kernels run one at a time under --pmc. "
+    der = {"note": ("per launch, averaged over the launches of a bench.py run (%d frames per pass); separate --pmc passes; kernels run one at a time under --pmc. "
                    "FETCH_SIZE / WRITE_SIZE are KiB; fabric bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md). "
-                   "SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* are quad-cycles.",
+                   "SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* are quad-cycles.") % FIF,
            "kernel_busy_cycles_per_cu": cu,
            "valu_instructions": p["SQ_INSTS_VALU"], "salu_instructions": p["SQ_INSTS_SALU"], "vmem_read_instructions": p["SQ_INSTS_VMEM_RD"], "lds_instructions": p["SQ_INSTS_LDS"],
            "valu_ipc_per_simd": p["SQ_INSTS_VALU"] / 1024 / cu,
@@ -80,7 +81,7 @@ cb = bench["cpu_baseline"]
 txt = """# profiles/round2 -- MI355X (gfx950), ROCm 7.2
 
 Workload of every file unless it says otherwise: `bench.py` defaults = synthetic 1 M random triangles, 128 scan-lines x 1024 sample
-paths per frame, 465 RF rows, max depth 10, one GPU, 32 frames in flight per pass.  Produced by `tools/profile_round.sh` on a gpurun
+paths per frame, 465 RF rows, max depth 10, one GPU, @FIF@ frames in flight per pass.  Produced by `tools/profile_round.sh` on a gpurun
 box and packaged by `tools/package_profiles.py`, which also wrote this file from the files beside it.
 
 | file | what |
@@ -90,10 +91,10 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 | `bench_unprofiled.json` | `python bench.py`: the JSON line (live PMC passes in child processes, CPU baseline, inline parity check) |
 | `bench_driver_cmd.json` | `python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command: one 20-frame pass per timed region) |
 | `pmc_bench.json` | the PMC block of `bench_unprofiled.json`, the labelled fall-back `bench.py` reads when it cannot profile itself |
-| `kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 64 --warmup 32 --no-cpu-baseline --no-latency-leg --no-pmc` (kernels overlap as in production) |
+| `kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps @FIF@ --warmup @FIF@ --no-cpu-baseline --no-latency-leg --no-pmc` (kernels overlap as in production) |
 | `kernels_standalone.txt` | the same with `MCRT_NO_OVERLAP=1`: every kernel alone on the GPU |
 | `pmc_k_trace_lane.json`, `pmc_k_march.json`, `pmc_k_shade.json` | separate `--pmc` passes (tools/pmc.sh), per-launch averages + derived figures |
-| `frame_timeline.txt`, `frame_timeline_one_frame.txt` | start / duration of every launch of one pass: 32 frames in flight, and one frame at a time |
+| `frame_timeline.txt`, `frame_timeline_one_frame.txt` | start / duration of every launch of one pass: @FIF@ frames in flight, and one frame at a time |
 | `baseline_configs.txt` | the five BASELINE.json configurations on one GPU (tools/configs.sh) |
 
 ## The two roofs (calibrated, not assumed)
@@ -112,7 +113,7 @@ line cost %.0f cycles per wave-load (%.1f B/cycle/CU) -- the TCP moves ~24 B per
 are shaped, twice that through `dword` / `dwordx2` loads of contiguous lanes.  What the walk pays per node is therefore the number of
 16-byte pieces a lane fetches: 7 with the 128-byte nodes of round 1, 4 with the 64-byte half-float nodes.
 
-## What the kernels do with them (per launch = one bounce of a 32-frame pass)
+## What the kernels do with them (per launch = one bounce of a @FIF@-frame pass)
 
 | kernel | alone | overlapped | VALU instr. | IPC / SIMD (of %.3f) | lanes active | waiting on memory | TCP lane-accesses / cycle / CU | fabric bytes |
 |---|---|---|---|---|---|---|---|---|
@@ -145,5 +146,6 @@ launch, flow at %.1f TB/s from the caches).
     bench["one_frame_at_a_time"]["ms_per_step"], r.get("frac") or 0.0, r.get("achieved") or 0.0, r["peak"],
     bench["parity_check"]["rf_bit_exact"], bench["parity_check"]["scan_lines"], cb["cores"], cb["host"]["cpu_count"], cb["cores_kept_busy"], cb["value"] / 1e6, cb["single_thread"]["value"] / 1e3,
     drv["value"] / 1e6, drv["ms_per_step"])
+txt = txt.replace("@FIF@", str(FIF))
 open(os.path.join(dst, "README.md"), "w").write(txt)
 print(txt)
