@@ -1089,6 +1089,9 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
         // atomicMin is exactly the contract's (smaller fraction, then smaller triangle id) rule -- the answer is the single walk's.
         // A launch then ends after its wavefronts' remaining WORK, not after their longest walk.  (Not in the counting build, whose
         // visit counts are those of one walk per ray.)
+        // Measured and not kept: the same hand-over BETWEEN wavefronts through tickets and entries in global memory
+        // (the heaviest wavefront's walks are chains with little to give away: its 230-odd node steps stayed, the pushes' round
+        // trips were added); one ray per four lanes at the start of a small launch; rays dealt out across the wavefronts.
         if (!STATS && queue_empty) {
             const bool thief = cur == CUR_IDLE && fresh;
             const bool donor = cur != CUR_IDLE && sp > sb && sb < MCRT_LANE_STACK;
