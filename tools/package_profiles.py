@@ -96,6 +96,7 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 | `pmc_k_trace_lane.json`, `pmc_k_march.json`, `pmc_k_shade.json` | separate `--pmc` passes (tools/pmc.sh), per-launch averages + derived figures |
 | `frame_timeline.txt`, `frame_timeline_one_frame.txt` | start / duration of every launch of one pass: @FIF@ frames in flight, and one frame at a time |
 | `baseline_configs.txt` | the five BASELINE.json configurations on one GPU (tools/configs.sh) |
+| `launch_tails.txt` | `tools/stamps.py 1024 F` with the `-DMCRT_STAMP_LITE` build for F = 1, 20, 128 frames in flight: per bounce the launch of the walk, when its queue ran dry, the wavefronts' mean start, mean and longest lifetime, node-step iterations per wavefront (mean, most) -- the ends of the launches that DESIGN.md 5.3 / 5.4 argue from (copied in by hand, not produced by profile_round.sh) |
 
 ## The two roofs (calibrated, not assumed)
 
