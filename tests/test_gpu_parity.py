@@ -352,6 +352,23 @@ def test_frames_in_flight_are_bit_identical(mcrt, orc, sphere, tex256):
     sim.close()
 
 
+def test_a_large_pass_is_bit_identical_too(mcrt, sphere, tex256):
+    """300 frames in one pass (the pass size bench.py's default sits between: 128) against one-at-a-time tracing of the first, a
+    middle and the last frame: the images must not depend on how many frames share the launches"""
+    cfg, sd = sphere
+    E, S, F = 24, 96, 300
+    tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256)
+    dev = sim.ctx.alloc(F * E * sim.R * 4)
+    sim.ctx.trace_frames(1000, F, dev)
+    batch = sim.ctx.d2h(dev, (F, E, sim.R))
+    for f in (0, 131, F - 1):
+        sim.trace(1000 + f)
+        assert np.array_equal(batch[f].view(np.uint32), sim.ctx.d2h(sim.rf_dev, (E, sim.R)).view(np.uint32)), f
+    assert not np.array_equal(batch[0].view(np.uint32), batch[1].view(np.uint32))       # (frames do differ: the random draws are keyed by frame)
+    sim.ctx.free(dev)
+    sim.close()
+
+
 def test_device_lbvh_gives_the_same_frames(mcrt, orc, tex256):
     """the BVH built on the GPU (Morton LBVH -> BVH4) is a different tree, yet hits, segments and the RF image
     are bit-identical to the host SAH tree's and to the oracle's (the closest-hit contract does not depend on the hierarchy);
