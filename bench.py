@@ -4,9 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload random1m|sphere|liver]
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one frame of the hot path over synthetic input already resident in HBM:
-clear -> trace (BVH closest-hit + interface sampling) -> RF accumulation -> [RCCL all-gather of the
-scan-line blocks when N > 1] -> PSF convolution.  Weak scaling by default (each rank traces
+A "step" is one whole B-mode frame of the hot path over synthetic input already resident in HBM
+(main.cpp:102-148): clear -> trace (BVH closest-hit + interface sampling) -> RF accumulation ->
+[RCCL all-gather of the scan-line blocks when N > 1] -> PSF convolution -> envelope -> scan
+conversion (400 x 500 image).  Weak scaling by default (each rank traces
 `--scanlines` = 128 scan-lines x 1024 sample paths; the frame has 128*N scan-lines);
 `--scanlines-total E` fixes the frame instead (strong scaling: BASELINE C4 = 256 x 8192,
 C5 = 512 x 16384 sharded over 2/4/8 GPUs).
@@ -17,7 +18,9 @@ the fewest, evenly sized passes.  Passes are DOUBLE-BUFFERED: the all-gather + P
 pass k run on a second stream beside the trace of pass k+1.  The timed region is EXACTLY K steps
 between barrier + synchronize pairs; it is repeated (at least 5 times, at least ~0.6 s in total)
 and the MEDIAN repeat is reported.  `--frames-in-flight 1` is the strict latency mode, also
-reported as `one_frame_at_a_time`.
+reported as `one_frame_at_a_time`; `sweep` is the same pass with a different probe pose in every
+frame (mcrt_trace_frames_poses: the moving probe of transducer.h:82-118).  `per_rank` carries every
+rank's trace / gather / post-processing time per step (HIP events on the streams they run on).
 
 The JSON line carries
   roofline      dominant kernel (k_trace) against the roof that binds it -- VALU issue, calibrated by
@@ -44,7 +47,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMD = 1024           # 256 CUs x 4 SIMD-32
-TRACE_KERNELS = ("k_trace_lane<false", "k_paths<false", "k_trace<false")   # the walk kernels of the timed build (lane walk, fused, quad walk)
+TRACE_KERNELS = ("k_trace_lane<false",)   # the walk kernel of the timed build
 
 
 def build_workload(m, name):
@@ -79,7 +82,7 @@ def parse_args():
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="BVH builder: host binned SAH (default) or the device LBVH")
     ap.add_argument("--min-time", type=float, default=0.6, help="the K-step timed region is repeated until this many seconds are covered (>= 5 repeats)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-latency-leg", action="store_true", help="skip the extra one-frame-at-a-time measurement (profiling runs)")
+    ap.add_argument("--no-latency-leg", action="store_true", help="skip the extra one-frame-at-a-time and moving-probe measurements (profiling runs)")
     ap.add_argument("--no-pmc", action="store_true", help="do not take the live rocprofv3 PMC passes (HBM traffic, VALU instructions of k_trace)")
     ap.add_argument("--no-overlap", action="store_true", help="gather + PSF on the trace stream (no double buffering)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the process rocprofv3 profiles: warm-up + one K-step region, nothing else
@@ -100,40 +103,65 @@ def passes(count, F):
 
 
 class Pipeline:
-    """trace -> gather -> PSF over double-buffered passes.  The context's kernels run on `s_trace`; the collective and the
-    convolution of a finished pass on `s_post`, ordered by events, so they overlap the next pass's trace."""
+    """trace -> gather -> PSF -> envelope -> scan conversion over double-buffered passes.  The context's trace kernels run on
+    `s_trace`; the collective and the post-processing of a finished pass on `s_post`, ordered by events, so they overlap the
+    next pass's trace.  Every stage of every pass is bracketed by HIP events on the stream it runs on (`times()`)."""
 
-    def __init__(self, torch, dist, ctx, psf, rank, world, E, e0, e1, R, F, backend, overlap):
+    OUT_ROWS, OUT_COLS = 400, 500           # rf_image's scan-converted image (main.cpp:33 via rfimage.h:183-215)
+
+    def __init__(self, torch, dist, ctx, psf, rank, world, E, e0, e1, R, F, backend, overlap, poses=None):
         from mcray_tracing_amd.dist import gather_rf
         self.torch, self.dist, self.ctx, self.psf, self.gather_rf = torch, dist, ctx, psf, gather_rf
         self.rank, self.world, self.E, self.e0, self.e1, self.R, self.F, self.backend = rank, world, E, e0, e1, R, F, backend
         self.s_trace = torch.cuda.Stream()
         self.s_post = torch.cuda.Stream() if overlap else self.s_trace
         self.buf = [torch.zeros((F, e1 - e0, R), dtype=torch.float32, device="cuda") for _ in range(2)]
+        self.bmode = [torch.zeros((F, self.OUT_ROWS, self.OUT_COLS), dtype=torch.float32, device="cuda") for _ in range(2)] if rank == 0 else None
         self.ev_traced = [torch.cuda.Event() for _ in range(2)]
         self.ev_posted = [torch.cuda.Event() for _ in range(2)]
-        self.frames = None          # the last pass's gathered + convolved images [nf][E][R] (rank 0)
+        self.frames = None          # the last pass's gathered + convolved + enveloped images [nf][E][R] (rank 0)
+        self.images = None          # ... and its scan-converted B-mode images [nf][400][500] (rank 0)
         self.last = (0, 0)          # (first frame id, frames) of the last pass
         self.k = 0
+        self.poses = poses          # (pos, dir) device tensors [F][E][3]: a probe pose per frame of a pass (the moving-probe leg)
+        self.marks = []             # per pass: five timing events (trace start/end on s_trace; gather start, gather end, post end on s_post)
+        self.timing = False
         ctx.set_stream(self.s_trace.cuda_stream)
+
+    def post(self, frames, nf, out):
+        """main.cpp:146-148 on the nf gathered frames [nf][E][R] (in place) -> out [nf][400][500], on the current stream of the context"""
+        self.ctx.convolve_frames(frames, nf, self.E, self.R, self.psf.axial_kernel, self.psf.lateral_kernel)
+        self.ctx.envelope_frames(frames, nf, self.E, self.R)
+        self.ctx.scan_convert_frames(frames, nf, self.E, self.R, out, out_rows=self.OUT_ROWS, out_cols=self.OUT_COLS)
 
     def run_pass(self, frame, nf):
         torch, i = self.torch, self.k & 1
         self.k += 1
         rf = self.buf[i]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if self.timing else None
         self.s_trace.wait_event(self.ev_posted[i])              # the pass that used this buffer two passes ago is done with it
         self.ctx.set_stream(self.s_trace.cuda_stream)
-        self.ctx.trace_frames(frame, nf, rf, self.e0, self.e1)
+        if ev: ev[0].record(self.s_trace)
+        if self.poses is not None:
+            self.ctx.trace_frames_poses(frame, self.poses[0][:nf], self.poses[1][:nf], rf, self.e0, self.e1)
+        else:
+            self.ctx.trace_frames(frame, nf, rf, self.e0, self.e1)
+        if ev: ev[1].record(self.s_trace)
         self.ev_traced[i].record(self.s_trace)
         self.s_post.wait_event(self.ev_traced[i])
         with torch.cuda.stream(self.s_post):
-            # ONE collective per pass (RCCL all-gather over xGMI of the [nf][E/N][R] blocks), then the PSF on the gathered frames
+            # ONE collective per pass (RCCL all-gather over xGMI of the [nf][E/N][R] blocks), then the rest of the B-mode frames on rank 0
+            if ev: ev[2].record(self.s_post)
             frames = self.gather_rf(rf[:nf], self.E, self.R, self.dist if self.world > 1 else None)
+            if ev: ev[3].record(self.s_post)
             if self.rank == 0:
                 self.ctx.set_stream(self.s_post.cuda_stream)
-                self.ctx.convolve_frames(frames, nf, self.E, self.R, self.psf.axial_kernel, self.psf.lateral_kernel)
+                self.post(frames, nf, self.bmode[i])
                 self.ctx.set_stream(self.s_trace.cuda_stream)
+                self.images = self.bmode[i][:nf]
+            if ev: ev[4].record(self.s_post)
             self.frames = frames
+        if ev: self.marks.append(ev)
         self.last = (frame, nf)
         self.ev_posted[i].record(self.s_post)
 
@@ -148,6 +176,15 @@ class Pipeline:
         if self.world > 1:
             self.dist.barrier()
         self.torch.cuda.synchronize()
+        self.ctx.synchronize()          # (raises if a persistent kernel's watchdog abandoned a launch: a number must not come from a broken frame)
+
+    def times(self, steps):
+        """ms per step of this rank's trace / gather / post-processing over the passes recorded since `timing` was switched on"""
+        t = {"trace_ms": 0.0, "gather_ms": 0.0, "post_ms": 0.0}
+        for ev in self.marks:
+            t["trace_ms"] += ev[0].elapsed_time(ev[1]); t["gather_ms"] += ev[2].elapsed_time(ev[3]); t["post_ms"] += ev[3].elapsed_time(ev[4])
+        self.marks = []
+        return {k: v / max(1, steps) for k, v in t.items()}
 
 
 def main():
@@ -218,14 +255,19 @@ def main():
     # Algorithmic bytes (adapted to the BVH4 nodes the walk reads: 64 B with half-float boxes for the lane-per-ray
     # walk, 128 B for the quad walk).  The dominant kernel is the walk, launched once per bounce and pass: per closest-hit query
     # nodes*64 B + triangles*48 B + the 32-B ray read and 32-B hit record written.
-    node_bytes = 128 if os.environ.get("MCRT_QUAD_WALK") else 64
+    node_bytes = 64
     trace_bytes_frame = (st["nodes_visited"] * node_bytes + st["tris_tested"] * 48 + st["queries"] * 64) / K
     # the rest of the frame, for the record: 64-B segment written + read, 8-B texture gather per RF step, RF block + bins
     other_bytes_frame = (st["segments"] * 128 + st["rf_steps"] * 8) / K + E_local * R * (4 + 8)
 
     # ---- the timed region: EXACTLY K steps between barrier + synchronize pairs, repeated; the median repeat is reported ----
-    pipe.run_steps(1000, W)
+    # (warm-up: at least W steps, rounded up to whole timed regions, so that the first timed repeat finds every buffer at its size)
+    W_run = -(-max(W, 1) // K) * K
+    for w0 in range(0, W_run, K):
+        pipe.run_steps(1000 + w0, K)
     ctx.enable_timing(True); ctx.kernel_time(reset=True)
+    pipe.sync()
+    pipe.timing = True
     reps, total, n_rep = [], 0.0, 0
     while n_rep < 5 or (total < args.min_time and n_rep < 200):
         pipe.sync()
@@ -240,6 +282,12 @@ def main():
         reps.append(dt); total += dt; n_rep += 1
     k_ms, k_n = ctx.kernel_time(reset=True)                    # HIP events around every k_trace launch, on the launching stream
     ctx.enable_timing(False)
+    pipe.timing = False
+    mine = dict(pipe.times(K * n_rep), rank=rank, scan_lines=[e0, e1])
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     dt = statistics.median(reps)
     launches_per_frame = k_n / (K * n_rep)                     # max_depth bounces / frames per pass
     alg_bytes = trace_bytes_frame / launches_per_frame
@@ -251,17 +299,19 @@ def main():
             f0, nf = pipe.last
             torch.cuda.synchronize()                               # (rank 0 only: no collective here)
             alone = torch.zeros((nf, E, R), dtype=torch.float32, device="cuda")
+            alone_img = torch.zeros((nf, pipe.OUT_ROWS, pipe.OUT_COLS), dtype=torch.float32, device="cuda")
             ctx.set_stream(pipe.s_trace.cuda_stream)
             ctx.trace_frames(f0, nf, alone, 0, E)
-            ctx.convolve_frames(alone, nf, E, R, psf.axial_kernel, psf.lateral_kernel)
+            pipe.post(alone, nf, alone_img)
             torch.cuda.synchronize()
-            gather_check = {"equal": bool(torch.equal(alone.view(torch.int32), pipe.frames.view(torch.int32))), "frames": nf, "first_frame": f0,
-                                   "scan_lines": E, "ranks": world, "backend": args.backend, "nonzero": int(torch.count_nonzero(alone).item())}
+            gather_check = {"equal": bool(torch.equal(alone.view(torch.int32), pipe.frames.view(torch.int32)) and torch.equal(alone_img.view(torch.int32), pipe.images.view(torch.int32))),
+                            "frames": nf, "first_frame": f0, "scan_lines": E, "ranks": world, "backend": args.backend,
+                            "nonzero": int(torch.count_nonzero(alone).item()), "nonzero_bmode": int(torch.count_nonzero(alone_img).item())}
         rays = E * S * K
         alg_gbs = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         pass_sizes = passes(K, F)
         out = {
-            "metric": "rays/sec (Monte-Carlo sample paths traced + accumulated + PSF-convolved per second)",
+            "metric": "rays/sec (Monte-Carlo sample paths traced + accumulated into whole B-mode frames: PSF, envelope, scan conversion)",
             "value": rays / dt, "unit": "rays/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "frames_per_sec": K / dt, "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -269,9 +319,11 @@ def main():
                        "scan_lines_total": E, "rays_per_scan_line": S, "triangles": int(sd.n_tri), "parallelism": "scanline-shard x%d" % world,
                        "frames_in_flight": F, "passes_per_timed_region": pass_sizes, "timed_region_repeats": n_rep,
                        "timed_seconds_total": total, "repeat_ms_per_step_min_median_max": [min(reps) / K * 1e3, dt / K * 1e3, max(reps) / K * 1e3],
-                       "overlap_gather_psf_with_next_trace": not args.no_overlap, "bvh_builder": args.bvh, "bvh_build_s": round(t_bvh, 3)},
+                       "overlap_gather_psf_with_next_trace": not args.no_overlap, "bvh_builder": args.bvh, "bvh_build_s": round(t_bvh, 3),
+                       "warmup_steps_run": W_run, "step": "clear, trace, accumulate, [all-gather], PSF, envelope, scan conversion to %dx%d" % (pipe.OUT_ROWS, pipe.OUT_COLS)},
+            "ranks_seen": world, "per_rank": per_rank,
         }
-        roof = {"kernel": "k_trace", "kernel_ms": k_ms, "launches": k_n, "launches_per_frame": launches_per_frame,
+        roof = {"kernel": "k_trace_lane<false>", "kernel_ms": k_ms, "launches": k_n, "launches_per_frame": launches_per_frame,
                 "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps_cache_served": alg_gbs, "node_bytes": node_bytes,
                 "trace_bytes_per_frame": trace_bytes_frame, "other_stage_bytes_per_frame": other_bytes_frame,
                 "per_frame": {k: v / K for k, v in st.items()}}
@@ -279,7 +331,7 @@ def main():
         if world == 1 and not args.no_pmc:
             pmc = live_pmc(args)
         if pmc is None:
-            pmc = committed_pmc(args, pass_sizes)
+            pmc = committed_pmc(args, pass_sizes, roof["per_frame"]["queries"] / launches_per_frame)
         roof.update(roofline_from(pmc, k_ms, alg_gbs))
         out["roofline"] = roof
         if world == 1 and F > 1 and not args.no_latency_leg:
@@ -292,6 +344,20 @@ def main():
                 pipe.sync(); lat.append(time.perf_counter() - t1)
             dt1 = statistics.median(lat)
             out["one_frame_at_a_time"] = {"value": E * S * K / dt1, "unit": "rays/s", "ms_per_step": dt1 / K * 1e3, "frames_per_sec": K / dt1}
+            # the moving probe: every frame of a pass with its own pose (a 30-degree sweep about the probe's axis over the pass, transducer.h:82-118)
+            sweep = [m.Transducer(E, position=cfg["transducerPosition"], angles_deg=np.asarray(cfg["transducerAngles"], np.float64) + np.array([30.0 * f / F - 15.0, 0.0, 0.0]))
+                     for f in range(F)]
+            pipe.poses = (torch.from_numpy(np.stack([t.pos for t in sweep])).cuda(), torch.from_numpy(np.stack([t.dir for t in sweep])).cuda())
+            pipe.run_steps(3000, K)
+            lat = []
+            for _ in range(3):
+                pipe.sync(); t1 = time.perf_counter()
+                pipe.run_steps(0, K)
+                pipe.sync(); lat.append(time.perf_counter() - t1)
+            pipe.poses = None
+            dts = statistics.median(lat)
+            out["sweep"] = {"value": E * S * K / dts, "unit": "rays/s", "ms_per_step": dts / K * 1e3, "frames_per_sec": K / dts, "frames_in_flight": F,
+                            "what": "the timed region with a different probe pose in every frame of a pass (mcrt_trace_frames_poses)"}
         if world == 1 and not args.no_cpu_baseline:
             # frame 0 of the timed workload, traced the way the timed region traces it (first pass), before the PSF
             ctx.set_stream(pipe.s_trace.cuda_stream)
@@ -310,7 +376,7 @@ def main():
 
 # ------------------------------------------------------------------------------------------------ roofline
 def valu_calibration():
-    """profiles/round2/valu_roof.json (tools/valu_roof.hip on the MI355X): the VALU issue ceiling in wave-instructions per
+    """profiles/round2/valu_roof.json (tools/valu_roof.hip on the MI355X; the tool and the chip have not changed since): the VALU issue ceiling in wave-instructions per
     cycle and SIMD.  It depends on the instruction class (0.24-0.29 for fp32 fma / min3 / packed / DPP / compare-select streams,
     0.45 for plain integer adds), so the roof the walk is priced against is the one measured for ITS mix: the register-only part of
     a BVH4 node step (packed subtract/multiply, min/max/min3/max3, compares, selects, integer key work) at the walk's occupancy
@@ -334,10 +400,16 @@ def roofline_from(pmc, k_ms, alg_gbs):
     cal = valu_calibration()
     peak = N_SIMD * cal["ipc_per_simd"] * cal["clock_ghz"]            # G wave-instructions / s
     r = {"bound": "valu", "unit": "Ginstr/s", "peak": peak, "peak_source": cal,
+         "peak_is": "the issue rate of a register-only replica of this kernel's node step (tools/valu_roof.hip), NOT the architectural rate: see frac_vs_*",
          "hbm_peak_GBps": HBM_PEAK_GBS, "algorithmic_over_hbm_peak": alg_gbs / HBM_PEAK_GBS}
     if pmc and pmc.get("valu_instructions_per_launch") and k_ms > 0:
         ach = pmc["valu_instructions_per_launch"] / (k_ms * 1e-3) / 1e9
-        r.update({"achieved": ach, "frac": ach / peak})
+        r.update({"achieved": ach, "frac": ach / peak, "frac_of_calibrated_mix": ach / peak,
+                  "frac_vs_best_class": ach / (N_SIMD * cal.get("best_class_ipc_per_simd", 0.449) * cal["clock_ghz"]),        # plain integer adds: the best class measured
+                  "frac_vs_architectural": ach / (N_SIMD * 0.5 * cal["clock_ghz"]),                                       # MI355X_MICROARCH.md: 2 cycles per wave64 instruction
+                  "derived": bool(pmc.get("derived"))})
+        if pmc.get("lane_utilisation") is not None:
+            r["valu_lane_utilisation"] = pmc["lane_utilisation"]
     else:
         r.update({"achieved": None, "frac": None})
     if pmc and pmc.get("traffic_bytes_per_launch") is not None and k_ms > 0:
@@ -361,8 +433,7 @@ def _pmc_rows(d):
                     break
     if not per:
         return {}, None
-    # the dominant walk kernel: bounce 0's shared walk also runs k_trace_lane in the fused pipeline, with few launches
-    name = max(per, key=lambda k: (k == "k_paths<false", max(len(v) for v in per[k].values())))
+    name = max(per, key=lambda k: max(len(v) for v in per[k].values()))
     return per[name], name
 
 
@@ -380,7 +451,8 @@ def live_pmc(args):
     tmp = tempfile.mkdtemp(prefix="mcrt_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for name, ctrs in (("sq", ["SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES", "SQ_WAVES", "SQ_INSTS_VMEM_RD"]), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+        for name, ctrs in (("sq", ["SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES", "SQ_WAVES", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"]),
+                           ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
             d = os.path.join(tmp, name)
             r = subprocess.run([exe, "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
@@ -399,25 +471,33 @@ def live_pmc(args):
         return {"source": "live: rocprofv3 --pmc child passes of this command (same pass sizes), per launch of the walk kernel", "kernel": got["kernel"],
                 "launches_profiled": got["SQ_INSTS_VALU"][1],
                 "valu_instructions_per_launch": got["SQ_INSTS_VALU"][0], "busy_cu_cycles_per_launch": got["SQ_BUSY_CU_CYCLES"][0] / 256.0,
-                "vmem_read_instructions_per_launch": got["SQ_INSTS_VMEM_RD"][0],
+                "vmem_read_instructions_per_launch": got["SQ_INSTS_VMEM_RD"][0], "salu_instructions_per_launch": got["SQ_INSTS_SALU"][0],
+                "lane_utilisation": got["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * got["SQ_ACTIVE_INST_VALU"][0]) if got["SQ_ACTIVE_INST_VALU"][0] else None,
                 "fetch_size_kib": got["FETCH_SIZE"][0], "write_size_kib": got["WRITE_SIZE"][0],
                 "traffic_bytes_per_launch": (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0}
     except KeyError:
         return None
 
 
-def committed_pmc(args, pass_sizes):
-    """fallback when no live pass could be taken: the committed passes, ONLY when they were taken on this configuration and
-    pass size -- labelled as such"""
+def committed_pmc(args, pass_sizes, queries_per_launch):
+    """Fallback when no live pass can be taken (N > 1: rocprofv3 cannot wrap one rank of a torchrun job from inside it): the
+    committed single-GPU passes of the same per-GPU workload.  The per-launch counters are used as they are when the pass sizes
+    match; otherwise the walk's VALU instructions are DERIVED as the committed instructions per closest-hit query x the queries this
+    run counted per launch (labelled `derived`), and the fabric bytes are left out."""
     try:
-        with open(os.path.join(ROOT, "profiles", "round2", "pmc_bench.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "round3", "pmc_bench.json")) as f:
             d = json.load(f)
-        key = [args.workload, args.scanlines, args.scanlines_total, args.rays, args.rows, args.gpus, pass_sizes]
-        if d.get("config_key") != key:
+        key = d.get("config_key")
+        if key[:1] != [args.workload] or key[3:5] != [args.rays, args.rows]:
             return None
         p = dict(d["pmc"])
-        p["source"] = "file: profiles/round2/pmc_bench.json (%s)" % d.get("taken_at", "?")
-        return p
+        if key == [args.workload, args.scanlines, args.scanlines_total, args.rays, args.rows, args.gpus, pass_sizes]:
+            p["source"] = "file: profiles/round3/pmc_bench.json (%s)" % d.get("taken_at", "?")
+            return p
+        per_query = d["valu_instructions_per_query"]
+        return {"source": "derived: profiles/round3/pmc_bench.json instructions per closest-hit query (%.1f, N = 1) x the %.0f queries per launch counted in this run" % (per_query, queries_per_launch),
+                "derived": True, "kernel": p.get("kernel"), "valu_instructions_per_launch": per_query * queries_per_launch,
+                "lane_utilisation": p.get("lane_utilisation"), "traffic_bytes_per_launch": None}
     except Exception:
         return None
 

@@ -11,6 +11,7 @@
  *   accumulation loop + rf_image::add_echo     main.cpp:106-144, rfimage.h:33-40 -> (fused in mcrt_trace_frame)
  *   rf_image.convolve(psf)                     main.cpp:146, rfimage.h:93-123 -> mcrt_convolve
  *   rf_image.envelope() / postprocess()        main.cpp:147-148, rfimage.h:54-91,125-140 -> mcrt_envelope / mcrt_scan_convert
+ *   transducer<N>::update() between frames     transducer.h:82-118, main.cpp:100 -> mcrt_set_transducer, mcrt_trace_frames_poses
  * A maintainer of the reference replaces main.cpp:102-148 with the calls shown in INTEGRATION.md.
  *
  * Conventions: every function returns 0 on success or a negative mcrt_status; the message is
@@ -154,6 +155,13 @@ int mcrt_trace_frame(mcrt_ctx *ctx, uint32_t frame_id, uint32_t e_begin, uint32_
  * Limits (MCRT_ERR_LIMIT beyond them): n_frames <= 1024 and n_frames x scan-lines x samples <= 2^27 paths per pass (a path takes
  * about 700 bytes of work buffers). */
 int mcrt_trace_frames(mcrt_ctx *ctx, uint32_t frame_id, uint32_t n_frames, uint32_t e_begin, uint32_t e_end, float *rf_dev);
+/* The same pass with a probe pose PER FRAME: pos / dir are [n_frames][E][3] tables (host or device memory), frame f of the pass is
+ * traced from the elements pos[f], dir[f] -- the moving probe the reference's loop is built for (transducer<N>::update(),
+ * transducer.h:82-118; inputmanager.cpp:117-121; the frame loop main.cpp:92-152 reads the transducer anew every frame).  Each image is
+ * bit-identical to mcrt_set_transducer(pos[f], dir[f]) followed by mcrt_trace_frame(frame_id + f).  The context's own transducer
+ * (mcrt_set_transducer) is neither needed nor changed. */
+int mcrt_trace_frames_poses(mcrt_ctx *ctx, uint32_t frame_id, uint32_t n_frames, uint32_t e_begin, uint32_t e_end,
+                            const float *pos /*[F][E][3]*/, const float *dir /*[F][E][3]*/, float *rf_dev);
 /* same, and additionally returns per-path data to HOST buffers (any may be NULL); synchronous.
  * hits [ne][S][B] int32 (-1 miss, -2 not cast); segs [ne][S][B]; seg_count [ne][S]. */
 int mcrt_trace_frame_debug(mcrt_ctx *ctx, uint32_t frame_id, uint32_t e_begin, uint32_t e_end, float *rf_dev,
@@ -170,10 +178,15 @@ int mcrt_convolve_frames(mcrt_ctx *ctx, float *rf_dev, uint32_t n_frames, uint32
                          const float *axial, uint32_t n_ax, const float *lateral, uint32_t n_lat);
 /* rf_image::envelope (rfimage.h:54-91) in place on a device image [E][R] */
 int mcrt_envelope(mcrt_ctx *ctx, float *rf_dev, uint32_t n_elements, uint32_t n_rows);
+/* the same on the n_frames images [n_frames][E][R] of a pass (main.cpp:147 once per frame), one launch */
+int mcrt_envelope_frames(mcrt_ctx *ctx, float *rf_dev, uint32_t n_frames, uint32_t n_elements, uint32_t n_rows);
 /* rf_image::postprocess scan conversion (rfimage.h:125-140,183-215), exact bilinear;
  * out_dev float [out_rows][out_cols] */
 int mcrt_scan_convert(mcrt_ctx *ctx, const float *rf_dev, uint32_t n_elements, uint32_t n_rows,
                       double radius_mm, double total_angle_rad, float *out_dev, uint32_t out_rows, uint32_t out_cols);
+/* the same on the n_frames images of a pass (main.cpp:148 once per frame), one launch; out_dev float [n_frames][out_rows][out_cols] */
+int mcrt_scan_convert_frames(mcrt_ctx *ctx, const float *rf_dev, uint32_t n_frames, uint32_t n_elements, uint32_t n_rows,
+                             double radius_mm, double total_angle_rad, float *out_dev, uint32_t out_rows, uint32_t out_cols);
 
 /* device [E][R]  ->  host [R][E] row-major (the cv::Mat layout of rfimage.h:217); synchronous */
 int mcrt_export_rf(mcrt_ctx *ctx, const float *rf_dev, uint32_t n_elements, uint32_t n_rows, float *host_rows_by_cols);

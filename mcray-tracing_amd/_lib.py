@@ -57,7 +57,7 @@ assert NODE_DTYPE.itemsize == 64 and SEGMENT_DTYPE.itemsize == 64 and C.sizeof(B
 # every symbol include/mcrt.h declares (tests/test_abi.py checks the .so exports each one)
 SYMBOLS = ["mcrt_last_error", "mcrt_version", "mcrt_device_count", "mcrt_create", "mcrt_destroy", "mcrt_set_stream",
            "mcrt_synchronize", "mcrt_default_params", "mcrt_set_params", "mcrt_get_params", "mcrt_import_rf", "mcrt_set_bvh_builder", "mcrt_upload_scene", "mcrt_update_triangles", "mcrt_refit_triangles", "mcrt_upload_texture",
-           "mcrt_set_transducer", "mcrt_trace_frame", "mcrt_trace_frames", "mcrt_trace_frame_debug", "mcrt_cast_rays", "mcrt_convolve", "mcrt_convolve_frames",
+           "mcrt_set_transducer", "mcrt_trace_frame", "mcrt_trace_frames", "mcrt_trace_frames_poses", "mcrt_envelope_frames", "mcrt_scan_convert_frames", "mcrt_trace_frame_debug", "mcrt_cast_rays", "mcrt_convolve", "mcrt_convolve_frames",
            "mcrt_envelope", "mcrt_scan_convert", "mcrt_export_rf", "mcrt_alloc", "mcrt_free", "mcrt_memcpy_d2h",
            "mcrt_memcpy_h2d", "mcrt_enable_stats", "mcrt_get_stats", "mcrt_enable_timing", "mcrt_get_kernel_time",
            "mcrt_build_bvh", "mcrt_free_bvh", "mcrt_get_bvh", "mcrt_build_bvh4", "mcrt_free_bvh4", "mcrt_get_bvh4", "mcrt_row_thresholds", "mcrt_generate_texture", "mcrt_psf_kernels",
@@ -94,6 +94,8 @@ def load_library():
         "mcrt_convolve": [vp, vp, u32, u32, vp, u32, vp, u32], "mcrt_envelope": [vp, vp, u32, u32],
         "mcrt_scan_convert": [vp, vp, u32, u32, C.c_double, C.c_double, vp, u32, u32],
         "mcrt_convolve_frames": [vp, vp, u32, u32, u32, vp, u32, vp, u32],
+        "mcrt_trace_frames_poses": [vp, u32, u32, u32, u32, vp, vp, vp], "mcrt_envelope_frames": [vp, vp, u32, u32, u32],
+        "mcrt_scan_convert_frames": [vp, vp, u32, u32, u32, C.c_double, C.c_double, vp, u32, u32],
         "mcrt_set_bvh_builder": [vp, i32], "mcrt_update_triangles": [vp, vp, u32], "mcrt_refit_triangles": [vp, vp, u32],
         "mcrt_export_rf": [vp, vp, u32, u32, vp], "mcrt_alloc": [vp, C.c_size_t, C.POINTER(vp)], "mcrt_free": [vp, vp],
         "mcrt_memcpy_d2h": [vp, vp, vp, C.c_size_t], "mcrt_memcpy_h2d": [vp, vp, vp, C.c_size_t],

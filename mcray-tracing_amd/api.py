@@ -217,6 +217,17 @@ class Context:
         e_end = self.params.n_elements if e_end is None else e_end
         check(self.L.mcrt_trace_frames(self.h, frame_id, n_frames, e_begin, e_end, ptr(rf_dev)))
 
+    def trace_frames_poses(self, frame_id, pos, dirs, rf_dev, e_begin=0, e_end=None, n_frames=None):
+        """a pass with a probe pose per frame: pos / dirs [F][E][3] (numpy arrays, CUDA torch tensors, or raw device pointers with
+        n_frames given); rf_dev [F][e_end-e_begin][R]"""
+        e_end = self.params.n_elements if e_end is None else e_end
+        if isinstance(pos, np.ndarray):
+            pos = np.ascontiguousarray(pos, np.float32); dirs = np.ascontiguousarray(dirs, np.float32)
+        if n_frames is None:
+            n_frames = pos.shape[0]
+            assert tuple(pos.shape) == (n_frames, self.params.n_elements, 3) and tuple(dirs.shape) == tuple(pos.shape)
+        check(self.L.mcrt_trace_frames_poses(self.h, frame_id, n_frames, e_begin, e_end, ptr(pos), ptr(dirs), ptr(rf_dev)))
+
     def trace_frame_debug(self, frame_id, rf_dev, e_begin=0, e_end=None, want_hits=True, want_segs=False):
         e_end = self.params.n_elements if e_end is None else e_end
         ne, S, B = e_end - e_begin, self.params.n_samples, self.params.max_depth
@@ -245,6 +256,12 @@ class Context:
 
     def envelope(self, rf_dev, n_elements, n_rows):
         check(self.L.mcrt_envelope(self.h, ptr(rf_dev), n_elements, n_rows))
+
+    def envelope_frames(self, rf_dev, n_frames, n_elements, n_rows):
+        check(self.L.mcrt_envelope_frames(self.h, ptr(rf_dev), n_frames, n_elements, n_rows))
+
+    def scan_convert_frames(self, rf_dev, n_frames, n_elements, n_rows, out_dev, radius_mm=30.0, total_angle=1.0471975511965976, out_rows=400, out_cols=500):
+        check(self.L.mcrt_scan_convert_frames(self.h, ptr(rf_dev), n_frames, n_elements, n_rows, radius_mm, total_angle, ptr(out_dev), out_rows, out_cols))
 
     def scan_convert(self, rf_dev, n_elements, n_rows, out_dev, radius_mm=30.0, total_angle=1.0471975511965976, out_rows=400, out_cols=500):
         check(self.L.mcrt_scan_convert(self.h, ptr(rf_dev), n_elements, n_rows, radius_mm, total_angle, ptr(out_dev), out_rows, out_cols))

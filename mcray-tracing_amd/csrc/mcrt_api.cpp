@@ -55,8 +55,10 @@ static Consts derive_consts(const mcrt_params &p)
 struct Work {
     hipStream_t stream = nullptr, side[MCRT_SIDE_STREAMS] = {};   // k_march of bounce b runs on side[b % n] (n = 1 unless MCRT_MARCH_STREAMS says otherwise)
     hipEvent_t ev_bounce[MCRT_MAX_BOUNCES] = {}, ev_join[MCRT_SIDE_STREAMS] = {}, ev_done = nullptr;
-    float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr;
-    unsigned long long *d_key0 = nullptr, *d_key1 = nullptr;
+    float4 *d_recs = nullptr;                                  // [paths][6] path records (mcrt_kernels.hip)
+    uint2 *d_tmp = nullptr;                                    // [paths] k_shade -> k_place
+    uint32_t *d_cls = nullptr; uint32_t cls_cap = 0, hist_bits = 0, cls_lines = 0;   // bundle tables: counts [cls_cap] | fill [cls_cap]
+    int *d_stack_ovf = nullptr; size_t ovf_cap = 0;            // traversal-stack overflow of THIS work set's walk (its launches run beside the other groups')
     uint32_t *d_q = nullptr, *d_counts = nullptr, *d_seg_count = nullptr, *d_cursors = nullptr;
     mcrt_segment *d_segs = nullptr; size_t segs_cap = 0;       // [paths][depth], only for the callers that ask for segments
     int32_t *d_hits = nullptr; size_t hits_cap = 0;            // [paths][depth], only for the callers that ask for hit indices
@@ -66,9 +68,10 @@ struct Work {
 // tuning knobs from the environment, read ONCE at mcrt_create (never on the frame path)
 struct Knobs {
     uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 4096;
-    bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false, quad_walk = false;
-    int pipeline = 1;                          // 1 = wavefront (a launch per stage and bounce: the default), 2 = fused path kernel, 0 = fused for passes of at most fused_max_paths
-    uint32_t fused_groups = 1, fused_max_paths = 1u << 20;
+    bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false;
+    int sort_bits = -1;                        // >= 0: queues SORTED by bundle = (scan-line, that many reflect / refract decisions at most; 0: by scan-line); -1: order-preserving compaction (the default)
+    uint32_t march_cus = 0;                    // CUs the accumulation's side stream is confined to (0 = no mask); the mask's bit order is the driver's
+    bool main_mask = false;                    // with march_cus: the walk / shade chain runs on its own stream confined to the OTHER CUs
 };
 static Knobs read_knobs()
 {
@@ -80,10 +83,9 @@ static Knobs read_knobs()
     if (const char *e = getenv("MCRT_MARCH_BLOCKS")) { int v = atoi(e); if (v >= 1) k.march_blocks = (uint32_t)v; }
     k.no_overlap = getenv("MCRT_NO_OVERLAP") != nullptr; k.no_priority = getenv("MCRT_NO_PRIORITY") != nullptr;
     k.no_fast_div = getenv("MCRT_NO_FAST_DIV") != nullptr; k.no_lean = getenv("MCRT_NO_LEAN") != nullptr;
-    k.quad_walk = getenv("MCRT_QUAD_WALK") != nullptr;
-    if (const char *e = getenv("MCRT_PIPELINE")) { if (!strcmp(e, "wavefront")) k.pipeline = 1; else if (!strcmp(e, "fused")) k.pipeline = 2; else if (!strcmp(e, "auto")) k.pipeline = 0; }
-    if (const char *e = getenv("MCRT_FUSED_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 16) k.fused_groups = (uint32_t)v; }
-    if (const char *e = getenv("MCRT_FUSED_MAX")) { long v = atol(e); if (v >= 0) k.fused_max_paths = (uint32_t)v; }       // the round-1 walk (four lanes per ray) instead of one lane per ray
+    if (const char *e = getenv("MCRT_SORT_BITS")) { int v = atoi(e); if (v >= -1 && v <= 10) k.sort_bits = v; }
+    if (const char *e = getenv("MCRT_MARCH_CUS")) { int v = atoi(e); if (v >= 0 && v <= 248) k.march_cus = (uint32_t)v; }
+    k.main_mask = getenv("MCRT_MAIN_MASK") != nullptr;
     return k;
 }
 
@@ -101,7 +103,7 @@ struct mcrt_ctx {
     uint32_t *d_error = nullptr;
     float4 *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr;
     mcrt_bvh4_node *walked_nodes = nullptr; bool walked_stale = true;   // host copy of the tree as the lane walk sees it (mcrt_get_bvh4)
-    uint4 *d_nodes_walk = nullptr; int *d_stack_ovf = nullptr;   // lane-per-ray walk: child-transposed nodes, traversal-stack overflow
+    uint4 *d_nodes_walk = nullptr; uint32_t nodes_walk_cap = 0;   // the walk's child-transposed half-float nodes
     uint4 *d_meshes = nullptr;
     uint32_t *d_tri_slot = nullptr;
     uint32_t n_mesh = 0, n_mat = 0, start_mat = 0, n_cu = 256;
@@ -114,6 +116,8 @@ struct mcrt_ctx {
     float2 *d_tex = nullptr; uint32_t tex_n = 0; bool tex_finite = false;
     // transducer
     float *d_pos = nullptr, *d_dir = nullptr; uint32_t n_el = 0;
+    const float *pose_pos = nullptr, *pose_dir = nullptr;      // set for the duration of mcrt_trace_frames_poses: device [F][E][3] per-frame probe poses
+    float *d_pose[2] = { nullptr, nullptr }; size_t pose_cap[2] = { 0, 0 };   // staging for pose tables handed over as host memory
     // accumulators
     long long *d_acc = nullptr; uint32_t *d_flags = nullptr; size_t acc_cap = 0, flag_cap = 0;
     uint32_t acc_clean_ne = 0, acc_clean_rows = 0;   // bins known to be all-zero for this shape (k_finalize leaves them so)
@@ -223,9 +227,9 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
 
 static void free_work_buffers(Work &w)
 {
-    hipFree(w.d_st0); hipFree(w.d_st1); hipFree(w.d_st2); hipFree(w.d_ray0); hipFree(w.d_ray1); hipFree(w.d_key0); hipFree(w.d_key1);
+    hipFree(w.d_recs); hipFree(w.d_tmp); hipFree(w.d_cls); w.d_cls = nullptr; w.cls_cap = 0;
     hipFree(w.d_q); hipFree(w.d_counts); hipFree(w.d_seg_count); hipFree(w.d_cursors); w.d_cursors = nullptr; hipFree(w.d_segs); hipFree(w.d_hits); hipFree(w.d_mrec);
-    w.d_st0 = w.d_st1 = w.d_st2 = w.d_ray0 = w.d_ray1 = nullptr; w.d_key0 = w.d_key1 = nullptr; w.d_q = w.d_counts = w.d_seg_count = nullptr;
+    w.d_recs = nullptr; w.d_tmp = nullptr; w.d_q = w.d_counts = w.d_seg_count = nullptr;
     w.d_segs = nullptr; w.segs_cap = 0; w.d_hits = nullptr; w.hits_cap = 0; w.d_mrec = nullptr; w.paths = 0; w.depth = 0;
 }
 
@@ -233,6 +237,7 @@ static void free_work(mcrt_ctx *c)
 {
     for (Work &w : c->work) {
         free_work_buffers(w);
+        hipFree(w.d_stack_ovf); w.d_stack_ovf = nullptr; w.ovf_cap = 0;
         for (int i = 0; i < MCRT_MAX_BOUNCES; i++) { if (w.ev_bounce[i]) hipEventDestroy(w.ev_bounce[i]); }
         for (int i = 0; i < MCRT_SIDE_STREAMS; i++) { if (w.ev_join[i]) hipEventDestroy(w.ev_join[i]); if (w.side[i]) hipStreamDestroy(w.side[i]); }
         if (w.ev_done) hipEventDestroy(w.ev_done);
@@ -256,10 +261,22 @@ static int get_work(mcrt_ctx *c, size_t g, Work **out)
     *out = &c->work[g];
     return MCRT_OK;
 }
+// a stream confined to CUs [lo, hi) of the device (hipExtStreamCreateWithCUMask; bit i of the mask = CU i in the driver's numbering)
+static int masked_stream(mcrt_ctx *c, uint32_t lo, uint32_t hi, hipStream_t *out)
+{
+    uint32_t mask[16] = {};
+    const uint32_t words = (c->n_cu + 31u) / 32u;
+    for (uint32_t i = lo; i < hi && i < c->n_cu; i++) mask[i >> 5] |= 1u << (i & 31u);
+    HIP_TRY(hipExtStreamCreateWithCUMask(out, words, mask));
+    return MCRT_OK;
+}
+
 // the stream of scan-line group g of the wavefront pipeline: group 0 runs on the context's stream, the others on their own
 static int work_stream(mcrt_ctx *c, Work &w, bool first, hipStream_t *out)
 {
-    if (first) { *out = c->stream; return MCRT_OK; }
+    const bool masked = c->knobs.march_cus && c->knobs.main_mask;
+    if (first && !masked) { *out = c->stream; return MCRT_OK; }
+    if (!w.stream && masked) { int rc = masked_stream(c, 0, c->n_cu - c->knobs.march_cus, &w.stream); if (rc) return rc; }
     if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
     *out = w.stream;
     return MCRT_OK;
@@ -268,6 +285,7 @@ static int work_stream(mcrt_ctx *c, Work &w, bool first, hipStream_t *out)
 // not queue behind k_march's (measured: k_shade took 0.4-0.7 ms instead of 0.1 ms when they did)
 static int side_stream(mcrt_ctx *c, Work &w, uint32_t i, hipStream_t *out)
 {
+    if (!w.side[i] && c->knobs.march_cus) { int rc = masked_stream(c, c->n_cu - c->knobs.march_cus, c->n_cu, &w.side[i]); if (rc) return rc; }
     if (!w.side[i]) {
         int prio_low = 0, prio_high = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
@@ -278,29 +296,27 @@ static int side_stream(mcrt_ctx *c, Work &w, uint32_t i, hipStream_t *out)
     return MCRT_OK;
 }
 
-// the lane-per-ray walk's view of the tree: child-transposed nodes (rebuilt whenever d_nodes changes) and, for trees whose
-// worst-case traversal stack exceeds the LDS part, the overflow array
+// the walk's view of the tree: child-transposed half-float nodes, rebuilt whenever d_nodes changes.  The buffer is kept while the
+// node count stays (a refit -- the per-frame path of a deforming scene -- then costs one kernel on the context's stream, no
+// allocation and no device-wide stall); nothing here synchronises: the next trace is ordered after it on the same stream.
 static int refresh_soa(mcrt_ctx *c)
 {
     c->walked_stale = true;
-    hipFree(c->d_nodes_walk); c->d_nodes_walk = nullptr;
-    hipFree(c->d_stack_ovf); c->d_stack_ovf = nullptr;
-    if (c->knobs.quad_walk || c->bvh4.n_nodes == 0) return MCRT_OK;
-    HIP_TRY(hipMalloc(&c->d_nodes_walk, 64 * (size_t)c->bvh4.n_nodes));
-    HIP_TRY(mcrt::launch_nodes_walk(c->d_nodes, c->bvh4.n_nodes, c->d_nodes_walk, c->stream));
-    const uint32_t lds_part = mcrt::lane_stack_entries();
-    if (c->bvh4.max_stack > lds_part) {
-        const uint32_t blocks = c->knobs.trace_blocks ? c->knobs.trace_blocks : c->n_cu * 5u;
-        HIP_TRY(hipMalloc(&c->d_stack_ovf, 4 * (size_t)(c->bvh4.max_stack - lds_part) * blocks * 256));
+    if (c->bvh4.n_nodes == 0) { hipFree(c->d_nodes_walk); c->d_nodes_walk = nullptr; c->nodes_walk_cap = 0; return MCRT_OK; }
+    if (c->nodes_walk_cap != c->bvh4.n_nodes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->d_nodes_walk); c->d_nodes_walk = nullptr; c->nodes_walk_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_nodes_walk, 64 * (size_t)c->bvh4.n_nodes));
+        c->nodes_walk_cap = c->bvh4.n_nodes;
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(mcrt::launch_nodes_walk(c->d_nodes, c->bvh4.n_nodes, c->d_nodes_walk, c->stream));
     return MCRT_OK;
 }
 
 static void free_scene(mcrt_ctx *c)
 {
     free(c->walked_nodes); c->walked_nodes = nullptr; c->walked_stale = true;
-    hipFree(c->d_nodes_walk); c->d_nodes_walk = nullptr; hipFree(c->d_stack_ovf); c->d_stack_ovf = nullptr;
+    hipFree(c->d_nodes_walk); c->d_nodes_walk = nullptr; c->nodes_walk_cap = 0;
     hipFree(c->d_nodes); hipFree(c->d_tris); hipFree(c->d_mats); hipFree(c->d_meshes); hipFree(c->d_tri_slot); c->d_tri_slot = nullptr;
     c->d_nodes = c->d_tris = c->d_mats = nullptr; c->d_meshes = nullptr;
     mcrt_free_bvh(&c->bvh);
@@ -316,6 +332,7 @@ extern "C" int mcrt_destroy(mcrt_ctx *c)
     free_scene(c);
     free_work(c);
     free(c->walked_nodes); c->walked_nodes = nullptr;
+    hipFree(c->d_pose[0]); hipFree(c->d_pose[1]);
     hipFree(c->d_tex); hipFree(c->d_pos); hipFree(c->d_dir); hipFree(c->d_acc); hipFree(c->d_flags); hipFree(c->d_tmp);
     hipFree(c->d_map_col); hipFree(c->d_map_row); hipFree(c->d_stats); hipFree(c->d_row_thr); hipFree(c->d_error); hipFree(c->d_mtab);
     for (auto &e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -645,15 +662,28 @@ static int check_ready(mcrt_ctx *c, uint32_t e0, uint32_t e1)
     if (!c->have_scene) return set_error(MCRT_ERR_INVALID, "no scene uploaded");
     if (!c->d_tex) return set_error(MCRT_ERR_INVALID, "no texture uploaded");
     if (c->tex_n != c->p.tex_n) return set_error(MCRT_ERR_INVALID, "texture is %u^3 but params say %u^3", c->tex_n, c->p.tex_n);
-    if (!c->d_pos) return set_error(MCRT_ERR_INVALID, "no transducer set");
-    if (c->n_el != c->p.n_elements) return set_error(MCRT_ERR_INVALID, "transducer has %u elements but params say %u", c->n_el, c->p.n_elements);
+    if (!c->pose_pos) {
+        if (!c->d_pos) return set_error(MCRT_ERR_INVALID, "no transducer set");
+        if (c->n_el != c->p.n_elements) return set_error(MCRT_ERR_INVALID, "transducer has %u elements but params say %u", c->n_el, c->p.n_elements);
+    }
     if (e0 >= e1 || e1 > c->p.n_elements) return set_error(MCRT_ERR_INVALID, "scan-line range [%u,%u) invalid for %u elements", e0, e1, c->p.n_elements);
     return MCRT_OK;
 }
 
-// out: 0 = RF image only, 1 = + hit indices, 2 = + the segment table (64 B per path and bounce: only allocated when asked for)
-static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne, int out)
+// bundle classes of a work set: (line, the last hist_bits decisions), line = the scan-line (all frames of the pass share the probe
+// pose: their rays of a scan-line are one bundle) or the (frame, scan-line) pair (a pose per frame); the class tables hold at most
+// 65536 entries (one workgroup, k_scan, sums them up), padded to the scan's 4096-entry stride
+static uint32_t bundle_hist_bits(const mcrt_ctx *c, uint32_t lines)
 {
+    uint32_t h = 0;
+    while ((int)h < c->knobs.sort_bits && ((uint64_t)lines << (h + 1)) <= 65536u) h++;
+    return h;
+}
+
+// out: 0 = RF image only, 1 = + hit indices, 2 = + the segment table (64 B per path and bounce: only allocated when asked for)
+static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne_frame, uint32_t n_frames, int out)
+{
+    const uint32_t ne = ne_frame * n_frames;
     const size_t np = (size_t)ne * c->p.n_samples;
     const uint32_t B = c->p.max_depth;
     if (out >= 2 && w.segs_cap < np * B) {
@@ -668,16 +698,37 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne, int out)
         HIP_TRY(hipMalloc(&w.d_hits, 4 * np * B));
         w.hits_cap = np * B;
     }
+    {   // traversal-stack entries beyond the LDS part, one slot per thread of THIS work set's walk launches
+        const uint32_t lds_part = mcrt::lane_stack_entries();
+        const uint32_t blocks = c->knobs.trace_blocks ? c->knobs.trace_blocks : c->n_cu * 5u;
+        const size_t need = c->bvh4.max_stack > lds_part ? (size_t)(c->bvh4.max_stack - lds_part) * blocks * 256 : 0;
+        if (need > w.ovf_cap) {
+            HIP_TRY(hipDeviceSynchronize());
+            hipFree(w.d_stack_ovf); w.d_stack_ovf = nullptr; w.ovf_cap = 0;
+            HIP_TRY(hipMalloc(&w.d_stack_ovf, 4 * need));
+            w.ovf_cap = need;
+        }
+    }
+    const uint32_t cls_lines = c->pose_pos ? ne : ne_frame, hist_bits = bundle_hist_bits(c, cls_lines);
+    const uint32_t cls_need = (uint32_t)((((uint64_t)cls_lines << hist_bits) + 4095u) & ~4095ull);
+    if (cls_need > w.cls_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        hipFree(w.d_cls); w.d_cls = nullptr; w.cls_cap = 0;
+        HIP_TRY(hipMalloc(&w.d_cls, 8 * (size_t)cls_need));
+        HIP_TRY(hipMemsetAsync(w.d_cls, 0, 8 * (size_t)cls_need, c->stream));
+        w.cls_cap = cls_need;
+    }
+    w.cls_lines = cls_lines; w.hist_bits = hist_bits;
     if (np <= w.paths && B <= w.depth) return MCRT_OK;
     HIP_TRY(hipDeviceSynchronize());
     {   // (the optional tables survive a re-allocation of the rest when they are large enough)
         mcrt_segment *sg = w.d_segs; const size_t sc = w.segs_cap; int32_t *ht = w.d_hits; const size_t hc = w.hits_cap;
-        w.d_segs = nullptr; w.d_hits = nullptr;
+        uint32_t *cl = w.d_cls; const uint32_t cc = w.cls_cap;
+        w.d_segs = nullptr; w.d_hits = nullptr; w.d_cls = nullptr;
         free_work_buffers(w);
-        w.d_segs = sg; w.segs_cap = sc; w.d_hits = ht; w.hits_cap = hc;
+        w.d_segs = sg; w.segs_cap = sc; w.d_hits = ht; w.hits_cap = hc; w.d_cls = cl; w.cls_cap = cc;
     }
-    HIP_TRY(hipMalloc(&w.d_st0, 32 * np)); HIP_TRY(hipMalloc(&w.d_st1, 32 * np)); HIP_TRY(hipMalloc(&w.d_st2, 32 * np));   // two halves: bounce parity
-    HIP_TRY(hipMalloc(&w.d_ray0, 32 * np)); HIP_TRY(hipMalloc(&w.d_ray1, 32 * np)); HIP_TRY(hipMalloc(&w.d_key0, 8 * np)); HIP_TRY(hipMalloc(&w.d_key1, 8 * np));
+    HIP_TRY(hipMalloc(&w.d_recs, 96 * np)); HIP_TRY(hipMalloc(&w.d_tmp, 8 * np));
     HIP_TRY(hipMalloc(&w.d_q, 8 * np)); HIP_TRY(hipMalloc(&w.d_seg_count, 4 * np));
     HIP_TRY(hipMalloc(&w.d_counts, 4 * (MCRT_MAX_BOUNCES + 1)));
     HIP_TRY(hipMalloc(&w.d_cursors, 4 * (size_t)MCRT_MAX_BOUNCES * MCRT_XCDS * MCRT_CURSOR_STRIDE));
@@ -690,19 +741,21 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne, int out)
 static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, uint32_t acc_e0, uint32_t acc_ne)
 {
     memset(&a, 0, sizeof a);
-    a.nodes = c->d_nodes; a.nodes_walk = c->d_nodes_walk; a.stack_ovf = c->d_stack_ovf; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
-    a.el_pos = c->d_pos; a.el_dir = c->d_dir; a.row_thr = c->d_row_thr;
+    a.nodes_walk = c->d_nodes_walk; a.stack_ovf = w.d_stack_ovf; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
+    a.el_pos = c->pose_pos ? c->pose_pos : c->d_pos; a.el_dir = c->pose_pos ? c->pose_dir : c->d_dir; a.pose_stride = c->pose_pos ? c->p.n_elements : 0u;
+    a.row_thr = c->d_row_thr;
     a.acc = c->d_acc; a.flags = c->d_flags;                 // the frame block [n_frames][acc_ne][R]; this group owns columns e0-acc_e0 ...
     a.acc_stride = acc_ne; a.acc_off = e0 - acc_e0;
-    a.st0 = w.d_st0; a.st1 = w.d_st1; a.st2 = w.d_st2; a.queue = w.d_q;
-    a.ray0 = w.d_ray0; a.ray1 = w.d_ray1; a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.cursors = w.d_cursors; a.segs = w.d_segs; a.hits = w.d_hits; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
+    a.recs = w.d_recs; a.queue = w.d_q; a.tmp = w.d_tmp;
+    a.cls_cnt = w.d_cls; a.cls_fill = w.d_cls + w.cls_cap; a.cls_cap = w.cls_cap; a.hist_bits = w.hist_bits; a.cls_lines = w.cls_lines; a.sort = c->knobs.sort_bits >= 0 ? 1u : 0u;
+    a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.cursors = w.d_cursors; a.segs = w.d_segs; a.hits = w.d_hits; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
     a.stats = c->d_stats; a.error_flag = c->d_error; a.stamps = c->d_stats + 8;
     a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
     a.e_begin = e0; a.ne_frame = e1 - e0; a.ne = (e1 - e0) * n_frames;   // n_frames consecutive frame ids traced as one pass
     a.ksplit_limit = c->knobs.ksplit_limit;   // bounces with fewer rays than this are cut into pieces (see k_trace)
     if (c->stats_on) a.ksplit_limit = 0;   // counting mode = one walk per ray, so the counts are those of a plain closest-hit walk
     for (int i = 0; i < 3; i++) { a.scene_lo[i] = c->scene_lo[i]; a.scene_hi[i] = c->scene_hi[i]; }
-    a.trace_blocks = c->knobs.trace_blocks ? c->knobs.trace_blocks : c->n_cu * 5u;   // persistent k_trace: 5 waves/SIMD = 5 four-wave workgroups per CU (1280 on the MI355X's 256 CUs)
+    a.trace_blocks = c->knobs.trace_blocks ? c->knobs.trace_blocks : (c->n_cu - (c->knobs.main_mask ? c->knobs.march_cus : 0u)) * 5u;   // persistent k_trace: 5 waves/SIMD = 5 four-wave workgroups per CU (1280 on the MI355X's 256 CUs)
     a.march_blocks = c->knobs.march_blocks;
     a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n; a.tex_mask = (c->tex_n & (c->tex_n - 1u)) == 0u ? c->tex_n - 1u : 0u;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
@@ -724,7 +777,7 @@ static uint32_t side_streams(const mcrt_ctx *c) { return c->knobs.march_streams;
 
 static int timing_events(mcrt_ctx *c, hipEvent_t *e0, hipEvent_t *e1);
 
-// one bounce of one group: k_trace + k_shade on the group's stream, k_march of the finished segments on its side stream.
+// one bounce of one group: k_trace_lane + k_shade + k_place on the group's stream, k_march of the finished segments on its side stream.
 // With timing enabled every k_trace launch (the dominant kernel) is bracketed by HIP events on the stream it is launched on.
 static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArgs &a, uint32_t b, bool accumulate, bool overlap)
 {
@@ -744,23 +797,6 @@ static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArg
         HIP_TRY(mcrt::launch_march(a, b, c->stats_on, st));
     }
     return MCRT_OK;
-}
-
-// scene::cast_rays (scene.cpp:50-183) [+ the accumulation loop] for scan-lines [e0,e1), split into `groups` independent
-// pipelines whose kernels run concurrently.  Everything is ordered after what is already queued on the context's stream, and
-// the context's stream waits for all of it.
-// Which pipeline traces a pass of `paths` sample paths.  The wavefront pipeline (a launch per stage and bounce; interface
-// physics in full wavefronts, accumulation beside the next bounce's walk) is the default at every size: measured on the
-// MI355X it beats the fused path kernel (five launches, one drain) both at 32 frames per pass (0.62 vs 1.20 ms per frame) and
-// one frame at a time (2.3 vs 3.0 ms) -- a path's bounces are a serial chain, and inside one kernel every link of it waits for
-// its wavefront's batch thresholds.  MCRT_PIPELINE=fused / auto select the fused kernel (kept: it is parity-tested and the
-// natural base for a queue-fed persistent design).
-static bool use_fused(const mcrt_ctx *c, size_t paths)
-{
-    if (!c->d_nodes_walk) return false;                     // (the fused kernel walks the child-transposed nodes)
-    if (c->knobs.pipeline == 1) return false;
-    if (c->knobs.pipeline == 2) return true;
-    return paths <= (size_t)c->knobs.fused_max_paths;
 }
 
 static int timing_events(mcrt_ctx *c, hipEvent_t *e0, hipEvent_t *e1)
@@ -783,8 +819,6 @@ static int timing_events(mcrt_ctx *c, hipEvent_t *e0, hipEvent_t *e1)
 static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, bool accumulate, uint32_t groups, int out)
 {
     const uint32_t ne = e1 - e0;
-    const bool fused = use_fused(c, (size_t)ne * n_frames * c->p.n_samples);
-    if (fused && out == 0 && !c->stats_on && groups == 1 && accumulate) groups = c->knobs.fused_groups;   // march of block g beside the paths of block g+1
     if (groups > ne) groups = ne;
     if (groups < 1) groups = 1;
     if (groups > 16) groups = 16;
@@ -794,44 +828,16 @@ static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0
     for (uint32_t g = 0; g < groups; g++) {
         int rc = get_work(c, g, &ws[g]); if (rc) return rc;
         const uint32_t b0 = e0 + (uint32_t)(((uint64_t)ne * g) / groups), b1 = e0 + (uint32_t)(((uint64_t)ne * (g + 1)) / groups);
-        rc = ensure_work(c, *ws[g], (b1 - b0) * n_frames, out); if (rc) return rc;
+        rc = ensure_work(c, *ws[g], b1 - b0, n_frames, out); if (rc) return rc;
         fill_args(c, *ws[g], args[g], frame, n_frames, b0, b1, e0, ne);
         args[g].want_segs = out >= 2 ? 1u : 0u;
         if (out < 1) args[g].hits = nullptr;
-    }
-    if (fused) {
-        // k_init -> shared bounce-0 walk -> k_paths (all bounces of every path) on the context's stream, block after block;
-        // each block's accumulation (ONE k_march over all its bounces) on its low-priority side stream beside the next block's paths
-        hipStream_t side = nullptr;
-        if (accumulate && overlap) { int rc = side_stream(c, *ws[0], 0, &side); if (rc) return rc; }     // ONE side stream: the blocks' accumulations run one after the other
-        for (uint32_t g = 0; g < groups; g++) {
-            hipStream_t st = c->stream;
-            HIP_TRY(mcrt::launch_init(args[g], st));
-            HIP_TRY(mcrt::launch_trace(args[g], 0u, c->stats_on, st));
-            hipEvent_t t0, t1;
-            { int rc = timing_events(c, &t0, &t1); if (rc) return rc; }
-            if (t0) HIP_TRY(hipEventRecord(t0, st));
-            HIP_TRY(mcrt::launch_paths(args[g], c->stats_on, st));
-            if (t1) HIP_TRY(hipEventRecord(t1, st));
-            if (accumulate && overlap) {
-                HIP_TRY(hipEventRecord(ws[g]->ev_bounce[0], st));
-                HIP_TRY(hipStreamWaitEvent(side, ws[g]->ev_bounce[0], 0));
-                HIP_TRY(mcrt::launch_march(args[g], mcrt::MCRT_ALL_BOUNCES, c->stats_on, side));
-            } else if (accumulate) {
-                HIP_TRY(mcrt::launch_march(args[g], mcrt::MCRT_ALL_BOUNCES, c->stats_on, st));
-            }
-        }
-        if (accumulate && overlap) {
-            HIP_TRY(hipEventRecord(ws[0]->ev_join[0], side));
-            HIP_TRY(hipStreamWaitEvent(c->stream, ws[0]->ev_join[0], 0));
-        }
-        return MCRT_OK;
     }
     std::vector<hipStream_t> gst(groups);
     for (uint32_t g = 0; g < groups; g++) { int rc = work_stream(c, *ws[g], g == 0, &gst[g]); if (rc) return rc; }
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
     for (uint32_t g = 0; g < groups; g++) {
-        if (g) HIP_TRY(hipStreamWaitEvent(gst[g], c->ev_start, 0));
+        if (gst[g] != c->stream) HIP_TRY(hipStreamWaitEvent(gst[g], c->ev_start, 0));
         HIP_TRY(mcrt::launch_init(args[g], gst[g]));
     }
     for (uint32_t b = 0; b < c->p.max_depth; b++)
@@ -846,7 +852,7 @@ static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0
                 HIP_TRY(hipStreamWaitEvent(gst[g], ws[g]->ev_join[i], 0));
             }
         }
-        if (g) {
+        if (gst[g] != c->stream) {
             HIP_TRY(hipEventRecord(ws[g]->ev_done, gst[g]));
             HIP_TRY(hipStreamWaitEvent(c->stream, ws[g]->ev_done, 0));
         }
@@ -878,6 +884,37 @@ extern "C" int mcrt_trace_frames(mcrt_ctx *c, uint32_t frame, uint32_t n_frames,
 extern "C" int mcrt_trace_frame(mcrt_ctx *c, uint32_t frame, uint32_t e0, uint32_t e1, float *rf_dev)
 {
     return mcrt_trace_frames(c, frame, 1, e0, e1, rf_dev);
+}
+
+// A pass whose frames each have their own probe pose (transducer.h:82-118 update() between the frames of main.cpp:92-152): the element
+// tables [n_frames][E][3] are staged in the context (host pointers are copied on the stream) and k_init reads frame f's rows.
+extern "C" int mcrt_trace_frames_poses(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1,
+                                       const float *pos, const float *dir, float *rf_dev)
+{
+    CTX_TRY(c);
+    if (!pos || !dir) return set_error(MCRT_ERR_INVALID, "mcrt_trace_frames_poses: null pose tables");
+    if (n_frames == 0 || n_frames > 1024) return set_error(MCRT_ERR_LIMIT, "n_frames must be 1..1024");
+    const uint32_t E = c->p.n_elements;
+    const size_t bytes = 12 * (size_t)n_frames * E;
+    const float *src[2] = { pos, dir };
+    const float *dev[2] = { nullptr, nullptr };
+    for (int k = 0; k < 2; k++) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, src[k]) == hipSuccess && at.type == hipMemoryTypeDevice) { dev[k] = src[k]; continue; }
+        (void)hipGetLastError();
+        if (c->pose_cap[k] < bytes) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            hipFree(c->d_pose[k]); c->d_pose[k] = nullptr; c->pose_cap[k] = 0;
+            HIP_TRY(hipMalloc(&c->d_pose[k], bytes));
+            c->pose_cap[k] = bytes;
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_pose[k], src[k], bytes, hipMemcpyHostToDevice, c->stream));
+        dev[k] = c->d_pose[k];
+    }
+    c->pose_pos = dev[0]; c->pose_dir = dev[1];
+    const int rc = mcrt_trace_frames(c, frame, n_frames, e0, e1, rf_dev);
+    c->pose_pos = c->pose_dir = nullptr;
+    return rc;
 }
 
 // copies the per-path tables (work set 0) to the host: segs [ne][S][B], seg_count [ne][S], hits [ne][S][B] (= segment.tri, -2 beyond the path's end)
@@ -952,12 +989,18 @@ extern "C" int mcrt_convolve(mcrt_ctx *c, float *rf_dev, uint32_t E, uint32_t R,
     return mcrt_convolve_frames(c, rf_dev, 1, E, R, ax, n_ax, lat, n_lat);
 }
 
-extern "C" int mcrt_envelope(mcrt_ctx *c, float *rf_dev, uint32_t E, uint32_t R)
+extern "C" int mcrt_envelope_frames(mcrt_ctx *c, float *rf_dev, uint32_t n_frames, uint32_t E, uint32_t R)
 {
     CTX_TRY(c);
-    if (!rf_dev || E == 0 || R == 0) return set_error(MCRT_ERR_INVALID, "mcrt_envelope: bad arguments");
-    HIP_TRY(mcrt::launch_envelope(rf_dev, E, R, c->stream));
+    if (!rf_dev || E == 0 || R == 0 || n_frames == 0) return set_error(MCRT_ERR_INVALID, "mcrt_envelope: bad arguments");
+    if ((uint64_t)n_frames * E > 0xffffffffull) return set_error(MCRT_ERR_LIMIT, "mcrt_envelope: too many scan-lines");
+    HIP_TRY(mcrt::launch_envelope(rf_dev, n_frames * E, R, c->stream));      // the scan-lines of all images are independent columns
     return MCRT_OK;
+}
+
+extern "C" int mcrt_envelope(mcrt_ctx *c, float *rf_dev, uint32_t E, uint32_t R)
+{
+    return mcrt_envelope_frames(c, rf_dev, 1, E, R);
 }
 
 // rfimage.h:183-215 create_mapping, evaluated once per geometry on the host (as the reference does in its constructor)
@@ -981,11 +1024,12 @@ static void build_maps(const mcrt_ctx *c, uint32_t E, uint32_t R, double radius_
         }
 }
 
-extern "C" int mcrt_scan_convert(mcrt_ctx *c, const float *rf_dev, uint32_t E, uint32_t R, double radius_mm, double total_angle,
-                                 float *out_dev, uint32_t orows, uint32_t ocols)
+extern "C" int mcrt_scan_convert_frames(mcrt_ctx *c, const float *rf_dev, uint32_t n_frames, uint32_t E, uint32_t R, double radius_mm, double total_angle,
+                                        float *out_dev, uint32_t orows, uint32_t ocols)
 {
     CTX_TRY(c);
-    if (!rf_dev || !out_dev || E == 0 || R == 0 || orows == 0 || ocols == 0) return set_error(MCRT_ERR_INVALID, "mcrt_scan_convert: bad arguments");
+    if (!rf_dev || !out_dev || E == 0 || R == 0 || orows == 0 || ocols == 0 || n_frames == 0) return set_error(MCRT_ERR_INVALID, "mcrt_scan_convert: bad arguments");
+    if (n_frames > 65535u) return set_error(MCRT_ERR_LIMIT, "mcrt_scan_convert: at most 65535 images per call");
     const uint32_t key[6] = { E, R, orows, ocols, c->p.speed_of_sound, 1u };
     const double keyd[2] = { radius_mm * 1e6 + total_angle, c->c.max_travel_us };
     if (memcmp(key, c->map_key, sizeof key) || memcmp(keyd, c->map_keyd, sizeof keyd)) {
@@ -998,8 +1042,14 @@ extern "C" int mcrt_scan_convert(mcrt_ctx *c, const float *rf_dev, uint32_t E, u
         HIP_TRY(hipMemcpy(c->d_map_row, mr.data(), mr.size() * 4, hipMemcpyHostToDevice));
         memcpy(c->map_key, key, sizeof key); memcpy(c->map_keyd, keyd, sizeof keyd);
     }
-    HIP_TRY(mcrt::launch_remap(rf_dev, E, R, c->d_map_col, c->d_map_row, out_dev, orows * ocols, c->stream));
+    HIP_TRY(mcrt::launch_remap(rf_dev, n_frames, E, R, c->d_map_col, c->d_map_row, out_dev, orows * ocols, c->stream));
     return MCRT_OK;
+}
+
+extern "C" int mcrt_scan_convert(mcrt_ctx *c, const float *rf_dev, uint32_t E, uint32_t R, double radius_mm, double total_angle,
+                                 float *out_dev, uint32_t orows, uint32_t ocols)
+{
+    return mcrt_scan_convert_frames(c, rf_dev, 1, E, R, radius_mm, total_angle, out_dev, orows, ocols);
 }
 
 extern "C" int mcrt_export_rf(mcrt_ctx *c, const float *rf_dev, uint32_t E, uint32_t R, float *host)

@@ -8,21 +8,21 @@ namespace mcrt {
 
 struct FrameArgs {
     // scene (HBM-resident, read-only)
-    const float4 *nodes;       // [n_nodes][8]  128-B BVH4 nodes (4 x 32-B child records)
-    const uint4 *nodes_walk;   // [n_nodes][4]  the lane-per-ray walk's 64-byte nodes: child-transposed half-float boxes (rounded outwards) + refs; null = quad walk
-    int *stack_ovf;            // [max_stack - MCRT_LANE_STACK][trace_blocks * 256] traversal-stack entries beyond the LDS part (lane-per-ray walk)
+    const uint4 *nodes_walk;   // [n_nodes][4]  the walk's 64-byte nodes: child-transposed half-float boxes (rounded outwards) + refs
+    int *stack_ovf;            // [max_stack - MCRT_LANE_STACK][trace_blocks * 256] traversal-stack entries beyond the LDS part (this work set's own)
     const float4 *tris;        // [T][6]        96-B triangle records, leaf order: n|dist, padded lo|id, padded hi|mesh, v0, v1, v2
     const uint4 *meshes;       // [n_mesh]      mat_inside, mat_outside, vascular, -
     const float4 *mats;        // [n_mat][2]    imp, att, mu0, mu1 | sigma, spec, shine, thick
     const float2 *tex;         // [n^3]         texture_noise, scattering_probability
-    const float *el_pos;       // [E][3]
-    const float *el_dir;       // [E][3]
+    const float *el_pos;       // [E][3], or [F][E][3] when the frames of a pass have their own probe poses (pose_stride = E)
+    const float *el_dir;       // same shape
     const double *row_thr;     // [R+1] row thresholds (see row_of)
     // per-frame work buffers; np = ne * S paths
-    float4 *st0, *st1, *st2;   // [np] path state: from,intensity | dir,media | distance_traveled(f64),outside,-
-    uint32_t *queue;           // [2][np] live path ids of bounce b in buffer b & 1
-    float4 *ray0, *ray1;       // [np][2] f2.xyz,to.x | to.yz, 1/d.x, 1/d.y   (d = to - f2; indexed by queue position), ping-pong
-    unsigned long long *key0, *key1;   // [np] closest hit per ray: fraction bits << 32 | triangle id (atomicMin), ping-pong by bounce parity
+    float4 *recs;              // [np][6] path records, indexed by path id, updated in place: from,intensity | dir,media | distance_traveled(f64),outside,history |
+                               //         ray f2.xyz,to.x | to.yz,1/d.x,1/d.y | closest hit of the ray (u64: fraction bits << 32 | triangle id, atomicMin), of the scan-line's bounce-0 ray (u64)
+    uint32_t *queue;           // [2][np] live path ids of bounce b in buffer b & 1, ordered by bundle = (scan-line, decision history)
+    uint2 *tmp;                // [np] k_shade -> k_place: path id, bundle class of the survivor (0xffffffff: the path ended), by queue position
+    uint32_t *cls_cnt, *cls_fill;   // [cls_cap] survivors per bundle class; first free queue position of the class
     const uint32_t *tri_slot;  // [T] triangle id -> position in the leaf-order triangle array
     uint32_t *counts;          // [MAX_BOUNCES+1] live rays per bounce
     uint32_t *cursors;         // [MAX_BOUNCES][MCRT_XCDS][MCRT_CURSOR_STRIDE] queue cursors of the persistent walk, one per XCD sub-queue
@@ -37,7 +37,7 @@ struct FrameArgs {
     uint32_t *error_flag;      // device word, bit 0: traversal stack overflow
     unsigned long long *stamps; // [80] diagnostic build (-DMCRT_STAMP) only
     // sizes / parameters
-    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, acc_stride, acc_off, trace_blocks, march_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift;
+    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, pose_stride, sort, cls_cap, cls_lines, hist_bits, acc_stride, acc_off, trace_blocks, march_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift;
     float scene_lo[3], scene_hi[3];   // bounds of the whole BVH
     float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs, tex_rcp, lean_bound;
     double axial_res_mm, time_step, row_dt, max_travel, sos_d, inv_row_dt;
@@ -53,12 +53,11 @@ hipError_t launch_nodes_walk(const float4 *nodes, uint32_t n_nodes, uint4 *out, 
 hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 *out, hipStream_t st);
 uint32_t lane_stack_entries();
 hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
-hipError_t launch_paths(const FrameArgs &a, bool stats, hipStream_t st);
 hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
 hipError_t launch_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t ne, uint32_t R, hipStream_t st);
 hipError_t launch_convolve(float *img, float *tmp, uint32_t n_img, uint32_t E, uint32_t R, const ConvTaps &taps, hipStream_t st);
 hipError_t launch_envelope(float *img, uint32_t E, uint32_t R, hipStream_t st);
-hipError_t launch_remap(const float *img, uint32_t E, uint32_t R, const float *map_col, const float *map_row, float *out, uint32_t n, hipStream_t st);
+hipError_t launch_remap(const float *img, uint32_t n_img, uint32_t E, uint32_t R, const float *map_col, const float *map_row, float *out, uint32_t n, hipStream_t st);
 hipError_t launch_transpose(const float *in, float *out, uint32_t E, uint32_t R, hipStream_t st);
 hipError_t launch_math_probe(int op, const double *x, const double *y, double *out, uint32_t n, hipStream_t st);
 hipError_t launch_verify_div(float res, float rcp, unsigned long long *bad, hipStream_t st);

@@ -1,8 +1,9 @@
 // mcrt_kernels.hip -- gfx950 kernels of the hot path.
 //
-//   k_init/k_trace/k_shade   scene::cast_rays (scene.cpp:50-183) + ray_physics (ray.cpp) as a wavefront pipeline:
-//                quad-cooperative BVH4 closest hit, then the interface physics, one launch each per bounce
-//   k_march      the RF accumulation loop (main.cpp:106-144, rfimage.h:33-40, volume.h:46-61), one quad per segment
+//   k_init/k_trace_lane/k_shade/k_place   scene::cast_rays (scene.cpp:50-183) + ray_physics (ray.cpp) as a wavefront pipeline:
+//                lane-per-ray BVH4 closest hit, then the interface physics, then the survivors sorted into coherent bundles,
+//                one launch each per bounce
+//   k_march      the RF accumulation loop (main.cpp:106-144, rfimage.h:33-40, volume.h:46-61), a lane pair / quad per segment
 //   k_finalize   fixed-point RF bins -> float image (+ clears the bins: rf_image::clear, rfimage.h:161)
 //   k_conv_*     rf_image::convolve (rfimage.h:93-123)
 //   k_envelope   rf_image::envelope (rfimage.h:54-91)
@@ -18,23 +19,11 @@
 #include "mcrt_detmath.h"
 #include "mcrt_kernels.h"
 
-#ifndef MCRT_REFILL_BATCH
-#define MCRT_REFILL_BATCH 4           // k_trace fetches and sets up new rays once this many of a wavefront's 16 quads are without one
-#endif
 #ifndef MCRT_SHADE_WAVES
 #define MCRT_SHADE_WAVES 5             // k_shade wavefronts per SIMD the register budget is set for
 #endif
 #ifndef MCRT_MARCH_PAIRS_FROM
 #define MCRT_MARCH_PAIRS_FROM 1048576    // k_march: lane pairs per segment for passes with at least this many paths, quads below
-#endif
-#ifndef MCRT_FETCH_BATCH
-#define MCRT_FETCH_BATCH 16         // queue positions a wavefront of k_trace claims per atomic
-#endif
-#ifndef MCRT_TRACE_WAVES
-#define MCRT_TRACE_WAVES 5          // waves per SIMD k_trace's register allocation must allow
-#endif
-#ifndef MCRT_LEAF_BATCH
-#define MCRT_LEAF_BATCH 5          // leave the inner-node phase once this many of a wave's 16 paths are parked on a leaf
 #endif
 
 namespace mcrt {
@@ -201,8 +190,8 @@ MCRT_DEV long long wave_sum_i64(long long v)
 // lanes of a path hold identical state), so the source lanes are always active.
 template <int CTRL> MCRT_DEV int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
 template <int CTRL> MCRT_DEV float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
-constexpr int QP_XOR1 = 0xB1;   // quad_perm [1,0,3,2]
-constexpr int QP_XOR2 = 0x4E;   // quad_perm [2,3,0,1]
+
+
 #define QP_BCAST(k) ((k) * 0x55)
 
 // row = (int)(t / row_dt) if that quotient is < R, else -1 (rfimage.h:33-40), WITHOUT the double division:
@@ -293,16 +282,39 @@ MCRT_DEV void rf_add(long long *bins, uint32_t *lflags, int row, float echo)
 //
 //   k_init            first_ray of every (scan-line, sample) path, scene.cpp:83-101            1 lane  / path
 //   for bounce b:
-//     k_trace         closest hit of every live ray: quad-cooperative BVH4 walk                 4 lanes / ray
+//     k_trace_lane    closest hit of every live ray: BVH4 walk                                  1 lane  / ray
 //     k_shade         thickness draw, travel, hit_boundary, segment record, next ray;           1 lane  / ray
-//                     survivors are compacted into the next bounce's queue (wave ballot + prefix)
+//                     counts the survivors per BUNDLE (scan-line, reflect/refract history)
+//     k_place         the survivors' path ids into the next bounce's queue, bundle after bundle  1 lane  / ray
 //   k_march           RF accumulation of every segment (main.cpp:112-140)                       2 lanes / segment
 //
 // Every stage therefore runs with full wavefronts of lanes doing the same thing: dead paths cost nothing after the
-// bounce they die in, the fp64-heavy interface physics is not replicated, and the lean walk kernel keeps 8 waves/SIMD.
+// bounce they die in, the fp64-heavy interface physics is not replicated, and the lean walk kernel keeps 5 waves/SIMD.
 // Paths draw random numbers from their own (scan-line, sample, bounce) counter and RF bins are integer sums, so the
-// image does not depend on queue order.
+// image does not depend on queue order -- which is therefore chosen for the WALK: the sample paths of a scan-line that took
+// the same reflect / refract decisions so far are nearly the same ray (scene::cast_rays advances the samples of an element
+// together, scene.cpp:102-110; the power-cosine perturbation at shininess 1e6 is ~1e-3 rad), so the queue of every bounce
+// is ordered by (scan-line, decision history) and a wavefront holds 64 rays of ONE bundle: its lanes fetch the same nodes,
+// park on the same leaves and finish together.
+//
+// A path's state lives in ONE 96-byte record indexed by the path id and is updated in place; only the 4-byte path ids move
+// between the queues:
+//     from.xyz intensity | dir.xyz media | distance_traveled (f64) outside history | ray f2.xyz to.x | to.yz 1/d.x 1/d.y |
+//     closest-hit word of the path's ray (u64), closest-hit word of the scan-line's shared bounce-0 ray (u64, first sample's record)
+// (a lane reading its record touches one or two 128-byte lines, all of whose bytes it uses: scattered records cost the vector
+// memory pipe about what coalesced SoA arrays did, tools/fetch_roof.hip).
 // =============================================================================================================
+// The six pieces of a record are six ARRAYS indexed by the path id ([6][paths] float4): with the order-preserving compaction a
+// queue is in near path-id order, so the lanes of a wavefront read neighbouring elements of each array (measured against 96-byte
+// array-of-structures records, -DMCRT_REC_AOS: k_shade 0.88 vs ... ms per 128-frame launch).
+[[maybe_unused]] constexpr uint32_t REC_Q = 6;   // float4 pieces per path record
+#ifdef MCRT_REC_AOS
+#define MCRT_REC(a, k, pid) ((a).recs[(size_t)(pid) * REC_Q + (k)])
+#else
+#define MCRT_REC(a, k, pid) ((a).recs[(size_t)(k) * ((size_t)(a).ne * (a).S) + (pid)])
+#endif
+// the two closest-hit words of path `pid`: of its own ray (which = 0), of its scan-line's shared bounce-0 ray (which = 1)
+#define MCRT_KEYW(a, pid, which) ((unsigned long long *)&MCRT_REC(a, 5, pid) + (which))
 
 struct Ray { f3 f2, to; };
 
@@ -329,323 +341,43 @@ MCRT_DEV Ray make_ray(f3 from, f3 dir, float intensity, float att, const FrameAr
 
 __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 {
-    uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;          // this thread fills queue position `pos`
     const uint32_t np = a.ne * a.S;
-    if (pid == 0) { a.counts[0] = np; for (uint32_t b = 1; b <= a.B; b++) a.counts[b] = 0u; }
-    if (pid < MCRT_MAX_BOUNCES * MCRT_XCDS) a.cursors[(size_t)pid * MCRT_CURSOR_STRIDE] = 0u;   // k_trace's queue cursors (relative, see there)
-    if (pid >= np) return;
+    if (pos == 0) { a.counts[0] = np; for (uint32_t b = 1; b <= a.B; b++) a.counts[b] = 0u; }
+    if (pos < MCRT_MAX_BOUNCES * MCRT_XCDS) a.cursors[(size_t)pos * MCRT_CURSOR_STRIDE] = 0u;   // k_trace_lane's queue cursors (relative, see there)
+    for (uint32_t c = pos; c < a.cls_cap; c += gridDim.x * blockDim.x) a.cls_cnt[c] = 0u;        // (k_shade's last workgroup leaves them zeroed; a pass that failed may not have)
+    if (pos >= np) return;
     // Queue position -> path.  Paths are numbered frame-major (pid = (frame * ne_frame + scan-line) * S + sample) but QUEUED
-    // scan-line-major: the F frames of a scan-line sit next to each other.  The queue is swept in order, so the rays in flight
-    // then belong to a few scan-lines (times all frames) and walk the same part of the BVH; later bounces inherit the order
-    // from the order-preserving compaction of k_shade.
+    // scan-line-major: the F frames of a scan-line sit next to each other -- bounce 0's bundles (every sample of a scan-line
+    // starts as the same ray; with one probe pose for the pass, so do its F frames).  The queue is swept in order, so the rays in
+    // flight belong to a few scan-lines (times all frames) and walk the same part of the BVH.
     const uint32_t F = a.ne / a.ne_frame;
-    const uint32_t pos = pid;                                          // this thread fills queue position `pos`
     const uint32_t qline = pos / a.S, sample = pos % a.S;
     const uint32_t scan = qline / F, fr = qline % F;
-    pid = (fr * a.ne_frame + scan) * a.S + sample;
-    const uint32_t e_abs = a.e_begin + scan;
-    const f3 from = mk(a.el_pos[3 * e_abs], a.el_pos[3 * e_abs + 1], a.el_pos[3 * e_abs + 2]);
-    const f3 dir = mk(a.el_dir[3 * e_abs], a.el_dir[3 * e_abs + 1], a.el_dir[3 * e_abs + 2]);
+    const uint32_t pid = (fr * a.ne_frame + scan) * a.S + sample;
+    const size_t pe = (size_t)fr * a.pose_stride + a.e_begin + scan;      // pose_stride = 0: one probe pose for every frame of the pass (transducer.h:64-67)
+    const f3 from = mk(a.el_pos[3 * pe], a.el_pos[3 * pe + 1], a.el_pos[3 * pe + 2]);
+    const f3 dir = mk(a.el_dir[3 * pe], a.el_dir[3 * pe + 1], a.el_dir[3 * pe + 2]);
     const float intensity = a.I0 / (float)a.S;
-    a.st0[pos] = make_float4(from.x, from.y, from.z, intensity);
-    a.st1[pos] = make_float4(dir.x, dir.y, dir.z, __int_as_float((int)a.start_mat));
-    a.st2[pos] = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), 0.0f);      // distance_traveled (double) | outside | -
+    MCRT_REC(a, 0, pid) = make_float4(from.x, from.y, from.z, intensity);
+    MCRT_REC(a, 1, pid) = make_float4(dir.x, dir.y, dir.z, __int_as_float((int)a.start_mat));
+    MCRT_REC(a, 2, pid) = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), __uint_as_float(0u));      // distance_traveled (double) | outside | decision history
+    const Ray r = make_ray(from, dir, intensity, a.mats[2 * a.start_mat].y, a);
+    MCRT_REC(a, 3, pid) = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
+    MCRT_REC(a, 4, pid) = make_float4(r.to.y, r.to.z, 1.0f / (r.to.x - r.f2.x), 1.0f / (r.to.y - r.f2.y));   // + two of the three reciprocals the walk needs
+    const float miss_lo = __uint_as_float((uint32_t)MCRT_KEY_MISS), miss_hi = __uint_as_float((uint32_t)(MCRT_KEY_MISS >> 32));
+    MCRT_REC(a, 5, pid) = make_float4(miss_lo, miss_hi, miss_lo, miss_hi);          // the path's own closest-hit word | the scan-line's bounce-0 word
     a.queue[pos] = pid;                                  // queue of bounce 0 (buffer 0 of two)
     a.seg_count[pid] = 0u;
-    if (pos < a.ne) a.key0[pos] = MCRT_KEY_MISS;          // bounce 0: one closest-hit word per queued scan-line
-    const Ray r = make_ray(from, dir, intensity, a.mats[2 * a.start_mat].y, a);
-    a.ray0[2 * pos] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
-    a.ray0[2 * pos + 1] = make_float4(r.to.y, r.to.z, 1.0f / (r.to.x - r.f2.x), 1.0f / (r.to.y - r.f2.y));   // + two of the three reciprocals the walk needs
 }
-
-// ---- closest hit: FOUR lanes (one DPP quad) own one ray; a wavefront holds 16 rays.  Each lane fetches ONE 32-byte
-// child record of the BVH4 node (the quad reads the node's 128 contiguous bytes), tests its box, and the quad ranks the
-// hit children with DPP exchanges; a leaf's triangle is tested by the quad together (see phase 2).  Traversal stacks live in LDS.
-// The kernel is PERSISTENT over the bounce's ray queue: a quad whose ray is finished writes its hit record and takes the
-// next unclaimed ray (from a wave-private pool refilled with one atomic on its XCD's queue cursor), so a wavefront's lanes do not idle behind its longest
-// walk.  Bounce 0 is special: every sample path of a scan-line starts as a copy of the same first_ray (scene.cpp:83-101),
-// so only ONE ray per scan-line is walked and k_shade hands the hit to all S samples.
-template <bool STATS>
-__global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, uint32_t b)
-{
-    __shared__ int stack[MCRT_STACK * 64];          // [MCRT_STACK][64 quads]: entry sp of quad q at sp*64 + q -> conflict-free
-    const int tid = threadIdx.x, lane = tid & 63, j = tid & 3, q = tid >> 2;
-    const uint32_t n_rays = (b == 0u) ? a.ne : a.counts[b];     // rays of this bounce (= closest-hit words)
-    // When a bounce has far fewer rays than the GPU has lanes, each ray is cut into K sub-ranges of its parameter interval
-    // inside the scene bounds and the K pieces are walked by K different quads: the launch then lasts as long as the longest
-    // PIECE instead of the longest ray.  Sub-ranges are half-open and partition [0,1), and every find goes through the ray's
-    // atomicMin word, so the result is exactly the single-walk answer.
-    const uint32_t K = ksplit(n_rays, a.ksplit_limit);
-    const uint32_t n = n_rays * K;                              // work items
-    const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
-    const uint32_t ray_stride = (b == 0u) ? a.S : 1u;           // bounce 0: the first path of each scan-line stands for all
-    unsigned long long *keys = (b & 1u) ? a.key1 : a.key0;     // per-ray closest-hit words of this bounce
-    unsigned long long st_nodes = 0, st_tris = 0, st_q = 0;
-
-    // WORK DISTRIBUTION, XCD-aware.  Workgroups are dealt round-robin to the 8 XCDs (workgroup w runs on XCD w % 8), each with
-    // its own L2.  The queue is cut into 8 contiguous sub-queues, one per XCD, each with its own cursor: an XCD sweeps ITS part
-    // of the queue in order, so the rays in flight on it belong to a few scan-lines (small L2 working set), and the returning
-    // atomics that hand out the work go to 8 addresses instead of one (same-address atomics serialise in L2 at ~6 ns each:
-    // 16 rays per atomic on a single cursor is 0.8 ms of atomics for a 2 M-ray bounce).  A wavefront whose sub-queue has run
-    // dry moves on to the next one, so the XCDs finish together.  Bounces with few items use one queue.
-    const uint32_t X = (n >= (uint32_t)MCRT_XCD_MIN_ITEMS) ? (uint32_t)MCRT_XCDS : 1u;
-    if (X == 1u && blockIdx.x * 64u >= n) return;
-    const uint32_t x_shift = (X == 1u) ? 0u : 3u;
-    static_assert(MCRT_XCDS == 8, "the sub-queue arithmetic shifts by 3");
-    uint32_t cur_x = blockIdx.x & (X - 1u), visited = 0;                // wave-uniform: the sub-queue this wavefront draws from
-#define MCRT_SUB_LO(sq) ((uint32_t)(((unsigned long long)n * (sq)) >> x_shift))      /* X is 1 or 8: shifts, not divisions */
-#define MCRT_SUB_STATIC(sq) (((gridDim.x - (sq) + X - 1u) >> x_shift) * 64u)      /* items of sub-queue sq assigned statically (one per quad) */
-    uint32_t *cursors = a.cursors + (size_t)b * MCRT_XCDS * MCRT_CURSOR_STRIDE;
-    uint32_t i = MCRT_SUB_LO(cur_x) + (blockIdx.x >> x_shift) * 64u + (uint32_t)q;     // the first item of each quad is assigned statically
-    if (i >= MCRT_SUB_LO(cur_x + 1u)) i = 0xffffffffu;                          // (a short sub-queue: fetch dynamically)
-    uint32_t ray_id = 0;
-#ifdef MCRT_STAMP
-    int nsteps = 0;
-#endif
-    bool exhausted = false;
-    f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1);
-    RayPairs rp = ray_pairs(f2, mk(1, 1, 1));
-    float t_lo = 0.0f;
-    Best best; best.frac = 1.0f; best.tri = -1;
-    // the walk's state is ONE register: cur >= 0 = inner node to visit, cur < 0 = ~(leaf descriptor) to test, CUR_IDLE = no
-    // walk in progress (a value no leaf descriptor takes), so "which quads are where" is a single integer compare
-    constexpr int CUR_IDLE = (int)0x80000000;
-    int sp = 0, cur = CUR_IDLE;
-    bool fresh = true;                                           // this quad needs a ray
-    const uint32_t bit_j = 1u << j, lane_off = (uint32_t)j << 5;
-    const uint32_t role_a = 16u * (uint32_t)((j == 3) ? 1 : 3 + j), role_b = 16u * (uint32_t)((j == 3) ? 2 : 3 + (j + 1) % 3);   // byte offsets of the two records of a triangle this lane reads (phase 2)
-#define MCRT_ON_INNER(c) __builtin_amdgcn_sicmp((c), -1, 38)                          /* mask of lanes with c >= 0     (ICMP_SGT) */
-#define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)        /* mask of lanes on a leaf        (ICMP_UGT) */
-#define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)                     /* mask of lanes in a walk        (ICMP_NE)  */
-#ifdef MCRT_STAMP
-    unsigned long long sc_refill = 0, sc_p1 = 0, sc_p2 = 0, sc_n1 = 0, sc_n2 = 0, sc_outer = 0, sc_t0 = __builtin_readcyclecounter(), sc_act1 = 0, sc_act2 = 0;
-    unsigned long long sc_nodes = 0, sc_pops = 0, sc_pop_dead = 0; bool from_pop = false;
-#define STAMP(var) { const unsigned long long t_ = __builtin_readcyclecounter(); var += t_ - sc_t0; sc_t0 = t_; }
-#else
-#define STAMP(var)
-#endif
-    uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
-#ifdef MCRT_STAMP
-    // launch timeline of bounce b (100 MHz wall clock): earliest wave start, earliest "queue is empty", latest wave end
-    const unsigned long long wc_start = wall_clock64();
-    if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 0], ~wc_start);
-#endif
-    for (;;) {
-        // ---- finished rays: report, then ask for the next ray ----
-        // The closest hit of a ray is ONE 64-bit word, (fraction bits << 32 | triangle id): fractions are in [0,1), so their bit
-        // patterns order like the values and an integer atomicMin IS the contract's rule (smaller fraction, then smaller id).
-        // The K pieces of a ray therefore just race their finds into the ray's word.
-        // (the report / fetch / set-up code below runs for the whole wavefront however few quads need it, so it waits until
-        //  MCRT_REFILL_BATCH quads are without a walk -- or nobody walks at all)
-        const bool do_refill = __popcll(__ballot(cur == CUR_IDLE && !exhausted && j == 0)) >= MCRT_REFILL_BATCH || MCRT_WALKING(cur) == 0ull;
-        if (do_refill) {
-        if (cur == CUR_IDLE && !fresh && !exhausted) {
-#ifdef MCRT_STAMP_HIST   /* (with -DMCRT_STAMP; its same-address atomics slow the kernel ~10x, so the timeline is then meaningless) */
-            if (j == 0 && b > 0u) { atomicAdd(&a.stamps[60 + (nsteps > 0 ? 32 - __clz(nsteps) : 0)], 1ull); }   // histogram of node visits per walk (log2 bins)
-#endif
-            if (j == 0 && best.tri >= 0) {
-                const unsigned long long word = ((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri;
-                if (K == 1u) keys[ray_id] = word;               // the only walker of this ray: a plain store
-                else atomicMin(&keys[ray_id], word);
-            }
-            fresh = true; i = 0xffffffffu;
-        }
-        // ---- (re)fill: quads without a ray take the next queue positions ----
-        const bool need = fresh && !exhausted;
-        const unsigned long long dynm = __ballot(need && i == 0xffffffffu && j == 0);
-        if (dynm) {
-            // dynamic fetch (after the static first assignment) from a wave-private pool of queue positions that is refilled
-            // MCRT_FETCH_BATCH at a time: one returning atomic per batch instead of one per finished ray
-            while (pool_next >= pool_end && !queue_empty) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&cursors[(size_t)cur_x * MCRT_CURSOR_STRIDE], (uint32_t)MCRT_FETCH_BATCH);
-                base = __shfl(base, 0, 64);
-                const uint32_t hi = MCRT_SUB_LO(cur_x + 1u);
-                const unsigned long long start = (unsigned long long)MCRT_SUB_LO(cur_x) + MCRT_SUB_STATIC(cur_x) + base;
-                if (start < hi) { pool_next = (uint32_t)start; pool_end = min((uint32_t)start + (uint32_t)MCRT_FETCH_BATCH, hi); }
-                else if (++visited >= X) queue_empty = true;             // every sub-queue has run dry
-                else cur_x = (cur_x + 1u) & (X - 1u);                    // this one has: help the next XCD's
-#ifdef MCRT_STAMP
-                if (queue_empty && lane == 0) atomicMax(&a.stamps[16 + 4 * b + 1], ~(unsigned long long)wall_clock64());
-#endif
-            }
-            if (need && i == 0xffffffffu) {
-                const uint32_t mine = pool_next + (uint32_t)__popcll(dynm & ((1ull << (lane & ~3)) - 1ull));
-                if (queue_empty) i = n;                                  // nothing left: this quad retires
-                else if (mine < pool_end) i = mine;                      // else: wait for the next batch (stay fresh)
-            }
-            const uint32_t taken = (uint32_t)__popcll(dynm);
-            pool_next = (pool_next + taken < pool_end) ? pool_next + taken : pool_end;
-        }
-        if (need && i != 0xffffffffu) {
-            if (i < n) {
-                uint32_t piece = 0u;                                     // the pieces of one ray land in different wavefronts
-                if (K == 1u) ray_id = i;                                 // (no division on the common path)
-                else { piece = i / n_rays; ray_id = i - piece * n_rays; }
-                const float4 r0 = rays[2 * (size_t)ray_id * ray_stride], r1 = rays[2 * (size_t)ray_id * ray_stride + 1];
-                f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
-                const f3 d = to - f2;
-                const f3 inv = mk(r1.z, r1.w, 1.0f / d.z);             // x and y reciprocals come with the ray record
-                rp = ray_pairs(f2, inv);
-                t_lo = 0.0f;
-                float t_hi = 1.0f;
-                if (K > 1u) {
-                    float tin, tout;
-                    if (slab(mk(a.scene_lo[0], a.scene_lo[1], a.scene_lo[2]), mk(a.scene_hi[0], a.scene_hi[1], a.scene_hi[2]), f2, inv, 0.0f, 1.0f, tin, tout)) {
-                        const float w = tout - tin;
-                        if (piece > 0u) t_lo = tin + w * ((float)piece / (float)K);
-                        if (piece + 1u < K) t_hi = tin + w * ((float)(piece + 1u) / (float)K);
-                    } else if (piece > 0u) t_hi = 0.0f;                  // the ray misses the scene: piece 0 reports the miss
-                }
-#ifdef MCRT_STAMP
-                nsteps = 0;
-#endif
-                best.frac = t_hi; best.tri = -1;
-                sp = 0; cur = (a.n_nodes != 0u && t_lo < t_hi) ? 0 : CUR_IDLE; fresh = false;   // (idle: an immediate miss)
-                if (STATS && j == 0 && piece == 0u) st_q++;
-            } else exhausted = true;
-        }
-        }   // do_refill
-        STAMP(sc_refill)
-        if (MCRT_WALKING(cur) == 0ull) { if (!__any(!exhausted)) break; else continue; }
-
-        // ---- phase 1: inner nodes, until enough rays are parked on a leaf (their triangle code then runs once for all) ----
-        const float tcap = fminf(1.0f, best.frac);               // best only changes in phase 2
-        for (;;) {
-            const unsigned long long inner = MCRT_ON_INNER(cur);
-            if (inner == 0ull) break;
-            if (__popcll(MCRT_ON_LEAF(cur)) >= 4 * MCRT_LEAF_BATCH) break;
-#ifdef MCRT_STAMP
-            sc_n1++; sc_act1 += __popcll(inner);
-#endif
-            if (cur >= 0) {
-                // 32-bit byte offset from the (uniform) array base: one VALU op and the scalar-base addressing mode
-                const float4 *N = (const float4 *)((const char *)a.nodes + (((uint32_t)cur << 7) + lane_off));
-                const float4 A = N[0], B = N[1];               // lo.xyz hi.x | hi.y hi.z ref pad
-                if (STATS && j == 0) st_nodes++;
-#ifdef MCRT_STAMP
-                nsteps++;
-#endif
-                const int ref = __float_as_int(B.z);
-                float tn, tx;
-                const bool hit = slab_pairs((v2f){ A.x, A.y }, (v2f){ A.z, A.w }, (v2f){ B.x, B.y }, rp, t_lo, tcap, tn, tx) && ref != MCRT_BVH4_EMPTY;
-                // Next node = the NEAREST hit child: t_near >= 0, so its bit pattern orders like the value; the two lowest bits are
-                // replaced by the slot number, which makes the key unique in the quad (nearly equal distances go by slot).
-                // The other hit children are stacked in slot order.  Visiting order only affects the work done, never the hit.
-                const uint32_t key = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)j) : 0xffffffffu;
-                uint32_t kmin = min(key, (uint32_t)dpp_i<QP_XOR1>((int)key));
-                kmin = min(kmin, (uint32_t)dpp_i<QP_XOR2>((int)kmin));
-                int w = hit ? (int)bit_j : 0;                   // the quad's hit bits, OR-ed across its lanes
-                w |= dpp_i<QP_XOR1>(w);
-                w |= dpp_i<QP_XOR2>(w);
-                const uint32_t hit4 = (uint32_t)w;
-                const int nh = __popc(hit4);
-                const int jn = (int)(kmin & 3u);                // slot of the nearest child (when there is one)
-                int cand = (key == kmin) ? ref : 0;
-                cand |= dpp_i<QP_XOR1>(cand);
-                cand |= dpp_i<QP_XOR2>(cand);
-#ifdef MCRT_STAMP
-                if (j == 0) { sc_nodes++; if (from_pop) { sc_pops++; if (nh == 0) sc_pop_dead++; } }
-                from_pop = nh == 0;
-#endif
-                if (nh == 0) {
-                    if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
-                    else cur = CUR_IDLE;
-                } else {                                       // mcrt_upload_scene rejected trees that need more than MCRT_STACK entries
-                    const uint32_t others = hit4 & ~(1u << jn);
-                    if (hit && key != kmin) stack[(sp + __popc(others & (bit_j - 1u))) * 64 + q] = ref;
-                    sp += nh - 1;
-                    cur = cand;
-                }
-            }
-        }
-        STAMP(sc_p1)
-#ifdef MCRT_STAMP
-        { const unsigned long long lm = MCRT_ON_LEAF(cur); if (lm) { sc_n2++; sc_act2 += __popcll(lm); } }
-#endif
-        // ---- phase 2: the parked leaves.  The four lanes of a ray share ONE triangle test (btTriangleRaycastCallback::
-        // processTriangle behind the padded-bounds rule): every lane evaluates the plane and the fraction from the triangle's
-        // stored normal and offset, then lanes 0-2 each take one edge test and lane 3 the ray's overlap with the triangle's
-        // stored padded bounds; the verdict is the AND over the quad.  Same IEEE operations as a sequential test, split over
-        // lanes -- the stored normal / offset / bounds are the contract's expressions, evaluated by k_expand_tris.
-        if ((uint32_t)cur > 0x80000000u) {
-            const uint32_t v = (uint32_t)~cur;
-            const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; k++) {               // quad-uniform; the builders make (mostly) one-triangle leaves
-                const char *T = (const char *)a.tris + (first + k) * 96u;      // (32-bit offsets: the upload rejects >= 2^28 triangles)
-                const float4 P = *(const float4 *)T;            // n.xyz | dot(v0, n)
-                const float4 A = *(const float4 *)(T + role_a), B = *(const float4 *)(T + role_b);      // lane 3: padded lo | id, padded hi | mesh;  lane j < 3: v_j, v_(j+1)%3
-                const f3 n = xyz(P);
-                const float da = dot(n, f2) - P.w;
-                const float db = dot(n, to) - P.w;
-                if (da * db >= 0.0f) continue;
-                const int id = dpp_i<QP_BCAST(3)>(__float_as_int(A.w));
-                const float proj = da - db;
-                const float frac = da / proj;
-                if (!(frac < best.frac || (frac == best.frac && id < best.tri)) || !(frac >= t_lo)) continue;
-                bool ok;
-                if (j == 3) {
-                    float tmin, tmax;
-                    ok = slab_pairs((v2f){ A.x, A.y }, (v2f){ A.z, B.x }, (v2f){ B.y, B.z }, rp, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax;
-                } else {
-                    const float edge_tol = A.w;                  // -1e-4 |n|^2, stored
-                    const float s = 1.0f - frac;
-                    const f3 p = mk(s * f2.x + frac * to.x, s * f2.y + frac * to.y, s * f2.z + frac * to.z);
-                    const f3 ap = xyz(A) - p, bp = xyz(B) - p;
-                    ok = dot(cross(ap, bp), n) >= edge_tol;
-                }
-                int all = ok ? 1 : 0;
-                all &= dpp_i<QP_XOR1>(all);
-                all &= dpp_i<QP_XOR2>(all);
-                if (all) { best.frac = frac; best.tri = id; }
-            }
-            if (STATS && j == 0) st_tris += cnt;
-#ifdef MCRT_STAMP
-            from_pop = true;
-#endif
-            if (sp > 0) { sp--; cur = stack[sp * 64 + q]; }
-            else cur = CUR_IDLE;
-        }
-        STAMP(sc_p2)
-#ifdef MCRT_STAMP
-        sc_outer++;
-#endif
-    }
-#undef MCRT_SUB_LO
-#undef MCRT_SUB_STATIC
-#undef MCRT_ON_INNER
-#undef MCRT_ON_LEAF
-#undef MCRT_WALKING
-#ifdef MCRT_STAMP
-    const long long pop_x = wave_sum_i64((long long)sc_nodes), pop_y = wave_sum_i64((long long)sc_pops), pop_z = wave_sum_i64((long long)sc_pop_dead);
-    if (lane == 0) {   // diagnostic build only: per-phase cycles and iteration counts, summed over wavefronts
-        atomicAdd(&a.stamps[0], sc_refill); atomicAdd(&a.stamps[1], sc_p1); atomicAdd(&a.stamps[2], sc_p2); atomicAdd(&a.stamps[3], sc_n1);
-        atomicAdd(&a.stamps[4], sc_n2); atomicAdd(&a.stamps[5], sc_outer); atomicAdd(&a.stamps[6], sc_act1); atomicAdd(&a.stamps[7], sc_act2); atomicAdd(&a.stamps[8], 1ull);
-        atomicAdd(&a.stamps[56], (unsigned long long)pop_x); atomicAdd(&a.stamps[57], (unsigned long long)pop_y); atomicAdd(&a.stamps[58], (unsigned long long)pop_z);
-        const unsigned long long wc_end = wall_clock64();
-        atomicMax(&a.stamps[16 + 4 * b + 2], wc_end); atomicAdd(&a.stamps[16 + 4 * b + 3], wc_end - wc_start);
-    }
-#endif
-    if (STATS) {
-        unsigned long long v[3] = { st_q, st_nodes, st_tris };
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            long long x = wave_sum_i64((long long)v[k]);
-            if (lane == 0 && x) atomicAdd(&a.stats[k], (unsigned long long)x);
-        }
-    }
-}
-
 
 // =============================================================================================================
-// k_trace_lane -- the same closest-hit walk with ONE LANE per ray (64 rays per wavefront instead of 16).
+// k_trace_lane -- the closest-hit walk (Bullet's rayTest, scene.cpp:115-126), ONE LANE per ray, 64 rays per wavefront.
 //
-// The quad walk above keeps 16 rays in flight per wavefront, two 16-byte loads each per node step: with five wavefronts per
-// SIMD a compute unit has 320 rays and 640 loads in flight, and the counters show its wavefronts parked on memory for more
-// than half of their life (SQ_WAIT_ANY 56 %) with the vector units at 41 % of their issue rate -- the walk is LATENCY-bound.
-// One lane per ray puts four times as many rays (and seven independent 16-byte loads per ray and step) behind every
-// wavefront, and spends fewer instructions per ray: no quad ranking exchanges, and the slab planes of two children at a time
-// go through the packed-f32 pipe (v_pk_add_f32 / v_pk_mul_f32).
+// (Round 1 walked a ray with a quad of four lanes, one child of the BVH4 node each: 16 rays in flight per wavefront, with the
+// counters showing its wavefronts parked on memory for more than half of their life -- latency-bound.  One lane per ray puts
+// four times as many rays behind every wavefront and spends fewer instructions per ray: no quad ranking exchanges, and the
+// slab planes of two children at a time go through the packed-f32 pipe.)
 //
 // Nodes are read from a COMPACT copy of the BVH4 (k_nodes_walk): 64 bytes per node instead of 128 -- the walk is bound by the
 // vector memory pipe (tools/fetch_roof.hip: a scattered 16-byte-per-lane load costs the compute unit's TCP ~0.75 lanes per
@@ -656,9 +388,9 @@ __global__ void __launch_bounds__(256, MCRT_TRACE_WAVES) k_trace(FrameArgs a, ui
 // padded bounds -- hits stay bit-identical, the walk visits ~2.5 % more nodes (measured on the 1 M-triangle
 // scene).  Unused slots are stored as the point box at +infinity, which no slab test hits (so the walk needs no EMPTY test).
 // mcrt_get_bvh4 hands out the tree AS WALKED (the decoded boxes), so a CPU walk of it counts exactly this walk's visits.
-// Per ray the arithmetic is the quad walk's, operation for operation: (plane - origin) * reciprocal, the same min/max
-// combination, the same nearest-child key (t_near bits with the slot number in the two low bits), the other hit children
-// stacked in slot order, and the same triangle test -- so hits AND visit counts equal the quad walk's, visit for visit.
+// Per ray the arithmetic is the contract's slab test, (plane - origin) * reciprocal with the min / max combination of slab();
+// the next node is the nearest hit child (key: t_near bits with the slot number in the two low bits), the other hit children
+// are stacked in slot order -- the order, and therefore the visit counts, of a sequential walk.
 // Traversal stacks: MCRT_LANE_STACK entries per lane in LDS ([entry][thread], conflict-free); deeper entries (only reachable on
 // degenerate paths of deep trees) go to a global overflow array.
 // =============================================================================================================
@@ -815,7 +547,7 @@ MCRT_DEV bool slab_combine(float t0x, float t0y, float t0z, float t1x, float t1y
     return tmin <= tmax;
 }
 
-// ---- the lane-per-ray walk's two steps, shared by k_trace_lane and k_paths ------------------------------------------------
+// ---- the lane-per-ray walk's two steps ---------------------------------------------------------------------------------
 // A lane's traversal stack: entries [sb, sp), entry e of thread t at lds[e * 256 + t] while e < MCRT_LANE_STACK, beyond that in the
 // global overflow array (only reachable on degenerate paths of deep trees).
 struct LaneStack { int *lds; int *ovf; size_t ovf_stride; int tid; };
@@ -969,17 +701,31 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
 {
     __shared__ int stack[MCRT_LANE_STACK * 256];      // [entry][thread]: entry sp of thread t at sp*256 + t -> conflict-free
     const int tid = threadIdx.x, lane = tid & 63;
+    // Bounce 0 is special: every sample path of a scan-line starts as a copy of the same first_ray (scene.cpp:83-101), so only
+    // ONE ray per (frame, scan-line) is walked -- the first sample's -- and k_shade hands its hit to all S samples.
     const uint32_t n_rays = (b == 0u) ? a.ne : a.counts[b];
+    // When a bounce has far fewer rays than the GPU has lanes, each ray is cut into K sub-ranges of its parameter interval inside
+    // the scene bounds and the K pieces are walked by K different lanes: the launch then lasts as long as the longest PIECE
+    // instead of the longest ray.  Sub-ranges are half-open and partition [0,1), and every find goes through the ray's atomicMin
+    // word, so the result is exactly the single-walk answer.
     const uint32_t K = ksplit(n_rays, a.ksplit_limit);
     const uint32_t n = n_rays * K;
-    const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
-    const uint32_t ray_stride = (b == 0u) ? a.S : 1u;
-    unsigned long long *keys = (b & 1u) ? a.key1 : a.key0;
+    const uint32_t *q_in = a.queue + (size_t)(b & 1u) * a.ne * a.S;      // path ids of this bounce's live rays, bundle after bundle
+    const uint32_t F = a.ne / a.ne_frame;
+    // the closest-hit word of the ray of path `p` (bounce 0: of the scan-line's shared ray, kept in its first sample's record)
+    const uint32_t key_which = (b == 0u) ? 1u : 0u;
+#define MCRT_KEYP(p) MCRT_KEYW(a, p, key_which)
     unsigned long long st_nodes = 0, st_tris = 0, st_q = 0;
     // (overflow entries of this lane: [entry - MCRT_LANE_STACK][grid thread])
     const LaneStack S = { stack, a.stack_ovf + ((size_t)blockIdx.x * 256 + tid), (size_t)gridDim.x * 256, tid };
 
-    // work distribution: as in k_trace (one sub-queue and cursor per XCD, swept in order), one item per LANE
+    // WORK DISTRIBUTION, XCD-aware.  Workgroups are dealt round-robin to the 8 XCDs (workgroup w runs on XCD w % 8), each with
+    // its own L2.  The queue is cut into 8 contiguous sub-queues, one per XCD, each with its own cursor: an XCD sweeps ITS part
+    // of the queue in order, so the rays in flight on it belong to a few scan-lines (small L2 working set), and the returning
+    // atomics that hand out the work go to 8 addresses instead of one (same-address atomics serialise in L2 at ~6 ns each).  A
+    // wavefront whose sub-queue has run dry moves on to the next one, so the XCDs finish together.  Bounces with few items use
+    // one queue.  The kernel is PERSISTENT over the bounce's queue: a lane whose ray is finished writes its hit word and takes
+    // the next unclaimed item (from a wave-private pool refilled with one atomic on its XCD's cursor).
     const uint32_t X = (n >= (uint32_t)MCRT_XCD_MIN_ITEMS) ? (uint32_t)MCRT_XCDS : 1u;
     if (X == 1u && blockIdx.x * 256u >= n) return;
     const uint32_t x_shift = (X == 1u) ? 0u : 3u;
@@ -989,7 +735,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
     uint32_t *cursors = a.cursors + (size_t)b * MCRT_XCDS * MCRT_CURSOR_STRIDE;
     uint32_t i = MCRT_SUB_LO(cur_x) + (blockIdx.x >> x_shift) * 256u + (uint32_t)tid;      // the first item of each lane is assigned statically
     if (i >= MCRT_SUB_LO(cur_x + 1u)) i = 0xffffffffu;
-    uint32_t ray_id = 0;
+    uint32_t ray_id = 0;                         // the path id whose record holds the ray and its closest-hit word
     bool exhausted = false, fresh = true;
     f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1), inv = mk(1, 1, 1);
     float t_lo = 0.0f;
@@ -1005,7 +751,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
     unsigned long long poll_old = 0; uint32_t poll_ray = 0; bool poll_pending = false;      // (see the end of the loop)
 #ifdef MCRT_STAMP
     // diagnostic build: cycles and lane counts per phase, summed over wavefronts (tools/stamps.py)
-    unsigned long long sc_refill = 0, sc_p1 = 0, sc_p2 = 0, sc_n1 = 0, sc_n2 = 0, sc_outer = 0, sc_t0 = __builtin_readcyclecounter(), sc_act1 = 0, sc_act2 = 0, sc_park1 = 0, sc_idle1 = 0, sc_adopt = 0;
+    unsigned long long sc_refill = 0, sc_p1 = 0, sc_p2 = 0, sc_n1 = 0, sc_n2 = 0, sc_outer = 0, sc_t0 = __builtin_readcyclecounter(), sc_act1 = 0, sc_act2 = 0, sc_park1 = 0, sc_idle1 = 0, sc_adopt = 0, sc_dist = 0;
 #define LSTAMP(var) { const unsigned long long t_ = __builtin_readcyclecounter(); var += t_ - sc_t0; sc_t0 = t_; }
 #else
 #define LSTAMP(var)
@@ -1026,8 +772,8 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
             if (cur == CUR_IDLE && !fresh) {
                 if (best.tri >= 0) {
                     const unsigned long long word = ((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri;
-                    if (K == 1u && !shared) keys[ray_id] = word;         // the only walker of this ray: a plain store
-                    else atomicMin(&keys[ray_id], word);
+                    if (K == 1u && !shared) *MCRT_KEYP(ray_id) = word;   // the only walker of this ray: a plain store
+                    else atomicMin(MCRT_KEYP(ray_id), word);
                 }
                 fresh = true; shared = false; helper = false; i = 0xffffffffu;
             }
@@ -1057,10 +803,11 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
             }
             if (need && i != 0xffffffffu) {
                 if (i < n) {
-                    uint32_t piece = 0u;
-                    if (K == 1u) ray_id = i;
-                    else { piece = i / n_rays; ray_id = i - piece * n_rays; }
-                    const float4 r0 = rays[2 * (size_t)ray_id * ray_stride], r1 = rays[2 * (size_t)ray_id * ray_stride + 1];
+                    uint32_t piece = 0u, idx = i;                        // the pieces of one ray land in different wavefronts
+                    if (K > 1u) { piece = i / n_rays; idx = i - piece * n_rays; }      // (no division on the common path)
+                    if (b == 0u) ray_id = ((idx % F) * a.ne_frame + idx / F) * a.S;     // queued scan-line idx = (scan-line, frame): its first sample's path
+                    else ray_id = q_in[idx];
+                    const float4 r0 = MCRT_REC(a, 3, ray_id), r1 = MCRT_REC(a, 4, ray_id);
                     f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
                     const f3 d = to - f2;
                     inv = mk(r1.z, r1.w, 1.0f / d.z);
@@ -1141,6 +888,12 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
 #endif
 #ifdef MCRT_STAMP
             sc_n1++; sc_act1 += __popcll(inner); sc_park1 += __popcll(MCRT_ON_LEAF(cur)); sc_idle1 += 64 - __popcll(MCRT_WALKING(cur));
+            for (unsigned long long rem = inner; rem != 0ull;) {             // distinct nodes among the stepping lanes: 1 = the wavefront walks as one ray
+                const int l0 = __ffsll((long long)rem) - 1;
+                const int v0 = __shfl(cur, l0, 64);
+                rem &= ~__ballot(cur == v0);
+                sc_dist++;
+            }
 #endif
             if (cur >= 0) {
                 if (STATS) st_nodes++;
@@ -1174,7 +927,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
             }
             if ((shared || K > 1u) && cur != CUR_IDLE) {
                 const unsigned long long word = (best.tri >= 0) ? (((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri) : ~0ull;
-                poll_old = atomicMin(&keys[ray_id], word); poll_ray = ray_id; poll_pending = true;
+                poll_old = atomicMin(MCRT_KEYP(ray_id), word); poll_ray = ray_id; poll_pending = true;
             }
         }
     }
@@ -1182,7 +935,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
     if (lane == 0) {
         atomicAdd(&a.stamps[0], sc_refill); atomicAdd(&a.stamps[1], sc_p1); atomicAdd(&a.stamps[2], sc_p2); atomicAdd(&a.stamps[3], sc_n1);
         atomicAdd(&a.stamps[4], sc_n2); atomicAdd(&a.stamps[5], sc_outer); atomicAdd(&a.stamps[6], sc_act1); atomicAdd(&a.stamps[7], sc_act2); atomicAdd(&a.stamps[8], 1ull);
-        atomicAdd(&a.stamps[56], sc_park1); atomicAdd(&a.stamps[57], sc_idle1); atomicAdd(&a.stamps[58], sc_adopt);
+        atomicAdd(&a.stamps[56], sc_park1); atomicAdd(&a.stamps[57], sc_idle1); atomicAdd(&a.stamps[58], sc_adopt); atomicAdd(&a.stamps[59], sc_dist);
     }
 #endif
 #if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
@@ -1200,6 +953,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
 #undef MCRT_ON_INNER
 #undef MCRT_ON_LEAF
 #undef MCRT_WALKING
+#undef MCRT_KEYP
     if (STATS) {
         unsigned long long v[3] = { st_q, st_nodes, st_tris };
 #pragma unroll
@@ -1212,7 +966,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
 
 // ---- interface interaction (scene.cpp:122-165, ray.cpp:11-97) of ONE path at bounce b, given its ray and the closest-hit
 // word of the walk: thickness draw, travel, hit_boundary, the segment's records, the continuing ray's state.  Returns whether
-// the path goes on.  Shared by the wavefront pipeline (k_shade) and the fused path kernel (k_paths): one body, one arithmetic.
+// the path goes on.
 struct PathState { f3 from, dir; float intensity; int media, outside; double dist_mm; };
 
 template <bool STATS>
@@ -1357,166 +1111,13 @@ MCRT_DEV bool shade_path(const FrameArgs &a, uint32_t b, uint32_t pid, PathState
 }
 
 
-// =============================================================================================================
-// k_paths -- the FUSED path kernel: every lane owns one sample path and carries it through ALL its bounces (walk, interface
-// physics, next ray) in one persistent launch, so a frame costs five launches (k_init, the shared bounce-0 walk, k_paths,
-// k_march over all bounces, k_finalize) instead of thirty-one, and drains once instead of once per bounce.  This is what one
-// frame at a time wants (the reference's own frame loop, main.cpp:92-152, is one frame at a time); big passes keep the
-// wavefront pipeline, whose interface physics runs in full wavefronts.
-//
-// The walk is k_trace_lane's (same node test, same order, same triangle test: hits and visit counts are identical); the
-// physics is shade_path(), the body k_shade runs.  A wavefront alternates between three kinds of work, each run for all the
-// lanes that need it at once: inner-node steps, parked leaves, and the interface physics of lanes whose walk has ended
-// (fp64-heavy, a few thousand instructions: it waits until MCRT_PATHS_SHADE_BATCH lanes need it, or nothing else is left).
-// Path state lives in st0..st2 at the path's queue position between its bounces, so the walk keeps its registers.
-// =============================================================================================================
-#ifndef MCRT_PATHS_SHADE_BATCH
-#define MCRT_PATHS_SHADE_BATCH 24
-#endif
-#ifndef MCRT_PATHS_REFILL
-#define MCRT_PATHS_REFILL 16
-#endif
-template <bool STATS>
-__global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_paths(FrameArgs a)
-{
-    __shared__ int stack[MCRT_LANE_STACK * 256];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t n = a.ne * a.S;                               // paths = positions of the bounce-0 queue (scan-line-major, see k_init)
-    unsigned long long st_nodes = 0, st_tris = 0, st_q = 0, st_seg = 0, st_hits = 0;
-    const LaneStack S = { stack, a.stack_ovf + ((size_t)blockIdx.x * 256 + tid), (size_t)gridDim.x * 256, tid };
-    const uint32_t X = (n >= (uint32_t)MCRT_XCD_MIN_ITEMS) ? (uint32_t)MCRT_XCDS : 1u;
-    if (X == 1u && blockIdx.x * 256u >= n) return;
-    const uint32_t x_shift = (X == 1u) ? 0u : 3u;
-    uint32_t cur_x = blockIdx.x & (X - 1u), visited = 0;
-#define MCRT_SUB_LO(sq) ((uint32_t)(((unsigned long long)n * (sq)) >> x_shift))
-#define MCRT_SUB_STATIC(sq) (((gridDim.x - (sq) + X - 1u) >> x_shift) * 256u)
-    uint32_t *cursors = a.cursors + (size_t)1 * MCRT_XCDS * MCRT_CURSOR_STRIDE;     // (slot 0 belongs to the bounce-0 walk)
-    uint32_t i = MCRT_SUB_LO(cur_x) + (blockIdx.x >> x_shift) * 256u + (uint32_t)tid;
-    if (i >= MCRT_SUB_LO(cur_x + 1u)) i = 0xffffffffu;
-    uint32_t pos = 0, pid = 0, bounce = 0;
-    bool exhausted = false, has_path = false, pend = false;      // pend: the walk of `bounce` has ended, the physics is due
-    f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1), inv = mk(1, 1, 1);
-    Best best; best.frac = 1.0f; best.tri = -1;
-    int sp = 0, cur = CUR_IDLE;
-#define MCRT_ON_INNER(c) __builtin_amdgcn_sicmp((c), -1, 38)
-#define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)
-#define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)
-    uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;
-    MCRT_WATCHDOG_DECL()
-    for (;;) {
-        MCRT_WATCHDOG_CHECK()
-        const unsigned long long walking = MCRT_WALKING(cur);
-        const unsigned long long pending = __ballot(pend);
-        // ---- lanes without a path take the next queue positions ----
-        if (__popcll(__ballot(!has_path && !exhausted)) >= MCRT_PATHS_REFILL || (walking == 0ull && pending == 0ull)) {
-            const bool need = !has_path && !exhausted;
-            const unsigned long long dynm = __ballot(need && i == 0xffffffffu);
-            if (dynm) {
-                while (pool_next >= pool_end && !queue_empty) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&cursors[(size_t)cur_x * MCRT_CURSOR_STRIDE], (uint32_t)MCRT_LANE_FETCH);
-                    base = __shfl(base, 0, 64);
-                    const uint32_t hi = MCRT_SUB_LO(cur_x + 1u);
-                    const unsigned long long start = (unsigned long long)MCRT_SUB_LO(cur_x) + MCRT_SUB_STATIC(cur_x) + base;
-                    if (start < hi) { pool_next = (uint32_t)start; pool_end = min((uint32_t)start + (uint32_t)MCRT_LANE_FETCH, hi); }
-                    else if (++visited >= X) queue_empty = true;
-                    else cur_x = (cur_x + 1u) & (X - 1u);
-                }
-                if (need && i == 0xffffffffu) {
-                    const uint32_t mine = pool_next + (uint32_t)__popcll(dynm & ((1ull << lane) - 1ull));
-                    if (queue_empty) i = n;
-                    else if (mine < pool_end) i = mine;
-                }
-                const uint32_t taken = (uint32_t)__popcll(dynm);
-                pool_next = (pool_next + taken < pool_end) ? pool_next + taken : pool_end;
-            }
-            if (need && i != 0xffffffffu) {
-                if (i < n) {
-                    // bounce 0: every sample of a scan-line starts as a copy of first_ray (scene.cpp:83-101), walked ONCE per scan-line
-                    // by the launch before this one; the path starts with that result in hand
-                    pos = i; pid = a.queue[pos]; bounce = 0u;
-                    const float4 r0 = a.ray0[2 * (size_t)pos], r1 = a.ray0[2 * (size_t)pos + 1];
-                    f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
-                    const unsigned long long key = a.key0[pos / a.S];
-                    best.frac = __uint_as_float((uint32_t)(key >> 32)); best.tri = (int)(uint32_t)key;
-                    has_path = true; pend = true; cur = CUR_IDLE; i = 0xffffffffu;
-                } else exhausted = true;
-            }
-        }
-        // ---- interface physics of the lanes whose walk has ended ----
-        const unsigned long long pending2 = __ballot(pend);
-        if (pending2 != 0ull && (__popcll(pending2) >= MCRT_PATHS_SHADE_BATCH || MCRT_WALKING(cur) == 0ull)) {
-            if (pend) {
-                PathState ps;
-                const float4 s0 = a.st0[pos], s1 = a.st1[pos], s2 = a.st2[pos];
-                ps.from = mk(s0.x, s0.y, s0.z); ps.intensity = s0.w;
-                ps.dir = mk(s1.x, s1.y, s1.z); ps.media = __float_as_int(s1.w);
-                ps.dist_mm = __hiloint2double(__float_as_int(s2.y), __float_as_int(s2.x));
-                ps.outside = __float_as_int(s2.z);
-                const unsigned long long key = ((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri;
-                bool reflected;
-                const bool alive = shade_path<STATS>(a, bounce, pid, ps, f2, to, key, reflected, st_seg, st_hits);
-                pend = false;
-                if (alive) {
-                    bounce++;
-                    a.st0[pos] = make_float4(ps.from.x, ps.from.y, ps.from.z, ps.intensity);
-                    a.st1[pos] = make_float4(ps.dir.x, ps.dir.y, ps.dir.z, __int_as_float(ps.media));
-                    a.st2[pos] = make_float4(__int_as_float(__double2loint(ps.dist_mm)), __int_as_float(__double2hiint(ps.dist_mm)), __int_as_float(ps.outside), 0.0f);
-                    const Ray r = make_ray(ps.from, ps.dir, ps.intensity, a.mats[2 * ps.media].y, a);
-                    f2 = r.f2; to = r.to;
-                    inv = mk(1.0f / (r.to.x - r.f2.x), 1.0f / (r.to.y - r.f2.y), 1.0f / (r.to.z - r.f2.z));
-                    best.frac = 1.0f; best.tri = -1;
-                    sp = 0;
-                    if (a.n_nodes != 0u) cur = 0; else { cur = CUR_IDLE; pend = true; }      // (no geometry: an immediate miss)
-                    if (STATS) st_q++;
-                } else has_path = false;
-            }
-        }
-        if (MCRT_WALKING(cur) == 0ull) {
-            if (__any(pend)) continue;
-            if (!__any(has_path || !exhausted)) break;
-            continue;
-        }
+// ---- interface interaction of a bounce's live rays: one lane per ray.  The path's record is updated in place; what moves is
+// its 4-byte id: into the next bounce's queue directly (the default, see below), or -- a.sort -- bundle by bundle: survivors are
+// COUNTED per bundle here -- class = (scan-line, the last hist_bits reflect / refract decisions; all
+// frames of a pass share a class); k_scan turns the counts into the bundles' first positions in the next bounce's queue, which
+// k_place then fills.  (RNG counters and RF bins do not depend on queue order: any order gives the same images.)
+MCRT_DEV uint32_t bundle_bits(uint32_t b, uint32_t hist_bits) { return (b + 1u < hist_bits) ? b + 1u : hist_bits; }
 
-        // ---- inner nodes, until enough lanes are parked on a leaf or wait for their physics ----
-        const float tcap = fminf(1.0f, best.frac);
-        const LaneRay lr = { (v2f){ f2.x, f2.x }, (v2f){ f2.y, f2.y }, (v2f){ f2.z, f2.z }, (v2f){ inv.x, inv.x }, (v2f){ inv.y, inv.y }, (v2f){ inv.z, inv.z },
-                             inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f };
-        for (;;) {
-            const unsigned long long inner = MCRT_ON_INNER(cur);
-            if (inner == 0ull) break;
-            if (__popcll(MCRT_ON_LEAF(cur)) >= MCRT_LANE_LEAF_BATCH) break;
-            if (__popcll(__ballot(pend)) >= 2 * MCRT_PATHS_SHADE_BATCH) break;
-            if (cur >= 0) {
-                if (STATS) st_nodes++;
-                lane_node_step(a, S, lr, 0.0f, tcap, cur, sp, 0);
-                if (cur == CUR_IDLE) pend = true;                 // the walk has ended: the physics is due
-            }
-        }
-        // ---- the parked leaves (the contract's triangle test, as in k_trace_lane) ----
-        if ((uint32_t)cur > 0x80000000u) {
-            const uint32_t cnt = lane_leaf_test(a, S, f2, to, inv, 0.0f, false, best, cur, sp, 0);
-            if (STATS) st_tris += cnt;
-            if (cur == CUR_IDLE) pend = true;
-        }
-    }
-#undef MCRT_SUB_LO
-#undef MCRT_SUB_STATIC
-#undef MCRT_ON_INNER
-#undef MCRT_ON_LEAF
-#undef MCRT_WALKING
-    if (STATS) {
-        unsigned long long v[5] = { st_q, st_nodes, st_tris, st_seg, st_hits };
-        const int slot[5] = { 0, 1, 2, 3, 5 };
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            long long x = wave_sum_i64((long long)v[k]);
-            if (lane == 0 && x) atomicAdd(&a.stats[slot[k]], (unsigned long long)x);
-        }
-    }
-}
-
-// ---- interface interaction of a bounce's live rays (wavefront pipeline): one lane per ray ----
 template <bool STATS>
 __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, uint32_t b)
 {
@@ -1524,69 +1125,135 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x * blockDim.x >= n) return;
     const int lane = threadIdx.x & 63;
-    // two queue buffers, ping-pong by bounce parity (like the path state)
     const uint32_t *q_in = a.queue + (size_t)(b & 1u) * a.ne * a.S;
-    uint32_t *q_out = a.queue + (size_t)((b + 1u) & 1u) * a.ne * a.S;
-    const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
-    float4 *rays_out = (b & 1u) ? a.ray0 : a.ray1;
-    const bool valid = i < n;
-    bool alive = false, reflected = false;
-    uint32_t pid = 0;
-    PathState ps; ps.from = mk(0, 0, 0); ps.dir = mk(0, 0, 1); ps.intensity = 0.0f; ps.media = 0; ps.outside = OUT_NONE; ps.dist_mm = 0.0;
+    const uint32_t hb = bundle_bits(b, a.hist_bits);
+    bool alive = false, qrefl = false;
+    uint32_t cls = 0xffffffffu, qpid = 0;
     unsigned long long st_seg = 0, st_hits = 0;
-    if (valid) {
-        pid = q_in[i];
-        // path state lives in queue order (ping-pong halves by bounce parity), so a wavefront reads and writes it coalesced
-        const size_t sin = (size_t)(b & 1u) * a.ne * a.S + i;
-        const float4 s0 = a.st0[sin], s1 = a.st1[sin], s2 = a.st2[sin];
+    if (i < n) {
+        const uint32_t pid = q_in[i];
+        const float4 s0 = MCRT_REC(a, 0, pid), s1 = MCRT_REC(a, 1, pid), s2 = MCRT_REC(a, 2, pid), r0 = MCRT_REC(a, 3, pid), r1 = MCRT_REC(a, 4, pid);
+        PathState ps;
         ps.from = mk(s0.x, s0.y, s0.z); ps.intensity = s0.w;
         ps.dir = mk(s1.x, s1.y, s1.z); ps.media = __float_as_int(s1.w);
         ps.dist_mm = __hiloint2double(__float_as_int(s2.y), __float_as_int(s2.x));
         ps.outside = __float_as_int(s2.z);
-        const float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
+        uint32_t hist = __float_as_uint(s2.w);
         const f3 f2 = mk(r0.x, r0.y, r0.z), to = mk(r0.w, r1.x, r1.y);
-        const size_t hi = (b == 0u) ? (size_t)(i / a.S) : (size_t)i;            // bounce 0: one walk per queued scan-line (see k_trace, k_init)
-        const unsigned long long key = ((b & 1u) ? a.key1 : a.key0)[hi];
+        // bounce 0: one walk per (frame, scan-line), its word sits in the first sample's record (see k_trace_lane, k_init)
+        const unsigned long long key = (b == 0u) ? *MCRT_KEYW(a, pid - pid % a.S, 1) : *MCRT_KEYW(a, pid, 0);
+        bool reflected = false;
         alive = shade_path<STATS>(a, b, pid, ps, f2, to, key, reflected, st_seg, st_hits);
-    }
-    const f3 from = ps.from, dir = ps.dir; const float intensity = ps.intensity; const int media = ps.media, outside = ps.outside; const double dist_mm = ps.dist_mm;
-
-    // survivors -> next bounce's queue (ballot + prefix; ONE atomic per workgroup: tens of thousands of returning atomics on the
-    // single counter would serialise in L2 and bound the kernel).  Inside a wavefront's block the reflected rays
-    // come first, then the refracted ones, each in queue order: the samples of a scan-line that took the same decisions stay
-    // adjacent, so the 16 rays of a k_trace wavefront mostly belong to one tight bundle (same nodes, similar walk length).
-    __shared__ uint32_t wave_live[4], block_base;
-    const unsigned long long live = __ballot(alive);
-    const unsigned long long live_refl = __ballot(alive && reflected);
-    const int wv = threadIdx.x >> 6;
-    if (lane == 0) wave_live[wv] = (uint32_t)__popcll(live);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t total = wave_live[0] + wave_live[1] + wave_live[2] + wave_live[3];
-        block_base = total ? atomicAdd(&a.counts[b + 1u], total) : 0u;
-    }
-    __syncthreads();
-    if (live) {
-        uint32_t base = block_base;
-        for (int w = 0; w < wv; w++) base += wave_live[w];
         if (alive) {
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const uint32_t pos = base + (reflected ? (uint32_t)__popcll(live_refl & below)
-                                                   : (uint32_t)__popcll(live_refl) + (uint32_t)__popcll(live & ~live_refl & below));
-            q_out[pos] = pid;
-            ((b & 1u) ? a.key0 : a.key1)[pos] = MCRT_KEY_MISS;            // the next bounce's closest-hit word of this ray
-            const size_t so = (size_t)((b + 1u) & 1u) * a.ne * a.S + pos;
-            a.st0[so] = make_float4(from.x, from.y, from.z, intensity);
-            a.st1[so] = make_float4(dir.x, dir.y, dir.z, __int_as_float(media));
-            a.st2[so] = make_float4(__int_as_float(__double2loint(dist_mm)), __int_as_float(__double2hiint(dist_mm)), __int_as_float(outside), 0.0f);
-            const Ray r = make_ray(from, dir, intensity, a.mats[2 * media].y, a);
-            rays_out[2 * (size_t)pos] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
-            rays_out[2 * (size_t)pos + 1] = make_float4(r.to.y, r.to.z, 1.0f / (r.to.x - r.f2.x), 1.0f / (r.to.y - r.f2.y));   // (one lane divides here instead of four in k_trace)
+            hist = (hist << 1) | (reflected ? 1u : 0u);
+            MCRT_REC(a, 0, pid) = make_float4(ps.from.x, ps.from.y, ps.from.z, ps.intensity);
+            MCRT_REC(a, 1, pid) = make_float4(ps.dir.x, ps.dir.y, ps.dir.z, __int_as_float(ps.media));
+            MCRT_REC(a, 2, pid) = make_float4(__int_as_float(__double2loint(ps.dist_mm)), __int_as_float(__double2hiint(ps.dist_mm)), __int_as_float(ps.outside), __uint_as_float(hist));
+            const Ray r = make_ray(ps.from, ps.dir, ps.intensity, a.mats[2 * ps.media].y, a);
+            MCRT_REC(a, 3, pid) = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
+            MCRT_REC(a, 4, pid) = make_float4(r.to.y, r.to.z, 1.0f / (r.to.x - r.f2.x), 1.0f / (r.to.y - r.f2.y));   // (one lane divides here, once per ray)
+            *MCRT_KEYW(a, pid, 0) = MCRT_KEY_MISS;                                // the next bounce's closest-hit word of this path
+            const uint32_t line = pid / a.S;                             // (frame, scan-line), frame-major
+            const uint32_t cl = a.cls_lines == a.ne_frame ? line % a.ne_frame : line;     // one probe pose for the pass: the frames of a scan-line are one bundle
+            cls = (cl << hb) | (hist & ((1u << hb) - 1u));
         }
+        if (a.sort) a.tmp[i] = make_uint2(pid, cls);
+        qpid = pid; qrefl = reflected;
+    }
+    if (!a.sort) {
+        // survivors -> next bounce's queue, ORDER-PRESERVING (ballot + prefix; ONE atomic per workgroup: tens of thousands of returning
+        // atomics on the single counter would serialise in L2 and bound the kernel).  Inside a wavefront's block the reflected rays
+        // come first, then the refracted ones, each in queue order: the samples of a scan-line that took the same decisions stay
+        // adjacent, and the queue stays in near path-id order (so neighbouring lanes of the next launches touch neighbouring records).
+        __shared__ uint32_t wave_live[4], block_base;
+        const unsigned long long live = __ballot(alive);
+        const unsigned long long live_refl = __ballot(alive && qrefl);
+        const int wv = threadIdx.x >> 6;
+        if (lane == 0) wave_live[wv] = (uint32_t)__popcll(live);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t total = wave_live[0] + wave_live[1] + wave_live[2] + wave_live[3];
+            block_base = total ? atomicAdd(&a.counts[b + 1u], total) : 0u;
+        }
+        __syncthreads();
+        if (alive) {
+            uint32_t base = block_base;
+            for (int w = 0; w < wv; w++) base += wave_live[w];
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint32_t pos = base + (qrefl ? (uint32_t)__popcll(live_refl & below)
+                                               : (uint32_t)__popcll(live_refl) + (uint32_t)__popcll(live & ~live_refl & below));
+            (a.queue + (size_t)((b + 1u) & 1u) * a.ne * a.S)[pos] = qpid;
+        }
+    }
+    // sorted queues: survivors per bundle, one atomic per wavefront and bundle it holds (one or two, each splitting in two)
+    for (unsigned long long rem = a.sort ? __ballot(alive) : 0ull; rem != 0ull;) {
+        const int l0 = __ffsll((long long)rem) - 1;
+        const uint32_t c0 = (uint32_t)__shfl((int)cls, l0, 64);
+        const unsigned long long m = __ballot(alive && cls == c0);
+        if (lane == l0) atomicAdd(&a.cls_cnt[c0], (uint32_t)__popcll(m));
+        rem &= ~m;
     }
     if (STATS) {
         long long x = wave_sum_i64((long long)st_seg), y = wave_sum_i64((long long)st_hits);
         if (lane == 0) { if (x) atomicAdd(&a.stats[3], (unsigned long long)x); if (y) atomicAdd(&a.stats[5], (unsigned long long)y); }
+    }
+}
+
+// ---- the counts of k_shade into queue positions: fill[c] = first position of bundle c in the next bounce's queue (bundles in class
+// order = scan-line-major), counts[b + 1] = their total; the counters are left zeroed for the next bounce.  ONE workgroup: the table
+// has at most 65536 entries, and a kernel boundary on either side orders it with the atomics before and after at no cost (a
+// "last workgroup done" scan inside k_shade needs a device-scope release per workgroup: an L2 write-back each, 7x the kernel's time).
+__global__ void __launch_bounds__(1024) k_scan(FrameArgs a, uint32_t b)
+{
+    __shared__ uint32_t s_part[1024];
+    const uint32_t hb = bundle_bits(b, a.hist_bits);
+    const uint32_t nt = a.cls_lines << hb;
+    if (a.counts[b] == 0u) return;                               // (nothing was counted: counts[b + 1] stays 0, the counters are zero)
+    uint32_t per = (nt + 1023u) / 1024u;
+    per = (per + 3u) & ~3u;                                      // four counters per load (the tables are padded to a multiple of 4096 entries)
+    const uint32_t c0 = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t c = c0; c < c0 + per; c += 4u) { const uint4 v = *(const uint4 *)&a.cls_cnt[c]; sum += (v.x + v.y) + (v.z + v.w); }
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {                   // inclusive scan of the 1024 partial sums
+        const uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;
+    for (uint32_t c = c0; c < c0 + per; c += 4u) {
+        const uint4 v = *(const uint4 *)&a.cls_cnt[c];
+        *(uint4 *)&a.cls_fill[c] = make_uint4(run, run + v.x, run + v.x + v.y, run + v.x + v.y + v.z);
+        run += (v.x + v.y) + (v.z + v.w);
+        *(uint4 *)&a.cls_cnt[c] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (threadIdx.x == 1023u) a.counts[b + 1u] = s_part[1023];
+}
+
+// ---- the survivors of bounce b into the queue of bounce b + 1, bundle after bundle (fill[] from k_scan); inside a bundle in the order
+// the wavefronts arrive ----
+__global__ void __launch_bounds__(256) k_place(FrameArgs a, uint32_t b)
+{
+    const uint32_t n = a.counts[b];
+    const int lane = threadIdx.x & 63;
+    uint32_t *q_out = a.queue + (size_t)((b + 1u) & 1u) * a.ne * a.S;
+    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+        const uint32_t i = base + threadIdx.x;
+        uint2 t = make_uint2(0u, 0xffffffffu);
+        if (i < n) t = a.tmp[i];
+        const bool alive = t.y != 0xffffffffu;
+        for (unsigned long long rem = __ballot(alive); rem != 0ull;) {
+            const int l0 = __ffsll((long long)rem) - 1;
+            const uint32_t c0 = (uint32_t)__shfl((int)t.y, l0, 64);
+            const unsigned long long m = __ballot(alive && t.y == c0);
+            uint32_t first = 0;
+            if (lane == l0) first = atomicAdd(&a.cls_fill[c0], (uint32_t)__popcll(m));
+            first = (uint32_t)__shfl((int)first, l0, 64);
+            if (alive && t.y == c0) q_out[first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = t.x;
+            rem &= ~m;
+        }
     }
 }
 
@@ -1897,6 +1564,7 @@ __global__ void k_remap(const float *img, uint32_t E, uint32_t R, const float *m
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    img += (size_t)blockIdx.y * E * R; out += (size_t)blockIdx.y * n;          // image blockIdx.y of a stack [n_img][E][R] -> [n_img][n]
     const float mx = map_col[i], my = map_row[i];
     const float fx = floorf(mx), fy = floorf(my);
     const float ax = mx - fx, ay = my - fy;
@@ -2023,33 +1691,14 @@ uint32_t lane_stack_entries() { return MCRT_LANE_STACK; }
 
 hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st)
 {
-    if (a.nodes_walk) {          // one lane per ray
-        uint32_t np = (b == 0u) ? a.ne : a.ne * a.S;
-        if (np < a.ksplit_limit) np = a.ksplit_limit;
-        const uint32_t blocks = (np + 255u) / 256u;
-        const dim3 grid(blocks < a.trace_blocks ? blocks : a.trace_blocks), blk(256);
-        if (stats) hipLaunchKernelGGL((k_trace_lane<true>), grid, blk, 0, st, a, b);
-        else hipLaunchKernelGGL((k_trace_lane<false>), grid, blk, 0, st, a, b);
-        return hipGetLastError();
-    }
     // persistent over the bounce's queue: at most trace_blocks workgroups (the rest of the queue is fetched dynamically);
     // the live-ray count is only known on the device, surplus blocks read it and leave
     uint32_t np = (b == 0u) ? a.ne : a.ne * a.S;
     if (np < a.ksplit_limit) np = a.ksplit_limit;          // small bounces are cut into up to ksplit_limit pieces
-    const uint32_t blocks = (np + 63u) / 64u;
+    const uint32_t blocks = (np + 255u) / 256u;
     const dim3 grid(blocks < a.trace_blocks ? blocks : a.trace_blocks), blk(256);
-    if (stats) hipLaunchKernelGGL((k_trace<true>), grid, blk, 0, st, a, b);
-    else hipLaunchKernelGGL((k_trace<false>), grid, blk, 0, st, a, b);
-    return hipGetLastError();
-}
-
-// the fused path kernel: bounce 0's shared walk must have run (launch_trace(a, 0, ...)); needs a.nodes_walk
-hipError_t launch_paths(const FrameArgs &a, bool stats, hipStream_t st)
-{
-    const uint32_t np = a.ne * a.S, blocks = (np + 255u) / 256u;
-    const dim3 grid(blocks < a.trace_blocks ? blocks : a.trace_blocks), blk(256);
-    if (stats) hipLaunchKernelGGL((k_paths<true>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((k_paths<false>), grid, blk, 0, st, a);
+    if (stats) hipLaunchKernelGGL((k_trace_lane<true>), grid, blk, 0, st, a, b);
+    else hipLaunchKernelGGL((k_trace_lane<false>), grid, blk, 0, st, a, b);
     return hipGetLastError();
 }
 
@@ -2059,6 +1708,11 @@ hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
     const dim3 grid((np + 255u) / 256u), blk(256);
     if (stats) hipLaunchKernelGGL((k_shade<true>), grid, blk, 0, st, a, b);
     else hipLaunchKernelGGL((k_shade<false>), grid, blk, 0, st, a, b);
+    if (a.sort && b + 1u < a.B) {                           // (the last bounce has no successor to queue for)
+        const uint32_t blocks = (np + 255u) / 256u;
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a, b);
+        hipLaunchKernelGGL(k_place, dim3(blocks < 2048u ? blocks : 2048u), blk, 0, st, a, b);
+    }
     return hipGetLastError();
 }
 
@@ -2105,9 +1759,9 @@ hipError_t launch_envelope(float *img, uint32_t E, uint32_t R, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_remap(const float *img, uint32_t E, uint32_t R, const float *map_col, const float *map_row, float *out, uint32_t n, hipStream_t st)
+hipError_t launch_remap(const float *img, uint32_t n_img, uint32_t E, uint32_t R, const float *map_col, const float *map_row, float *out, uint32_t n, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_remap, dim3((n + 255) / 256), dim3(256), 0, st, img, E, R, map_col, map_row, out, n);
+    hipLaunchKernelGGL(k_remap, dim3((n + 255) / 256, n_img), dim3(256), 0, st, img, E, R, map_col, map_row, out, n);
     return hipGetLastError();
 }
 

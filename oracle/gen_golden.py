@@ -12,7 +12,14 @@ subprocess.check_call(["make", "-C", here, "ref"])
 probe = os.path.join(here, "_ref", "ref_probe")
 if not os.path.exists(probe):
     sys.exit("reference not mounted; cannot regenerate goldens")
-data = json.loads(subprocess.check_output([probe]))
+ref = os.environ.get("MCRT_REFERENCE", "/root/reference")
+scenes = []
+for sub in ("sphere", "ircad11"):
+    d = os.path.join(ref, "examples", sub)
+    for f in sorted(os.listdir(d)):
+        if f.endswith(".scene"):
+            scenes.append("%s=%s" % (f, os.path.join(d, f)))
+data = json.loads(subprocess.check_output([probe] + scenes))
 data["_generated_by"] = "oracle/gen_golden.py (oracle/ref_probe.cpp compiled against /root/reference headers)"
 out = os.path.join(here, "..", "tests", "golden", "ref_probe.json")
 with open(out, "w") as f:

@@ -6,6 +6,8 @@
 //   src/psf.h            -> PSF taps                         (main.cpp:54 parameters)
 //   src/volume.h         -> tissue texture (hash, sums, samples, get_scattering probes)
 //   include/units/units.h-> the unit arithmetic of main.cpp:23-37,114-139 and rfimage.h:33-51,178-180
+//   include/nlohmann/json.hpp + examples/**/*.scene -> the fields scene::parse_config (scene.cpp:185-247) and main.cpp:62-72 read,
+//                           converted as the reference converts them (json number -> float), for every scene file that loads
 // Built by oracle/Makefile into oracle/_ref/ref_probe (git-ignored); run by oracle/gen_golden.py,
 // which writes tests/golden/ref_probe.json.  Only this container has /root/reference.
 #include <cstdio>
@@ -19,6 +21,9 @@
 #undef private
 #include "psf.h"                 // note: redefines M_PI as 3.14159 (psf.h:9)
 #include <units/units.h>
+#include <nlohmann/json.hpp>
+#include <fstream>
+#include <string>
 
 using namespace units::literals;
 using namespace units::velocity;
@@ -51,9 +56,67 @@ struct rf_axis {
 template <unsigned int a, unsigned int s> constexpr meters_per_second_t rf_axis<a, s>::speed_of_sound_;
 template <unsigned int a, unsigned int s> constexpr micrometer_t rf_axis<a, s>::axial_resolution_;
 
-int main()
+// the fields scene::parse_config (scene.cpp:185-247) and main.cpp:62-72 read from a .scene file, in the reference's own conversions
+// (float x = json number), as one JSON object; floats as bit patterns.  A file the reference could not load (json.at throws, e.g.
+// ircad11.scene lacks shininess / thickness) is reported as {"error": ...}.
+static void dump_scene(const char *path)
+{
+    try {
+        std::ifstream in(path);
+        if (!in) { printf("{\"error\":\"cannot open\"}"); return; }
+        nlohmann::json j;
+        in >> j;
+        std::string out = "{";
+        auto f3 = [&](const char *key) {
+            const auto &v = j.at(key);
+            char buf[128]; const float a = v[0], b = v[1], c = v[2];
+            snprintf(buf, sizeof buf, "\"%s\":[%u,%u,%u],", key, fbits(a), fbits(b), fbits(c));
+            out += buf;
+        };
+        f3("transducerPosition"); f3("transducerAngles"); f3("origin"); f3("spacing");
+        { char buf[96]; const float sc = j.at("scaling"); snprintf(buf, sizeof buf, "\"scaling\":%u,", fbits(sc)); out += buf; }
+        { const std::string sm = j.at("startingMaterial"); out += "\"startingMaterial\":\"" + sm + "\","; }
+        out += "\"materials\":[";
+        bool first = true;
+        for (const auto &m : j.at("materials")) {
+            const std::string name = m.at("name");
+            const float v[8] = { m.at("impedance"), m.at("attenuation"), m.at("mu0"), m.at("mu1"), m.at("sigma"), m.at("specularity"), m.at("shininess"), m.at("thickness") };
+            char buf[256];
+            snprintf(buf, sizeof buf, "%s[\"%s\",%u,%u,%u,%u,%u,%u,%u,%u]", first ? "" : ",", name.c_str(), fbits(v[0]), fbits(v[1]), fbits(v[2]), fbits(v[3]), fbits(v[4]), fbits(v[5]), fbits(v[6]), fbits(v[7]));
+            out += buf; first = false;
+        }
+        out += "],\"meshes\":[";
+        first = true;
+        for (const auto &m : j.at("meshes")) {
+            const std::string file = m.at("file"), mat = m.at("material"), outm = m.at("outsideMaterial");
+            const bool rigid = m.at("rigid"), vasc = m.at("vascular"), on = m.at("outsideNormals");
+            const auto &d = m.at("deltas");
+            const float d0 = d[0], d1 = d[1], d2 = d[2];
+            char buf[512];
+            snprintf(buf, sizeof buf, "%s[\"%s\",%d,%d,%u,%u,%u,%d,\"%s\",\"%s\"]", first ? "" : ",", file.c_str(), (int)rigid, (int)vasc, fbits(d0), fbits(d1), fbits(d2), (int)on, mat.c_str(), outm.c_str());
+            out += buf; first = false;
+        }
+        out += "]}";
+        fputs(out.c_str(), stdout);
+    } catch (const std::exception &ex) {
+        std::string msg = ex.what();
+        for (auto &ch : msg) if (ch == '"' || ch == '\\') ch = '\'';
+        printf("{\"error\":\"%s\"}", msg.c_str());
+    }
+}
+
+int main(int argc, char **argv)
 {
     printf("{\n");
+    // ---- the reference's example scenes through its own JSON reader (argv: the .scene files, as name=path) ----
+    printf("\"scenes\": {");
+    for (int i = 1; i < argc; i++) {
+        const char *eq = strchr(argv[i], '=');
+        if (!eq) continue;
+        printf("%s\"%.*s\": ", i > 1 ? "," : "", (int)(eq - argv[i]), argv[i]);
+        dump_scene(eq + 1);
+    }
+    printf("},\n");
     // ---- psf (main.cpp:54: psf<7,13,7,145>{4.5f, 0.05f, 0.2f, 0.1f}) ----
     {
         const psf<7, 13, 7, 145> p{ transducer_frequency, 0.05f, 0.2f, 0.1f };

@@ -512,13 +512,13 @@ def test_randomised_configurations(mcrt, orc, case, monkeypatch):
     """a sweep over shapes and parameters nobody picked by hand: odd element / sample / row counts, depths 1..16, both builders,
     textures of several sizes, TIR sanitising on and off, frequency, seed, frames in flight -- hits and RF bit for bit"""
     rng = np.random.default_rng(1000 + case)
-    # every fourth case through the fused path kernel, one through the round-1 quad walk (the library reads its knobs at mcrt_create)
-    for k in ("MCRT_PIPELINE", "MCRT_QUAD_WALK"):
+    # every fourth case with queues sorted into bundles (by 0, 1 or 2 decisions), one with two scan-line groups on two streams (the library reads its knobs at mcrt_create)
+    for k in ("MCRT_SORT_BITS", "MCRT_GROUPS"):
         monkeypatch.delenv(k, raising=False)
     if case % 4 == 3:
-        monkeypatch.setenv("MCRT_PIPELINE", "fused")
+        monkeypatch.setenv("MCRT_SORT_BITS", str(case % 3))
     if case == 6:
-        monkeypatch.setenv("MCRT_QUAD_WALK", "1")
+        monkeypatch.setenv("MCRT_GROUPS", "2")
     if case % 3 == 0:
         cfg, meshes = mcrt.synth.random_scene(int(rng.integers(2000, 30000)), 8, seed=int(rng.integers(1, 1000)))
     elif case % 3 == 1:
@@ -689,16 +689,18 @@ def test_reference_style_program_on_the_host_shim(mcrt, orc, tex256, tmp_path):
     assert np.abs(host[m] - fused[m]).max() <= RTOL_REF * peak
 
 
-def test_pipelines_and_walks_agree(mcrt, orc, tex256, monkeypatch):
-    """the three ways a pass can be traced -- fused path kernel (small passes), wavefront pipeline with the lane-per-ray walk
-    (big passes), wavefront pipeline with the round-1 quad walk -- give bit-identical hits, segments, RF images and visit counts,
-    all equal to the oracle's"""
+def test_queue_order_and_groups_do_not_change_anything(mcrt, orc, tex256, monkeypatch):
+    """the order of a bounce's queue is free (counter-keyed RNG, integer RF bins): order-preserving compaction (the default), queues
+    sorted into bundles by the full decision history, by two decisions, by scan-line alone, two scan-line groups on two streams, and
+    the accumulation confined to its own CUs all give bit-identical hits, segments, RF images and visit counts, equal to the oracle's."""
     cfg, meshes = mcrt.synth.random_scene(60000, 8, seed=5)
     sd = mcrt.scene_io.build_scene(cfg, meshes)
     E, S, frame = 24, 160, 11
     got = {}
-    for name, env in (("fused", {"MCRT_PIPELINE": "fused"}), ("wavefront_lane", {"MCRT_PIPELINE": "wavefront"}), ("wavefront_quad", {"MCRT_PIPELINE": "wavefront", "MCRT_QUAD_WALK": "1"})):
-        for k in ("MCRT_PIPELINE", "MCRT_QUAD_WALK"):
+    variants = (("preserved", {}), ("history", {"MCRT_SORT_BITS": "10"}), ("two_bits", {"MCRT_SORT_BITS": "2"}), ("scanline", {"MCRT_SORT_BITS": "0"}),
+                ("two_groups", {"MCRT_GROUPS": "2"}), ("sorted_groups", {"MCRT_GROUPS": "2", "MCRT_SORT_BITS": "10"}), ("masked", {"MCRT_MARCH_CUS": "64", "MCRT_MAIN_MASK": "1"}))
+    for name, env in variants:
+        for k in ("MCRT_SORT_BITS", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)                               # (the library reads its knobs once, at mcrt_create)
@@ -713,31 +715,140 @@ def test_pipelines_and_walks_agree(mcrt, orc, tex256, monkeypatch):
         batch = sim.ctx.d2h(dev, (3, E, sim.R))
         sim.ctx.free(dev)
         nodes, btri, _ = sim.ctx.get_bvh()
-        nodes4 = sim.ctx.get_bvh4()[0]                            # the tree as THIS walk reads it (half-float boxes for the lane walk)
+        nodes4 = sim.ctx.get_bvh4()[0]
         sim.close()
         got[name] = (hits, segs.tobytes(), cnt, rf, st, batch[1].T.copy(), nodes4)
-    for k in ("MCRT_PIPELINE", "MCRT_QUAD_WALK"):
+    for k in ("MCRT_SORT_BITS", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK"):
         monkeypatch.delenv(k, raising=False)
-    a = got["fused"]
-    for name in ("wavefront_lane", "wavefront_quad"):
+    a = got["preserved"]
+    for name in [v[0] for v in variants[1:]]:
         b = got[name]
         assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2]), name
         assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)), name
-    # the two pipelines of the lane walk read the same nodes: same visit counts; the quad walk reads the builders' float boxes
-    assert {k: v for k, v in a[4].items() if k != "rf_steps"} == {k: v for k, v in got["wavefront_lane"][4].items() if k != "rf_steps"}
-    assert np.array_equal(a[6], got["wavefront_lane"][6]) and not np.array_equal(a[6], got["wavefront_quad"][6])
-    assert got["wavefront_quad"][4]["nodes_visited"] <= a[4]["nodes_visited"] <= 1.1 * got["wavefront_quad"][4]["nodes_visited"]
+        assert {k: v for k, v in a[4].items() if k != "rf_steps"} == {k: v for k, v in b[4].items() if k != "rf_steps"}, name
     for name, g in got.items():
         assert np.array_equal(g[5].view(np.uint32), g[3].view(np.uint32)), name
     p = orc.default_params(n_elements=E, n_samples=S)
     p0 = orc.default_params(n_elements=E, n_samples=S, max_depth=1)
-    for name in ("fused", "wavefront_quad"):                      # each walk's counts against the oracle walking the tree that walk reads
-        g = got[name]
-        osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
-        osc.set_bvh4(g[6])
-        o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=16)
-        assert np.array_equal(g[0], o["hits"]), name
-        _assert_rf(g[3], o)
-        o0 = osc.trace_frame(p0, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=16, want_ref=False, want_fix=False)["stats"]
-        for k in ("queries", "nodes_visited", "tris_tested"):
-            assert g[4][k] == o["stats"][k] - o0[k] + o0[k] // S, (name, k)
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
+    osc.set_bvh4(a[6])
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=16)
+    assert np.array_equal(a[0], o["hits"])
+    _assert_rf(a[3], o)
+    o0 = osc.trace_frame(p0, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=16, want_ref=False, want_fix=False)["stats"]
+    for k in ("queries", "nodes_visited", "tris_tested"):
+        assert a[4][k] == o["stats"][k] - o0[k] + o0[k] // S, k
+
+
+def test_deep_tree_overflow_stacks_of_two_groups(mcrt, orc, tex256, monkeypatch):
+    """a tree whose worst-case traversal stack exceeds the walk's 32 LDS entries, traced as TWO scan-line groups whose walks
+    run side by side: each group owns its overflow array, so hits stay the oracle's"""
+    rng = np.random.default_rng(77)
+    # triangles at ten nested scales around a point on the probe's line of sight: the SAH tree splits the scales off one by one and
+    # gets deep (worst-case stack 51 entries), and the rays through the centre cross every scale
+    n, levels = 20000, 10
+    k = rng.integers(0, levels, size=n)
+    scale = (0.5 ** k).astype(np.float32)
+    c = (rng.uniform(-1, 1, size=(n, 3)).astype(np.float32) * scale[:, None] * np.array([8, 6, 6], np.float32)) + np.array([-2, 0, 0], np.float32)
+    e1 = rng.uniform(-0.3, 0.3, size=(n, 3)).astype(np.float32) * scale[:, None]
+    e2 = rng.uniform(-0.3, 0.3, size=(n, 3)).astype(np.float32) * scale[:, None]
+    tri = np.concatenate([c, c + e1, c + e2], axis=1).astype(np.float32)
+    cfg, meshes = mcrt.synth.random_scene(64, 8, seed=3)
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    sd.tri = np.ascontiguousarray(tri); sd.tri_mesh = (np.arange(n) % len(sd.meshes)).astype(np.uint32)
+    E, S = 16, 96
+    out = {}
+    for groups in ("1", "2"):
+        monkeypatch.setenv("MCRT_GROUPS", groups)
+        tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256)
+        _, max_stack = sim.ctx.get_bvh4()
+        dev = sim.ctx.alloc(2 * E * sim.R * 4)
+        sim.ctx.trace_frames(4, 2, dev)
+        out[groups] = sim.ctx.d2h(dev, (2, E, sim.R))
+        sim.ctx.free(dev)
+        if groups == "1":
+            hits, _, _ = sim.ctx.trace_frame_debug(5, sim.rf_dev)
+            nodes4 = sim.ctx.get_bvh4()[0]; _, btri, _ = sim.ctx.get_bvh()
+        sim.close()
+    monkeypatch.delenv("MCRT_GROUPS", raising=False)
+    assert np.array_equal(out["1"].view(np.uint32), out["2"].view(np.uint32))
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
+    osc.set_bvh4(nodes4, btri)
+    o = osc.trace_frame(orc.default_params(n_elements=E, n_samples=S), tr.pos, tr.dir, tex256, frame_id=5, use_bvh=2, n_threads=16, want_ref=False)
+    assert np.array_equal(hits, o["hits"])
+    assert np.array_equal(out["2"][1].T.view(np.uint32), o["rf"].view(np.uint32))
+    assert max_stack > 32, "the scene was meant to need the overflow stack (max_stack %d)" % max_stack
+
+
+def test_per_frame_poses_in_one_pass(mcrt, orc, sphere, tex256):
+    """mcrt_trace_frames_poses: the frames of a pass each with their own probe pose (the moving probe of transducer.h:82-118 /
+    inputmanager.cpp:117-121) == the same frames traced one at a time with mcrt_set_transducer between them, bit for bit; one of
+    them against the oracle; host and device pose tables alike; scan-line shards too"""
+    cfg, sd = sphere
+    E, S, F, f0 = 24, 96, 6, 40
+    tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256)
+    base = np.asarray(cfg["transducerAngles"], np.float64)
+    poses = []
+    for f in range(F):                                           # the probe rotates and slides a little between frames
+        t = mcrt.Transducer(E, position=np.asarray(cfg["transducerPosition"], np.float64) + np.array([0.0, 0.15 * f, -0.1 * f]),
+                            angles_deg=base + np.array([1.5 * f, -0.7 * f, 2.0 * f]))
+        poses.append(t)
+    pos = np.stack([t.pos for t in poses]); dirs = np.stack([t.dir for t in poses])
+    dev = sim.ctx.alloc(F * E * sim.R * 4)
+    sim.ctx.trace_frames_poses(f0, pos, dirs, dev)
+    batch = sim.ctx.d2h(dev, (F, E, sim.R))
+    for f in range(F):
+        sim.ctx.set_transducer(poses[f].pos, poses[f].dir)
+        sim.trace(f0 + f)
+        one = sim.ctx.d2h(sim.rf_dev, (E, sim.R))
+        assert np.array_equal(batch[f].view(np.uint32), one.view(np.uint32)), f
+    assert not np.array_equal(batch[0].view(np.uint32), batch[F - 1].view(np.uint32))
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
+    o = osc.trace_frame(orc.default_params(n_elements=E, n_samples=S), poses[3].pos, poses[3].dir, tex256, frame_id=f0 + 3, use_bvh=False, n_threads=8, want_ref=False)
+    assert np.array_equal(batch[3].T.view(np.uint32), o["rf"].view(np.uint32))
+    # device-resident pose tables, and a shard of the scan-lines
+    dpos, ddir = sim.ctx.alloc(pos.nbytes), sim.ctx.alloc(dirs.nbytes)
+    sim.ctx.h2d(dpos, pos); sim.ctx.h2d(ddir, dirs)
+    sim.ctx.trace_frames_poses(f0, dpos, ddir, dev, n_frames=F)
+    assert np.array_equal(sim.ctx.d2h(dev, (F, E, sim.R)).view(np.uint32), batch.view(np.uint32))
+    sim.ctx.trace_frames_poses(f0, dpos, ddir, dev, 5, 17, n_frames=F)
+    assert np.array_equal(sim.ctx.d2h(dev, (F, 12, sim.R)).view(np.uint32), batch[:, 5:17].view(np.uint32))
+    sim.ctx.free(dpos); sim.ctx.free(ddir)
+    # the context's own transducer is untouched: a plain pass afterwards uses the pose set last with mcrt_set_transducer
+    sim.ctx.trace_frames(f0 + F - 1, 1, dev)
+    assert np.array_equal(sim.ctx.d2h(dev, (1, E, sim.R))[0].view(np.uint32), batch[F - 1].view(np.uint32))
+    import ctypes
+    assert sim.ctx.L.mcrt_trace_frames_poses(sim.ctx.h, 0, 2, 0, E, None, None, ctypes.c_void_p(dev)) == -1      # MCRT_ERR_INVALID: no pose tables
+    sim.ctx.free(dev)
+    sim.close()
+
+
+def test_whole_bmode_frames_of_a_pass(mcrt, orc, sphere, tex256):
+    """main.cpp:146-148 for every frame of a pass in three launches: mcrt_convolve_frames, mcrt_envelope_frames,
+    mcrt_scan_convert_frames == the per-image calls == the oracle, bit for bit"""
+    cfg, sd = sphere
+    E, S, F = 64, 48, 4
+    tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256, sanitize_tir=1)
+    R = sim.R
+    dev = sim.ctx.alloc(F * E * R * 4); out = sim.ctx.alloc(F * 400 * 500 * 4); one = sim.ctx.alloc(400 * 500 * 4)
+    sim.ctx.trace_frames(3, F, dev)
+    raw = sim.ctx.d2h(dev, (F, E, R))
+    sim.ctx.convolve_frames(dev, F, E, R, sim.psf.axial_kernel, sim.psf.lateral_kernel)
+    sim.ctx.envelope_frames(dev, F, E, R)
+    env = sim.ctx.d2h(dev, (F, E, R))
+    sim.ctx.scan_convert_frames(dev, F, E, R, out)
+    sc = sim.ctx.d2h(out, (F, 400, 500))
+    ax, lat = orc.psf()
+    for f in range(F):
+        sim.trace(3 + f); sim.convolve()
+        sim.ctx.envelope(sim.rf_dev, E, R)
+        assert np.array_equal(env[f].view(np.uint32), sim.ctx.d2h(sim.rf_dev, (E, R)).view(np.uint32)), f
+        sim.ctx.scan_convert(sim.rf_dev, E, R, one)
+        assert np.array_equal(sc[f].view(np.uint32), sim.ctx.d2h(one, (400, 500)).view(np.uint32)), f
+        ref_env = orc.envelope(orc.convolve(np.ascontiguousarray(raw[f].T), ax, lat))
+        assert np.array_equal(env[f].T.view(np.uint32), ref_env.view(np.uint32)), f
+        assert np.array_equal(sc[f].view(np.uint32), orc.scan_convert(ref_env).view(np.uint32)), f
+    assert np.count_nonzero(sc[F - 1]) > 10000
+    for d in (dev, out, one):
+        sim.ctx.free(d)
+    sim.close()

@@ -33,12 +33,9 @@ if v[8]:      # (a -DMCRT_STAMP_LITE build carries only the timeline)
     print("k_march: %d waves, loop iterations %.1f per wave; step iterations %.1f per wave with %.2f of 16 quads active; iterations with a finishing quad %.1f; refill rounds %.1f"
           % (v[14], v[9] / max(v[14], 1), v[10] / max(v[14], 1), v[11] / max(v[10], 1), v[12] / max(v[14], 1), v[13] / max(v[14], 1)))
     if v[124]: print("k_march cycle shares: hand-out and finished segments %.1f%%, advance %.1f%%, voxel + gathers %.1f%%, rows and bins %.1f%% (of the loop's %.0f cycles per wavefront)" % tuple([100.0 * v[120 + k] / v[124] for k in range(4)] + [v[124] / max(v[14], 1)]))
-    if os.environ.get("MCRT_QUAD_WALK"):
-        print("node visits %d, of them after a pop (previous node had no hit child) %d, of those again without a hit child %d" % (v[56], v[57], v[58]))
-    else:
-        print("lane walk, per node-step iteration: %.1f lanes stepping, %.1f parked on a leaf, %.1f without a walk; subtrees adopted %d" % (v[6] / max(v[3], 1), v[56] / max(v[3], 1), v[57] / max(v[3], 1), v[58]))
+    print("lane walk, per node-step iteration: %.1f lanes stepping on %.1f distinct nodes, %.1f parked on a leaf, %.1f without a walk; subtrees adopted %d" % (v[6] / max(v[3], 1), v[59] / max(v[3], 1), v[56] / max(v[3], 1), v[57] / max(v[3], 1), v[58]))
 M = (1 << 64) - 1
-lane = not os.environ.get("MCRT_QUAD_WALK")
+lane = True
 print("bounce   launch us   queue empty at us (share of launch)   wavefronts   mean wave lifetime us   mean time after the queue ran dry us | mean start us  longest life us | node-step iterations per wave: mean, most")
 for b in range(10):
     s0, s1, e, life = v[16 + 4 * b: 20 + 4 * b]
