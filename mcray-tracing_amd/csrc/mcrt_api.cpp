@@ -55,9 +55,8 @@ static Consts derive_consts(const mcrt_params &p)
 struct Work {
     hipStream_t stream = nullptr, side[MCRT_SIDE_STREAMS] = {};   // k_march of bounce b runs on side[b % n] (n = 1 unless MCRT_MARCH_STREAMS says otherwise)
     hipEvent_t ev_bounce[MCRT_MAX_BOUNCES] = {}, ev_join[MCRT_SIDE_STREAMS] = {}, ev_done = nullptr;
-    float4 *d_recs = nullptr;                                  // [paths][6] path records (mcrt_kernels.hip)
-    uint2 *d_tmp = nullptr;                                    // [paths] k_shade -> k_place
-    uint32_t *d_cls = nullptr; uint32_t cls_cap = 0, hist_bits = 0, cls_lines = 0;   // bundle tables: counts [cls_cap] | fill [cls_cap]
+    float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr;
+    unsigned long long *d_key0 = nullptr, *d_key1 = nullptr;
     int *d_stack_ovf = nullptr; size_t ovf_cap = 0;            // traversal-stack overflow of THIS work set's walk (its launches run beside the other groups')
     uint32_t *d_q = nullptr, *d_counts = nullptr, *d_seg_count = nullptr, *d_cursors = nullptr;
     mcrt_segment *d_segs = nullptr; size_t segs_cap = 0;       // [paths][depth], only for the callers that ask for segments
@@ -69,7 +68,6 @@ struct Work {
 struct Knobs {
     uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 4096;
     bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false;
-    int sort_bits = -1;                        // >= 0: queues SORTED by bundle = (scan-line, that many reflect / refract decisions at most; 0: by scan-line); -1: order-preserving compaction (the default)
     uint32_t march_cus = 0;                    // CUs the accumulation's side stream is confined to (0 = no mask); the mask's bit order is the driver's
     bool main_mask = false;                    // with march_cus: the walk / shade chain runs on its own stream confined to the OTHER CUs
 };
@@ -83,7 +81,6 @@ static Knobs read_knobs()
     if (const char *e = getenv("MCRT_MARCH_BLOCKS")) { int v = atoi(e); if (v >= 1) k.march_blocks = (uint32_t)v; }
     k.no_overlap = getenv("MCRT_NO_OVERLAP") != nullptr; k.no_priority = getenv("MCRT_NO_PRIORITY") != nullptr;
     k.no_fast_div = getenv("MCRT_NO_FAST_DIV") != nullptr; k.no_lean = getenv("MCRT_NO_LEAN") != nullptr;
-    if (const char *e = getenv("MCRT_SORT_BITS")) { int v = atoi(e); if (v >= -1 && v <= 10) k.sort_bits = v; }
     if (const char *e = getenv("MCRT_MARCH_CUS")) { int v = atoi(e); if (v >= 0 && v <= 248) k.march_cus = (uint32_t)v; }
     k.main_mask = getenv("MCRT_MAIN_MASK") != nullptr;
     return k;
@@ -227,9 +224,9 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
 
 static void free_work_buffers(Work &w)
 {
-    hipFree(w.d_recs); hipFree(w.d_tmp); hipFree(w.d_cls); w.d_cls = nullptr; w.cls_cap = 0;
+    hipFree(w.d_st0); hipFree(w.d_st1); hipFree(w.d_st2); hipFree(w.d_ray0); hipFree(w.d_ray1); hipFree(w.d_key0); hipFree(w.d_key1);
     hipFree(w.d_q); hipFree(w.d_counts); hipFree(w.d_seg_count); hipFree(w.d_cursors); w.d_cursors = nullptr; hipFree(w.d_segs); hipFree(w.d_hits); hipFree(w.d_mrec);
-    w.d_recs = nullptr; w.d_tmp = nullptr; w.d_q = w.d_counts = w.d_seg_count = nullptr;
+    w.d_st0 = w.d_st1 = w.d_st2 = w.d_ray0 = w.d_ray1 = nullptr; w.d_key0 = w.d_key1 = nullptr; w.d_q = w.d_counts = w.d_seg_count = nullptr;
     w.d_segs = nullptr; w.segs_cap = 0; w.d_hits = nullptr; w.hits_cap = 0; w.d_mrec = nullptr; w.paths = 0; w.depth = 0;
 }
 
@@ -670,16 +667,6 @@ static int check_ready(mcrt_ctx *c, uint32_t e0, uint32_t e1)
     return MCRT_OK;
 }
 
-// bundle classes of a work set: (line, the last hist_bits decisions), line = the scan-line (all frames of the pass share the probe
-// pose: their rays of a scan-line are one bundle) or the (frame, scan-line) pair (a pose per frame); the class tables hold at most
-// 65536 entries (one workgroup, k_scan, sums them up), padded to the scan's 4096-entry stride
-static uint32_t bundle_hist_bits(const mcrt_ctx *c, uint32_t lines)
-{
-    uint32_t h = 0;
-    while ((int)h < c->knobs.sort_bits && ((uint64_t)lines << (h + 1)) <= 65536u) h++;
-    return h;
-}
-
 // out: 0 = RF image only, 1 = + hit indices, 2 = + the segment table (64 B per path and bounce: only allocated when asked for)
 static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne_frame, uint32_t n_frames, int out)
 {
@@ -709,26 +696,16 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne_frame, uint32_t n_frame
             w.ovf_cap = need;
         }
     }
-    const uint32_t cls_lines = c->pose_pos ? ne : ne_frame, hist_bits = bundle_hist_bits(c, cls_lines);
-    const uint32_t cls_need = (uint32_t)((((uint64_t)cls_lines << hist_bits) + 4095u) & ~4095ull);
-    if (cls_need > w.cls_cap) {
-        HIP_TRY(hipDeviceSynchronize());
-        hipFree(w.d_cls); w.d_cls = nullptr; w.cls_cap = 0;
-        HIP_TRY(hipMalloc(&w.d_cls, 8 * (size_t)cls_need));
-        HIP_TRY(hipMemsetAsync(w.d_cls, 0, 8 * (size_t)cls_need, c->stream));
-        w.cls_cap = cls_need;
-    }
-    w.cls_lines = cls_lines; w.hist_bits = hist_bits;
     if (np <= w.paths && B <= w.depth) return MCRT_OK;
     HIP_TRY(hipDeviceSynchronize());
     {   // (the optional tables survive a re-allocation of the rest when they are large enough)
         mcrt_segment *sg = w.d_segs; const size_t sc = w.segs_cap; int32_t *ht = w.d_hits; const size_t hc = w.hits_cap;
-        uint32_t *cl = w.d_cls; const uint32_t cc = w.cls_cap;
-        w.d_segs = nullptr; w.d_hits = nullptr; w.d_cls = nullptr;
+        w.d_segs = nullptr; w.d_hits = nullptr;
         free_work_buffers(w);
-        w.d_segs = sg; w.segs_cap = sc; w.d_hits = ht; w.hits_cap = hc; w.d_cls = cl; w.cls_cap = cc;
+        w.d_segs = sg; w.segs_cap = sc; w.d_hits = ht; w.hits_cap = hc;
     }
-    HIP_TRY(hipMalloc(&w.d_recs, 96 * np)); HIP_TRY(hipMalloc(&w.d_tmp, 8 * np));
+    HIP_TRY(hipMalloc(&w.d_st0, 32 * np)); HIP_TRY(hipMalloc(&w.d_st1, 32 * np)); HIP_TRY(hipMalloc(&w.d_st2, 32 * np));   // two halves: bounce parity
+    HIP_TRY(hipMalloc(&w.d_ray0, 32 * np)); HIP_TRY(hipMalloc(&w.d_ray1, 32 * np)); HIP_TRY(hipMalloc(&w.d_key0, 8 * np)); HIP_TRY(hipMalloc(&w.d_key1, 8 * np));
     HIP_TRY(hipMalloc(&w.d_q, 8 * np)); HIP_TRY(hipMalloc(&w.d_seg_count, 4 * np));
     HIP_TRY(hipMalloc(&w.d_counts, 4 * (MCRT_MAX_BOUNCES + 1)));
     HIP_TRY(hipMalloc(&w.d_cursors, 4 * (size_t)MCRT_MAX_BOUNCES * MCRT_XCDS * MCRT_CURSOR_STRIDE));
@@ -746,9 +723,8 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     a.row_thr = c->d_row_thr;
     a.acc = c->d_acc; a.flags = c->d_flags;                 // the frame block [n_frames][acc_ne][R]; this group owns columns e0-acc_e0 ...
     a.acc_stride = acc_ne; a.acc_off = e0 - acc_e0;
-    a.recs = w.d_recs; a.queue = w.d_q; a.tmp = w.d_tmp;
-    a.cls_cnt = w.d_cls; a.cls_fill = w.d_cls + w.cls_cap; a.cls_cap = w.cls_cap; a.hist_bits = w.hist_bits; a.cls_lines = w.cls_lines; a.sort = c->knobs.sort_bits >= 0 ? 1u : 0u;
-    a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.cursors = w.d_cursors; a.segs = w.d_segs; a.hits = w.d_hits; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
+    a.st0 = w.d_st0; a.st1 = w.d_st1; a.st2 = w.d_st2; a.queue = w.d_q;
+    a.ray0 = w.d_ray0; a.ray1 = w.d_ray1; a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.cursors = w.d_cursors; a.segs = w.d_segs; a.hits = w.d_hits; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
     a.stats = c->d_stats; a.error_flag = c->d_error; a.stamps = c->d_stats + 8;
     a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
     a.e_begin = e0; a.ne_frame = e1 - e0; a.ne = (e1 - e0) * n_frames;   // n_frames consecutive frame ids traced as one pass
@@ -777,7 +753,7 @@ static uint32_t side_streams(const mcrt_ctx *c) { return c->knobs.march_streams;
 
 static int timing_events(mcrt_ctx *c, hipEvent_t *e0, hipEvent_t *e1);
 
-// one bounce of one group: k_trace_lane + k_shade + k_place on the group's stream, k_march of the finished segments on its side stream.
+// one bounce of one group: k_trace_lane + k_shade on the group's stream, k_march of the finished segments on its side stream.
 // With timing enabled every k_trace launch (the dominant kernel) is bracketed by HIP events on the stream it is launched on.
 static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArgs &a, uint32_t b, bool accumulate, bool overlap)
 {
@@ -993,7 +969,8 @@ extern "C" int mcrt_envelope_frames(mcrt_ctx *c, float *rf_dev, uint32_t n_frame
 {
     CTX_TRY(c);
     if (!rf_dev || E == 0 || R == 0 || n_frames == 0) return set_error(MCRT_ERR_INVALID, "mcrt_envelope: bad arguments");
-    if ((uint64_t)n_frames * E > 0xffffffffull) return set_error(MCRT_ERR_LIMIT, "mcrt_envelope: too many scan-lines");
+    if ((uint64_t)n_frames * E > 0x7fffffffull) return set_error(MCRT_ERR_LIMIT, "mcrt_envelope: too many scan-lines");
+    if (R > MCRT_MAX_ROWS) return set_error(MCRT_ERR_LIMIT, "mcrt_envelope: at most %d rows", MCRT_MAX_ROWS);
     HIP_TRY(mcrt::launch_envelope(rf_dev, n_frames * E, R, c->stream));      // the scan-lines of all images are independent columns
     return MCRT_OK;
 }

@@ -18,11 +18,10 @@ struct FrameArgs {
     const float *el_dir;       // same shape
     const double *row_thr;     // [R+1] row thresholds (see row_of)
     // per-frame work buffers; np = ne * S paths
-    float4 *recs;              // [np][6] path records, indexed by path id, updated in place: from,intensity | dir,media | distance_traveled(f64),outside,history |
-                               //         ray f2.xyz,to.x | to.yz,1/d.x,1/d.y | closest hit of the ray (u64: fraction bits << 32 | triangle id, atomicMin), of the scan-line's bounce-0 ray (u64)
-    uint32_t *queue;           // [2][np] live path ids of bounce b in buffer b & 1, ordered by bundle = (scan-line, decision history)
-    uint2 *tmp;                // [np] k_shade -> k_place: path id, bundle class of the survivor (0xffffffff: the path ended), by queue position
-    uint32_t *cls_cnt, *cls_fill;   // [cls_cap] survivors per bundle class; first free queue position of the class
+    float4 *st0, *st1, *st2;   // [2][np] path state in queue order, two halves by bounce parity: from,intensity | dir,media | distance_traveled(f64),outside,-
+    uint32_t *queue;           // [2][np] live path ids of bounce b in buffer b & 1
+    float4 *ray0, *ray1;       // [np][2] f2.xyz,to.x | to.yz, 1/d.x, 1/d.y   (d = to - f2; indexed by queue position), ping-pong
+    unsigned long long *key0, *key1;   // [np] closest hit per ray: fraction bits << 32 | triangle id (atomicMin), ping-pong by bounce parity
     const uint32_t *tri_slot;  // [T] triangle id -> position in the leaf-order triangle array
     uint32_t *counts;          // [MAX_BOUNCES+1] live rays per bounce
     uint32_t *cursors;         // [MAX_BOUNCES][MCRT_XCDS][MCRT_CURSOR_STRIDE] queue cursors of the persistent walk, one per XCD sub-queue
@@ -37,7 +36,7 @@ struct FrameArgs {
     uint32_t *error_flag;      // device word, bit 0: traversal stack overflow
     unsigned long long *stamps; // [80] diagnostic build (-DMCRT_STAMP) only
     // sizes / parameters
-    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, pose_stride, sort, cls_cap, cls_lines, hist_bits, acc_stride, acc_off, trace_blocks, march_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift;
+    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, pose_stride, acc_stride, acc_off, trace_blocks, march_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift;
     float scene_lo[3], scene_hi[3];   // bounds of the whole BVH
     float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs, tex_rcp, lean_bound;
     double axial_res_mm, time_step, row_dt, max_travel, sos_d, inv_row_dt;

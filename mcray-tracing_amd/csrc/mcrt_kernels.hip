@@ -1,8 +1,7 @@
 // mcrt_kernels.hip -- gfx950 kernels of the hot path.
 //
-//   k_init/k_trace_lane/k_shade/k_place   scene::cast_rays (scene.cpp:50-183) + ray_physics (ray.cpp) as a wavefront pipeline:
-//                lane-per-ray BVH4 closest hit, then the interface physics, then the survivors sorted into coherent bundles,
-//                one launch each per bounce
+//   k_init/k_trace_lane/k_shade   scene::cast_rays (scene.cpp:50-183) + ray_physics (ray.cpp) as a wavefront pipeline:
+//                lane-per-ray BVH4 closest hit, then the interface physics, one launch each per bounce
 //   k_march      the RF accumulation loop (main.cpp:106-144, rfimage.h:33-40, volume.h:46-61), a lane pair / quad per segment
 //   k_finalize   fixed-point RF bins -> float image (+ clears the bins: rf_image::clear, rfimage.h:161)
 //   k_conv_*     rf_image::convolve (rfimage.h:93-123)
@@ -57,27 +56,21 @@ MCRT_DEV bool slab(f3 lo, f3 hi, f3 o, f3 inv, float tlow, float tcap, float &tm
     return tmin <= tmax;
 }
 
-// The same test on a BVH4 child record (lo.xyz hi.x | hi.y hi.z ..) with the six plane distances computed as three
-// float pairs (v_pk_add_f32 / v_pk_mul_f32): identical IEEE operations, half the instructions.  The ray's origin and
-// reciprocal direction are kept in the matching pair order.
-typedef float v2f __attribute__((ext_vector_type(2)));
-struct RayPairs { v2f o_xy, o_zx, o_yz, i_xy, i_zx, i_yz; };
-MCRT_DEV RayPairs ray_pairs(f3 o, f3 inv)
+// The contract's plane distance (round 3): ONE fused multiply-add per plane, t = fl(plane * inv + c) with c = -(o * inv) rounded once
+// per ray and axis.  For a fixed ray it is a monotone function of the plane, which is all the order-independence argument needs
+// (DESIGN.md 3).  The reciprocal direction is kept FINITE: 1/0 (a ray parallel to an axis) and overflowing quotients become
+// +-2^100, so every distance is a finite number (|plane| < 2^20 in any scene) and the argument needs no special cases; the sign of
+// the huge distance still says on which side of the plane the origin lies.
+MCRT_DEV float rcp_dir(float d) { const float r = 1.0f / d; return r > 0x1p+100f ? 0x1p+100f : (r < -0x1p+100f ? -0x1p+100f : r); }
+MCRT_DEV f3 ray_c(f3 o, f3 inv) { return mk(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); }
+// ray parameter interval of a box under that rule (the triangles' padded bounds: the eligibility test of the contract)
+MCRT_DEV bool slab_c(f3 lo, f3 hi, f3 c, f3 inv, float tlow, float tcap, float &tmin_o, float &tmax_o)
 {
-    RayPairs r;
-    r.o_xy = (v2f){ o.x, o.y }; r.o_zx = (v2f){ o.z, o.x }; r.o_yz = (v2f){ o.y, o.z };
-    r.i_xy = (v2f){ inv.x, inv.y }; r.i_zx = (v2f){ inv.z, inv.x }; r.i_yz = (v2f){ inv.y, inv.z };
-    return r;
-}
-MCRT_DEV bool slab_pairs(v2f lo_xy, v2f loz_hix, v2f hi_yz, const RayPairs &r, float tlow, float tcap, float &tmin_o, float &tmax_o)
-{
-    const v2f a = (lo_xy - r.o_xy) * r.i_xy;        // t0x t0y
-    const v2f b = (loz_hix - r.o_zx) * r.i_zx;      // t0z t1x
-    const v2f c = (hi_yz - r.o_yz) * r.i_yz;        // t1y t1z
-    // The final combination is written as the four machine instructions it is: through fmaxf/fminf the compiler re-quiets the
-    // loop-invariant tlow / tcap operands (v_max x,x) in every iteration, which the NaN-dropping min/max do not need.
-    float lo3 = fminf(b.x, c.y), hi3 = fmaxf(b.x, c.y), tmin, tmax;
-    const float lo1 = fminf(a.x, b.y), lo2 = fminf(a.y, c.x), hi1 = fmaxf(a.x, b.y), hi2 = fmaxf(a.y, c.x);
+    const float t0x = fmaf(lo.x, inv.x, c.x), t1x = fmaf(hi.x, inv.x, c.x);
+    const float t0y = fmaf(lo.y, inv.y, c.y), t1y = fmaf(hi.y, inv.y, c.y);
+    const float t0z = fmaf(lo.z, inv.z, c.z), t1z = fmaf(hi.z, inv.z, c.z);
+    float lo3 = fminf(t0z, t1z), hi3 = fmaxf(t0z, t1z), tmin, tmax;
+    const float lo1 = fminf(t0x, t1x), lo2 = fminf(t0y, t1y), hi1 = fmaxf(t0x, t1x), hi2 = fmaxf(t0y, t1y);
     asm("v_max_f32 %0, %1, %2" : "=v"(lo3) : "v"(lo3), "v"(tlow));
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmin) : "v"(lo1), "v"(lo2), "v"(lo3));
     asm("v_min_f32 %0, %1, %2" : "=v"(hi3) : "v"(hi3), "v"(tcap));
@@ -85,6 +78,8 @@ MCRT_DEV bool slab_pairs(v2f lo_xy, v2f loz_hix, v2f hi_yz, const RayPairs &r, f
     tmin_o = tmin; tmax_o = tmax;
     return tmin <= tmax;
 }
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // the walk only needs (fraction, triangle): k_shade looks the plane of the winner up again
 struct Best { float frac; int tri; };
@@ -284,37 +279,18 @@ MCRT_DEV void rf_add(long long *bins, uint32_t *lflags, int row, float echo)
 //   for bounce b:
 //     k_trace_lane    closest hit of every live ray: BVH4 walk                                  1 lane  / ray
 //     k_shade         thickness draw, travel, hit_boundary, segment record, next ray;           1 lane  / ray
-//                     counts the survivors per BUNDLE (scan-line, reflect/refract history)
-//     k_place         the survivors' path ids into the next bounce's queue, bundle after bundle  1 lane  / ray
+//                     survivors are compacted into the next bounce's queue (wave ballot + prefix)
 //   k_march           RF accumulation of every segment (main.cpp:112-140)                       2 lanes / segment
 //
 // Every stage therefore runs with full wavefronts of lanes doing the same thing: dead paths cost nothing after the
 // bounce they die in, the fp64-heavy interface physics is not replicated, and the lean walk kernel keeps 5 waves/SIMD.
 // Paths draw random numbers from their own (scan-line, sample, bounce) counter and RF bins are integer sums, so the
-// image does not depend on queue order -- which is therefore chosen for the WALK: the sample paths of a scan-line that took
-// the same reflect / refract decisions so far are nearly the same ray (scene::cast_rays advances the samples of an element
-// together, scene.cpp:102-110; the power-cosine perturbation at shininess 1e6 is ~1e-3 rad), so the queue of every bounce
-// is ordered by (scan-line, decision history) and a wavefront holds 64 rays of ONE bundle: its lanes fetch the same nodes,
-// park on the same leaves and finish together.
-//
-// A path's state lives in ONE 96-byte record indexed by the path id and is updated in place; only the 4-byte path ids move
-// between the queues:
-//     from.xyz intensity | dir.xyz media | distance_traveled (f64) outside history | ray f2.xyz to.x | to.yz 1/d.x 1/d.y |
-//     closest-hit word of the path's ray (u64), closest-hit word of the scan-line's shared bounce-0 ray (u64, first sample's record)
-// (a lane reading its record touches one or two 128-byte lines, all of whose bytes it uses: scattered records cost the vector
-// memory pipe about what coalesced SoA arrays did, tools/fetch_roof.hip).
+// image does not depend on queue order.  Path state, rays and closest-hit words live in QUEUE ORDER and are compacted with
+// the queue every bounce (ping-pong halves by bounce parity): every launch reads and writes them densely and coalesced.
+// (Round 3 measured the alternative the sample loop of scene.cpp:102-110 suggests -- queues SORTED into bundles of the sample
+// paths of a scan-line with the same reflect / refract history, path state in place by path id: 58 vs 56 % of the walk's lanes
+// active, the pass 8 % slower; DESIGN.md 5.4, profiles/round3/exp_*.)
 // =============================================================================================================
-// The six pieces of a record are six ARRAYS indexed by the path id ([6][paths] float4): with the order-preserving compaction a
-// queue is in near path-id order, so the lanes of a wavefront read neighbouring elements of each array (measured against 96-byte
-// array-of-structures records, -DMCRT_REC_AOS: k_shade 0.88 vs ... ms per 128-frame launch).
-[[maybe_unused]] constexpr uint32_t REC_Q = 6;   // float4 pieces per path record
-#ifdef MCRT_REC_AOS
-#define MCRT_REC(a, k, pid) ((a).recs[(size_t)(pid) * REC_Q + (k)])
-#else
-#define MCRT_REC(a, k, pid) ((a).recs[(size_t)(k) * ((size_t)(a).ne * (a).S) + (pid)])
-#endif
-// the two closest-hit words of path `pid`: of its own ray (which = 0), of its scan-line's shared bounce-0 ray (which = 1)
-#define MCRT_KEYW(a, pid, which) ((unsigned long long *)&MCRT_REC(a, 5, pid) + (which))
 
 struct Ray { f3 f2, to; };
 
@@ -345,12 +321,11 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
     const uint32_t np = a.ne * a.S;
     if (pos == 0) { a.counts[0] = np; for (uint32_t b = 1; b <= a.B; b++) a.counts[b] = 0u; }
     if (pos < MCRT_MAX_BOUNCES * MCRT_XCDS) a.cursors[(size_t)pos * MCRT_CURSOR_STRIDE] = 0u;   // k_trace_lane's queue cursors (relative, see there)
-    for (uint32_t c = pos; c < a.cls_cap; c += gridDim.x * blockDim.x) a.cls_cnt[c] = 0u;        // (k_shade's last workgroup leaves them zeroed; a pass that failed may not have)
     if (pos >= np) return;
     // Queue position -> path.  Paths are numbered frame-major (pid = (frame * ne_frame + scan-line) * S + sample) but QUEUED
-    // scan-line-major: the F frames of a scan-line sit next to each other -- bounce 0's bundles (every sample of a scan-line
-    // starts as the same ray; with one probe pose for the pass, so do its F frames).  The queue is swept in order, so the rays in
-    // flight belong to a few scan-lines (times all frames) and walk the same part of the BVH.
+    // scan-line-major: the F frames of a scan-line sit next to each other.  The queue is swept in order, so the rays in flight
+    // then belong to a few scan-lines (times all frames) and walk the same part of the BVH; later bounces inherit the order
+    // from the order-preserving compaction of k_shade.
     const uint32_t F = a.ne / a.ne_frame;
     const uint32_t qline = pos / a.S, sample = pos % a.S;
     const uint32_t scan = qline / F, fr = qline % F;
@@ -359,16 +334,15 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
     const f3 from = mk(a.el_pos[3 * pe], a.el_pos[3 * pe + 1], a.el_pos[3 * pe + 2]);
     const f3 dir = mk(a.el_dir[3 * pe], a.el_dir[3 * pe + 1], a.el_dir[3 * pe + 2]);
     const float intensity = a.I0 / (float)a.S;
-    MCRT_REC(a, 0, pid) = make_float4(from.x, from.y, from.z, intensity);
-    MCRT_REC(a, 1, pid) = make_float4(dir.x, dir.y, dir.z, __int_as_float((int)a.start_mat));
-    MCRT_REC(a, 2, pid) = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), __uint_as_float(0u));      // distance_traveled (double) | outside | decision history
-    const Ray r = make_ray(from, dir, intensity, a.mats[2 * a.start_mat].y, a);
-    MCRT_REC(a, 3, pid) = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
-    MCRT_REC(a, 4, pid) = make_float4(r.to.y, r.to.z, 1.0f / (r.to.x - r.f2.x), 1.0f / (r.to.y - r.f2.y));   // + two of the three reciprocals the walk needs
-    const float miss_lo = __uint_as_float((uint32_t)MCRT_KEY_MISS), miss_hi = __uint_as_float((uint32_t)(MCRT_KEY_MISS >> 32));
-    MCRT_REC(a, 5, pid) = make_float4(miss_lo, miss_hi, miss_lo, miss_hi);          // the path's own closest-hit word | the scan-line's bounce-0 word
+    a.st0[pos] = make_float4(from.x, from.y, from.z, intensity);
+    a.st1[pos] = make_float4(dir.x, dir.y, dir.z, __int_as_float((int)a.start_mat));
+    a.st2[pos] = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), 0.0f);      // distance_traveled (double) | outside | -
     a.queue[pos] = pid;                                  // queue of bounce 0 (buffer 0 of two)
     a.seg_count[pid] = 0u;
+    if (pos < a.ne) a.key0[pos] = MCRT_KEY_MISS;          // bounce 0: one closest-hit word per queued (scan-line, frame)
+    const Ray r = make_ray(from, dir, intensity, a.mats[2 * a.start_mat].y, a);
+    a.ray0[2 * pos] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
+    a.ray0[2 * pos + 1] = make_float4(r.to.y, r.to.z, rcp_dir(r.to.x - r.f2.x), rcp_dir(r.to.y - r.f2.y));   // + two of the three reciprocals the walk needs
 }
 
 // =============================================================================================================
@@ -420,9 +394,6 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 #endif
 #ifndef MCRT_MARCH_WAVES
 #define MCRT_MARCH_WAVES 6           // waves per SIMD the register budget of k_march is set for (7: 14 spilled registers, 789 vs 750 us per launch; 5: 777)
-#endif
-#ifndef MCRT_LANE_SIGN_SELECT
-#define MCRT_LANE_SIGN_SELECT 1      // lane_node_step: near / far planes picked by the sign of the reciprocal direction
 #endif
 #ifndef MCRT_MARCH_ROW_EST
 #define MCRT_MARCH_ROW_EST 1         // k_march: a step's RF row is guessed from its time (see row_near), not from the lane's previous row
@@ -507,44 +478,17 @@ __global__ void k_nodes_walk_decode(const uint4 *in, uint32_t n_nodes, float4 *o
     }
 }
 
-// the four children's plane distances from a packed pair of half-float words: (plane - origin) * reciprocal, two children per
-// packed operation
-struct Planes4 { v2f a, b; };
-MCRT_DEV Planes4 planes4(uint32_t w01, uint32_t w23, v2f o, v2f inv)
+// the four children's plane distances from a packed pair of half-float words: the contract's t = fl(plane * inv + c), c = -(o * inv),
+// ONE mixed-precision fma per plane (v_fma_mix_f32 reads the half operand directly; op_sel picks the half of the word)
+struct Planes4 { float a0, a1, b0, b1; };
+MCRT_DEV Planes4 planes4(uint32_t w01, uint32_t w23, float c, float inv)
 {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const h2 p01 = __builtin_bit_cast(h2, w01), p23 = __builtin_bit_cast(h2, w23);
     Planes4 r;
-#ifdef MCRT_NO_FMA_MIX
-    r.a = ((v2f){ (float)p01.x, (float)p01.y } - o) * inv;
-    r.b = ((v2f){ (float)p23.x, (float)p23.y } - o) * inv;
-#else
-    // plane - origin as fma(plane, 1, -origin): the product is exact, so this IS the IEEE subtraction -- and the mixed-precision
-    // fma (v_fma_mix_f32) reads the half operand directly (op_sel picks the half of the word), which saves the 24 conversions
-    const float mo = -o.x;
-    float a0, a1, b0, b1;
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(a0) : "v"(w01), "v"(mo));
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(a1) : "v"(w01), "v"(mo));
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(b0) : "v"(w23), "v"(mo));
-    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(b1) : "v"(w23), "v"(mo));
-    (void)p01; (void)p23;
-    r.a = (v2f){ a0, a1 } * inv;
-    r.b = (v2f){ b0, b1 } * inv;
-#endif
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r.a0) : "v"(w01), "v"(inv), "v"(c));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.a1) : "v"(w01), "v"(inv), "v"(c));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r.b0) : "v"(w23), "v"(inv), "v"(c));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.b1) : "v"(w23), "v"(inv), "v"(c));
     return r;
-}
-
-// slab interval of one child from its six plane distances (the combination of slab_pairs, same instructions)
-MCRT_DEV bool slab_combine(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z, float tlow, float tcap, float &tmin_o)
-{
-    float lo3 = fminf(t0z, t1z), hi3 = fmaxf(t0z, t1z), tmin, tmax;
-    const float lo1 = fminf(t0x, t1x), lo2 = fminf(t0y, t1y), hi1 = fmaxf(t0x, t1x), hi2 = fmaxf(t0y, t1y);
-    asm("v_max_f32 %0, %1, %2" : "=v"(lo3) : "v"(lo3), "v"(tlow));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmin) : "v"(lo1), "v"(lo2), "v"(lo3));
-    asm("v_min_f32 %0, %1, %2" : "=v"(hi3) : "v"(hi3), "v"(tcap));
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(hi1), "v"(hi2), "v"(hi3));
-    tmin_o = tmin;
-    return tmin <= tmax;
 }
 
 // ---- the lane-per-ray walk's two steps ---------------------------------------------------------------------------------
@@ -562,7 +506,7 @@ MCRT_DEV void lane_push(const LaneStack &S, int &sp, int v)
     if (sp < MCRT_LANE_STACK) S.lds[sp * 256 + S.tid] = v; else S.ovf[(size_t)(sp - MCRT_LANE_STACK) * S.ovf_stride] = v;
     sp++;
 }
-struct LaneRay { v2f oxx, oyy, ozz, ixx, iyy, izz; bool nx, ny, nz; };     // origin and reciprocal direction, each component twice (packed operands); reciprocal negative?
+struct LaneRay { float cx, cy, cz, ix, iy, iz; bool nx, ny, nz; };     // c = -(origin * reciprocal direction) and the reciprocal direction; reciprocal negative?
 
 // slab interval of one child from the distances of its three NEAR and three FAR planes
 MCRT_DEV bool slab_near_far(float nx, float ny, float nz, float fx, float fy, float fz, float tlow, float tcap, float &tmin_o)
@@ -581,30 +525,20 @@ MCRT_DEV void lane_node_step(const FrameArgs &a, const LaneStack &S, const LaneR
 {
     const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
     const uint4 Q0 = N[0], Q1 = N[1], Q2 = N[2], RF = N[3];
-    // six plane distances of the four children (halves -> floats, then (plane - origin) * reciprocal, two children per packed operation)
-#if MCRT_LANE_SIGN_SELECT
+    // six plane distances of the four children
     // Which plane of a slab the ray meets first follows from the SIGN of the reciprocal direction (low plane for a positive one):
     // the packed words of the near and far planes are picked per axis (12 selects) instead of ordering the 24 distances afterwards
-    // (24 min / max).  With low <= high and monotone rounding the picked distances ARE the minimum and maximum whenever both are
-    // numbers; where one is not (origin exactly on a plane the ray runs parallel to) the interval comes out wider, never narrower --
-    // a node may be entered that min/max would have skipped, the triangle tests (unchanged) decide as before.
-    const Planes4 XN = planes4(r.nx ? Q1.z : Q0.x, r.nx ? Q1.w : Q0.y, r.oxx, r.ixx), XF = planes4(r.nx ? Q0.x : Q1.z, r.nx ? Q0.y : Q1.w, r.oxx, r.ixx);
-    const Planes4 YN = planes4(r.ny ? Q2.x : Q0.z, r.ny ? Q2.y : Q0.w, r.oyy, r.iyy), YF = planes4(r.ny ? Q0.z : Q2.x, r.ny ? Q0.w : Q2.y, r.oyy, r.iyy);
-    const Planes4 ZN = planes4(r.nz ? Q2.z : Q1.x, r.nz ? Q2.w : Q1.y, r.ozz, r.izz), ZF = planes4(r.nz ? Q1.x : Q2.z, r.nz ? Q1.y : Q2.w, r.ozz, r.izz);
+    // (24 min / max).  With low <= high and a monotone distance function the picked distances ARE the minimum and maximum whenever
+    // both are numbers; where one is not (rays parallel to an axis) the interval comes out wider, never narrower -- a node may be
+    // entered that min/max would have skipped, the triangle tests decide as before.
+    const Planes4 XN = planes4(r.nx ? Q1.z : Q0.x, r.nx ? Q1.w : Q0.y, r.cx, r.ix), XF = planes4(r.nx ? Q0.x : Q1.z, r.nx ? Q0.y : Q1.w, r.cx, r.ix);
+    const Planes4 YN = planes4(r.ny ? Q2.x : Q0.z, r.ny ? Q2.y : Q0.w, r.cy, r.iy), YF = planes4(r.ny ? Q0.z : Q2.x, r.ny ? Q0.w : Q2.y, r.cy, r.iy);
+    const Planes4 ZN = planes4(r.nz ? Q2.z : Q1.x, r.nz ? Q2.w : Q1.y, r.cz, r.iz), ZF = planes4(r.nz ? Q1.x : Q2.z, r.nz ? Q1.y : Q2.w, r.cz, r.iz);
     float tn0, tn1, tn2, tn3;
-    const bool h0 = slab_near_far(XN.a.x, YN.a.x, ZN.a.x, XF.a.x, YF.a.x, ZF.a.x, t_lo, tcap, tn0);
-    const bool h1 = slab_near_far(XN.a.y, YN.a.y, ZN.a.y, XF.a.y, YF.a.y, ZF.a.y, t_lo, tcap, tn1);
-    const bool h2 = slab_near_far(XN.b.x, YN.b.x, ZN.b.x, XF.b.x, YF.b.x, ZF.b.x, t_lo, tcap, tn2);
-    const bool h3 = slab_near_far(XN.b.y, YN.b.y, ZN.b.y, XF.b.y, YF.b.y, ZF.b.y, t_lo, tcap, tn3);
-#else
-    const Planes4 X0 = planes4(Q0.x, Q0.y, r.oxx, r.ixx), Y0 = planes4(Q0.z, Q0.w, r.oyy, r.iyy), Z0 = planes4(Q1.x, Q1.y, r.ozz, r.izz);
-    const Planes4 X1 = planes4(Q1.z, Q1.w, r.oxx, r.ixx), Y1 = planes4(Q2.x, Q2.y, r.oyy, r.iyy), Z1 = planes4(Q2.z, Q2.w, r.ozz, r.izz);
-    float tn0, tn1, tn2, tn3;
-    const bool h0 = slab_combine(X0.a.x, Y0.a.x, Z0.a.x, X1.a.x, Y1.a.x, Z1.a.x, t_lo, tcap, tn0);
-    const bool h1 = slab_combine(X0.a.y, Y0.a.y, Z0.a.y, X1.a.y, Y1.a.y, Z1.a.y, t_lo, tcap, tn1);
-    const bool h2 = slab_combine(X0.b.x, Y0.b.x, Z0.b.x, X1.b.x, Y1.b.x, Z1.b.x, t_lo, tcap, tn2);
-    const bool h3 = slab_combine(X0.b.y, Y0.b.y, Z0.b.y, X1.b.y, Y1.b.y, Z1.b.y, t_lo, tcap, tn3);
-#endif
+    const bool h0 = slab_near_far(XN.a0, YN.a0, ZN.a0, XF.a0, YF.a0, ZF.a0, t_lo, tcap, tn0);
+    const bool h1 = slab_near_far(XN.a1, YN.a1, ZN.a1, XF.a1, YF.a1, ZF.a1, t_lo, tcap, tn1);
+    const bool h2 = slab_near_far(XN.b0, YN.b0, ZN.b0, XF.b0, YF.b0, ZF.b0, t_lo, tcap, tn2);
+    const bool h3 = slab_near_far(XN.b1, YN.b1, ZN.b1, XF.b1, YF.b1, ZF.b1, t_lo, tcap, tn3);
     // nearest hit child first (key unique per node: t_near bits with the slot number in the two low bits), the others are
     // stacked in slot order -- exactly the quad walk's order
     const uint32_t k0 = h0 ? ((__float_as_uint(tn0) & ~3u) | 0u) : 0xffffffffu, k1 = h1 ? ((__float_as_uint(tn1) & ~3u) | 1u) : 0xffffffffu;
@@ -614,18 +548,20 @@ MCRT_DEV void lane_node_step(const FrameArgs &a, const LaneStack &S, const LaneR
     asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));      // (the child references are fetched WITH the boxes, not after the tests in a second round trip)
     if (kmin == 0xffffffffu) { lane_pop(S, cur, sp, sb); return; }
     const bool p0 = h0 && k0 != kmin, p1 = h1 && k1 != kmin, p2 = h2 && k2 != kmin, p3 = h3 && k3 != kmin;
-    if (__builtin_expect(__any(sp + 3 > MCRT_LANE_STACK), 0)) {       // (some lane may leave the LDS part: the general form)
+    if (__builtin_expect(__any(sp + 4 > MCRT_LANE_STACK), 0)) {       // (some lane may leave the LDS part: the general form)
         if (p0) lane_push(S, sp, r0);
         if (p1) lane_push(S, sp, r1);
         if (p2) lane_push(S, sp, r2);
         if (p3) lane_push(S, sp, r3);
     } else {
+        // four UNCONDITIONAL stores instead of four branches: a reference that is not kept is overwritten by the next one (its
+        // offset does not advance), and the last lands above the new top of the stack (inside the lane's column: sp + 3 < 32)
         int *top = &S.lds[sp * 256 + S.tid];
         const int s1 = p0 ? 256 : 0, s2 = s1 + (p1 ? 256 : 0), s3 = s2 + (p2 ? 256 : 0);
-        if (p0) top[0] = r0;
-        if (p1) top[s1] = r1;
-        if (p2) top[s2] = r2;
-        if (p3) top[s3] = r3;
+        top[0] = r0;
+        top[s1] = r1;
+        top[s2] = r2;
+        top[s3] = r3;
         sp += (s3 >> 8) + (p3 ? 1 : 0);
     }
     const uint32_t jn = kmin & 3u;
@@ -635,7 +571,7 @@ MCRT_DEV void lane_node_step(const FrameArgs &a, const LaneStack &S, const LaneR
 // one leaf: the contract's triangle test (btTriangleRaycastCallback::processTriangle behind the padded-bounds rule) on each of its
 // triangles, then the next stack entry.  helper: the lane walks an adopted subtree (see k_trace_lane): a triangle at exactly the
 // owner's closest fraction is a candidate.  Returns the number of triangles of the leaf.
-MCRT_DEV uint32_t lane_leaf_test(const FrameArgs &a, const LaneStack &S, f3 f2, f3 to, f3 inv, float t_lo, bool helper, Best &best, int &cur, int &sp, int sb)
+MCRT_DEV uint32_t lane_leaf_test(const FrameArgs &a, const LaneStack &S, f3 f2, f3 to, f3 inv, f3 rc, float t_lo, bool helper, Best &best, int &cur, int &sp, int sb)
 {
     const uint32_t v = (uint32_t)~cur;
     const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
@@ -665,8 +601,7 @@ MCRT_DEV uint32_t lane_leaf_test(const FrameArgs &a, const LaneStack &S, f3 f2, 
         const float frac = da / proj;
         if (!(frac < best.frac || (frac == best.frac && (id < best.tri || (helper && best.tri < 0)))) || !(frac >= t_lo)) continue;
         float tmin, tmax;
-        const RayPairs rp = ray_pairs(f2, inv);
-        if (!(slab_pairs((v2f){ PL.x, PL.y }, (v2f){ PL.z, PH.x }, (v2f){ PH.y, PH.z }, rp, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax)) continue;
+        if (!(slab_c(xyz(PL), xyz(PH), rc, inv, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax)) continue;
 #if MCRT_LEAF_PREFETCH < 2
         const float4 V0 = T[3], V1 = T[4], V2 = T[5];
 #endif
@@ -710,11 +645,10 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
     // word, so the result is exactly the single-walk answer.
     const uint32_t K = ksplit(n_rays, a.ksplit_limit);
     const uint32_t n = n_rays * K;
-    const uint32_t *q_in = a.queue + (size_t)(b & 1u) * a.ne * a.S;      // path ids of this bounce's live rays, bundle after bundle
-    const uint32_t F = a.ne / a.ne_frame;
-    // the closest-hit word of the ray of path `p` (bounce 0: of the scan-line's shared ray, kept in its first sample's record)
-    const uint32_t key_which = (b == 0u) ? 1u : 0u;
-#define MCRT_KEYP(p) MCRT_KEYW(a, p, key_which)
+    const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;           // rays and closest-hit words in queue order, ping-pong by bounce parity
+    const uint32_t ray_stride = (b == 0u) ? a.S : 1u;          // bounce 0: the first sample of each queued scan-line stands for all
+    unsigned long long *keys = (b & 1u) ? a.key1 : a.key0;
+#define MCRT_KEYP(p) (&keys[p])
     unsigned long long st_nodes = 0, st_tris = 0, st_q = 0;
     // (overflow entries of this lane: [entry - MCRT_LANE_STACK][grid thread])
     const LaneStack S = { stack, a.stack_ovf + ((size_t)blockIdx.x * 256 + tid), (size_t)gridDim.x * 256, tid };
@@ -735,7 +669,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
     uint32_t *cursors = a.cursors + (size_t)b * MCRT_XCDS * MCRT_CURSOR_STRIDE;
     uint32_t i = MCRT_SUB_LO(cur_x) + (blockIdx.x >> x_shift) * 256u + (uint32_t)tid;      // the first item of each lane is assigned statically
     if (i >= MCRT_SUB_LO(cur_x + 1u)) i = 0xffffffffu;
-    uint32_t ray_id = 0;                         // the path id whose record holds the ray and its closest-hit word
+    uint32_t ray_id = 0;                         // queue position of the ray (and of its closest-hit word)
     bool exhausted = false, fresh = true;
     f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1), inv = mk(1, 1, 1);
     float t_lo = 0.0f;
@@ -803,14 +737,13 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
             }
             if (need && i != 0xffffffffu) {
                 if (i < n) {
-                    uint32_t piece = 0u, idx = i;                        // the pieces of one ray land in different wavefronts
-                    if (K > 1u) { piece = i / n_rays; idx = i - piece * n_rays; }      // (no division on the common path)
-                    if (b == 0u) ray_id = ((idx % F) * a.ne_frame + idx / F) * a.S;     // queued scan-line idx = (scan-line, frame): its first sample's path
-                    else ray_id = q_in[idx];
-                    const float4 r0 = MCRT_REC(a, 3, ray_id), r1 = MCRT_REC(a, 4, ray_id);
+                    uint32_t piece = 0u;                                 // the pieces of one ray land in different wavefronts
+                    if (K == 1u) ray_id = i;                             // (no division on the common path)
+                    else { piece = i / n_rays; ray_id = i - piece * n_rays; }
+                    const float4 r0 = rays[2 * (size_t)ray_id * ray_stride], r1 = rays[2 * (size_t)ray_id * ray_stride + 1];
                     f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
                     const f3 d = to - f2;
-                    inv = mk(r1.z, r1.w, 1.0f / d.z);
+                    inv = mk(r1.z, r1.w, rcp_dir(d.z));
                     t_lo = 0.0f;
                     float t_hi = 1.0f;
                     if (K > 1u) {
@@ -876,8 +809,8 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
         const float tcap = fminf(1.0f, best.frac);               // best only changes in phase 2
         const bool thieves_wait = !STATS && queue_empty && __any(cur == CUR_IDLE && fresh);     // (then phase 1 is cut short: see MCRT_LANE_ADOPT_STEPS)
         int steps_left = MCRT_LANE_ADOPT_STEPS;
-        const LaneRay lr = { (v2f){ f2.x, f2.x }, (v2f){ f2.y, f2.y }, (v2f){ f2.z, f2.z }, (v2f){ inv.x, inv.x }, (v2f){ inv.y, inv.y }, (v2f){ inv.z, inv.z },
-                             inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f };
+        const f3 rc = ray_c(f2, inv);
+        const LaneRay lr = { rc.x, rc.y, rc.z, inv.x, inv.y, inv.z, inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f };
         for (;;) {
             const unsigned long long inner = MCRT_ON_INNER(cur);
             if (inner == 0ull) break;
@@ -907,7 +840,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
         // ---- phase 2: the parked leaves; the triangle test of the contract (btTriangleRaycastCallback::processTriangle behind
         // the padded-bounds rule), one lane per ray, same expressions as the quad walk's shared test ----
         if ((uint32_t)cur > 0x80000000u) {
-            const uint32_t cnt = lane_leaf_test(a, S, f2, to, inv, t_lo, helper, best, cur, sp, sb);
+            const uint32_t cnt = lane_leaf_test(a, S, f2, to, inv, rc, t_lo, helper, best, cur, sp, sb);
             if (STATS) st_tris += cnt;
         }
         LSTAMP(sc_p2)
@@ -1111,13 +1044,7 @@ MCRT_DEV bool shade_path(const FrameArgs &a, uint32_t b, uint32_t pid, PathState
 }
 
 
-// ---- interface interaction of a bounce's live rays: one lane per ray.  The path's record is updated in place; what moves is
-// its 4-byte id: into the next bounce's queue directly (the default, see below), or -- a.sort -- bundle by bundle: survivors are
-// COUNTED per bundle here -- class = (scan-line, the last hist_bits reflect / refract decisions; all
-// frames of a pass share a class); k_scan turns the counts into the bundles' first positions in the next bounce's queue, which
-// k_place then fills.  (RNG counters and RF bins do not depend on queue order: any order gives the same images.)
-MCRT_DEV uint32_t bundle_bits(uint32_t b, uint32_t hist_bits) { return (b + 1u < hist_bits) ? b + 1u : hist_bits; }
-
+// ---- interface interaction of a bounce's live rays: one lane per ray ----
 template <bool STATS>
 __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, uint32_t b)
 {
@@ -1125,135 +1052,69 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x * blockDim.x >= n) return;
     const int lane = threadIdx.x & 63;
+    // two queue buffers, ping-pong by bounce parity (like the path state)
     const uint32_t *q_in = a.queue + (size_t)(b & 1u) * a.ne * a.S;
-    const uint32_t hb = bundle_bits(b, a.hist_bits);
-    bool alive = false, qrefl = false;
-    uint32_t cls = 0xffffffffu, qpid = 0;
+    uint32_t *q_out = a.queue + (size_t)((b + 1u) & 1u) * a.ne * a.S;
+    const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
+    float4 *rays_out = (b & 1u) ? a.ray0 : a.ray1;
+    const bool valid = i < n;
+    bool alive = false, reflected = false;
+    uint32_t pid = 0;
+    PathState ps; ps.from = mk(0, 0, 0); ps.dir = mk(0, 0, 1); ps.intensity = 0.0f; ps.media = 0; ps.outside = OUT_NONE; ps.dist_mm = 0.0;
     unsigned long long st_seg = 0, st_hits = 0;
-    if (i < n) {
-        const uint32_t pid = q_in[i];
-        const float4 s0 = MCRT_REC(a, 0, pid), s1 = MCRT_REC(a, 1, pid), s2 = MCRT_REC(a, 2, pid), r0 = MCRT_REC(a, 3, pid), r1 = MCRT_REC(a, 4, pid);
-        PathState ps;
+    if (valid) {
+        pid = q_in[i];
+        // path state lives in queue order (ping-pong halves by bounce parity), so a wavefront reads and writes it coalesced
+        const size_t sin = (size_t)(b & 1u) * a.ne * a.S + i;
+        const float4 s0 = a.st0[sin], s1 = a.st1[sin], s2 = a.st2[sin];
         ps.from = mk(s0.x, s0.y, s0.z); ps.intensity = s0.w;
         ps.dir = mk(s1.x, s1.y, s1.z); ps.media = __float_as_int(s1.w);
         ps.dist_mm = __hiloint2double(__float_as_int(s2.y), __float_as_int(s2.x));
         ps.outside = __float_as_int(s2.z);
-        uint32_t hist = __float_as_uint(s2.w);
+        const float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
         const f3 f2 = mk(r0.x, r0.y, r0.z), to = mk(r0.w, r1.x, r1.y);
-        // bounce 0: one walk per (frame, scan-line), its word sits in the first sample's record (see k_trace_lane, k_init)
-        const unsigned long long key = (b == 0u) ? *MCRT_KEYW(a, pid - pid % a.S, 1) : *MCRT_KEYW(a, pid, 0);
-        bool reflected = false;
+        const size_t hi = (b == 0u) ? (size_t)(i / a.S) : (size_t)i;            // bounce 0: one walk per queued (scan-line, frame) (see k_trace_lane, k_init)
+        const unsigned long long key = ((b & 1u) ? a.key1 : a.key0)[hi];
         alive = shade_path<STATS>(a, b, pid, ps, f2, to, key, reflected, st_seg, st_hits);
-        if (alive) {
-            hist = (hist << 1) | (reflected ? 1u : 0u);
-            MCRT_REC(a, 0, pid) = make_float4(ps.from.x, ps.from.y, ps.from.z, ps.intensity);
-            MCRT_REC(a, 1, pid) = make_float4(ps.dir.x, ps.dir.y, ps.dir.z, __int_as_float(ps.media));
-            MCRT_REC(a, 2, pid) = make_float4(__int_as_float(__double2loint(ps.dist_mm)), __int_as_float(__double2hiint(ps.dist_mm)), __int_as_float(ps.outside), __uint_as_float(hist));
-            const Ray r = make_ray(ps.from, ps.dir, ps.intensity, a.mats[2 * ps.media].y, a);
-            MCRT_REC(a, 3, pid) = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
-            MCRT_REC(a, 4, pid) = make_float4(r.to.y, r.to.z, 1.0f / (r.to.x - r.f2.x), 1.0f / (r.to.y - r.f2.y));   // (one lane divides here, once per ray)
-            *MCRT_KEYW(a, pid, 0) = MCRT_KEY_MISS;                                // the next bounce's closest-hit word of this path
-            const uint32_t line = pid / a.S;                             // (frame, scan-line), frame-major
-            const uint32_t cl = a.cls_lines == a.ne_frame ? line % a.ne_frame : line;     // one probe pose for the pass: the frames of a scan-line are one bundle
-            cls = (cl << hb) | (hist & ((1u << hb) - 1u));
-        }
-        if (a.sort) a.tmp[i] = make_uint2(pid, cls);
-        qpid = pid; qrefl = reflected;
     }
-    if (!a.sort) {
-        // survivors -> next bounce's queue, ORDER-PRESERVING (ballot + prefix; ONE atomic per workgroup: tens of thousands of returning
-        // atomics on the single counter would serialise in L2 and bound the kernel).  Inside a wavefront's block the reflected rays
-        // come first, then the refracted ones, each in queue order: the samples of a scan-line that took the same decisions stay
-        // adjacent, and the queue stays in near path-id order (so neighbouring lanes of the next launches touch neighbouring records).
-        __shared__ uint32_t wave_live[4], block_base;
-        const unsigned long long live = __ballot(alive);
-        const unsigned long long live_refl = __ballot(alive && qrefl);
-        const int wv = threadIdx.x >> 6;
-        if (lane == 0) wave_live[wv] = (uint32_t)__popcll(live);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t total = wave_live[0] + wave_live[1] + wave_live[2] + wave_live[3];
-            block_base = total ? atomicAdd(&a.counts[b + 1u], total) : 0u;
-        }
-        __syncthreads();
+    const f3 from = ps.from, dir = ps.dir; const float intensity = ps.intensity; const int media = ps.media, outside = ps.outside; const double dist_mm = ps.dist_mm;
+
+    // survivors -> next bounce's queue (ballot + prefix; ONE atomic per workgroup: tens of thousands of returning atomics on the
+    // single counter would serialise in L2 and bound the kernel).  Inside a wavefront's block the reflected rays
+    // come first, then the refracted ones, each in queue order: the samples of a scan-line that took the same decisions stay
+    // adjacent, so the rays of a k_trace_lane wavefront mostly belong to a few tight bundles (same nodes, similar walk length).
+    __shared__ uint32_t wave_live[4], block_base;
+    const unsigned long long live = __ballot(alive);
+    const unsigned long long live_refl = __ballot(alive && reflected);
+    const int wv = threadIdx.x >> 6;
+    if (lane == 0) wave_live[wv] = (uint32_t)__popcll(live);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = wave_live[0] + wave_live[1] + wave_live[2] + wave_live[3];
+        block_base = total ? atomicAdd(&a.counts[b + 1u], total) : 0u;
+    }
+    __syncthreads();
+    if (live) {
+        uint32_t base = block_base;
+        for (int w = 0; w < wv; w++) base += wave_live[w];
         if (alive) {
-            uint32_t base = block_base;
-            for (int w = 0; w < wv; w++) base += wave_live[w];
             const unsigned long long below = (1ull << lane) - 1ull;
-            const uint32_t pos = base + (qrefl ? (uint32_t)__popcll(live_refl & below)
-                                               : (uint32_t)__popcll(live_refl) + (uint32_t)__popcll(live & ~live_refl & below));
-            (a.queue + (size_t)((b + 1u) & 1u) * a.ne * a.S)[pos] = qpid;
+            const uint32_t pos = base + (reflected ? (uint32_t)__popcll(live_refl & below)
+                                                   : (uint32_t)__popcll(live_refl) + (uint32_t)__popcll(live & ~live_refl & below));
+            q_out[pos] = pid;
+            ((b & 1u) ? a.key0 : a.key1)[pos] = MCRT_KEY_MISS;            // the next bounce's closest-hit word of this ray
+            const size_t so = (size_t)((b + 1u) & 1u) * a.ne * a.S + pos;
+            a.st0[so] = make_float4(from.x, from.y, from.z, intensity);
+            a.st1[so] = make_float4(dir.x, dir.y, dir.z, __int_as_float(media));
+            a.st2[so] = make_float4(__int_as_float(__double2loint(dist_mm)), __int_as_float(__double2hiint(dist_mm)), __int_as_float(outside), 0.0f);
+            const Ray r = make_ray(from, dir, intensity, a.mats[2 * media].y, a);
+            rays_out[2 * (size_t)pos] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
+            rays_out[2 * (size_t)pos + 1] = make_float4(r.to.y, r.to.z, rcp_dir(r.to.x - r.f2.x), rcp_dir(r.to.y - r.f2.y));   // (one lane divides here, once per ray)
         }
-    }
-    // sorted queues: survivors per bundle, one atomic per wavefront and bundle it holds (one or two, each splitting in two)
-    for (unsigned long long rem = a.sort ? __ballot(alive) : 0ull; rem != 0ull;) {
-        const int l0 = __ffsll((long long)rem) - 1;
-        const uint32_t c0 = (uint32_t)__shfl((int)cls, l0, 64);
-        const unsigned long long m = __ballot(alive && cls == c0);
-        if (lane == l0) atomicAdd(&a.cls_cnt[c0], (uint32_t)__popcll(m));
-        rem &= ~m;
     }
     if (STATS) {
         long long x = wave_sum_i64((long long)st_seg), y = wave_sum_i64((long long)st_hits);
         if (lane == 0) { if (x) atomicAdd(&a.stats[3], (unsigned long long)x); if (y) atomicAdd(&a.stats[5], (unsigned long long)y); }
-    }
-}
-
-// ---- the counts of k_shade into queue positions: fill[c] = first position of bundle c in the next bounce's queue (bundles in class
-// order = scan-line-major), counts[b + 1] = their total; the counters are left zeroed for the next bounce.  ONE workgroup: the table
-// has at most 65536 entries, and a kernel boundary on either side orders it with the atomics before and after at no cost (a
-// "last workgroup done" scan inside k_shade needs a device-scope release per workgroup: an L2 write-back each, 7x the kernel's time).
-__global__ void __launch_bounds__(1024) k_scan(FrameArgs a, uint32_t b)
-{
-    __shared__ uint32_t s_part[1024];
-    const uint32_t hb = bundle_bits(b, a.hist_bits);
-    const uint32_t nt = a.cls_lines << hb;
-    if (a.counts[b] == 0u) return;                               // (nothing was counted: counts[b + 1] stays 0, the counters are zero)
-    uint32_t per = (nt + 1023u) / 1024u;
-    per = (per + 3u) & ~3u;                                      // four counters per load (the tables are padded to a multiple of 4096 entries)
-    const uint32_t c0 = threadIdx.x * per;
-    uint32_t sum = 0;
-    for (uint32_t c = c0; c < c0 + per; c += 4u) { const uint4 v = *(const uint4 *)&a.cls_cnt[c]; sum += (v.x + v.y) + (v.z + v.w); }
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024u; d <<= 1) {                   // inclusive scan of the 1024 partial sums
-        const uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0u;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_part[threadIdx.x] - sum;
-    for (uint32_t c = c0; c < c0 + per; c += 4u) {
-        const uint4 v = *(const uint4 *)&a.cls_cnt[c];
-        *(uint4 *)&a.cls_fill[c] = make_uint4(run, run + v.x, run + v.x + v.y, run + v.x + v.y + v.z);
-        run += (v.x + v.y) + (v.z + v.w);
-        *(uint4 *)&a.cls_cnt[c] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    if (threadIdx.x == 1023u) a.counts[b + 1u] = s_part[1023];
-}
-
-// ---- the survivors of bounce b into the queue of bounce b + 1, bundle after bundle (fill[] from k_scan); inside a bundle in the order
-// the wavefronts arrive ----
-__global__ void __launch_bounds__(256) k_place(FrameArgs a, uint32_t b)
-{
-    const uint32_t n = a.counts[b];
-    const int lane = threadIdx.x & 63;
-    uint32_t *q_out = a.queue + (size_t)((b + 1u) & 1u) * a.ne * a.S;
-    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
-        const uint32_t i = base + threadIdx.x;
-        uint2 t = make_uint2(0u, 0xffffffffu);
-        if (i < n) t = a.tmp[i];
-        const bool alive = t.y != 0xffffffffu;
-        for (unsigned long long rem = __ballot(alive); rem != 0ull;) {
-            const int l0 = __ffsll((long long)rem) - 1;
-            const uint32_t c0 = (uint32_t)__shfl((int)t.y, l0, 64);
-            const unsigned long long m = __ballot(alive && t.y == c0);
-            uint32_t first = 0;
-            if (lane == l0) first = atomicAdd(&a.cls_fill[c0], (uint32_t)__popcll(m));
-            first = (uint32_t)__shfl((int)first, l0, 64);
-            if (alive && t.y == c0) q_out[first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = t.x;
-            rem &= ~m;
-        }
     }
 }
 
@@ -1534,27 +1395,48 @@ __global__ void k_conv_lateral(const float *tmp, float *img, uint32_t n_img, uin
     img[i] = conv;
 }
 
-// rfimage.h:54-91: one lane per scan-line (the scan is sequential along the line)
-__global__ void k_envelope(float *img, uint32_t E, uint32_t R)
+// rfimage.h:54-91, one WAVEFRONT per scan-line.  The reference walks a column once: whenever the signal stops ascending at row i
+// (a concave peak), the rows [last peak, i) are overwritten with the line from |last peak| to |c[i]|.  The comparisons only ever
+// read rows the walk has not overwritten yet, so the peaks are a pure function of the input column:
+//     peak(i) = (c[i-1] < c[i]) && !(c[i] < c[i+1]),  1 <= i <= R-2      (`ascending` after step j is exactly c[j] < c[j+1])
+// and row j becomes  last*(1-alpha) + next*alpha  with last / next the peaks around it (prev <= j < next; before the first peak
+// `last` is the signed c[0] at row 0, rfimage.h:64), rows after the last peak stay.  Same float expressions as the sequential loop,
+// evaluated by 64 lanes from an LDS copy of the column: previous / next peak by a wave-wide max / min scan over lane-contiguous chunks.
+// (One lane per column, the round-2 kernel, is a chain of 465 dependent global loads: 650 us per call however few the columns.)
+__global__ void __launch_bounds__(64) k_envelope(float *img, uint32_t E, uint32_t R)
 {
-    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= E || R < 2) return;
-    float *c = img + (size_t)col * R;
-    bool ascending = c[0] < c[1];
-    uint32_t last_peak_pos = 0;
-    float last_peak = c[0];
-    for (uint32_t i = 1; i + 1 < R; i++) {
-        if (c[i] < c[i + 1]) ascending = true;
-        else if (ascending) {
-            ascending = false;
-            const float new_peak = fabsf(c[i]);
-            for (uint32_t j = last_peak_pos; j < i; j++) {
-                const float alpha = ((float)j - (float)last_peak_pos) / ((float)i - (float)last_peak_pos);
-                c[j] = last_peak * (1 - alpha) + new_peak * alpha;
-            }
-            last_peak_pos = i;
-            last_peak = new_peak;
-        }
+    __shared__ float col[MCRT_MAX_ROWS];
+    __shared__ unsigned short prv[MCRT_MAX_ROWS], nxt[MCRT_MAX_ROWS];
+    const uint32_t lane = threadIdx.x;
+    if (blockIdx.x >= E || R < 2) return;
+    float *c = img + (size_t)blockIdx.x * R;
+    for (uint32_t r = lane; r < R; r += 64u) col[r] = c[r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    const uint32_t per = (R + 63u) / 64u, r0 = min(R, lane * per), r1 = min(R, r0 + per);
+    constexpr uint32_t NONE = 0xffffu;
+    auto peak = [&](uint32_t i) { return i >= 1u && i + 1u < R && (col[i - 1u] < col[i]) && !(col[i] < col[i + 1u]); };
+    // last peak at or before each row (0 = the start of the column), first peak after it
+    uint32_t last = 0u, first = NONE;
+    for (uint32_t i = r0; i < r1; i++) if (peak(i)) { last = i; if (first == NONE) first = i; }
+    uint32_t before = last, after = first;                    // inclusive scans over the lanes' chunks ...
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)before, d, 64), dn = (uint32_t)__shfl_down((int)after, d, 64);
+        if ((int)lane >= d) before = max(before, up);
+        if ((int)lane + d < 64) after = min(after, dn);
+    }
+    uint32_t run_prev = (uint32_t)__shfl_up((int)before, 1, 64), run_next = (uint32_t)__shfl_down((int)after, 1, 64);      // ... made exclusive
+    if (lane == 0u) run_prev = 0u;
+    if (lane == 63u) run_next = NONE;
+    for (uint32_t i = r0; i < r1; i++) { if (peak(i)) run_prev = i; prv[i] = (unsigned short)run_prev; }
+    for (uint32_t i = r1; i > r0; i--) { nxt[i - 1u] = (unsigned short)run_next; if (peak(i - 1u)) run_next = i - 1u; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = lane; j < R; j += 64u) {
+        const uint32_t p = prv[j], q = nxt[j];
+        if (q == NONE) continue;                               // past the last peak: untouched
+        const float last_peak = p == 0u ? col[0] : fabsf(col[p]), new_peak = fabsf(col[q]);
+        const float alpha = ((float)j - (float)p) / ((float)q - (float)p);
+        c[j] = last_peak * (1 - alpha) + new_peak * alpha;
     }
 }
 
@@ -1708,11 +1590,6 @@ hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
     const dim3 grid((np + 255u) / 256u), blk(256);
     if (stats) hipLaunchKernelGGL((k_shade<true>), grid, blk, 0, st, a, b);
     else hipLaunchKernelGGL((k_shade<false>), grid, blk, 0, st, a, b);
-    if (a.sort && b + 1u < a.B) {                           // (the last bounce has no successor to queue for)
-        const uint32_t blocks = (np + 255u) / 256u;
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a, b);
-        hipLaunchKernelGGL(k_place, dim3(blocks < 2048u ? blocks : 2048u), blk, 0, st, a, b);
-    }
     return hipGetLastError();
 }
 
@@ -1755,7 +1632,7 @@ hipError_t launch_convolve(float *img, float *tmp, uint32_t n_img, uint32_t E, u
 
 hipError_t launch_envelope(float *img, uint32_t E, uint32_t R, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_envelope, dim3((E + 63) / 64), dim3(64), 0, st, img, E, R);
+    hipLaunchKernelGGL(k_envelope, dim3(E), dim3(64), 0, st, img, E, R);
     return hipGetLastError();
 }
 

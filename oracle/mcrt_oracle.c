@@ -366,12 +366,23 @@ static inline void tri_bounds(const float *t9, float pad_abs, float lo[3], float
     for (int a = 0; a < 3; a++) { lo[a] = lo[a] - pad; hi[a] = hi[a] + pad; }
 }
 
+/* The contract's plane distance (round 3): ONE fused multiply-add per plane, t = fl(plane * inv + c) with c = -(o * inv) rounded
+ * once per ray and axis -- instead of (plane - o) * inv.  For a fixed ray it is a monotone function of the plane (the exact
+ * plane * inv + c is, and rounding is monotone), which is all the order-independence argument needs: a box that
+ * contains another yields the wider interval.  The reciprocal direction is kept finite (rcp_dir), so no distance is ever undefined. */
+static inline v3 ray_c(v3 o, v3 inv) { return V(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)); }
+/* the reciprocal direction, kept FINITE: 1/0 (a ray parallel to an axis) and overflowing quotients become +-2^100, so every plane
+ * distance is a finite number (|plane| < 2^20 in any scene) and the monotonicity argument needs no special cases; the sign of the
+ * huge distance still says on which side of the plane the origin lies (to within the rounding of o * inv) */
+#define ORC_INV_MAX 0x1p+100f
+static inline float rcp_dir(float d) { float r = 1.0f / d; return r > ORC_INV_MAX ? ORC_INV_MAX : (r < -ORC_INV_MAX ? -ORC_INV_MAX : r); }
+
 /* ray parameter interval [tmin,tmax] (clamped to [0,tcap]) in which o + t*d lies inside the box */
-static inline int slab(const float lo[3], const float hi[3], v3 o, v3 inv, float tcap, float *tmin_o, float *tmax_o)
+static inline int slab(const float lo[3], const float hi[3], v3 c, v3 inv, float tcap, float *tmin_o, float *tmax_o)
 {
-    float t0x = (lo[0] - o.x) * inv.x, t1x = (hi[0] - o.x) * inv.x;
-    float t0y = (lo[1] - o.y) * inv.y, t1y = (hi[1] - o.y) * inv.y;
-    float t0z = (lo[2] - o.z) * inv.z, t1z = (hi[2] - o.z) * inv.z;
+    float t0x = fmaf(lo[0], inv.x, c.x), t1x = fmaf(hi[0], inv.x, c.x);
+    float t0y = fmaf(lo[1], inv.y, c.y), t1y = fmaf(hi[1], inv.y, c.y);
+    float t0z = fmaf(lo[2], inv.z, c.z), t1z = fmaf(hi[2], inv.z, c.z);
     float tmin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
     float tmax = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tcap));
     *tmin_o = tmin; *tmax_o = tmax;
@@ -383,11 +394,11 @@ static inline int slab(const float lo[3], const float hi[3], v3 o, v3 inv, float
  * instead of ordering the two distances.  Identical to slab() whenever both distances are numbers (lo <= hi, monotone rounding);
  * where one is not (origin exactly on a plane the ray runs parallel to) fmaxf / fminf drop it and the interval is the wider one.
  * Node tests only steer the walk: the answer is decided by tri_test, which keeps slab(). */
-static inline int slab_node(const float lo[3], const float hi[3], v3 o, v3 inv, float tcap, float *tmin_o)
+static inline int slab_node(const float lo[3], const float hi[3], v3 c, v3 inv, float tcap, float *tmin_o)
 {
-    float nx = ((inv.x < 0.0f ? hi[0] : lo[0]) - o.x) * inv.x, fx = ((inv.x < 0.0f ? lo[0] : hi[0]) - o.x) * inv.x;
-    float ny = ((inv.y < 0.0f ? hi[1] : lo[1]) - o.y) * inv.y, fy = ((inv.y < 0.0f ? lo[1] : hi[1]) - o.y) * inv.y;
-    float nz = ((inv.z < 0.0f ? hi[2] : lo[2]) - o.z) * inv.z, fz = ((inv.z < 0.0f ? lo[2] : hi[2]) - o.z) * inv.z;
+    float nx = fmaf(inv.x < 0.0f ? hi[0] : lo[0], inv.x, c.x), fx = fmaf(inv.x < 0.0f ? lo[0] : hi[0], inv.x, c.x);
+    float ny = fmaf(inv.y < 0.0f ? hi[1] : lo[1], inv.y, c.y), fy = fmaf(inv.y < 0.0f ? lo[1] : hi[1], inv.y, c.y);
+    float nz = fmaf(inv.z < 0.0f ? hi[2] : lo[2], inv.z, c.z), fz = fmaf(inv.z < 0.0f ? lo[2] : hi[2], inv.z, c.z);
     float tmin = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
     float tmax = fminf(fminf(fx, fy), fminf(fz, tcap));
     *tmin_o = tmin;
@@ -399,7 +410,7 @@ static inline int slab_node(const float lo[3], const float hi[3], v3 o, v3 inv, 
  *   - a hit counts only if its fraction lies inside the ray's overlap with the triangle's padded bounds
  *     (float noise far from the triangle can otherwise pass the three edge tests on a 1e9-long segment);
  *   - smaller fraction wins; equal fraction -> smaller triangle id. */
-static inline void tri_test(const float *t9, int32_t id, v3 from, v3 to, v3 inv, float pad_abs, hit_t *best)
+static inline void tri_test(const float *t9, int32_t id, v3 from, v3 to, v3 inv, v3 rc, float pad_abs, hit_t *best)
 {
     v3 v0 = V(t9[0], t9[1], t9[2]), v1 = V(t9[3], t9[4], t9[5]), v2 = V(t9[6], t9[7], t9[8]);
     v3 v10 = vsub(v1, v0), v20 = vsub(v2, v0);
@@ -413,7 +424,7 @@ static inline void tri_test(const float *t9, int32_t id, v3 from, v3 to, v3 inv,
     if (frac < best->frac || (frac == best->frac && id < best->tri)) {
         float lo[3], hi[3], tmin, tmax;
         tri_bounds(t9, pad_abs, lo, hi);
-        if (!slab(lo, hi, from, inv, 1.0f, &tmin, &tmax)) return;
+        if (!slab(lo, hi, rc, inv, 1.0f, &tmin, &tmax)) return;
         if (!(frac >= tmin && frac <= tmax)) return;
         float edge_tol = vdot(n, n) * -0.0001f;
         float s = 1.0f - frac;
@@ -438,7 +449,8 @@ static inline void tri_test(const float *t9, int32_t id, v3 from, v3 to, v3 inv,
 static void walk_bvh(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stats *st)
 {
     v3 d = vsub(to, from);
-    v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    v3 inv = V(rcp_dir(d.x), rcp_dir(d.y), rcp_dir(d.z));
+    const v3 rc = ray_c(from, inv);
     int32_t stack[ORC_STACK];
     int sp = 0;
     int32_t cur = 0;
@@ -448,8 +460,8 @@ static void walk_bvh(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stats
             const orc_bvh_node *N = &sc->nodes[cur];
             nn++;
             float tn0, tn1, tx0, tx1;
-            int h0 = slab(N->lo0, N->hi0, from, inv, fminf(1.0f, best->frac), &tn0, &tx0);
-            int h1 = slab(N->lo1, N->hi1, from, inv, fminf(1.0f, best->frac), &tn1, &tx1);
+            int h0 = slab(N->lo0, N->hi0, rc, inv, fminf(1.0f, best->frac), &tn0, &tx0);
+            int h1 = slab(N->lo1, N->hi1, rc, inv, fminf(1.0f, best->frac), &tn1, &tx1);
             if (h0 && h1) {
                 int32_t nearc = N->c0, farc = N->c1;
                 if (tn1 < tn0) { nearc = N->c1; farc = N->c0; }
@@ -464,7 +476,7 @@ static void walk_bvh(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stats
             for (uint32_t i = 0; i < cnt; i++) {
                 const float *t = sc->bvh_tri + (size_t)(first + i) * 12;
                 float t9[9] = { t[0], t[1], t[2], t[4], t[5], t[6], t[8], t[9], t[10] };
-                tri_test(t9, (int32_t)f2u(t[3]), from, to, inv, sc->pad_abs, best);
+                tri_test(t9, (int32_t)f2u(t[3]), from, to, inv, rc, sc->pad_abs, best);
                 nt++;
             }
         }
@@ -483,7 +495,8 @@ static void walk_bvh4(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stat
 {
     const orc_bvh4_child *nodes = (const orc_bvh4_child *)sc->nodes4;
     v3 d = vsub(to, from);
-    v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    v3 inv = V(rcp_dir(d.x), rcp_dir(d.y), rcp_dir(d.z));
+    const v3 rc = ray_c(from, inv);
     int32_t stack[ORC_STACK];
     int sp = 0;
     int32_t cur = 0;
@@ -496,7 +509,7 @@ static void walk_bvh4(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stat
             float tcap = fminf(1.0f, best->frac);
             for (int k = 0; k < 4; k++) {
                 float hi[3] = { N[k].hix, N[k].hiy, N[k].hiz }, tn;
-                int h = slab_node(N[k].lo, hi, from, inv, tcap, &tn) && N[k].ref != ORC_BVH4_EMPTY;
+                int h = slab_node(N[k].lo, hi, rc, inv, tcap, &tn) && N[k].ref != ORC_BVH4_EMPTY;
                 key[k] = h ? ((f2u(tn) & ~3u) | (uint32_t)k) : 0xffffffffu; ref[k] = N[k].ref; nh += h;   /* t_near >= 0: bits order like the value */
             }
             if (nh > 0) {
@@ -520,7 +533,7 @@ static void walk_bvh4(const orc_scene *sc, v3 from, v3 to, hit_t *best, orc_stat
             for (uint32_t i = 0; i < cnt; i++) {
                 const float *t = sc->bvh_tri + (size_t)(first + i) * 12;
                 float t9[9] = { t[0], t[1], t[2], t[4], t[5], t[6], t[8], t[9], t[10] };
-                tri_test(t9, (int32_t)f2u(t[3]), from, to, inv, sc->pad_abs, best);
+                tri_test(t9, (int32_t)f2u(t[3]), from, to, inv, rc, sc->pad_abs, best);
                 nt++;
             }
         }
@@ -542,8 +555,9 @@ int32_t orc_closest_hit(const orc_scene *sc, const float from_[3], const float t
         walk_bvh(sc, from, to, &best, st);
     } else {
         v3 d = vsub(to, from);
-        v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        for (uint32_t i = 0; i < sc->n_tri; i++) tri_test(sc->tri + (size_t)i * 9, (int32_t)i, from, to, inv, sc->pad_abs, &best);
+        v3 inv = V(rcp_dir(d.x), rcp_dir(d.y), rcp_dir(d.z));
+        const v3 rc = ray_c(from, inv);
+        for (uint32_t i = 0; i < sc->n_tri; i++) tri_test(sc->tri + (size_t)i * 9, (int32_t)i, from, to, inv, rc, sc->pad_abs, &best);
         if (st) st->tris_tested += sc->n_tri;
     }
     if (best.tri < 0) return -1;

@@ -512,11 +512,11 @@ def test_randomised_configurations(mcrt, orc, case, monkeypatch):
     """a sweep over shapes and parameters nobody picked by hand: odd element / sample / row counts, depths 1..16, both builders,
     textures of several sizes, TIR sanitising on and off, frequency, seed, frames in flight -- hits and RF bit for bit"""
     rng = np.random.default_rng(1000 + case)
-    # every fourth case with queues sorted into bundles (by 0, 1 or 2 decisions), one with two scan-line groups on two streams (the library reads its knobs at mcrt_create)
-    for k in ("MCRT_SORT_BITS", "MCRT_GROUPS"):
+    # every fourth case without cutting the rays of small bounces into pieces, one with two scan-line groups on two streams (the library reads its knobs at mcrt_create)
+    for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS"):
         monkeypatch.delenv(k, raising=False)
     if case % 4 == 3:
-        monkeypatch.setenv("MCRT_SORT_BITS", str(case % 3))
+        monkeypatch.setenv("MCRT_KSPLIT_LIMIT", "0")
     if case == 6:
         monkeypatch.setenv("MCRT_GROUPS", "2")
     if case % 3 == 0:
@@ -689,18 +689,18 @@ def test_reference_style_program_on_the_host_shim(mcrt, orc, tex256, tmp_path):
     assert np.abs(host[m] - fused[m]).max() <= RTOL_REF * peak
 
 
-def test_queue_order_and_groups_do_not_change_anything(mcrt, orc, tex256, monkeypatch):
-    """the order of a bounce's queue is free (counter-keyed RNG, integer RF bins): order-preserving compaction (the default), queues
-    sorted into bundles by the full decision history, by two decisions, by scan-line alone, two scan-line groups on two streams, and
-    the accumulation confined to its own CUs all give bit-identical hits, segments, RF images and visit counts, equal to the oracle's."""
+def test_schedules_do_not_change_anything(mcrt, orc, tex256, monkeypatch):
+    """how a pass is scheduled is free (counter-keyed RNG, integer RF bins): the default, scan-line groups on their own streams, rays
+    of small bounces cut into pieces or not, the accumulation (and the walk) confined to their own CUs, everything on one stream -- all
+    give bit-identical hits, segments, RF images and visit counts, equal to the oracle's."""
     cfg, meshes = mcrt.synth.random_scene(60000, 8, seed=5)
     sd = mcrt.scene_io.build_scene(cfg, meshes)
     E, S, frame = 24, 160, 11
     got = {}
-    variants = (("preserved", {}), ("history", {"MCRT_SORT_BITS": "10"}), ("two_bits", {"MCRT_SORT_BITS": "2"}), ("scanline", {"MCRT_SORT_BITS": "0"}),
-                ("two_groups", {"MCRT_GROUPS": "2"}), ("sorted_groups", {"MCRT_GROUPS": "2", "MCRT_SORT_BITS": "10"}), ("masked", {"MCRT_MARCH_CUS": "64", "MCRT_MAIN_MASK": "1"}))
+    variants = (("default", {}), ("two_groups", {"MCRT_GROUPS": "2"}), ("three_groups_no_split", {"MCRT_GROUPS": "3", "MCRT_KSPLIT_LIMIT": "0"}),
+                ("masked", {"MCRT_MARCH_CUS": "64", "MCRT_MAIN_MASK": "1"}), ("march_masked", {"MCRT_MARCH_CUS": "96"}), ("no_overlap", {"MCRT_NO_OVERLAP": "1"}))
     for name, env in variants:
-        for k in ("MCRT_SORT_BITS", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK"):
+        for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)                               # (the library reads its knobs once, at mcrt_create)
@@ -718,9 +718,9 @@ def test_queue_order_and_groups_do_not_change_anything(mcrt, orc, tex256, monkey
         nodes4 = sim.ctx.get_bvh4()[0]
         sim.close()
         got[name] = (hits, segs.tobytes(), cnt, rf, st, batch[1].T.copy(), nodes4)
-    for k in ("MCRT_SORT_BITS", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK"):
+    for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP"):
         monkeypatch.delenv(k, raising=False)
-    a = got["preserved"]
+    a = got["default"]
     for name in [v[0] for v in variants[1:]]:
         b = got[name]
         assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2]), name
