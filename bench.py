@@ -488,7 +488,7 @@ def committed_pmc(args, pass_sizes, queries_per_launch):
         with open(os.path.join(ROOT, "profiles", "round3", "pmc_bench.json")) as f:
             d = json.load(f)
         key = d.get("config_key")
-        if key[:1] != [args.workload] or key[3:5] != [args.rays, args.rows]:
+        if key[:1] != [args.workload] or key[4] != args.rows:            # (the instructions per query are the scene's, to a few per cent whatever the ray count)
             return None
         p = dict(d["pmc"])
         if key == [args.workload, args.scanlines, args.scanlines_total, args.rays, args.rows, args.gpus, pass_sizes]:

@@ -409,7 +409,10 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
                                      // (measured per leaf phase: 5833 / 4597 / 4153 cycles; frame 0.512 / 0.506 / 0.505 ms)
 #endif
 #ifndef MCRT_LANE_FETCH
-#define MCRT_LANE_FETCH 64           // queue positions a wavefront claims per atomic
+#define MCRT_LANE_FETCH 128          // queue positions a wavefront claims per atomic in a LARGE launch (>= MCRT_LANE_FETCH_FROM items), 64 below: measured
+#endif                               // 0.434 / 0.426 / 0.426 ms per frame with 64 / 128 / 256 at 128 frames in flight (16.7 M items), 0.523 / 0.531 with 64 / 128 on
+#ifndef MCRT_LANE_FETCH_FROM         // a 20-frame pass (2.6 M items: what a wavefront holds back at the end of the queue weighs more there)
+#define MCRT_LANE_FETCH_FROM 4194304
 #endif
 
 // float -> half, rounded towards -infinity / +infinity (integer steps on the half's bit pattern from the nearest-even conversion)
@@ -682,6 +685,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
 #define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)
 #define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)
     uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
+    const uint32_t fetch = n >= (uint32_t)MCRT_LANE_FETCH_FROM ? (uint32_t)MCRT_LANE_FETCH : 64u;
     unsigned long long poll_old = 0; uint32_t poll_ray = 0; bool poll_pending = false;      // (see the end of the loop)
 #ifdef MCRT_STAMP
     // diagnostic build: cycles and lane counts per phase, summed over wavefronts (tools/stamps.py)
@@ -716,11 +720,11 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
             if (dynm) {
                 while (pool_next >= pool_end && !queue_empty) {
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&cursors[(size_t)cur_x * MCRT_CURSOR_STRIDE], (uint32_t)MCRT_LANE_FETCH);
+                    if (lane == 0) base = atomicAdd(&cursors[(size_t)cur_x * MCRT_CURSOR_STRIDE], fetch);
                     base = __shfl(base, 0, 64);
                     const uint32_t hi = MCRT_SUB_LO(cur_x + 1u);
                     const unsigned long long start = (unsigned long long)MCRT_SUB_LO(cur_x) + MCRT_SUB_STATIC(cur_x) + base;
-                    if (start < hi) { pool_next = (uint32_t)start; pool_end = min((uint32_t)start + (uint32_t)MCRT_LANE_FETCH, hi); }
+                    if (start < hi) { pool_next = (uint32_t)start; pool_end = min((uint32_t)start + fetch, hi); }
                     else if (++visited >= X) queue_empty = true;
                     else cur_x = (cur_x + 1u) & (X - 1u);
 #if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)

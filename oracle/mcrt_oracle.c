@@ -770,12 +770,13 @@ static inline void fix_add(int64_t *acc, uint8_t *flag, float echo)
 /* Optional companion of rf_ref: the SAME echoes added in the SAME (reference) order, but into doubles.  The float image is what
  * the reference's `cv::Mat += echo` produces; the distance between the two is that running float sum's own rounding error,
  * which grows with the number of samples per scan-line.  Set by orc_set_ref64 around a call that requests rf_ref (tests only;
- * one call at a time). */
+ * one call at a time: orc_trace_frame reads the pointer once, before its parallel region, and hands it to the sinks). */
 static double *g_ref64 = NULL;
 void orc_set_ref64(double *buf) { g_ref64 = buf; }
 
 typedef struct {
     float *rf_ref; uint32_t ref_cols, ref_col;       /* [R][cols] */
+    double *rf_ref64;                                 /* the same image carried in double (same shape), or NULL */
     int64_t *rf_fix; uint8_t *rf_flags;               /* [R] of this element */
 } rf_sink;
 
@@ -787,7 +788,7 @@ static inline void add_echo(const rf_sink *k, const orc_consts *c, uint32_t n_ro
         int r = (int)row;
         if (k->rf_ref) {
             k->rf_ref[(size_t)r * k->ref_cols + k->ref_col] += echo;
-            if (g_ref64) g_ref64[(size_t)r * k->ref_cols + k->ref_col] += (double)echo;
+            if (k->rf_ref64) k->rf_ref64[(size_t)r * k->ref_cols + k->ref_col] += (double)echo;
         }
         if (k->rf_fix) fix_add(&k->rf_fix[r], k->rf_flags ? &k->rf_flags[r] : NULL, echo);
     }
@@ -893,6 +894,7 @@ static void trace_path(const orc_scene *sc, const orc_params *prm, const orc_con
     if (seg_count) *seg_count = nseg;
 }
 
+#define ORC_PRIV_ROWS 2048      /* rows of a sample block's private bins (on the task's stack); more rows: one task per scan-line */
 void orc_trace_frame(const orc_scene *sc, const orc_params *p,
                      const float *el_pos, const float *el_dir, const float *texture,
                      uint32_t frame_id, uint32_t e_begin, uint32_t e_end, int use_bvh, int n_threads,
@@ -904,12 +906,13 @@ void orc_trace_frame(const orc_scene *sc, const orc_params *p,
     const uint32_t ne = e_end - e_begin, S = p->n_samples, B = p->max_depth, R = p->n_rows;
     orc_stats total; memset(&total, 0, sizeof total);
     if (n_threads < 1) n_threads = 1;
+    double *const ref64 = rf_ref ? g_ref64 : NULL;     /* read ONCE, before the parallel region: the sinks carry it from here on */
     /* Tasks = (scan-line, block of samples).  The reference-order float image adds a scan-line's echoes strictly in
      * sample order (main.cpp:106-144), so it is only produced with one task per scan-line; the fixed-point image is an
      * integer sum and may be cut into sample blocks, which is what keeps every core of a many-core host busy
      * (block sums are merged with integer adds: the result does not depend on the cut). */
     uint32_t chunks = 1;
-    if (!rf_ref && ne > 0 && (uint32_t)n_threads > ne / 2u) {
+    if (!rf_ref && ne > 0 && (uint32_t)n_threads > ne / 2u && R <= ORC_PRIV_ROWS) {
         chunks = (4u * (uint32_t)n_threads + ne - 1u) / ne;
         if (chunks > S) chunks = S;
         if (chunks < 1u) chunks = 1u;
@@ -928,12 +931,14 @@ void orc_trace_frame(const orc_scene *sc, const orc_params *p,
         v3 pos = V(el_pos[3 * e], el_pos[3 * e + 1], el_pos[3 * e + 2]);
         v3 dir = V(el_dir[3 * e], el_dir[3 * e + 1], el_dir[3 * e + 2]);
         rf_sink k;
-        k.rf_ref = rf_ref; k.ref_cols = ne; k.ref_col = ei;
+        k.rf_ref = rf_ref; k.ref_cols = ne; k.ref_col = ei; k.rf_ref64 = ref64;
         k.rf_fix = rf_fix ? rf_fix + (size_t)ei * R : NULL;
         k.rf_flags = rf_flags ? rf_flags + (size_t)ei * R : NULL;
         int64_t *priv_fix = NULL; uint8_t *priv_flags = NULL;
+        int64_t stack_fix[ORC_PRIV_ROWS]; uint8_t stack_flags[ORC_PRIV_ROWS];      /* (R <= 2048 in every caller: no allocation that could fail) */
         if (chunks > 1u && rf_fix) {                    /* private bins of this block, merged below */
-            priv_fix = (int64_t *)calloc(R, sizeof(int64_t)); priv_flags = (uint8_t *)calloc(R, 1);
+            priv_fix = stack_fix; priv_flags = stack_flags;
+            memset(priv_fix, 0, sizeof(int64_t) * R); memset(priv_flags, 0, R);
             k.rf_fix = priv_fix; k.rf_flags = rf_flags ? priv_flags : NULL;
         }
         for (uint32_t s = s0; s < s1; s++) {
@@ -951,9 +956,13 @@ void orc_trace_frame(const orc_scene *sc, const orc_params *p,
 #endif
                     dst[r] += priv_fix[r];
                 }
-                if (rf_flags && priv_flags[r]) rf_flags[(size_t)ei * R + r] = 1;     /* (every writer stores the same value) */
+                if (rf_flags && priv_flags[r]) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+                    rf_flags[(size_t)ei * R + r] = 1;
+                }
             }
-            free(priv_fix); free(priv_flags);
         }
 #ifdef _OPENMP
 #pragma omp critical

@@ -57,11 +57,23 @@ def test_product_does_not_touch_the_oracle():
                 assert "oracle" not in txt.lower() or f in ("synth.py",) and "mcrt_oracle" not in txt, (dp, f)
 
 
-def test_reference_style_program_compiles_against_the_host_shim():
-    """host/reference_style_main.cpp uses the reference's class surface (volume, psf, rf_image::add_echo / clear /
-    micros_traveled / get_dt, scene::cast_rays<S,E>(transducer&), scene::distance, transducer::print/update): it must
-    compile and link against host/mcrt_host.hpp + libmcrt_hip.so (run on the GPU by tests/test_gpu_parity.py)"""
+def _build_host_surface_test():
+    """tests/host/host_surface_test.cpp against host/mcrt_host.hpp + libmcrt_hip.so -> tests/host/host_surface_test"""
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.check_call(["make", "-C", os.path.join(root, "mcray-tracing_amd"), "reference_style_main", "mattausch_hip"])
-    assert os.path.exists(os.path.join(root, "mcray-tracing_amd", "reference_style_main"))
+    pkg = os.path.join(root, "mcray-tracing_amd")
+    exe = os.path.join(root, "tests", "host", "host_surface_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(root, "include"), "-I", os.path.join(pkg, "host"), "-o", exe,
+                           os.path.join(root, "tests", "host", "host_surface_test.cpp"), "-L", pkg, "-lmcrt_hip", "-Wl,-rpath," + pkg])
+    return exe
+
+
+def test_host_shim_surface_test_compiles(mcrt):
+    """the shim's class surface (transducer<N>, psf<>, volume<>, json, scene::cast_rays<S,E>(transducer&) / distance / step,
+    rf_image::clear / add_echo / micros_traveled / get_dt / convolve / envelope / postprocess / save, ray_physics::segment) as used by
+    tests/host/host_surface_test.cpp must compile and link against libmcrt_hip.so (it runs on the GPU: tests/test_gpu_parity.py); the
+    product's own CLI builds too"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.path.exists(_build_host_surface_test())
+    subprocess.check_call(["make", "-C", os.path.join(root, "mcray-tracing_amd"), "mattausch_hip"])

@@ -641,6 +641,16 @@ def test_two_ranks_gather_equals_single_process():
     r, out = _run_bench([a for a in small if a not in ("--scanlines", "16")] + ["--scanlines-total", "24", "--backend", g["backend"]], nproc=2, timeout=300)
     assert r is not None and r.returncode == 0 and out is not None, "" if r is None else (r.stderr or "")[-800:]
     assert out["scaling"] == "strong" and out["config"]["scan_lines_total"] == 24 and out["gather_check"]["equal"]
+    assert out["ranks_seen"] == 2 and [p["rank"] for p in out["per_rank"]] == [0, 1] and all(p["trace_ms"] > 0 for p in out["per_rank"])
+    assert out["per_rank"][0]["scan_lines"] == [0, 12] and out["per_rank"][1]["scan_lines"] == [12, 24]
+    # BASELINE C4's shape as it is sharded over GPUs: the 1 M-triangle scene, 256 scan-lines x 8192 rays over the two ranks; the
+    # gathered whole B-mode frames (PSF, envelope, scan conversion after the gather) equal one process's, and the line explains itself
+    r, out = _run_bench(["--workload", "random1m", "--scanlines-total", "256", "--rays", "8192", "--steps", "2", "--warmup", "2", "--frames-in-flight", "2",
+                         "--no-cpu-baseline", "--no-latency-leg", "--no-pmc", "--same-gpu", "--check-gather", "--min-time", "0.05", "--backend", g["backend"]], nproc=2, timeout=500)
+    assert r is not None and r.returncode == 0 and out is not None, "" if r is None else (r.stderr or "")[-800:]
+    assert out["scaling"] == "strong" and out["config"]["scan_lines_total"] == 256 and out["config"]["rays_per_scan_line"] == 8192
+    assert out["gather_check"]["equal"] and out["gather_check"]["nonzero_bmode"] > 10000 and out["ranks_seen"] == 2
+    assert out["roofline"]["frac"] is not None and out["roofline"]["derived"] is True and 0.0 < out["roofline"]["frac"] < 1.0
 
 
 def test_bench_line_contract_and_inline_parity():
@@ -657,21 +667,20 @@ def test_bench_line_contract_and_inline_parity():
     assert out["roofline"]["bound"] == "valu" and out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["seconds"] >= 5.0
 
 
-def test_reference_style_program_on_the_host_shim(mcrt, orc, tex256, tmp_path):
-    """host/reference_style_main.cpp is written the way the reference's main.cpp is (volume, psf, rf_image::clear/add_echo/
-    micros_traveled, scene::cast_rays<5,512>(transducer), scene::distance, convolve/envelope/postprocess): its host-side
-    accumulation over the GPU-cast segments must agree with the fused GPU frame and with the oracle's reference-order image"""
+def test_host_shim_surface(mcrt, orc, tex256, tmp_path):
+    """tests/host/host_surface_test.cpp calls every public method of the C++ host shim once and checks the result (exit code =
+    failed checks); the RF image it deposits echo by echo on the host (rf_image::add_echo over the segments of scene::cast_rays<5,512>)
+    must agree with the frame the GPU accumulates and with the oracle's reference-order image"""
     import json, os, subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.check_call(["make", "-C", os.path.join(root, "mcray-tracing_amd"), "reference_style_main"])
-    exe = os.path.join(root, "mcray-tracing_amd", "reference_style_main")
+    from test_abi import _build_host_surface_test
+    exe = _build_host_surface_test()
     cfg, meshes = mcrt.synth.sphere_scene(3)
     cfg["workingDirectory"] = str(tmp_path) + "/"
     for f, (V, F) in meshes.items():
         mcrt.scene_io.save_obj(str(tmp_path / f), V, F)
     (tmp_path / "sphere.scene").write_text(json.dumps(cfg))
     r = subprocess.run([exe, str(tmp_path / "sphere.scene"), str(tmp_path / "host.bin"), str(tmp_path / "fused.bin")], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.returncode == 0 and "host surface: 0 check(s) failed" in r.stdout, r.stdout + r.stderr
     assert "rf_image: 465, 512" in r.stdout
     host = np.fromfile(str(tmp_path / "host.bin"), np.float32).reshape(465, 512)
     fused = np.fromfile(str(tmp_path / "fused.bin"), np.float32).reshape(465, 512)

@@ -25,7 +25,10 @@ json.dump(drv, open(os.path.join(dst, "bench_driver_cmd.json"), "w"), indent=1)
 pm = bench["roofline"].get("pmc")
 if pm:
     key = ["random1m", 128, 0, 1024, 465, 1, bench["config"]["passes_per_timed_region"]]
-    json.dump({"config_key": key, "taken_at": "packaged from the bench run in bench_unprofiled.json", "pmc": pm}, open(os.path.join(dst, "pmc_bench.json"), "w"), indent=1)
+    r_ = bench["roofline"]
+    per_query = pm["valu_instructions_per_launch"] / (r_["per_frame"]["queries"] / r_["launches_per_frame"])      # what bench.py derives an N > 1 roofline from
+    json.dump({"config_key": key, "taken_at": "packaged from the bench run in bench_unprofiled.json", "valu_instructions_per_query": per_query, "pmc": pm},
+              open(os.path.join(dst, "pmc_bench.json"), "w"), indent=1)
 
 # ---- kernel statistics (overlapped = production; standalone = MCRT_NO_OVERLAP=1)
 shutil.copy(glob.glob(os.path.join(out, "pmc_" + tag, "stats", "*", "*kernel_stats.csv"))[0], os.path.join(dst, "kernel_stats.csv"))
@@ -59,9 +62,10 @@ for kernel, name in (("k_trace_lane<false", "pmc_k_trace_lane.json"), ("k_march<
     pmc[name] = der
 
 # ---- README
-cal = json.load(open(os.path.join(dst, "valu_roof.json")))
+roofs = os.path.join(root, "profiles", "round2")       # the two roofs were calibrated in round 2 (same tool, same chip)
+cal = json.load(open(os.path.join(roofs, "valu_roof.json")))
 mix5 = [r for r in cal["results"] if r["class"].startswith("BVH4 node-step mix") and r["waves_per_simd"] == 5][0]
-fet = json.load(open(os.path.join(dst, "fetch_roof.json")))
+fet = json.load(open(os.path.join(roofs, "fetch_roof.json")))
 
 
 def fr(lanes, nbytes, table):
@@ -78,7 +82,7 @@ for line in open(os.path.join(dst, "kernels_standalone.txt")):
             alone[k] = float(line.split(" avg ")[1].split()[0])
 r = bench["roofline"]; t = pmc["pmc_k_trace_lane.json"]; m = pmc["pmc_k_march.json"]; s = pmc["pmc_k_shade.json"]
 cb = bench["cpu_baseline"]
-txt = """# profiles/round2 -- MI355X (gfx950), ROCm 7.2
+txt = """# profiles/round3 -- MI355X (gfx950), ROCm 7.2
 
 Workload of every file unless it says otherwise: `bench.py` defaults = synthetic 1 M random triangles, 128 scan-lines x 1024 sample
 paths per frame, 465 RF rows, max depth 10, one GPU, @FIF@ frames in flight per pass.  Produced by `tools/profile_round.sh` on a gpurun
@@ -86,8 +90,8 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 
 | file | what |
 |---|---|
-| `valu_roof.json`, `valu_roof_pmc.json` | `tools/valu_roof.hip`: VALU issue rate per instruction class at 1/2/4/5/8 wavefronts per SIMD from in-kernel `s_memtime` stamps, and the same launches under `rocprofv3 --pmc` (SQ_INSTS_VALU / SQ_BUSY_CU_CYCLES agree with the stamps to the third digit) |
-| `fetch_roof.json` | `tools/fetch_roof.hip`: cost of a wave-level global load in the CU's vector memory pipe by access shape and cache level |
+| `../round2/valu_roof.json`, `valu_roof_pmc.json`, `fetch_roof.json` | the two calibrated roofs (`tools/valu_roof.hip`, `tools/fetch_roof.hip`), measured in round 2 on the same chip with the same tools: not repeated |
+| `exp_*` | this round's experiments, copied in by hand (DESIGN.md 5.5): queues sorted into ray bundles against the order-preserving compaction (`exp_sorted_bundles_*`, `exp_unsorted_*`: per-bounce PMC of the walk, stamp-build lane statistics, refill / leaf-batch thresholds with sorted queues), kernels with path state in place by path id (`exp_records_kernels_standalone.txt`), CU-masked streams (`exp_cu_masks.txt`) |
 | `bench_unprofiled.json` | `python bench.py`: the JSON line (live PMC passes in child processes, CPU baseline, inline parity check) |
 | `bench_driver_cmd.json` | `python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command: one 20-frame pass per timed region) |
 | `pmc_bench.json` | the PMC block of `bench_unprofiled.json`, the labelled fall-back `bench.py` reads when it cannot profile itself |
@@ -96,7 +100,6 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 | `pmc_k_trace_lane.json`, `pmc_k_march.json`, `pmc_k_shade.json` | separate `--pmc` passes (tools/pmc.sh), per-launch averages + derived figures |
 | `frame_timeline.txt`, `frame_timeline_one_frame.txt` | start / duration of every launch of one pass: @FIF@ frames in flight, and one frame at a time |
 | `baseline_configs.txt` | the five BASELINE.json configurations on one GPU (tools/configs.sh) |
-| `launch_tails.txt` | `tools/stamps.py 1024 F` with the `-DMCRT_STAMP_LITE` build for F = 1, 20, 128 frames in flight: per bounce the launch of the walk, when its queue ran dry, the wavefronts' mean start, mean and longest lifetime, node-step iterations per wavefront (mean, most) -- the ends of the launches that DESIGN.md 5.3 / 5.4 argue from (copied in by hand, not produced by profile_round.sh) |
 
 ## The two roofs (calibrated, not assumed)
 
@@ -104,7 +107,7 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 many wavefronts share the SIMD: `v_fma_f32` independent streams reach %.3f instructions per cycle and SIMD at 8 waves, `v_min3_f32`,
 `v_pk_mul_f32`, DPP moves and compare/select pairs 0.24-0.26, `v_fma_f64` / `v_mul_f64` 0.24; only plain integer adds (0.45) and
 dependent `v_fma_f32` chains of many waves (0.44) come near the 2-cycle figure of the micro-architecture guide.  The register-only
-part of a BVH4 node step (packed subtract / multiply, min / max / min3 / max3, compares, selects, key arithmetic) issues at
+part of a BVH4 node step (as it was in round 2: packed subtract / multiply, min / max / min3 / max3, compares, selects, key arithmetic) issues at
 **%.3f instructions per cycle and SIMD at 5 waves per SIMD, clock %.2f GHz** -- the roof `bench.py` prices the walk against
 (1024 SIMDs x %.3f x %.2f GHz = %.0f G wave-instructions per second).
 
@@ -113,6 +116,8 @@ when the data is in L1 (%.2f lanes per cycle), the same from L2, and %.0f cycles
 line cost %.0f cycles per wave-load (%.1f B/cycle/CU) -- the TCP moves ~24 B per cycle and CU through `dwordx4` loads however they
 are shaped, twice that through `dword` / `dwordx2` loads of contiguous lanes.  What the walk pays per node is therefore the number of
 16-byte pieces a lane fetches: 7 with the 128-byte nodes of round 1, 4 with the 64-byte half-float nodes.
+`bench.py` also reports the walk against the best class measured (`frac_vs_best_class`, 0.449) and against the guide's two cycles per
+instruction (`frac_vs_architectural`, 0.5).
 
 ## What the kernels do with them (per launch = one bounce of a @FIF@-frame pass)
 
@@ -128,11 +133,12 @@ both pipes are loaded to about the same degree.  The BVH is served on-die: L1 hi
 %.0f MB per launch -- `bench.py` reports it as `hbm_measured_frac` = %.3f of the 8 TB/s HBM figure (the algorithmic bytes, %.1f GB per
 launch, flow at %.1f TB/s from the caches).
 
-`bench_unprofiled.json`: **%.1f M rays/s, %.3f ms per frame (%.0f frames/s)**, timed region repeated %d times (min / median / max
+`bench_unprofiled.json` (a step is a WHOLE B-mode frame: trace, accumulate, PSF, envelope, scan conversion): **%.1f M rays/s, %.3f ms per frame (%.0f frames/s)**, timed region repeated %d times (min / median / max
 %.3f / %.3f / %.3f ms per frame); one frame at a time %.2f ms per frame; roofline `frac` = %.2f of the VALU ceiling
 (%.0f of %.0f G wave-instructions per second, wall time of the launches, tails and the concurrently running `k_march` included);
 `parity_check.rf_bit_exact` = %s on %d scan-lines.  CPU baseline (the oracle, %d usable cores of %d hardware threads, %.1f kept busy):
-%.2f M rays/s, one thread %.1f k rays/s.  `bench_driver_cmd.json` (one 20-frame pass): %.1f M rays/s, %.3f ms per frame.
+%.2f M rays/s, one thread %.1f k rays/s.  `bench_driver_cmd.json` (one 20-frame pass): %.1f M rays/s, %.3f ms per frame; the same pass with a
+different probe pose in every frame (`sweep`): %.3f ms per frame.
 """ % (
     max(x["simd_ipc"] for x in cal["results"] if x["class"] == "v_fma_f32 independent"), mix5["simd_ipc"], mix5["clock_ghz"], mix5["simd_ipc"], mix5["clock_ghz"], 1024 * mix5["simd_ipc"] * mix5["clock_ghz"],
     fr(1, 16, "16 KiB")["cycles_per_wave_load_per_cu"], 64 / fr(1, 16, "16 KiB")["cycles_per_wave_load_per_cu"], fr(1, 16, "64 MiB")["cycles_per_wave_load_per_cu"],
@@ -146,7 +152,7 @@ launch, flow at %.1f TB/s from the caches).
     bench["value"] / 1e6, bench["ms_per_step"], bench["frames_per_sec"], bench["config"]["timed_region_repeats"], *bench["config"]["repeat_ms_per_step_min_median_max"],
     bench["one_frame_at_a_time"]["ms_per_step"], r.get("frac") or 0.0, r.get("achieved") or 0.0, r["peak"],
     bench["parity_check"]["rf_bit_exact"], bench["parity_check"]["scan_lines"], cb["cores"], cb["host"]["cpu_count"], cb["cores_kept_busy"], cb["value"] / 1e6, cb["single_thread"]["value"] / 1e3,
-    drv["value"] / 1e6, drv["ms_per_step"])
+    drv["value"] / 1e6, drv["ms_per_step"], drv["sweep"]["ms_per_step"])
 txt = txt.replace("@FIF@", str(FIF))
 open(os.path.join(dst, "README.md"), "w").write(txt)
 print(txt)
