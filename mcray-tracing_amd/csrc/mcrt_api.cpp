@@ -66,7 +66,7 @@ struct Work {
 
 // tuning knobs from the environment, read ONCE at mcrt_create (never on the frame path)
 struct Knobs {
-    uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 4096;
+    uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 0;   // march_blocks 0: launch_march picks
     bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false;
     uint32_t march_cus = 0;                    // CUs the accumulation's side stream is confined to (0 = no mask); the mask's bit order is the driver's
     bool main_mask = false;                    // with march_cus: the walk / shade chain runs on its own stream confined to the OTHER CUs
