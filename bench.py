@@ -412,6 +412,19 @@ def roofline_from(pmc, k_ms, alg_gbs):
             r["valu_lane_utilisation"] = pmc["lane_utilisation"]
     else:
         r.update({"achieved": None, "frac": None})
+    if pmc and pmc.get("tcp_lane_accesses_per_launch") and pmc.get("busy_cu_cycles_per_launch"):
+        # the OTHER roof of the walk: the CU's vector memory pipe, in lane-accesses per cycle and CU, against the rate
+        # tools/fetch_roof.hip measured for scattered 16-byte-per-lane loads (profiles/round2/fetch_roof.json); counters of the walk alone
+        tcp_peak = 0.75
+        try:
+            fr = json.load(open(os.path.join(ROOT, "profiles", "round2", "fetch_roof.json")))
+            row = [x for x in fr["results"] if x["lanes_per_run"] == 1 and x["bytes_per_lane"] == 16 and x["table"].startswith("16 KiB")][0]
+            tcp_peak = 64.0 / row["cycles_per_wave_load_per_cu"]
+        except Exception:
+            pass
+        ach = pmc["tcp_lane_accesses_per_launch"] / 256.0 / pmc["busy_cu_cycles_per_launch"]
+        r["second_roof"] = {"what": "vector memory pipe (TCP) of a CU: lane-accesses per cycle, scattered 16-byte-per-lane loads", "achieved": ach, "peak": tcp_peak,
+                            "frac": ach / tcp_peak, "source": "SQ/TCP counters of the walk's launches; peak: profiles/round2/fetch_roof.json"}
     if pmc and pmc.get("traffic_bytes_per_launch") is not None and k_ms > 0:
         r["traffic"] = pmc["traffic_bytes_per_launch"]
         r["hbm_measured_GBps"] = pmc["traffic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9
@@ -452,7 +465,7 @@ def live_pmc(args):
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         for name, ctrs in (("sq", ["SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES", "SQ_WAVES", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"]),
-                           ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+                           ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("tcp", ["TCP_TOTAL_CACHE_ACCESSES_sum"])):
             d = os.path.join(tmp, name)
             r = subprocess.run([exe, "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
@@ -473,6 +486,7 @@ def live_pmc(args):
                 "valu_instructions_per_launch": got["SQ_INSTS_VALU"][0], "busy_cu_cycles_per_launch": got["SQ_BUSY_CU_CYCLES"][0] / 256.0,
                 "vmem_read_instructions_per_launch": got["SQ_INSTS_VMEM_RD"][0], "salu_instructions_per_launch": got["SQ_INSTS_SALU"][0],
                 "lane_utilisation": got["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * got["SQ_ACTIVE_INST_VALU"][0]) if got["SQ_ACTIVE_INST_VALU"][0] else None,
+                "tcp_lane_accesses_per_launch": got["TCP_TOTAL_CACHE_ACCESSES_sum"][0],
                 "fetch_size_kib": got["FETCH_SIZE"][0], "write_size_kib": got["WRITE_SIZE"][0],
                 "traffic_bytes_per_launch": (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0}
     except KeyError:

@@ -1138,7 +1138,9 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
 // With the sorted tiles (750 us): the steps' echoes as straight-line code (row confirmed by two reads, zero adds into a spare bin, the
 // rest left to a general path entered when any lane needs it) -- the loop issues two scalar instructions for three vector ones, but
 // the straight line keeps four echoes and rows alive: 20 spilled registers at 6 waves/SIMD (1255 us), 784 us at 5; the zero adds
-// all meet in one LDS word (869 / 757 us).  Taking parts of the step out (wrong images, timing only): no gathers 693, no row
+// all meet in one LDS word (869 / 757 us).  Round 3, the same idea with the add itself the only masked instruction (common case = estimate
+// confirmed and echo small; the rest collected in a bit mask for a general path entered when any lane needs it): 2341 vs 2263 us per
+// 128-frame launch -- the work done for steps that are not valid costs more than the branches it replaces.  Taking parts of the step out (wrong images, timing only): no gathers 693, no row
 // search 679, no adds 707, none of the three 570 us, no loop at all 8 us (cycle stamps of the full kernel: hand-out 17 %, advance 4 %, voxel + gathers 27 %,
 // rows and bins with the wait for the gathers 51 %).
 template <bool STATS, int G>
