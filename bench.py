@@ -425,6 +425,11 @@ def roofline_from(pmc, k_ms, alg_gbs):
         ach = pmc["tcp_lane_accesses_per_launch"] / 256.0 / pmc["busy_cu_cycles_per_launch"]
         r["second_roof"] = {"what": "vector memory pipe (TCP) of a CU: lane-accesses per cycle, scattered 16-byte-per-lane loads", "achieved": ach, "peak": tcp_peak,
                             "frac": ach / tcp_peak, "source": "SQ/TCP counters of the walk's launches; peak: profiles/round2/fetch_roof.json"}
+        if r.get("frac") is not None:
+            # which of the walk's two pipes is the fuller one (a fraction above 1 on the second roof: part of the lanes share lines)
+            r["binding_roof"] = "vector memory pipe (second_roof)" if ach / tcp_peak > r["frac"] else "valu issue (frac)"
+            r["note"] = ("an instruction-RATE fraction falls when instructions are removed from the same work: round 3 cut the walk's VALU instructions per "
+                         "launch by 12 % (1579 M -> 1386 M at 128 frames in flight); kernel_ms and value are the figures of merit")
     if pmc and pmc.get("traffic_bytes_per_launch") is not None and k_ms > 0:
         r["traffic"] = pmc["traffic_bytes_per_launch"]
         r["hbm_measured_GBps"] = pmc["traffic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9
