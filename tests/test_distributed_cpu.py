@@ -1,6 +1,6 @@
 """The N>1 path on CPU: world_size-2 `gloo` processes shard the scan-lines exactly as bench.py does on GPUs (same
 shard_range / gather_rf helpers), with the oracle standing in for the kernel, and must reproduce the single-process frame
-bit for bit -- including the PSF convolution applied to the gathered image on rank 0."""
+bit for bit -- including the PSF convolution, envelope and scan conversion applied to the gathered image on rank 0."""
 import os
 import sys
 import numpy as np
@@ -59,6 +59,10 @@ def test_two_rank_scanline_sharding_matches_single_process(tmp_path, orc, mcrt, 
     assert np.array_equal(np.load(out + ".f3.npy").T.view(np.uint32), ref3.view(np.uint32))
     ax, lat = orc.psf()
     assert np.array_equal(orc.convolve(np.ascontiguousarray(got.T), ax, lat).view(np.uint32), orc.convolve(ref, ax, lat).view(np.uint32))
+    # ... and the rest of the B-mode frame rank 0 computes from the gathered image (main.cpp:146-148), as bench.py's step does
+    bmode = lambda img: orc.scan_convert(orc.envelope(orc.convolve(img, ax, lat)), out_rows=100, out_cols=125)
+    a, b = bmode(np.ascontiguousarray(got.T)), bmode(ref)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.count_nonzero(a) > 100
 
 
 def test_shard_range_covers_every_scanline(mcrt):
