@@ -127,8 +127,9 @@ extern "C" int mcrt_build_bvh(const float *tri, const uint32_t *tri_mesh, uint32
     // Padding (DESIGN.md "Closest hit"): Bullet's triangle test accepts points up to 1e-4 of the triangle's
     // height outside an edge, and the slab arithmetic rounds; each triangle's bounds are widened accordingly.
     // A triangle is eligible only while the ray overlaps ITS padded bounds (as in Bullet's per-triangle BVH
-    // leaves); node boxes are exact unions of those, and the float slab test is monotone under containment,
-    // so node culling can never remove an eligible triangle.
+    // leaves); node boxes are exact unions of those, and the contract's plane distance fl(plane * inv + c) (one fma, finite
+    // reciprocal: DESIGN.md 3) is a monotone function of the plane, so a box that contains another yields the wider interval
+    // and node culling can never remove an eligible triangle.
     float scale = 0.f;
     for (size_t i = 0; i < (size_t)n_tri * 9; i++) { float a = std::fabs(tri[i]); if (a > scale && std::isfinite(a)) scale = a; }
     const float abs_pad = 4e-6f * std::max(scale, 1e-3f);
