@@ -92,6 +92,27 @@ def _visit_counts(mcrt, orc, sim, osc, tr, tex, p_kw, frame, S, o_stats, threads
         assert st[k] == o_stats[k], k
 
 
+def _tree_against_brute_force(mcrt, orc, cfg, sd, sim, E, tex, threads, frame=5, S2=64, n_lines=2, seed=2026):
+    """The tree the PRODUCT built, at this size (the counted walk of the big tests runs over the product's own tree, so a
+    builder that lost triangles at scale would pass): every triangle id sits in the leaf-order array exactly once, and on the same
+    tree a block of rays of every bounce -- seeded scan-lines x 64 samples, ~500 closest-hit queries per line, each over ALL
+    triangles -- gives the BRUTE-FORCE answer, on the GPU and in the oracle's walk alike.  Closes `sim`."""
+    _, btri, _ = sim.ctx.get_bvh()
+    assert np.array_equal(np.sort(btri.view(np.uint32)[:, 3]), np.arange(sd.n_tri, dtype=np.uint32))
+    sim.close()
+    tr2, sim2, osc2 = _setup(mcrt, orc, cfg, sd, E, S2, tex)
+    hits2, _, _ = sim2.ctx.trace_frame_debug(frame, sim2.rf_dev)
+    p2 = orc.default_params(n_elements=E, n_samples=S2)
+    n_q = 0
+    for e in sorted(int(x) for x in np.random.default_rng(seed).choice(E, size=n_lines, replace=False)):
+        brute = osc2.trace_frame(p2, tr2.pos, tr2.dir, tex, frame_id=frame, e_begin=e, e_end=e + 1, use_bvh=0, n_threads=threads, want_ref=False, want_fix=False)
+        walked = osc2.trace_frame(p2, tr2.pos, tr2.dir, tex, frame_id=frame, e_begin=e, e_end=e + 1, use_bvh=2, n_threads=threads, want_ref=False, want_fix=False)
+        assert np.array_equal(brute["hits"], walked["hits"]) and np.array_equal(brute["hits"][0], hits2[e]), e
+        n_q += brute["stats"]["queries"] - S2                        # (bounces >= 1)
+    sim2.close()
+    return n_q
+
+
 def test_headline_1m_triangles_128x1024(mcrt, orc, tex256):
     """the workload `metric` is quoted on and bench.py times: every scan-line against the oracle"""
     cfg, meshes = mcrt.synth.random_scene(1_000_000, 8, 12345)
@@ -118,25 +139,7 @@ def test_headline_1m_triangles_128x1024(mcrt, orc, tex256):
     o3 = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=3, use_bvh=2, n_threads=threads, want_hits=False, want_ref=False)
     assert np.array_equal(batch[3].T.view(np.uint32), o3["rf"].view(np.uint32))
     sim.ctx.free(dev)
-    # ---- the tree itself, at this size (the counted walk above runs over the PRODUCT's tree, so a builder that lost
-    # triangles at scale would pass): every triangle id sits in the leaf-order array exactly once, and on the same tree a block of
-    # rays of every bounce -- two seeded scan-lines x 64 samples, ~1000 closest-hit queries of ~10^6 triangle tests each -- gives the
-    # BRUTE-FORCE answer, on the GPU and in the oracle's walk alike
-    _, btri, _ = sim.ctx.get_bvh()
-    assert np.array_equal(np.sort(btri.view(np.uint32)[:, 3]), np.arange(sd.n_tri, dtype=np.uint32))
-    sim.close()
-    S2 = 64
-    tr2, sim2, osc2 = _setup(mcrt, orc, cfg, sd, E, S2, tex256)
-    hits2, _, _ = sim2.ctx.trace_frame_debug(5, sim2.rf_dev)
-    p2 = orc.default_params(n_elements=E, n_samples=S2)
-    n_q = 0
-    for e in sorted(int(x) for x in np.random.default_rng(2026).choice(E, size=2, replace=False)):
-        brute = osc2.trace_frame(p2, tr2.pos, tr2.dir, tex256, frame_id=5, e_begin=e, e_end=e + 1, use_bvh=0, n_threads=threads, want_ref=False, want_fix=False)
-        walked = osc2.trace_frame(p2, tr2.pos, tr2.dir, tex256, frame_id=5, e_begin=e, e_end=e + 1, use_bvh=2, n_threads=threads, want_ref=False, want_fix=False)
-        assert np.array_equal(brute["hits"], walked["hits"]) and np.array_equal(brute["hits"][0], hits2[e]), e
-        n_q += brute["stats"]["queries"] - S2                        # (bounces >= 1)
-    assert n_q >= 512
-    sim2.close()
+    assert _tree_against_brute_force(mcrt, orc, cfg, sd, sim, E, tex256, threads) >= 512
 
 
 def test_c3_liver_128x4096(mcrt, orc, tex256):
@@ -156,7 +159,7 @@ def test_c3_liver_128x4096(mcrt, orc, tex256):
     assert (hits >= 0).sum() > E * S
     assert_rf(rf, o)
     _visit_counts(mcrt, orc, sim, osc, tr, tex256, p_kw, frame, S, o["stats"], threads)
-    sim.close()
+    assert _tree_against_brute_force(mcrt, orc, cfg, sd, sim, E, tex256, threads, n_lines=4) >= 512      # (the liver scene's tree: C3 and C5)
 
 
 def test_c4_1m_triangles_256x8192(mcrt, orc, tex256):
