@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MCRT_VERSION 100
+#define MCRT_VERSION 103   /* round 3: + mcrt_trace_frames_poses, mcrt_envelope_frames, mcrt_scan_convert_frames; the slab rule of the closest-hit contract is one fma per plane */
 
 typedef enum {
     MCRT_OK = 0,
