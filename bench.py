@@ -33,6 +33,7 @@ The JSON line carries
 import argparse
 import csv
 import glob
+import gc
 import json
 import os
 import shutil
@@ -263,12 +264,15 @@ def main():
     # ---- the timed region: EXACTLY K steps between barrier + synchronize pairs, repeated; the median repeat is reported ----
     # (warm-up: at least W steps, rounded up to whole timed regions, so that the first timed repeat finds every buffer at its size)
     W_run = -(-max(W, 1) // K) * K
+    ctx.enable_timing(True)                                    # (before the warm-up: its HIP events are created there, not in the first timed repeat)
+    pipe.timing = True
     for w0 in range(0, W_run, K):
         pipe.run_steps(1000 + w0, K)
-    ctx.enable_timing(True); ctx.kernel_time(reset=True)
     pipe.sync()
-    pipe.timing = True
-    reps, total, n_rep = [], 0.0, 0
+    ctx.kernel_time(reset=True); pipe.times(1)
+    reps, total, n_rep, k_sum, k_n = [], 0.0, 0, 0.0, 0
+    stage = {"trace_ms": 0.0, "gather_ms": 0.0, "post_ms": 0.0}
+    gc.collect(); gc.disable()                                 # (as timeit does: a full collection of the interpreter's heap is tens of ms, a whole repeat at this size)
     while n_rep < 5 or (total < args.min_time and n_rep < 200):
         pipe.sync()
         t0 = time.perf_counter()
@@ -280,10 +284,15 @@ def main():
             dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)       # MAX over ranks (every rank then takes the same loop decisions)
         dt = float(dt_t.item())
         reps.append(dt); total += dt; n_rep += 1
-    k_ms, k_n = ctx.kernel_time(reset=True)                    # HIP events around every k_trace launch, on the launching stream
+        a_ms, a_n = ctx.kernel_time(reset=True)                # harvested per repeat (outside the clock), so the same HIP events serve every repeat
+        k_sum += a_ms * a_n; k_n += a_n
+        for k_, v_ in pipe.times(1).items():
+            stage[k_] += v_
+    gc.enable()
+    k_ms = k_sum / max(k_n, 1)                                 # HIP events around every k_trace launch, on the launching stream
     ctx.enable_timing(False)
     pipe.timing = False
-    mine = dict(pipe.times(K * n_rep), rank=rank, scan_lines=[e0, e1])
+    mine = dict({k_: v_ / (K * n_rep) for k_, v_ in stage.items()}, rank=rank, scan_lines=[e0, e1])
     per_rank = [mine]
     if world > 1:
         per_rank = [None] * world
@@ -318,7 +327,7 @@ def main():
             "config": {"workload": "%s; %d scan-lines x %d rays per GPU, %d RF rows, max depth 10" % (label, E_local, S, R),
                        "scan_lines_total": E, "rays_per_scan_line": S, "triangles": int(sd.n_tri), "parallelism": "scanline-shard x%d" % world,
                        "frames_in_flight": F, "passes_per_timed_region": pass_sizes, "timed_region_repeats": n_rep,
-                       "timed_seconds_total": total, "repeat_ms_per_step_min_median_max": [min(reps) / K * 1e3, dt / K * 1e3, max(reps) / K * 1e3],
+                       "timed_seconds_total": total, "repeat_ms_per_step_min_median_max": [min(reps) / K * 1e3, dt / K * 1e3, max(reps) / K * 1e3], "slowest_repeat": reps.index(max(reps)),
                        "overlap_gather_psf_with_next_trace": not args.no_overlap, "bvh_builder": args.bvh, "bvh_build_s": round(t_bvh, 3),
                        "warmup_steps_run": W_run, "step": "clear, trace, accumulate, [all-gather], PSF, envelope, scan conversion to %dx%d" % (pipe.OUT_ROWS, pipe.OUT_COLS)},
             "ranks_seen": world, "per_rank": per_rank,
