@@ -114,6 +114,10 @@ int mcrt_destroy(mcrt_ctx *ctx);
  * default stream: to order the kernels with work on HIP's legacy stream pass hipStreamLegacy explicitly, and with a
  * framework's stream (torch.cuda.Stream().cuda_stream) pass that handle. */
 int mcrt_set_stream(mcrt_ctx *ctx, void *hip_stream);
+/* Waits for the context's stream AND reads the context's device error word: MCRT_ERR_LIMIT when a launch since the last call was
+ * abandoned (a persistent kernel's watchdog expired, a traversal stack ran out).  A caller that synchronises by other means (its own
+ * stream, a framework's synchronize) must still call this to learn of such a launch; until it does -- the call clears the word --
+ * every RF image the context finalises is NaN throughout, so that a broken frame cannot pass for an image. */
 int mcrt_synchronize(mcrt_ctx *ctx);
 
 int mcrt_default_params(mcrt_params *p);
@@ -243,6 +247,9 @@ int mcrt_debug_philox(mcrt_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2
  * latest wave end, summed wave lifetimes; the first two stored complemented), out[60..119] per-bounce wavefront counts, start
  * times, longest lifetime and node-step iterations, out[120..129] cycle sums of k_march's sections (tools/stamps.py decodes them); all zero otherwise */
 int mcrt_debug_stamps(mcrt_ctx *ctx, uint64_t out[200], int reset);
+/* test hook: ORs `bits` into the context's device error word on its stream, as an abandoned launch would (bit 0: traversal stack ran
+ * out, bit 1: kernel watchdog expired) -- what mcrt_synchronize reports and what turns finalised RF images into NaN until it is asked */
+int mcrt_debug_set_error(mcrt_ctx *ctx, uint32_t bits);
 
 #ifdef __cplusplus
 }

@@ -138,6 +138,10 @@ class Context:
     def synchronize(self):
         check(self.L.mcrt_synchronize(self.h))
 
+    def debug_set_error(self, bits):
+        """test hook: mark the context as an abandoned launch would (mcrt_debug_set_error)"""
+        check(self.L.mcrt_debug_set_error(self.h, int(bits)))
+
     def upload_scene(self, sd):
         meshes = (MeshRec * len(sd.meshes))(*[MeshRec(a, b, c, 0) for a, b, c in sd.meshes])
         sp = np.asarray(sd.spacing, np.float32)

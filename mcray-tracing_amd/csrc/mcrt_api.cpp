@@ -852,7 +852,7 @@ extern "C" int mcrt_trace_frames(mcrt_ctx *c, uint32_t frame, uint32_t n_frames,
     const uint32_t lines = (e1 - e0) * n_frames;
     rc = ensure_acc(c, lines); if (rc) return rc;
     rc = run_frame(c, frame, n_frames, e0, e1, true, frame_groups(c), 0); if (rc) return rc;
-    HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, lines, c->p.n_rows, c->stream));
+    HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, lines, c->p.n_rows, c->d_error, c->stream));
     c->acc_clean_ne = lines; c->acc_clean_rows = c->p.n_rows;
     return MCRT_OK;
 }
@@ -924,7 +924,7 @@ extern "C" int mcrt_trace_frame_debug(mcrt_ctx *c, uint32_t frame, uint32_t e0, 
     if (!rf_dev) return set_error(MCRT_ERR_INVALID, "null rf_dev");
     rc = ensure_acc(c, e1 - e0); if (rc) return rc;
     rc = run_frame(c, frame, 1, e0, e1, true, 1, segs ? 2 : 1); if (rc) return rc;   // one group: the per-path tables are contiguous
-    HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, e1 - e0, c->p.n_rows, c->stream));
+    HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, e1 - e0, c->p.n_rows, c->d_error, c->stream));
     c->acc_clean_ne = e1 - e0; c->acc_clean_rows = c->p.n_rows;
     return copy_out(c, e1 - e0, hits, segs, seg_count);
 }
@@ -1093,6 +1093,17 @@ extern "C" int mcrt_debug_stamps(mcrt_ctx *c, uint64_t out[200], int reset)
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, c->d_stats + 8, 200 * 8, hipMemcpyDeviceToHost));
     if (reset) { HIP_TRY(hipMemsetAsync(c->d_stats + 8, 0, 200 * 8, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_debug_set_error(mcrt_ctx *c, uint32_t bits)
+{
+    CTX_TRY(c);
+    uint32_t e = 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(&e, c->d_error, 4, hipMemcpyDeviceToHost));
+    e |= bits;
+    HIP_TRY(hipMemcpy(c->d_error, &e, 4, hipMemcpyHostToDevice));
     return MCRT_OK;
 }
 

@@ -1359,14 +1359,16 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
     for (uint32_t r = tid; r < nf; r += nthr) { const uint32_t f = lflags[r]; if (f) atomicOr(&a.flags[row * nf + r], f); }
 }
 
-// fixed-point bins -> float RF image [ne][R]; clears the bins for the next frame
-__global__ void k_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t ne, uint32_t R)
+// fixed-point bins -> float RF image [ne][R]; clears the bins for the next frame.  A frame whose launches set the context's device
+// error word (a persistent kernel abandoned by its watchdog, a traversal stack that ran out) is written as NaN throughout: a caller that
+// synchronises on its own stream and never asks mcrt_synchronize cannot mistake it for an image.
+__global__ void k_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t ne, uint32_t R, const uint32_t *error_flag)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)ne * R) return;
     const uint32_t e = (uint32_t)(i / R), r = (uint32_t)(i % R);
     const uint32_t nf = (R + 31u) >> 5;
-    const bool bad = (flags[(size_t)e * nf + (r >> 5)] >> (r & 31)) & 1u;
+    const bool bad = ((flags[(size_t)e * nf + (r >> 5)] >> (r & 31)) & 1u) || *error_flag != 0u;
     const long long v = acc[i];
     rf[i] = bad ? __uint_as_float(0x7fc00000u) : (float)((double)v * 0x1p-40);
     acc[i] = 0;
@@ -1625,10 +1627,10 @@ hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
     return hipGetLastError();
 }
 
-hipError_t launch_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t ne, uint32_t R, hipStream_t st)
+hipError_t launch_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t ne, uint32_t R, const uint32_t *error_flag, hipStream_t st)
 {
     const size_t n = (size_t)ne * R;
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, acc, flags, rf, ne, R);
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, acc, flags, rf, ne, R, error_flag);
     const size_t nf = (size_t)ne * ((R + 31u) >> 5);
     hipLaunchKernelGGL(k_clear_flags, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, flags, nf);
     return hipGetLastError();

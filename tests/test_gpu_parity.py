@@ -298,6 +298,23 @@ def test_pass_size_limits(mcrt, sphere, tex256):
     sim.ctx.free(dev); sim.close()
 
 
+def test_abandoned_launch_poisons_frames_until_asked(mcrt, sphere, tex256):
+    """a launch abandoned by a kernel watchdog sets the context's device error word: every image finalised from then on is NaN
+    throughout, mcrt_synchronize reports MCRT_ERR_LIMIT once and clears it, the next frame is the frame again"""
+    cfg, sd = sphere
+    tr, sim = _sim(mcrt, cfg, sd, 16, 64, texture=tex256)
+    good = sim.frame(3, convolve=False).copy()
+    assert np.isfinite(good).all() and np.abs(good).sum() > 0
+    sim.ctx.debug_set_error(2)
+    assert np.isnan(sim.frame(3, convolve=False)).all()
+    assert np.isnan(sim.frame(4, convolve=False)).all()   # sticky: nobody has asked yet
+    with pytest.raises(mcrt.McrtError, match="watchdog"):
+        sim.ctx.synchronize()
+    sim.ctx.synchronize()                              # reported once
+    assert np.array_equal(sim.frame(3, convolve=False).view(np.uint32), good.view(np.uint32))
+    sim.close()
+
+
 def test_cpp_host_cli_matches_oracle(mcrt, orc, tex256, tmp_path):
     """the C++ host mirror (host/mcrt_host.hpp: JSON scene file, OBJ meshes, transducer<512>, psf, rf_image) driven by the
     mattausch_hip CLI with the reference's launch shape (512 x 5) against the oracle: trace + convolve + envelope"""
