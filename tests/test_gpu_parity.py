@@ -2,6 +2,8 @@
 oracle on the same seeded inputs.  Bars: hit indices bit-exact; fixed-point RF image bit-exact against the
 oracle's contract accumulation; within 1e-4 (relative to the image peak) of the oracle's float summation in
 the reference's order (main.cpp:106-144); PSF convolution bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -524,7 +526,7 @@ def test_duplicated_triangles_every_hit_is_a_tie(mcrt, orc, tex256, shape):
         sim.close()
 
 
-@pytest.mark.parametrize("case", range(16))
+@pytest.mark.parametrize("case", range(int(os.environ.get("MCRT_FUZZ_CASES", "16"))))      # (a longer one-off sweep: MCRT_FUZZ_CASES=300)
 def test_randomised_configurations(mcrt, orc, case, monkeypatch):
     """a sweep over shapes and parameters nobody picked by hand: odd element / sample / row counts, depths 1..16, both builders,
     textures of several sizes, TIR sanitising on and off, frequency, seed, frames in flight -- hits and RF bit for bit"""
