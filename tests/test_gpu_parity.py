@@ -117,6 +117,46 @@ def test_c1_sphere_32x64_bruteforce(mcrt, orc, sphere, tex256):
     sim.close()
 
 
+@pytest.mark.parametrize("builder", ["sah", "lbvh"])
+def test_axis_parallel_rays_and_rays_in_box_planes(mcrt, orc, sphere, tex256, builder):
+    """the slab rule's corner cases (one fma per plane with a finite reciprocal): rays along the axes (zero and negative-zero
+    direction components), rays lying IN a face plane / along an edge of the axis-aligned box, through the face's diagonal (a tie
+    between its two triangles), from inside the sphere, pointing away, and with components so small that the reciprocal is clamped
+    -- hits, segments and RF against brute force"""
+    cfg, sd = sphere
+    V = sd.tri.reshape(-1, 3)
+    lo, hi = V.min(0), V.max(0)                          # the box's faces are the scene bounds
+    tiny, den = np.float32(1e-30), np.float32(1e-45)
+    el = [((-13.5, 0, 0), (1, 0, 0)), ((-13.5, 0, 0), (1, -0.0, 0.0)), ((-13.5, 0, 0), (1, 0.0, -0.0)),
+          ((-13.5, hi[1], 0), (1, 0, 0)), ((-13.5, hi[1], hi[2]), (1, 0, 0)), ((-13.5, lo[1], 0.5), (1, 0, 0)),
+          ((0, 0, 0), (0, 1, 0)), ((0, 0, 0), (0, 0, 1)), ((0, 0, 0), (0, -1, 0)), ((0, 0, 0), (-1, 0, 0)), ((0, 0, 0), (0, 0, -1)),
+          ((-13.5, 0, 0), (1, tiny, 0)), ((-13.5, 0, 0), (1, -tiny, den)), ((-13.5, 0, 0), (1, 1e-38, -1e-38)),
+          ((-13.5, 2, 0), (1, 0, 0)), ((-13.5, 0, 2), (1, 0, 0)), ((-13.5, 0, 0), (-1, 0, 0)), ((0, hi[1], 0), (0, -1, 0)),
+          ((lo[0], lo[1], lo[2]), (1, 1, 1)), ((hi[0], 0, 0), (-1, 0, 0)), ((0, 0, -13.5), (0, 0, 1)), ((0.25, -13.5, 0.25), (0, 1, 0))]
+    pos = np.array([e[0] for e in el], np.float32)
+    d = np.array([e[1] for e in el], np.float32)
+    d[18] /= np.float32(np.sqrt(3.0))
+    E, S = len(el), 48
+    tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256, bvh_builder=builder)
+    sim.ctx.set_transducer(pos, d)
+    hits, segs, cnt = sim.ctx.trace_frame_debug(2, sim.rf_dev, want_segs=True)
+    rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
+    p = orc.default_params(n_elements=E, n_samples=S)
+    o = osc.trace_frame(p, pos, d, tex256, frame_id=2, use_bvh=False, n_threads=16, want_segs=True)
+    assert (o["hits"][:, :, 0] >= 0).sum() >= 12 * S, "most of these rays must hit something"
+    assert np.array_equal(hits, o["hits"])
+    assert np.array_equal(cnt, o["seg_count"])
+    assert segs.tobytes() == o["segs"].tobytes()
+    _assert_rf(rf, o)
+    # ... and the oracle's walk of the product's tree agrees with its own brute force on them
+    nodes4, _ = sim.ctx.get_bvh4(); _, btri, _ = sim.ctx.get_bvh()
+    osc.set_bvh4(nodes4, btri)
+    o2 = osc.trace_frame(p, pos, d, tex256, frame_id=2, use_bvh=2, n_threads=16, want_ref=False)
+    assert np.array_equal(o2["hits"], o["hits"])
+    sim.close()
+
+
 def test_c2_sphere_128x1024_depth512(mcrt, orc, sphere, tex256):
     """BASELINE config 2: 128 scan-lines x 1024 rays, 512 RF rows, GPU BVH vs CPU parity (oracle walks the product's BVH,
     itself validated against brute force in tests/test_host_pieces.py)"""
