@@ -12,7 +12,7 @@ for spec in "$@"; do
   for v in $vars; do
     if [[ "$v" == LIB=* ]]; then envs="$envs MCRT_LIB=$PWD/mcray-tracing_amd/build/libmcrt_hip_${v#LIB=}.so"; else envs="$envs $v"; fi
   done
-  env $envs timeout 90 python bench.py --steps 128 --warmup 128 --no-cpu-baseline --no-latency-leg --no-pmc ${BENCH_ARGS} > gpurun_out/tune/$name.log 2>&1
+  env $envs timeout 90 python bench.py --steps ${BENCH_STEPS:-128} --warmup ${BENCH_STEPS:-128} --no-cpu-baseline --no-latency-leg --no-pmc ${BENCH_ARGS} > gpurun_out/tune/$name.log 2>&1
   python3 - "$name" <<'PY'
 import json,sys
 name=sys.argv[1]
