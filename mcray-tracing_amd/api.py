@@ -138,6 +138,12 @@ class Context:
     def synchronize(self):
         check(self.L.mcrt_synchronize(self.h))
 
+    def debug_fast_paths(self):
+        """(fast voxel quotient, branch-free voxel cell, entries of k_march's padded LDS image or 0) of the last traced frame"""
+        out = (C.c_uint32 * 4)()
+        check(self.L.mcrt_debug_fast_paths(self.h, out))
+        return bool(out[0]), bool(out[1]), int(out[2])
+
     def debug_set_error(self, bits):
         """test hook: mark the context as an abandoned launch would (mcrt_debug_set_error)"""
         check(self.L.mcrt_debug_set_error(self.h, int(bits)))

@@ -122,6 +122,7 @@ struct mcrt_ctx {
     // row thresholds (exact replacement of the per-echo double division) and the verified fast division by tex_res
     double *d_row_thr = nullptr; uint32_t thr_rows = 0; double thr_dt = 0.0;
     float verified_res = 0.0f; bool fast_div = false, fast_div_all = false;
+    float last_lean_bound = 0.0f; uint32_t last_march_rows = 0;   // what the last frame's kernels were given (mcrt_debug_fast_paths)
     // per-material table of k_march (depends on the materials, the axial step and the frequency)
     float4 *d_mtab = nullptr; uint32_t mtab_n = 0; float mtab_key[2] = { 0.0f, 0.0f }; bool mtab_valid = false;
     // scan-conversion maps
@@ -747,6 +748,17 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     }
     a.axial_res_mm = c->c.axial_res_mm; a.time_step = c->c.time_step_us; a.row_dt = c->c.row_dt_us;
     a.max_travel = c->c.max_travel_us; a.sos_d = (double)c->p.speed_of_sound; a.inv_row_dt = 1.0 / c->c.row_dt_us;
+    // k_march's fast variant: the reference's 256^3 texture with the branch-free cell, and an LDS image long enough for the row
+    // guess of every valid step -- t < max_travel, and rounding is monotone, so (int)(t * inv_row_dt) <= (int)(max_travel * inv_row_dt)
+    a.march_rows = 0u;
+    {
+        const double g = a.max_travel * a.inv_row_dt;
+        if (a.lean_bound > 0.0f && c->tex_n == 256u && g >= 0.0 && g < (double)(MCRT_MAX_ROWS + 1)) {
+            const uint32_t gmax = (uint32_t)g;
+            a.march_rows = (gmax + 2u > c->p.n_rows + 1u) ? gmax + 2u : c->p.n_rows + 1u;
+        }
+    }
+    c->last_lean_bound = a.lean_bound; c->last_march_rows = a.march_rows;
 }
 
 static uint32_t side_streams(const mcrt_ctx *c) { return c->knobs.march_streams; }
@@ -1093,6 +1105,14 @@ extern "C" int mcrt_debug_stamps(mcrt_ctx *c, uint64_t out[200], int reset)
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, c->d_stats + 8, 200 * 8, hipMemcpyDeviceToHost));
     if (reset) { HIP_TRY(hipMemsetAsync(c->d_stats + 8, 0, 200 * 8, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_debug_fast_paths(mcrt_ctx *c, uint32_t out[4])
+{
+    CTX_TRY(c);
+    if (!out) return set_error(MCRT_ERR_INVALID, "null out pointer");
+    out[0] = c->fast_div ? 1u : 0u; out[1] = c->last_lean_bound > 0.0f ? 1u : 0u; out[2] = c->last_march_rows; out[3] = 0u;
     return MCRT_OK;
 }
 

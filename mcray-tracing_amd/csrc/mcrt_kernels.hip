@@ -189,18 +189,22 @@ template <int CTRL> MCRT_DEV float dpp_f(float v) { return __int_as_float(dpp_i<
 
 #define QP_BCAST(k) ((k) * 0x55)
 
+// The LDS image of a scan-line in k_march: entry r = { thr[r], bin[r] }, 16 bytes -- a step's two thresholds and its bin are then
+// three constant offsets from ONE address (row << 4), with no base register.
+struct RowBin { double thr; long long bin; };
+
 // row = (int)(t / row_dt) if that quotient is < R, else -1 (rfimage.h:33-40), WITHOUT the double division:
 // thr[r] (host-computed, mcrt_row_thresholds) is the smallest double t whose IEEE quotient fl(t/row_dt) is >= r, so the
 // row is the largest r with thr[r] <= t.  Exactly equivalent to the division for every double t >= 0.
-MCRT_DEV int row_of(double t, const double *thr, uint32_t R, double inv_dt, double thr_end)
+MCRT_DEV int row_of(double t, const RowBin *rb, uint32_t R, double inv_dt, double thr_end)
 {
     if (!(t < thr_end) || !(t >= 0.0)) return -1;
     int r = (int)(t * inv_dt);                                   // within one row of the answer
     r = r < 0 ? 0 : (r > (int)R - 1 ? (int)R - 1 : r);
-    const double lo = thr[r], hi = thr[r + 1];
+    const double lo = rb[r].thr, hi = rb[r + 1].thr;
     if ((t < lo) | !(t < hi)) {                                  // the estimate missed by a rounding: walk to the row
-        while (t < thr[r]) r--;
-        while (t >= thr[r + 1]) r++;
+        while (t < rb[r].thr) r--;
+        while (t >= rb[r + 1].thr) r++;
     }
     return r;
 }
@@ -208,12 +212,15 @@ MCRT_DEV int row_of(double t, const double *thr, uint32_t R, double inv_dt, doub
 // the same row when a good guess is at hand: two threshold reads confirm it.  (k_march's guess is t * inv_dt itself, which misses
 // only by a rounding: a guess from the lane's previous row + its stride misses whenever the row advances by one more than the
 // stride -- every tenth step or so, i.e. in EVERY step of a wavefront some lane would take the search below, for all 64.)
-MCRT_DEV int row_near(double t, int guess, const double *thr, uint32_t R, double inv_dt, double thr_end)
+// PADDED: the image holds entries up to the largest guess a valid step can make ((int)(max_travel * inv_dt), + 1), those beyond
+// thr[R] filled with -inf -- the guess needs no clamp, and a time beyond the image fails "t < hi" and is sorted out by row_of.
+template <bool PADDED>
+MCRT_DEV int row_near(double t, int guess, const RowBin *rb, uint32_t R, double inv_dt, double thr_end)
 {
-    const int r = guess < 0 ? 0 : (guess > (int)R - 1 ? (int)R - 1 : guess);
-    const double lo = thr[r], hi = thr[r + 1];
+    const int r = PADDED ? guess : (guess < 0 ? 0 : (guess > (int)R - 1 ? (int)R - 1 : guess));
+    const double lo = rb[r].thr, hi = rb[r + 1].thr;
     if ((t >= lo) & (t < hi)) return r;                          // (false for NaN, negative times and times beyond the image)
-    return row_of(t, thr, R, inv_dt, thr_end);
+    return row_of(t, rb, R, inv_dt, thr_end);
 }
 
 // x / tex_res, correctly rounded, as two fmas around a multiply by the rounded reciprocal (Markstein's correction).
@@ -250,6 +257,18 @@ MCRT_DEV uint32_t vox_cell_lean(f3 p, const FrameArgs &a)
 {
     return (((vox_lean1(p.x, a) << a.tex_shift) | vox_lean1(p.y, a)) << a.tex_shift) | vox_lean1(p.z, a);
 }
+// ... and when the texture is the reference's 256^3 (volume.h:19): the three low bytes packed by two v_perm_b32
+MCRT_DEV uint32_t vox_q(float x, const FrameArgs &a)
+{
+    const float q0 = x * a.tex_rcp;
+    const float r = fmaf(-q0, a.tex_res, x);
+    return (uint32_t)(int)fmaf(r, a.tex_rcp, q0);
+}
+MCRT_DEV uint32_t vox_cell_lean256(f3 p, const FrameArgs &a)
+{
+    const uint32_t yz = __builtin_amdgcn_perm(vox_q(p.y, a), vox_q(p.z, a), 0x0c0c0400u);      // { z.b0, y.b0, 0, 0 }
+    return __builtin_amdgcn_perm(vox_q(p.x, a), yz, 0x0c040100u);                                // { z.b0, y.b0, x.b0, 0 }
+}
 MCRT_DEV float abs_sum(f3 p) { return (fabsf(p.x) + fabsf(p.y)) + fabsf(p.z); }   // >= every |coordinate|; NaN/inf propagate
 
 // one echo into the scan-line's fixed-point LDS bins (2^-40 units; integer adds commute, so the image does not depend
@@ -263,12 +282,12 @@ MCRT_DEV long long fix40(float echo)
     return (long long)__double_as_longlong(x) - (long long)__double_as_longlong(0x1.8p52);
 }
 
-MCRT_DEV void rf_add(long long *bins, uint32_t *lflags, int row, float echo)
+MCRT_DEV void rf_add(RowBin *rb, uint32_t *lflags, int row, float echo)
 {
     if (row < 0) return;
     if (!(fabsf(echo) < 1024.0f)) { atomicOr(&lflags[row >> 5], 1u << (row & 31)); return; }
     const long long v = fix40(echo);
-    if (v != 0) atomicAdd((unsigned long long *)&bins[row], (unsigned long long)v);
+    if (v != 0) atomicAdd((unsigned long long *)&rb[row].bin, (unsigned long long)v);
 }
 
 // =============================================================================================================
@@ -1143,7 +1162,10 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
 // 128-frame launch -- the work done for steps that are not valid costs more than the branches it replaces.  Taking parts of the step out (wrong images, timing only): no gathers 693, no row
 // search 679, no adds 707, none of the three 570 us, no loop at all 8 us (cycle stamps of the full kernel: hand-out 17 %, advance 4 %, voxel + gathers 27 %,
 // rows and bins with the wait for the gathers 51 %).
-template <bool STATS, int G>
+// FAST (round 3): the reference's 256^3 texture with the branch-free cell, and an LDS image padded to the largest row guess of a
+// valid step -- no texture size, shift, row count or LDS base in the step's instructions (the generic kernel had spilled those
+// scalars: ~13 v_readlane per four steps).
+template <bool STATS, int G, bool FAST>
 __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, uint32_t b, uint32_t chunks)
 {
     constexpr int H = 8 / G;                 // RF steps per lane and iteration: a group does G*H = 8 consecutive steps
@@ -1153,15 +1175,13 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
     constexpr int REFILL = (64 / G) / MCRT_MARCH_REFILL_DIV;   // new segments are handed out while at least a quarter of the wavefront's groups are idle or finished
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, j = tid & (G - 1);
-    const uint32_t R = a.R, nf = (R + 31u) >> 5;
-    long long *bins = (long long *)smem;
-    uint32_t *lflags = (uint32_t *)(bins + ((R + 1u) & ~1u));
-    double *thr = (double *)(lflags + ((nf + 3u) & ~3u));
-    uint32_t *sort_cnt = (uint32_t *)(thr + ((R + 2u) & ~1u)) + wv * 64;                   // this wavefront's 64 length classes ...
-    unsigned char *sort_list = (unsigned char *)((uint32_t *)(thr + ((R + 2u) & ~1u)) + 4 * 64) + wv * MCRT_MARCH_TILE;   // ... and its tile's slots, longest first
-    for (uint32_t r = tid; r < R; r += nthr) bins[r] = 0;
+    const uint32_t R = a.R, nf = (R + 31u) >> 5, nrt = FAST ? a.march_rows : R + 1u;      // entries of the LDS image (march_lds_bytes)
+    RowBin *rb = (RowBin *)smem;
+    uint32_t *lflags = (uint32_t *)(rb + nrt);
+    uint32_t *sort_cnt = lflags + ((nf + 3u) & ~3u) + wv * 64;                              // this wavefront's 64 length classes ...
+    unsigned char *sort_list = (unsigned char *)(lflags + ((nf + 3u) & ~3u) + 4 * 64) + wv * MCRT_MARCH_TILE;   // ... and its tile's slots, longest first
+    for (uint32_t r = tid; r < nrt; r += nthr) { rb[r].thr = r <= R ? a.row_thr[r] : -__builtin_inf(); rb[r].bin = 0; }
     for (uint32_t r = tid; r < nf; r += nthr) lflags[r] = 0u;
-    for (uint32_t r = tid; r <= R; r += nthr) thr[r] = a.row_thr[r];
     __syncthreads();
 
     // XCD-aware numbering: workgroup w runs on XCD w % 8; give every XCD a CONTIGUOUS range of scan-lines, so that the texture
@@ -1237,7 +1257,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
             if (fin) {
                 if (j == 0) {
                     const double te = t_start + a.time_step * (double)(uint32_t)(steps - 1u);
-                    rf_add(bins, lflags, row_of(te, thr, R, a.inv_row_dt, thr_end), seg_refl / (float)a.S);
+                    rf_add(rb, lflags, row_of(te, rb, R, a.inv_row_dt, thr_end), seg_refl / (float)a.S);
                 }
                 busy = false;
                 if (all_b && seg_b + 1u < seg_n) { seg_b++; MCRT_LOAD_SEGMENT() }      // the path's next segment
@@ -1320,7 +1340,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
             float2 vox[H];
             if (reach < a.lean_bound) {
 #pragma unroll
-                for (int h = 0; h < H; h++) vox[h] = a.tex[vox_cell_lean(myp[h], a)];
+                for (int h = 0; h < H; h++) vox[h] = a.tex[FAST ? vox_cell_lean256(myp[h], a) : vox_cell_lean(myp[h], a)];
             } else {
 #pragma unroll
                 for (int h = 0; h < H; h++) vox[h] = myv[h] ? a.tex[vox_cell(myp[h], a)] : make_float2(0.0f, 0.0f);
@@ -1330,8 +1350,8 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
             for (int h = 0; h < H; h++) {
                 if (myv[h]) {
                     const float scattering = vox[h].y >= m_dens ? vox[h].x * m_sigma + m_mu : 0.0f;
-                    const int row = row_near(myt[h], MCRT_MARCH_ROW_EST ? (int)(myt[h] * a.inv_row_dt) : row_guess, thr, R, a.inv_row_dt, thr_end);
-                    rf_add(bins, lflags, row, myin[h] * scattering);
+                    const int row = row_near<FAST && MCRT_MARCH_ROW_EST>(myt[h], MCRT_MARCH_ROW_EST ? (int)(myt[h] * a.inv_row_dt) : row_guess, rb, R, a.inv_row_dt, thr_end);
+                    rf_add(rb, lflags, row, myin[h] * scattering);
                     if (!MCRT_MARCH_ROW_EST) row_guess = (row >= 0 ? row : row_guess) + G;
                     if (STATS) st_steps++;
                 }
@@ -1353,7 +1373,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
     // row of the frame's RF block: [frame][scan-line of the whole block]; this launch covers scan-lines [acc_off, acc_off+ne_frame)
     const size_t row = (size_t)(line / a.ne_frame) * a.acc_stride + a.acc_off + line % a.ne_frame;
     for (uint32_t r = tid; r < R; r += nthr) {
-        const long long v = bins[r];
+        const long long v = rb[r].bin;
         if (v != 0) atomicAdd((unsigned long long *)&a.acc[row * R + r], (unsigned long long)v);
     }
     for (uint32_t r = tid; r < nf; r += nthr) { const uint32_t f = lflags[r]; if (f) atomicOr(&a.flags[row * nf + r], f); }
@@ -1529,7 +1549,8 @@ __global__ void k_verify_div(float res, float rcp, unsigned long long *bad)
         const float q0 = x * rcp;
         const float r = fmaf(-q0, res, x);
         const float q = fmaf(r, rcp, q0);
-        if (__float_as_uint(q) != __float_as_uint(x / res)) local++;
+        if (!(q == x / res)) local++;          // as VALUES: for x = -0 the sequence gives +0 where the division gives -0, and both are cell 0 (the one
+                                               // bit pattern in the gate where the two differ for 0.145 -- a bitwise comparison here kept the whole fast path switched off)
     }
     if (local) atomicAdd(bad, local);
 }
@@ -1554,10 +1575,10 @@ __global__ void k_philox_probe(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c
 // ---------------------------------------------------------------------------------------------
 // launchers (called from mcrt_api.cpp, which is plain C++)
 // ---------------------------------------------------------------------------------------------
-size_t march_lds_bytes(uint32_t R)
+size_t march_lds_bytes(uint32_t R, uint32_t rows)               // rows: entries of the { threshold, bin } image (R + 1, or FrameArgs::march_rows)
 {
-    const size_t bins = (size_t)((R + 1u) & ~1u) * 8, flg = (size_t)((((R + 31u) >> 5) + 3u) & ~3u) * 4, thr = (size_t)((R + 2u) & ~1u) * 8;
-    return bins + flg + thr + 4 * (64 * 4 + MCRT_MARCH_TILE);        // + per wavefront: 64 length-class counters, one tile of slot numbers
+    const size_t img = (size_t)rows * 16, flg = (size_t)((((R + 31u) >> 5) + 3u) & ~3u) * 4;
+    return img + flg + 4 * (64 * 4 + MCRT_MARCH_TILE);        // + per wavefront: 64 length-class counters, one tile of slot numbers
 }
 
 hipError_t launch_init(const FrameArgs &a, hipStream_t st)
@@ -1618,12 +1639,14 @@ hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1u) chunks = 1u;
     const dim3 grid(a.ne * chunks), blk(256);
-    const size_t lds = march_lds_bytes(a.R);
+    const bool fast = !stats && a.march_rows != 0u;            // (FrameArgs::march_rows: set when the fast kernel's conditions hold)
+    const size_t lds = march_lds_bytes(a.R, fast ? a.march_rows : a.R + 1u);
     // lanes per segment: pairs give the higher throughput when there is plenty of work (515 vs 524 us per launch with 16 frames in
     // flight), quads the shorter iterations that matter when one frame at a time is traced (2.19 vs 2.37 ms per frame)
     const bool pairs = (size_t)a.ne * a.S >= (size_t)MCRT_MARCH_PAIRS_FROM;
-    if (stats) { if (pairs) hipLaunchKernelGGL((k_march<true, 2>), grid, blk, lds, st, a, b, chunks); else hipLaunchKernelGGL((k_march<true, 4>), grid, blk, lds, st, a, b, chunks); }
-    else { if (pairs) hipLaunchKernelGGL((k_march<false, 2>), grid, blk, lds, st, a, b, chunks); else hipLaunchKernelGGL((k_march<false, 4>), grid, blk, lds, st, a, b, chunks); }
+    if (stats) { if (pairs) hipLaunchKernelGGL((k_march<true, 2, false>), grid, blk, lds, st, a, b, chunks); else hipLaunchKernelGGL((k_march<true, 4, false>), grid, blk, lds, st, a, b, chunks); }
+    else if (fast) { if (pairs) hipLaunchKernelGGL((k_march<false, 2, true>), grid, blk, lds, st, a, b, chunks); else hipLaunchKernelGGL((k_march<false, 4, true>), grid, blk, lds, st, a, b, chunks); }
+    else { if (pairs) hipLaunchKernelGGL((k_march<false, 2, false>), grid, blk, lds, st, a, b, chunks); else hipLaunchKernelGGL((k_march<false, 4, false>), grid, blk, lds, st, a, b, chunks); }
     return hipGetLastError();
 }
 

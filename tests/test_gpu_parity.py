@@ -340,6 +340,31 @@ def test_pass_size_limits(mcrt, sphere, tex256):
     sim.ctx.free(dev); sim.close()
 
 
+def test_fast_paths_are_on_for_the_reference_constants(mcrt, orc, sphere, tex256):
+    """the RF accumulation's fast paths are switched on by checks made on the device (the reciprocal-multiply voxel quotient must
+    equal IEEE division for every float in its gate); for the reference's constants (0.145 mm texels, 256^3, 100 us) they must be ON
+    -- from round 1 to round 3 a bitwise comparison of -0 with +0 had kept them off, unnoticed -- and switching them off by the
+    knobs changes no bit of the image"""
+    cfg, sd = sphere
+    E, S = 16, 96
+    tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256)
+    rf = sim.frame(1, convolve=False).copy()
+    fast_div, lean, rows = sim.ctx.debug_fast_paths()
+    assert fast_div and lean and rows == max(sim.R + 1, 467)      # (100 us x 4.658 rows per us: the largest row guess is 465)
+    sim.close()
+    for knob in ("MCRT_NO_LEAN", "MCRT_NO_FAST_DIV"):
+        os.environ[knob] = "1"
+        try:
+            tr2, sim2 = _sim(mcrt, cfg, sd, E, S, texture=tex256)
+            rf2 = sim2.frame(1, convolve=False).copy()
+            f2 = sim2.ctx.debug_fast_paths()
+            sim2.close()
+        finally:
+            del os.environ[knob]
+        assert f2[2] == 0 and not f2[1]
+        assert np.array_equal(rf2.view(np.uint32), rf.view(np.uint32)), knob
+
+
 def test_abandoned_launch_poisons_frames_until_asked(mcrt, sphere, tex256):
     """a launch abandoned by a kernel watchdog sets the context's device error word: every image finalised from then on is NaN
     throughout, mcrt_synchronize reports MCRT_ERR_LIMIT once and clears it, the next frame is the frame again"""
