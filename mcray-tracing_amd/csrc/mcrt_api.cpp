@@ -732,7 +732,8 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     a.ksplit_limit = c->knobs.ksplit_limit;   // bounces with fewer rays than this are cut into pieces (see k_trace)
     if (c->stats_on) a.ksplit_limit = 0;   // counting mode = one walk per ray, so the counts are those of a plain closest-hit walk
     for (int i = 0; i < 3; i++) { a.scene_lo[i] = c->scene_lo[i]; a.scene_hi[i] = c->scene_hi[i]; }
-    a.trace_blocks = c->knobs.trace_blocks ? c->knobs.trace_blocks : (c->n_cu - (c->knobs.main_mask ? c->knobs.march_cus : 0u)) * 5u;   // persistent k_trace: 5 waves/SIMD = 5 four-wave workgroups per CU (1280 on the MI355X's 256 CUs)
+    a.trace_blocks = c->knobs.trace_blocks ? c->knobs.trace_blocks : (c->n_cu - (c->knobs.main_mask ? c->knobs.march_cus : 0u)) * 4u;   // persistent k_trace: 4 four-wave workgroups per CU (1024 on the MI355X's 256 CUs) of the 5 its registers and LDS allow --
+                                                                                  // the fifth's registers go to a k_march wavefront beside them (since k_march's fast path: 0.446 -> 0.428 ms per frame on a 20-frame pass, 0.366 -> 0.364 at 128)
     a.march_blocks = c->knobs.march_blocks;
     a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n; a.tex_mask = (c->tex_n & (c->tex_n - 1u)) == 0u ? c->tex_n - 1u : 0u;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
