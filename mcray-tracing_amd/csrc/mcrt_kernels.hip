@@ -1162,6 +1162,9 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
 // 128-frame launch -- the work done for steps that are not valid costs more than the branches it replaces.  Taking parts of the step out (wrong images, timing only): no gathers 693, no row
 // search 679, no adds 707, none of the three 570 us, no loop at all 8 us (cycle stamps of the full kernel: hand-out 17 %, advance 4 %, voxel + gathers 27 %,
 // rows and bins with the wait for the gathers 51 %).
+// With the fast path (1397 us per 128-frame launch alone): one lane per segment instead of a pair (four steps per lane and iteration, no
+// redundant advance): 1420 us; the row guessed from the lane's previous row + G instead of from its time (two double operations less per
+// step): 1426 us.
 // FAST (round 3): the reference's 256^3 texture with the branch-free cell, and an LDS image padded to the largest row guess of a
 // valid step -- no texture size, shift, row count or LDS base in the step's instructions (the generic kernel had spilled those
 // scalars: ~13 v_readlane per four steps).
