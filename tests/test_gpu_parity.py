@@ -592,7 +592,7 @@ def test_duplicated_triangles_every_hit_is_a_tie(mcrt, orc, tex256, shape):
 
 
 @pytest.mark.parametrize("case", range(int(os.environ.get("MCRT_FUZZ_CASES", "16"))))      # (a longer one-off sweep: MCRT_FUZZ_CASES=300)
-def test_randomised_configurations(mcrt, orc, case, monkeypatch):
+def test_randomised_configurations(mcrt, orc, case, monkeypatch, tex256):
     """a sweep over shapes and parameters nobody picked by hand: odd element / sample / row counts, depths 1..16, both builders,
     textures of several sizes, TIR sanitising on and off, frequency, seed, frames in flight -- hits and RF bit for bit"""
     rng = np.random.default_rng(1000 + case)
@@ -612,13 +612,13 @@ def test_randomised_configurations(mcrt, orc, case, monkeypatch):
     sd = mcrt.scene_io.build_scene(cfg, meshes)
     E, S = int(rng.integers(1, 40)), int(rng.integers(1, 200))
     R, B = int(rng.integers(20, 700)), int(rng.integers(1, 17))
-    tex_n = int(rng.choice([4, 16, 37, 64]))
+    tex_n = int(rng.choice([4, 16, 37, 64, 256]))           # (256: the reference's own texture -- k_march's fast variant, with odd row counts)
     freq = float(rng.choice([2.5, 4.5, 7.0]))
     sanitize = int(rng.integers(0, 2))
     seed = int(rng.integers(0, 2 ** 31))
     F = int(rng.integers(1, 5))
     builder = "lbvh" if (case % 2 and sd.n_tri >= 8) else "sah"
-    tex = rng.normal(size=(tex_n, tex_n, tex_n, 2)).astype(np.float32)
+    tex = tex256 if tex_n == 256 else rng.normal(size=(tex_n, tex_n, tex_n, 2)).astype(np.float32)
     tr = mcrt.Transducer(E, frequency=freq, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
     sim = mcrt.Simulator(sd, tr, n_samples=S, n_rows=R, texture=tex, tex_n=tex_n, max_depth=B, sanitize_tir=sanitize, seed=seed, bvh_builder=builder)
     frame0 = int(rng.integers(0, 1000))
