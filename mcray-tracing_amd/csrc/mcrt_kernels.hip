@@ -3,6 +3,7 @@
 //   k_init/k_trace_lane/k_shade   scene::cast_rays (scene.cpp:50-183) + ray_physics (ray.cpp) as a wavefront pipeline:
 //                lane-per-ray BVH4 closest hit, then the interface physics, one launch each per bounce
 //   k_march      the RF accumulation loop (main.cpp:106-144, rfimage.h:33-40, volume.h:46-61), a lane pair / quad per segment
+//                (a generic variant, and a fast one for the reference's 256^3 texture and time axis)
 //   k_finalize   fixed-point RF bins -> float image (+ clears the bins: rf_image::clear, rfimage.h:161)
 //   k_conv_*     rf_image::convolve (rfimage.h:93-123)
 //   k_envelope   rf_image::envelope (rfimage.h:54-91)
