@@ -250,7 +250,7 @@ int mcrt_debug_stamps(mcrt_ctx *ctx, uint64_t out[200], int reset);
 /* which of the RF accumulation's fast paths the context's LAST traced frame ran with (they are switched on by checks made on the
  * device, and a check that fails silently costs a third of the frame): out[0] the reciprocal-multiply voxel quotient (verified
  * exhaustively against IEEE division for params.tex_res), out[1] the branch-free voxel cell, out[2] the entries of the padded
- * { threshold, bin } image of k_march's fast variant (0: generic variant), out[3] reserved */
+ * { threshold, bin } image of k_march's fast variant (0: generic variant), out[3] the passes this context has replayed as HIP graphs so far */
 int mcrt_debug_fast_paths(mcrt_ctx *ctx, uint32_t out[4]);
 /* test hook: ORs `bits` into the context's device error word on its stream, as an abandoned launch would (bit 0: traversal stack ran
  * out, bit 1: kernel watchdog expired) -- what mcrt_synchronize reports and what turns finalised RF images into NaN until it is asked */

@@ -67,7 +67,7 @@ struct Work {
 // tuning knobs from the environment, read ONCE at mcrt_create (never on the frame path)
 struct Knobs {
     uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 0;   // march_blocks 0: launch_march picks
-    bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false;
+    bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false, graph = false;
     uint32_t march_cus = 0;                    // CUs the accumulation's side stream is confined to (0 = no mask); the mask's bit order is the driver's
     bool main_mask = false;                    // with march_cus: the walk / shade chain runs on its own stream confined to the OTHER CUs
 };
@@ -81,6 +81,7 @@ static Knobs read_knobs()
     if (const char *e = getenv("MCRT_MARCH_BLOCKS")) { int v = atoi(e); if (v >= 1) k.march_blocks = (uint32_t)v; }
     k.no_overlap = getenv("MCRT_NO_OVERLAP") != nullptr; k.no_priority = getenv("MCRT_NO_PRIORITY") != nullptr;
     k.no_fast_div = getenv("MCRT_NO_FAST_DIV") != nullptr; k.no_lean = getenv("MCRT_NO_LEAN") != nullptr;
+    k.graph = getenv("MCRT_GRAPH") != nullptr;   // passes replayed as HIP graphs (measured slower on ROCm 7.2: see trace_frames_graph)
     if (const char *e = getenv("MCRT_MARCH_CUS")) { int v = atoi(e); if (v >= 0 && v <= 248) k.march_cus = (uint32_t)v; }
     k.main_mask = getenv("MCRT_MAIN_MASK") != nullptr;
     return k;
@@ -122,6 +123,12 @@ struct mcrt_ctx {
     // row thresholds (exact replacement of the per-echo double division) and the verified fast division by tex_res
     double *d_row_thr = nullptr; uint32_t thr_rows = 0; double thr_dt = 0.0;
     float verified_res = 0.0f; bool fast_div = false, fast_div_all = false;
+    // HIP graphs of whole passes (mcrt_trace_frames): the ~35 launches of a pass replayed as one graph launch.  An entry is keyed by the
+    // kernel arguments of the pass (every pointer and parameter the kernels see, frame number excepted), its output buffer and stream;
+    // the frame number reaches the kernels through the entry's device word (d_frame_words[1 + slot]; word 0 stays 0 for direct launches).
+    struct GraphEntry { mcrt::FrameArgs key; float *rf = nullptr; hipStream_t stream = nullptr; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t used = 0; bool live = false; };
+    GraphEntry graphs[MCRT_GRAPH_SLOTS]; uint64_t graph_tick = 0; bool graph_off = false; uint32_t graph_launches = 0;
+    uint32_t *d_frame_words = nullptr;
     float last_lean_bound = 0.0f; uint32_t last_march_rows = 0;   // what the last frame's kernels were given (mcrt_debug_fast_paths)
     // per-material table of k_march (depends on the materials, the axial step and the frequency)
     float4 *d_mtab = nullptr; uint32_t mtab_n = 0; float mtab_key[2] = { 0.0f, 0.0f }; bool mtab_valid = false;
@@ -215,7 +222,8 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     c->c = derive_consts(c->p);
     c->stream = c->own_stream;
     if (hipMalloc(&c->d_stats, 256 * sizeof(unsigned long long)) != hipSuccess || hipMemsetAsync(c->d_stats, 0, 256 * sizeof(unsigned long long), c->stream) != hipSuccess ||
-        hipMalloc(&c->d_error, 4) != hipSuccess || hipMemsetAsync(c->d_error, 0, 4, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        hipMalloc(&c->d_error, 4) != hipSuccess || hipMemsetAsync(c->d_error, 0, 4, c->stream) != hipSuccess ||
+        hipMalloc(&c->d_frame_words, 4 * (1 + MCRT_GRAPH_SLOTS)) != hipSuccess || hipMemsetAsync(c->d_frame_words, 0, 4 * (1 + MCRT_GRAPH_SLOTS), c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
         hipStreamDestroy(c->own_stream); delete c; return set_error(MCRT_ERR_HIP, "hipMalloc failed");
     }
     { int rc = prepare_tables(c); if (rc) { mcrt_destroy(c); return rc; } }
@@ -333,6 +341,8 @@ extern "C" int mcrt_destroy(mcrt_ctx *c)
     hipFree(c->d_pose[0]); hipFree(c->d_pose[1]);
     hipFree(c->d_tex); hipFree(c->d_pos); hipFree(c->d_dir); hipFree(c->d_acc); hipFree(c->d_flags); hipFree(c->d_tmp);
     hipFree(c->d_map_col); hipFree(c->d_map_row); hipFree(c->d_stats); hipFree(c->d_row_thr); hipFree(c->d_error); hipFree(c->d_mtab);
+    for (auto &g : c->graphs) { if (g.exec) hipGraphExecDestroy(g.exec); if (g.graph) hipGraphDestroy(g.graph); }
+    hipFree(c->d_frame_words);
     for (auto &e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (c->ev_start) hipEventDestroy(c->ev_start);
     hipStreamDestroy(c->own_stream);
@@ -735,7 +745,7 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     a.trace_blocks = c->knobs.trace_blocks ? c->knobs.trace_blocks : (c->n_cu - (c->knobs.main_mask ? c->knobs.march_cus : 0u)) * 4u;   // persistent k_trace: 4 four-wave workgroups per CU (1024 on the MI355X's 256 CUs) of the 5 its registers and LDS allow --
                                                                                   // the fifth's registers go to a k_march wavefront beside them (since k_march's fast path: 0.446 -> 0.428 ms per frame on a 20-frame pass, 0.366 -> 0.364 at 128)
     a.march_blocks = c->knobs.march_blocks;
-    a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n; a.tex_mask = (c->tex_n & (c->tex_n - 1u)) == 0u ? c->tex_n - 1u : 0u;
+    a.frame = frame; a.frame_dev = c->d_frame_words; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n; a.tex_mask = (c->tex_n & (c->tex_n - 1u)) == 0u ? c->tex_n - 1u : 0u;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
     a.freq = c->p.frequency; a.eps = c->p.intensity_epsilon; a.I0 = c->p.initial_intensity; a.offs = c->p.ray_start_offset;
     a.sx = c->spacing[0]; a.sy = c->spacing[1]; a.sz = c->spacing[2]; a.tex_res = c->p.tex_res; a.axial_res_f = c->c.axial_res_f; a.pad_abs = c->bvh.pad_abs; a.tex_rcp = 1.0f / c->p.tex_res; a.fast_div = c->fast_div ? 1u : 0u;
@@ -805,15 +815,15 @@ static int timing_events(mcrt_ctx *c, hipEvent_t *e0, hipEvent_t *e1)
 // scene::cast_rays (scene.cpp:50-183) [+ the accumulation loop] for scan-lines [e0,e1), split into `groups` independent
 // scan-line blocks.  Everything is ordered after what is already queued on the context's stream, and the context's stream
 // waits for all of it.
-static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, bool accumulate, uint32_t groups, int out)
+// (prepare_frame: buffers and kernel arguments of the groups; enqueue_frame: the launches)
+static int prepare_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, uint32_t &groups, int out,
+                         std::vector<mcrt::FrameArgs> &args, std::vector<Work *> &ws)
 {
     const uint32_t ne = e1 - e0;
     if (groups > ne) groups = ne;
     if (groups < 1) groups = 1;
     if (groups > 16) groups = 16;
-    const bool overlap = !c->knobs.no_overlap;
-    std::vector<mcrt::FrameArgs> args(groups);
-    std::vector<Work *> ws(groups);
+    args.resize(groups); ws.resize(groups);
     for (uint32_t g = 0; g < groups; g++) {
         int rc = get_work(c, g, &ws[g]); if (rc) return rc;
         const uint32_t b0 = e0 + (uint32_t)(((uint64_t)ne * g) / groups), b1 = e0 + (uint32_t)(((uint64_t)ne * (g + 1)) / groups);
@@ -822,6 +832,13 @@ static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0
         args[g].want_segs = out >= 2 ? 1u : 0u;
         if (out < 1) args[g].hits = nullptr;
     }
+    return MCRT_OK;
+}
+
+static int enqueue_frame(mcrt_ctx *c, const std::vector<mcrt::FrameArgs> &args, const std::vector<Work *> &ws, bool accumulate)
+{
+    const uint32_t groups = (uint32_t)args.size();
+    const bool overlap = !c->knobs.no_overlap;
     std::vector<hipStream_t> gst(groups);
     for (uint32_t g = 0; g < groups; g++) { int rc = work_stream(c, *ws[g], g == 0, &gst[g]); if (rc) return rc; }
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
@@ -849,9 +866,80 @@ static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0
     return MCRT_OK;
 }
 
+static int run_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, bool accumulate, uint32_t groups, int out)
+{
+    std::vector<mcrt::FrameArgs> args; std::vector<Work *> ws;
+    int rc = prepare_frame(c, frame, n_frames, e0, e1, groups, out, args, ws); if (rc) return rc;
+    return enqueue_frame(c, args, ws, accumulate);
+}
+
 static uint32_t frame_groups(const mcrt_ctx *c)
 {
     return c->stats_on ? 1u : c->knobs.groups;
+}
+
+// A pass as ONE graph launch.  The ~35 launches of a pass (k_init, per bounce the walk, the shade and -- on the side stream -- the
+// accumulation, k_finalize) are dependent kernels a few microseconds apart; for small passes (one frame at a time: 10 walks of
+// ~130 us) the boundaries between them are a tenth of the frame.  The first pass of a shape is enqueued directly (it also creates
+// the streams and events the capture needs), the second is captured from the very same code (stream capture follows the side
+// stream through its events) and instantiated, every later one is a 4-byte device word with the frame number + hipGraphLaunch.
+// The key of an entry is the kernels' whole argument block: whatever changes a pointer or a parameter (a new scene, a refit that
+// reallocates, other parameters, another output buffer or stream) simply misses, and the least recently used entry is replaced.
+// Not used when kernels are counted or timed individually (stats, mcrt_enable_timing), with scan-line groups or CU masks.
+// MEASURED (MI355X, ROCm 7.2, 128 x 1024 rays, 1 M triangles) and therefore OFF unless MCRT_GRAPH is set: one frame at a time 2.30 ms per
+// frame as a graph against 1.51 ms with direct launches, a 128-frame pass with per-frame poses 0.411 against 0.369 -- the runtime
+// replays the graph's two branches (chain and accumulation) through its own streams with more synchronisation than the hand-placed
+// events of the direct path.  Kept as a knob, parity-tested (test_passes_replayed_as_hip_graphs).
+static int trace_frames_graph(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, float *rf_dev, uint32_t lines, bool *done)
+{
+    *done = false;
+    if (!c->knobs.graph || c->graph_off || c->stats_on || c->timing_on || frame_groups(c) != 1u || c->knobs.march_cus) return MCRT_OK;
+    std::vector<mcrt::FrameArgs> args; std::vector<Work *> ws;
+    uint32_t groups = 1;
+    int rc = prepare_frame(c, 0u, n_frames, e0, e1, groups, 0, args, ws); if (rc) return rc;
+    mcrt::FrameArgs key = args[0]; key.frame_dev = nullptr;
+    int slot = -1, lru = 0;
+    for (int i = 0; i < MCRT_GRAPH_SLOTS; i++) {
+        const mcrt_ctx::GraphEntry &g = c->graphs[i];
+        if (g.live && g.rf == rf_dev && g.stream == c->stream && memcmp(&g.key, &key, sizeof key) == 0) { slot = i; break; }
+        if (!c->graphs[i].live) lru = i; else if (c->graphs[lru].live && g.used < c->graphs[lru].used) lru = i;
+    }
+    if (slot < 0) {          // first pass of this shape: remember it, run it directly
+        mcrt_ctx::GraphEntry &g = c->graphs[lru];
+        if (g.exec || g.graph) HIP_TRY(hipStreamSynchronize(g.stream == c->stream ? c->stream : g.stream));   // (a replaced graph may still be running)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+        if (g.graph) hipGraphDestroy(g.graph);
+        g.exec = nullptr; g.graph = nullptr; g.key = key; g.rf = rf_dev; g.stream = c->stream; g.used = ++c->graph_tick; g.live = true;
+        return MCRT_OK;
+    }
+    mcrt_ctx::GraphEntry &g = c->graphs[slot];
+    g.used = ++c->graph_tick;
+    uint32_t *word = c->d_frame_words + 1 + slot;
+    if (!g.exec) {            // second pass: capture what the direct path enqueues
+        args[0].frame_dev = word;
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+            const int rq = enqueue_frame(c, args, ws, true);
+            const hipError_t ef = rq ? hipSuccess : mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, lines, c->p.n_rows, c->d_error, c->stream);
+            const hipError_t ee = hipStreamEndCapture(c->stream, &graph);            // (always: the stream must leave capture mode)
+            ok = rq == 0 && ef == hipSuccess && ee == hipSuccess && graph != nullptr;
+            if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        }
+        if (!ok) {             // this runtime will not capture the pass: direct launches from now on
+            (void)hipGetLastError();
+            if (exec) hipGraphExecDestroy(exec);
+            if (graph) hipGraphDestroy(graph);
+            c->graph_off = true; g.live = false;
+            return MCRT_OK;
+        }
+        g.graph = graph; g.exec = exec;
+    }
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)word, (int)frame, 1, c->stream));
+    HIP_TRY(hipGraphLaunch(g.exec, c->stream));
+    c->graph_launches++;
+    *done = true;
+    return MCRT_OK;
 }
 
 extern "C" int mcrt_trace_frames(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, float *rf_dev)
@@ -864,8 +952,12 @@ extern "C" int mcrt_trace_frames(mcrt_ctx *c, uint32_t frame, uint32_t n_frames,
         return set_error(MCRT_ERR_LIMIT, "%u frames x %u scan-lines x %u samples: more than 2^27 paths in one pass", n_frames, e1 - e0, c->p.n_samples);
     const uint32_t lines = (e1 - e0) * n_frames;
     rc = ensure_acc(c, lines); if (rc) return rc;
-    rc = run_frame(c, frame, n_frames, e0, e1, true, frame_groups(c), 0); if (rc) return rc;
-    HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, lines, c->p.n_rows, c->d_error, c->stream));
+    bool done = false;
+    rc = trace_frames_graph(c, frame, n_frames, e0, e1, rf_dev, lines, &done); if (rc) return rc;
+    if (!done) {
+        rc = run_frame(c, frame, n_frames, e0, e1, true, frame_groups(c), 0); if (rc) return rc;
+        HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, lines, c->p.n_rows, c->d_error, c->stream));
+    }
     c->acc_clean_ne = lines; c->acc_clean_rows = c->p.n_rows;
     return MCRT_OK;
 }
@@ -1113,7 +1205,7 @@ extern "C" int mcrt_debug_fast_paths(mcrt_ctx *c, uint32_t out[4])
 {
     CTX_TRY(c);
     if (!out) return set_error(MCRT_ERR_INVALID, "null out pointer");
-    out[0] = c->fast_div ? 1u : 0u; out[1] = c->last_lean_bound > 0.0f ? 1u : 0u; out[2] = c->last_march_rows; out[3] = 0u;
+    out[0] = c->fast_div ? 1u : 0u; out[1] = c->last_lean_bound > 0.0f ? 1u : 0u; out[2] = c->last_march_rows; out[3] = c->graph_launches;
     return MCRT_OK;
 }
 

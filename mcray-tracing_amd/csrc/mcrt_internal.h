@@ -19,3 +19,4 @@
 namespace mcrt {
 int set_error(int code, const char *fmt, ...);
 }
+#define MCRT_GRAPH_SLOTS 8            // passes of different shapes / output buffers whose HIP graphs a context keeps (least recently used replaced)

@@ -17,6 +17,7 @@ struct FrameArgs {
     const float *el_pos;       // [E][3], or [F][E][3] when the frames of a pass have their own probe poses (pose_stride = E)
     const float *el_dir;       // same shape
     const double *row_thr;     // [R+1] row thresholds (see row_of)
+    const uint32_t *frame_dev; // a device word ADDED to `frame`: 0 for direct launches; the frame number itself when the pass is replayed as a HIP graph (frame = 0 then)
     // per-frame work buffers; np = ne * S paths
     float4 *st0, *st1, *st2;   // [2][np] path state in queue order, two halves by bounce parity: from,intensity | dir,media | distance_traveled(f64),outside,-
     uint32_t *queue;           // [2][np] live path ids of bounce b in buffer b & 1

@@ -947,7 +947,7 @@ MCRT_DEV bool shade_path(const FrameArgs &a, uint32_t b, uint32_t pid, PathState
         }
         const uint32_t line = pid / a.S, fr = line / a.ne_frame;      // (two divisions; the remainders by multiply-subtract)
         const uint32_t e_abs = a.e_begin + (line - fr * a.ne_frame);
-        Rng g; g.k0 = a.seed; g.k1 = a.frame + fr; g.element = e_abs; g.sample = pid - line * a.S; g.bounce = b;
+        Rng g; g.k0 = a.seed; g.k1 = a.frame + *a.frame_dev + fr; g.element = e_abs; g.sample = pid - line * a.S; g.bounce = b;
         const float4 m0 = a.mats[2 * media];   // imp, att, mu0, mu1  (second half: sigma, spec, shine, thick)
         const float att = m0.y;
 
