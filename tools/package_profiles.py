@@ -92,6 +92,7 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 |---|---|
 | `../round2/valu_roof.json`, `valu_roof_pmc.json`, `fetch_roof.json` | the two calibrated roofs (`tools/valu_roof.hip`, `tools/fetch_roof.hip`), measured in round 2 on the same chip with the same tools: not repeated |
 | `exp_*` | this round's experiments, copied in by hand (DESIGN.md 5.5): queues sorted into ray bundles against the order-preserving compaction (`exp_sorted_bundles_*`, `exp_unsorted_*`: per-bounce PMC of the walk, stamp-build lane statistics, refill / leaf-batch thresholds with sorted queues), kernels with path state in place by path id (`exp_records_kernels_standalone.txt`), CU-masked streams (`exp_cu_masks.txt`) |
+| `fetch_roof_same.json` | `tools/fetch_roof_same.hip` on the box: what lanes on ONE address cost the vector memory pipe (only whole adjacent quads are cheaper: 0.3 of four), and inactive lanes (nothing) |
 | `bench_unprofiled.json` | `python bench.py`: the JSON line (live PMC passes in child processes, CPU baseline, inline parity check) |
 | `bench_driver_cmd.json` | `python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command: one 20-frame pass per timed region) |
 | `pmc_bench.json` | the PMC block of `bench_unprofiled.json`, the labelled fall-back `bench.py` reads when it cannot profile itself |
