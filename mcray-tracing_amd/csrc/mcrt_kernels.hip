@@ -642,6 +642,14 @@ MCRT_DEV uint32_t lane_leaf_test(const FrameArgs &a, const LaneStack &S, f3 f2, 
     return cnt;
 }
 
+// population count of a wave mask as a 32-bit SCALAR (a comparison of __popcll's 64-bit result is compiled to a vector instruction)
+MCRT_DEV uint32_t popc_mask(unsigned long long m)
+{
+    uint32_t n = (uint32_t)__builtin_popcount((uint32_t)m) + (uint32_t)__builtin_popcount((uint32_t)(m >> 32));
+    asm volatile("" : "+s"(n));
+    return n;
+}
+
 // position of the r-th (0-based) set bit of a 64-bit mask (r < popcount): binary search on popcounts
 MCRT_DEV int nth_set_bit(unsigned long long m, uint32_t r)
 {
@@ -725,7 +733,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
         MCRT_WATCHDOG_CHECK()
         // ---- finished rays report and idle lanes take new ones, once enough of them wait (the code runs for the whole wavefront) ----
         // (once the queue has run dry, finished lanes report at once: they are the helpers of the donation step below)
-        const bool do_refill = __popcll(__ballot(cur == CUR_IDLE && !exhausted)) >= MCRT_LANE_REFILL || MCRT_WALKING(cur) == 0ull ||
+        const bool do_refill = popc_mask(__ballot(cur == CUR_IDLE && !exhausted)) >= (uint32_t)MCRT_LANE_REFILL || MCRT_WALKING(cur) == 0ull ||
                                (queue_empty && __any(cur == CUR_IDLE && !fresh));
         if (do_refill) {
             if (cur == CUR_IDLE && !fresh) {
@@ -832,14 +840,15 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
 
         // ---- phase 1: inner nodes, until enough lanes are parked on a leaf ----
         const float tcap = fminf(1.0f, best.frac);               // best only changes in phase 2
-        const bool thieves_wait = !STATS && queue_empty && __any(cur == CUR_IDLE && fresh);     // (then phase 1 is cut short: see MCRT_LANE_ADOPT_STEPS)
+        // (then phase 1 is cut short: see MCRT_LANE_ADOPT_STEPS; held as scalars -- as a per-lane condition it made the whole loop a divergent one)
+        const int thieves_wait = __builtin_amdgcn_readfirstlane((!STATS && queue_empty && __any(cur == CUR_IDLE && fresh)) ? 1 : 0);
         int steps_left = MCRT_LANE_ADOPT_STEPS;
         const f3 rc = ray_c(f2, inv);
         const LaneRay lr = { rc.x, rc.y, rc.z, inv.x, inv.y, inv.z, inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f };
         for (;;) {
             const unsigned long long inner = MCRT_ON_INNER(cur);
             if (inner == 0ull) break;
-            if (__popcll(MCRT_ON_LEAF(cur)) >= MCRT_LANE_LEAF_BATCH) break;
+            if (popc_mask(MCRT_ON_LEAF(cur)) >= (uint32_t)MCRT_LANE_LEAF_BATCH) break;     // (as 32-bit scalars: a 64-bit comparison is a vector instruction)
             if (thieves_wait && --steps_left < 0) break;
 #if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
             wc_steps++;
@@ -1257,7 +1266,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
         // slots are code the whole wavefront runs however few quads need it, so both wait until REFILL quads are
         // finished or idle (or nothing is left to step) ----
         const bool fin = busy && !more;
-        if (__popcll(__ballot((!busy || fin) && j == 0)) >= REFILL || !__any(busy && more)) {
+        if (popc_mask(__ballot((!busy || fin) && j == 0)) >= (uint32_t)REFILL || !__any(busy && more)) {
             if (fin) {
                 if (j == 0) {
                     const double te = t_start + a.time_step * (double)(uint32_t)(steps - 1u);
@@ -1308,7 +1317,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
                     continue;
                 }
                 const unsigned long long want = __ballot(!busy && j == 0);
-                if (__popcll(want) < REFILL) break;
+                if (popc_mask(want) < (uint32_t)REFILL) break;
 #ifdef MCRT_STAMP
                 mc_refill++;
 #endif
