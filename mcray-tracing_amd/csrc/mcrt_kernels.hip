@@ -415,9 +415,6 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 #ifndef MCRT_MARCH_WAVES
 #define MCRT_MARCH_WAVES 6           // waves per SIMD the register budget of k_march is set for (7: 14 spilled registers, 789 vs 750 us per launch; 5: 777)
 #endif
-#ifndef MCRT_MARCH_ROW_EST
-#define MCRT_MARCH_ROW_EST 1         // k_march: a step's RF row is guessed from its time (see row_near), not from the lane's previous row
-#endif
 #ifndef MCRT_MARCH_TILE
 #define MCRT_MARCH_TILE 256          // slots a wavefront of k_march sorts by segment length at a time (a multiple of 64, at most 256: one byte per slot)
 #endif
@@ -1226,7 +1223,6 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
     float inten = 0.0f, k_att = 0.0f, seg_refl = 0.0f, m_dens = 0.0f, m_sigma = 0.0f, m_mu = 0.0f;
     uint32_t sidx = 0, steps = 0;
     bool more = false;
-    int row_guess = 0;
     // b == MCRT_ALL_BOUNCES: the launch accumulates EVERY bounce's segments; a group then walks its path's segments one after
     // the other (seg_b = the one in progress, seg_n = how many the path has) before it takes the next slot
     const bool all_b = b == MCRT_ALL_BOUNCES;
@@ -1245,8 +1241,6 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
         const bool silent = a.tex_finite && m_mu == 0.0f && m_sigma == 0.0f; \
         more = !silent && steps > 0u && t < a.max_travel; \
         _Pragma("unroll") for (int u = 1; u < G; u++) if (j >= u) MCRT_ADVANCE() \
-        /* first guess of this lane's RF row; afterwards each own step lies G steps (a little over G rows) further */ \
-        row_guess = (t >= 0.0 && t < thr_end) ? (int)(t * a.inv_row_dt) : 0; \
         busy = true; }
 #define MCRT_ADVANCE() { point = point + delta; t = t + a.time_step; inten *= k_att; }
 #ifdef MCRT_STAMP
@@ -1359,13 +1353,18 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
                 for (int h = 0; h < H; h++) vox[h] = myv[h] ? a.tex[vox_cell(myp[h], a)] : make_float2(0.0f, 0.0f);
             }
             MSTAMP(mt_vox)
+            // the steps' rows while the gathers are in flight (LDS reads do not wait for them, and the times are dead afterwards:
+            // 1407 -> 1382 us per 128-frame launch against looking each row up just before its add); a step's row is guessed from its
+            // time, which misses only by a rounding -- the lane's previous row + its stride misses whenever the row advances by one more
+            int rows[H];
+#pragma unroll
+            for (int h = 0; h < H; h++)
+                rows[h] = myv[h] ? row_near<FAST>(myt[h], (int)(myt[h] * a.inv_row_dt), rb, R, a.inv_row_dt, thr_end) : -1;
 #pragma unroll
             for (int h = 0; h < H; h++) {
                 if (myv[h]) {
                     const float scattering = vox[h].y >= m_dens ? vox[h].x * m_sigma + m_mu : 0.0f;
-                    const int row = row_near<FAST && MCRT_MARCH_ROW_EST>(myt[h], MCRT_MARCH_ROW_EST ? (int)(myt[h] * a.inv_row_dt) : row_guess, rb, R, a.inv_row_dt, thr_end);
-                    rf_add(rb, lflags, row, myin[h] * scattering);
-                    if (!MCRT_MARCH_ROW_EST) row_guess = (row >= 0 ? row : row_guess) + G;
+                    rf_add(rb, lflags, rows[h], myin[h] * scattering);
                     if (STATS) st_steps++;
                 }
             }
