@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
     unsigned long long poll_old = 0; uint32_t poll_ray = 0; bool poll_pending = false;      // (see the end of the loop)
 #ifdef MCRT_STAMP
     // diagnostic build: cycles and lane counts per phase, summed over wavefronts (tools/stamps.py)
-    unsigned long long sc_refill = 0, sc_p1 = 0, sc_p2 = 0, sc_n1 = 0, sc_n2 = 0, sc_outer = 0, sc_t0 = __builtin_readcyclecounter(), sc_act1 = 0, sc_act2 = 0, sc_park1 = 0, sc_idle1 = 0, sc_adopt = 0, sc_dist = 0;
+    unsigned long long sc_refill = 0, sc_p1 = 0, sc_p2 = 0, sc_n1 = 0, sc_n2 = 0, sc_outer = 0, sc_t0 = __builtin_readcyclecounter(), sc_act1 = 0, sc_act2 = 0, sc_park1 = 0, sc_idle1 = 0, sc_adopt = 0, sc_dist = 0, sc_rclaim = 0, sc_rload = 0, sc_rounds = 0, sc_rlanes = 0;
 #define LSTAMP(var) { const unsigned long long t_ = __builtin_readcyclecounter(); var += t_ - sc_t0; sc_t0 = t_; }
 #else
 #define LSTAMP(var)
@@ -765,6 +765,10 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                 const uint32_t taken = (uint32_t)__popcll(dynm);
                 pool_next = (pool_next + taken < pool_end) ? pool_next + taken : pool_end;
             }
+            LSTAMP(sc_rclaim)
+#ifdef MCRT_STAMP
+            sc_rounds++; sc_rlanes += __popcll(__ballot(need && i != 0xffffffffu && i < n));
+#endif
             if (need && i != 0xffffffffu) {
                 if (i < n) {
                     uint32_t piece = 0u;                                 // the pieces of one ray land in different wavefronts
@@ -789,6 +793,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                     if (STATS && piece == 0u) st_q++;
                 } else exhausted = true;
             }
+            LSTAMP(sc_rload)
         }
         if (MCRT_WALKING(cur) == 0ull) { if (!__any(!exhausted)) break; else continue; }
 
@@ -900,6 +905,7 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
         atomicAdd(&a.stamps[0], sc_refill); atomicAdd(&a.stamps[1], sc_p1); atomicAdd(&a.stamps[2], sc_p2); atomicAdd(&a.stamps[3], sc_n1);
         atomicAdd(&a.stamps[4], sc_n2); atomicAdd(&a.stamps[5], sc_outer); atomicAdd(&a.stamps[6], sc_act1); atomicAdd(&a.stamps[7], sc_act2); atomicAdd(&a.stamps[8], 1ull);
         atomicAdd(&a.stamps[56], sc_park1); atomicAdd(&a.stamps[57], sc_idle1); atomicAdd(&a.stamps[58], sc_adopt); atomicAdd(&a.stamps[59], sc_dist);
+        atomicAdd(&a.stamps[130], sc_rclaim); atomicAdd(&a.stamps[131], sc_rload); atomicAdd(&a.stamps[132], sc_rounds); atomicAdd(&a.stamps[133], sc_rlanes);
     }
 #endif
 #if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)

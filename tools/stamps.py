@@ -26,8 +26,11 @@ v = [int(x) for x in out]
 if v[8]:      # (a -DMCRT_STAMP_LITE build carries only the timeline)
     names = ["refill cyc", "phase1 cyc", "phase2 cyc", "phase1 iters", "phase2 iters", "outer iters", "active lanes p1 (sum)", "active lanes p2 (sum)", "waves"]
     for n, x in zip(names, v): print("%-24s %16d" % (n, x))
-    tot = v[0] + v[1] + v[2]
-    print("shares: refill %.1f%%  phase1 %.1f%%  phase2 %.1f%%" % (100 * v[0] / tot, 100 * v[1] / tot, 100 * v[2] / tot))
+    tot = v[0] + v[1] + v[2] + v[130] + v[131]
+    if v[132]:
+        print("refill rounds %d (%.1f per wave, %.1f lanes each): report + claim %.0f cycles, ray load + set-up %.0f cycles, hand-over + rest %.0f cycles per round" % (
+            v[132], v[132] / v[8], v[133] / v[132], v[130] / v[132], v[131] / v[132], v[0] / v[132]))
+    print("shares: refill %.1f%%  phase1 %.1f%%  phase2 %.1f%%" % (100 * (v[0] + v[130] + v[131]) / tot, 100 * v[1] / tot, 100 * v[2] / tot))
     print("cycles per phase-1 iteration %.0f (avg active lanes %.1f/64); per phase-2 iteration %.0f (avg parked lanes %.1f/64)" % (v[1] / max(v[3], 1), v[6] / max(v[3], 1), v[2] / max(v[4], 1), v[7] / max(v[4], 1)))
     print("per wave: %.0f cycles, %.1f node iterations, %.1f leaf iterations" % (tot / v[8], v[3] / v[8], v[4] / v[8]))
     print("k_march: %d waves, loop iterations %.1f per wave; step iterations %.1f per wave with %.2f of 16 quads active; iterations with a finishing quad %.1f; refill rounds %.1f"
