@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define MCRT_VERSION 103   /* round 3: + mcrt_trace_frames_poses, mcrt_envelope_frames, mcrt_scan_convert_frames; the slab rule of the closest-hit contract is one fma per plane */
+#define MCRT_VERSION 104   /* round 3: + mcrt_trace_frames_poses, mcrt_envelope_frames, mcrt_scan_convert_frames; the slab rule of the closest-hit contract is one fma per plane;
+                              104: + the test hooks mcrt_debug_set_error, mcrt_debug_fast_paths; RF images are NaN while the device error word is set */
 
 typedef enum {
     MCRT_OK = 0,
