@@ -111,7 +111,9 @@ int mcrt_device_count(void);
 
 int mcrt_create(int device, mcrt_ctx **out);
 int mcrt_destroy(mcrt_ctx *ctx);
-/* The stream every asynchronous entry point enqueues on.  NULL = the context's own (non-blocking) stream -- NOT the legacy
+/* The stream every asynchronous entry point enqueues on.  Calls are ordered on the stream they were issued on; the one cross-stream
+ * guarantee: a trace issued after mcrt_set_stream waits for the device work of the last scene upload / update / refit wherever that ran.
+ *  NULL = the context's own (non-blocking) stream -- NOT the legacy
  * default stream: to order the kernels with work on HIP's legacy stream pass hipStreamLegacy explicitly, and with a
  * framework's stream (torch.cuda.Stream().cuda_stream) pass that handle. */
 int mcrt_set_stream(mcrt_ctx *ctx, void *hip_stream);
@@ -165,6 +167,8 @@ int mcrt_trace_frames(mcrt_ctx *ctx, uint32_t frame_id, uint32_t n_frames, uint3
  * transducer.h:82-118; inputmanager.cpp:117-121; the frame loop main.cpp:92-152 reads the transducer anew every frame).  Each image is
  * bit-identical to mcrt_set_transducer(pos[f], dir[f]) followed by mcrt_trace_frame(frame_id + f).  The context's own transducer
  * (mcrt_set_transducer) is neither needed nor changed. */
+/* Lifetime: a table in HOST memory is copied before the call returns (free or rewrite it at once); a table in DEVICE memory is read by
+ * the pass on the context's stream -- keep it unchanged until that work has finished. */
 int mcrt_trace_frames_poses(mcrt_ctx *ctx, uint32_t frame_id, uint32_t n_frames, uint32_t e_begin, uint32_t e_end,
                             const float *pos /*[F][E][3]*/, const float *dir /*[F][E][3]*/, float *rf_dev);
 /* same, and additionally returns per-path data to HOST buffers (any may be NULL); synchronous.
@@ -181,7 +185,8 @@ int mcrt_convolve(mcrt_ctx *ctx, float *rf_dev, uint32_t n_elements, uint32_t n_
 /* the same on the n_frames images [n_frames][E][R] of an mcrt_trace_frames pass, in one launch per convolution pass */
 int mcrt_convolve_frames(mcrt_ctx *ctx, float *rf_dev, uint32_t n_frames, uint32_t n_elements, uint32_t n_rows,
                          const float *axial, uint32_t n_ax, const float *lateral, uint32_t n_lat);
-/* rf_image::envelope (rfimage.h:54-91) in place on a device image [E][R] */
+/* rf_image::envelope (rfimage.h:54-91) in place on a device image [E][R].  n_rows <= 2048 (MCRT_ERR_LIMIT beyond: a wavefront holds
+ * its scan-line in LDS) -- the limit mcrt_params.n_rows has anyway; an image brought in through mcrt_import_rf is bound by it too. */
 int mcrt_envelope(mcrt_ctx *ctx, float *rf_dev, uint32_t n_elements, uint32_t n_rows);
 /* the same on the n_frames images [n_frames][E][R] of a pass (main.cpp:147 once per frame), one launch */
 int mcrt_envelope_frames(mcrt_ctx *ctx, float *rf_dev, uint32_t n_frames, uint32_t n_elements, uint32_t n_rows);
@@ -189,6 +194,11 @@ int mcrt_envelope_frames(mcrt_ctx *ctx, float *rf_dev, uint32_t n_frames, uint32
  * out_dev float [out_rows][out_cols] */
 int mcrt_scan_convert(mcrt_ctx *ctx, const float *rf_dev, uint32_t n_elements, uint32_t n_rows,
                       double radius_mm, double total_angle_rad, float *out_dev, uint32_t out_rows, uint32_t out_cols);
+/* rf_image::create_mapping (rfimage.h:183-215) alone, on the host (no GPU needed): map_row = the reference's map_x (ROW coordinate
+ * in the RF image), map_col = its map_y (COLUMN coordinate), each [out_rows][out_cols] row-major -- what mcrt_scan_convert gathers
+ * with.  max_travel_us / speed_of_sound are rf_image's unsigned template parameters (100, 1500; main.cpp:36). */
+int mcrt_scan_maps(uint32_t n_elements, uint32_t n_rows, double radius_mm, double total_angle_rad, uint32_t max_travel_us,
+                   uint32_t speed_of_sound, uint32_t out_rows, uint32_t out_cols, float *map_row, float *map_col);
 /* the same on the n_frames images of a pass (main.cpp:148 once per frame), one launch; out_dev float [n_frames][out_rows][out_cols] */
 int mcrt_scan_convert_frames(mcrt_ctx *ctx, const float *rf_dev, uint32_t n_frames, uint32_t n_elements, uint32_t n_rows,
                              double radius_mm, double total_angle_rad, float *out_dev, uint32_t out_rows, uint32_t out_cols);
@@ -253,8 +263,9 @@ int mcrt_debug_stamps(mcrt_ctx *ctx, uint64_t out[200], int reset);
  * exhaustively against IEEE division for params.tex_res), out[1] the branch-free voxel cell, out[2] the entries of the padded
  * { threshold, bin } image of k_march's fast variant (0: generic variant), out[3] the passes this context has replayed as HIP graphs so far */
 int mcrt_debug_fast_paths(mcrt_ctx *ctx, uint32_t out[4]);
-/* test hook: ORs `bits` into the context's device error word on its stream, as an abandoned launch would (bit 0: traversal stack ran
- * out, bit 1: kernel watchdog expired) -- what mcrt_synchronize reports and what turns finalised RF images into NaN until it is asked */
+/* TEST HOOK, refused (MCRT_ERR_INVALID) unless the context was created with MCRT_TEST_HOOKS set in the environment: ORs `bits` into the
+ * context's device error word on its stream, as an abandoned launch would (bit 0: traversal stack ran out, bit 1: kernel watchdog
+ * expired) -- what mcrt_synchronize reports and what turns finalised RF images into NaN until it is asked */
 int mcrt_debug_set_error(mcrt_ctx *ctx, uint32_t bits);
 
 #ifdef __cplusplus

@@ -61,7 +61,7 @@ SYMBOLS = ["mcrt_last_error", "mcrt_version", "mcrt_device_count", "mcrt_create"
            "mcrt_envelope", "mcrt_scan_convert", "mcrt_export_rf", "mcrt_alloc", "mcrt_free", "mcrt_memcpy_d2h",
            "mcrt_memcpy_h2d", "mcrt_enable_stats", "mcrt_get_stats", "mcrt_enable_timing", "mcrt_get_kernel_time",
            "mcrt_build_bvh", "mcrt_free_bvh", "mcrt_get_bvh", "mcrt_build_bvh4", "mcrt_free_bvh4", "mcrt_get_bvh4", "mcrt_row_thresholds", "mcrt_generate_texture", "mcrt_psf_kernels",
-           "mcrt_transducer_elements", "mcrt_debug_math", "mcrt_debug_philox", "mcrt_debug_stamps", "mcrt_debug_set_error", "mcrt_debug_fast_paths"]
+           "mcrt_transducer_elements", "mcrt_debug_math", "mcrt_debug_philox", "mcrt_debug_stamps", "mcrt_debug_set_error", "mcrt_debug_fast_paths", "mcrt_scan_maps"]
 
 
 def build_library(force=False):
@@ -107,6 +107,7 @@ def load_library():
         "mcrt_generate_texture": [vp, u32], "mcrt_psf_kernels": [C.c_float, C.c_float, C.c_float, u32, vp, u32, vp, u32],
         "mcrt_transducer_elements": [u32, C.c_double, C.c_double, vp, vp, vp, vp],
         "mcrt_debug_math": [vp, i32, vp, vp, vp, u32], "mcrt_debug_philox": [vp, vp, vp, vp], "mcrt_debug_stamps": [vp, vp, i32], "mcrt_debug_set_error": [vp, u32], "mcrt_debug_fast_paths": [vp, vp],
+        "mcrt_scan_maps": [u32, u32, C.c_double, C.c_double, u32, u32, u32, u32, vp, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)

@@ -73,6 +73,13 @@ def host_transducer(n_elements, radius_cm, sep_mm, position, angles_deg):
     return pos, d
 
 
+def host_scan_maps(n_elements, n_rows, radius_mm=30.0, total_angle=1.0471975511965976, max_travel_us=100, speed_of_sound=1500, out_rows=400, out_cols=500):
+    """rf_image::create_mapping (rfimage.h:183-215) as the library evaluates it: (map_row, map_col), each [out_rows][out_cols]"""
+    mr = np.zeros((out_rows, out_cols), np.float32); mc = np.zeros((out_rows, out_cols), np.float32)
+    check(load_library().mcrt_scan_maps(n_elements, n_rows, radius_mm, total_angle, max_travel_us, speed_of_sound, out_rows, out_cols, ptr(mr), ptr(mc)))
+    return mr, mc
+
+
 class Transducer:
     """transducer<N>(frequency, radius, element_separation, position, angles) -- transducer.h:24-62.
     main.cpp:28-29,66: total aperture 60 deg on a 3 cm radius; separation = amplitude * radius / N."""

@@ -70,6 +70,7 @@ struct Knobs {
     bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false, graph = false;
     uint32_t march_cus = 0;                    // CUs the accumulation's side stream is confined to (0 = no mask); the mask's bit order is the driver's
     bool main_mask = false;                    // with march_cus: the walk / shade chain runs on its own stream confined to the OTHER CUs
+    bool test_hooks = false;                   // MCRT_TEST_HOOKS: mcrt_debug_set_error may poison the context (tests only)
 };
 static Knobs read_knobs()
 {
@@ -84,6 +85,7 @@ static Knobs read_knobs()
     k.graph = getenv("MCRT_GRAPH") != nullptr;   // passes replayed as HIP graphs (measured slower on ROCm 7.2: see trace_frames_graph)
     if (const char *e = getenv("MCRT_MARCH_CUS")) { int v = atoi(e); if (v >= 0 && v <= 248) k.march_cus = (uint32_t)v; }
     k.main_mask = getenv("MCRT_MAIN_MASK") != nullptr;
+    k.test_hooks = getenv("MCRT_TEST_HOOKS") != nullptr;
     return k;
 }
 
@@ -115,7 +117,9 @@ struct mcrt_ctx {
     // transducer
     float *d_pos = nullptr, *d_dir = nullptr; uint32_t n_el = 0;
     const float *pose_pos = nullptr, *pose_dir = nullptr;      // set for the duration of mcrt_trace_frames_poses: device [F][E][3] per-frame probe poses
-    float *d_pose[2] = { nullptr, nullptr }; size_t pose_cap[2] = { 0, 0 };   // staging for pose tables handed over as host memory
+    float *d_pose[2] = { nullptr, nullptr }; size_t pose_cap[2] = { 0, 0 };   // staging for pose tables handed over as host memory:
+    float *h_pose[2] = { nullptr, nullptr }; hipEvent_t ev_pose = nullptr; bool pose_copy_pending = false;   // the caller's table is copied into pinned memory the context owns before the call returns
+    hipEvent_t ev_scene = nullptr; hipStream_t scene_stream = nullptr; bool scene_pending = false;   // the last scene update's device work (refresh_soa), for traces issued on ANOTHER stream
     // accumulators
     long long *d_acc = nullptr; uint32_t *d_flags = nullptr; size_t acc_cap = 0, flag_cap = 0;
     uint32_t acc_clean_ne = 0, acc_clean_rows = 0;   // bins known to be all-zero for this shape (k_finalize leaves them so)
@@ -214,6 +218,7 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     c->device = device;
     c->knobs = read_knobs();
     if (prop.multiProcessorCount > 0) c->n_cu = (uint32_t)prop.multiProcessorCount;
+    if (c->knobs.march_cus + 8u > c->n_cu) c->knobs.march_cus = c->n_cu > 8u ? c->n_cu - 8u : 0u;   // (the CU-mask knobs always leave both sides at least 8 CUs)
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return set_error(MCRT_ERR_HIP, "hipStreamCreate failed"); }
     c->stream = c->own_stream;
     hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming);
@@ -303,8 +308,10 @@ static int side_stream(mcrt_ctx *c, Work &w, uint32_t i, hipStream_t *out)
 }
 
 // the walk's view of the tree: child-transposed half-float nodes, rebuilt whenever d_nodes changes.  The buffer is kept while the
-// node count stays (a refit -- the per-frame path of a deforming scene -- then costs one kernel on the context's stream, no
-// allocation and no device-wide stall); nothing here synchronises: the next trace is ordered after it on the same stream.
+// node count stays (a refit -- the per-frame path of a deforming scene -- then costs one kernel on the context's stream and no
+// allocation HERE; mcrt_refit_triangles itself still frees its staging copy of the vertices, which synchronises the device).
+// Nothing here waits: the rebuild is ordered on the stream it was issued on, and an event recorded behind it orders a trace that
+// is issued on ANOTHER stream after mcrt_set_stream (enqueue_frame waits for it).
 static int refresh_soa(mcrt_ctx *c)
 {
     c->walked_stale = true;
@@ -316,6 +323,9 @@ static int refresh_soa(mcrt_ctx *c)
         c->nodes_walk_cap = c->bvh4.n_nodes;
     }
     HIP_TRY(mcrt::launch_nodes_walk(c->d_nodes, c->bvh4.n_nodes, c->d_nodes_walk, c->stream));
+    if (!c->ev_scene) HIP_TRY(hipEventCreateWithFlags(&c->ev_scene, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->ev_scene, c->stream));
+    c->scene_stream = c->stream; c->scene_pending = true;
     return MCRT_OK;
 }
 
@@ -339,6 +349,10 @@ extern "C" int mcrt_destroy(mcrt_ctx *c)
     free_work(c);
     free(c->walked_nodes); c->walked_nodes = nullptr;
     hipFree(c->d_pose[0]); hipFree(c->d_pose[1]);
+    if (c->h_pose[0]) hipHostFree(c->h_pose[0]);
+    if (c->h_pose[1]) hipHostFree(c->h_pose[1]);
+    if (c->ev_pose) hipEventDestroy(c->ev_pose);
+    if (c->ev_scene) hipEventDestroy(c->ev_scene);
     hipFree(c->d_tex); hipFree(c->d_pos); hipFree(c->d_dir); hipFree(c->d_acc); hipFree(c->d_flags); hipFree(c->d_tmp);
     hipFree(c->d_map_col); hipFree(c->d_map_row); hipFree(c->d_stats); hipFree(c->d_row_thr); hipFree(c->d_error); hipFree(c->d_mtab);
     for (auto &g : c->graphs) { if (g.exec) hipGraphExecDestroy(g.exec); if (g.graph) hipGraphDestroy(g.graph); }
@@ -841,6 +855,7 @@ static int enqueue_frame(mcrt_ctx *c, const std::vector<mcrt::FrameArgs> &args, 
     const bool overlap = !c->knobs.no_overlap;
     std::vector<hipStream_t> gst(groups);
     for (uint32_t g = 0; g < groups; g++) { int rc = work_stream(c, *ws[g], g == 0, &gst[g]); if (rc) return rc; }
+    if (c->scene_pending && c->scene_stream != c->stream) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_scene, 0));   // a scene update issued on another stream
     HIP_TRY(hipEventRecord(c->ev_start, c->stream));
     for (uint32_t g = 0; g < groups; g++) {
         if (gst[g] != c->stream) HIP_TRY(hipStreamWaitEvent(gst[g], c->ev_start, 0));
@@ -906,7 +921,7 @@ static int trace_frames_graph(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, ui
     }
     if (slot < 0) {          // first pass of this shape: remember it, run it directly
         mcrt_ctx::GraphEntry &g = c->graphs[lru];
-        if (g.exec || g.graph) HIP_TRY(hipStreamSynchronize(g.stream == c->stream ? c->stream : g.stream));   // (a replaced graph may still be running)
+        if (g.exec || g.graph) HIP_TRY(hipDeviceSynchronize());   // (a replaced graph may still be running; its stream was the caller's and may be gone: wait for the device, not for a stored handle)
         if (g.exec) hipGraphExecDestroy(g.exec);
         if (g.graph) hipGraphDestroy(g.graph);
         g.exec = nullptr; g.graph = nullptr; g.key = key; g.rf = rf_dev; g.stream = c->stream; g.used = ++c->graph_tick; g.live = true;
@@ -979,18 +994,31 @@ extern "C" int mcrt_trace_frames_poses(mcrt_ctx *c, uint32_t frame, uint32_t n_f
     const size_t bytes = 12 * (size_t)n_frames * E;
     const float *src[2] = { pos, dir };
     const float *dev[2] = { nullptr, nullptr };
+    // A table in HOST memory belongs to the caller and may be pageable: it is copied into pinned memory the context owns before this
+    // call returns (the caller may free or rewrite it at once), and goes to the device from there on the stream.  The staging buffers are
+    // reused: the copy of the previous call (an early node of the previous pass, not the pass) is waited for first.
+    bool staged = false;
     for (int k = 0; k < 2; k++) {
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, src[k]) == hipSuccess && at.type == hipMemoryTypeDevice) { dev[k] = src[k]; continue; }
         (void)hipGetLastError();
+        if (c->pose_copy_pending) { HIP_TRY(hipEventSynchronize(c->ev_pose)); c->pose_copy_pending = false; }
         if (c->pose_cap[k] < bytes) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             hipFree(c->d_pose[k]); c->d_pose[k] = nullptr; c->pose_cap[k] = 0;
+            if (c->h_pose[k]) { hipHostFree(c->h_pose[k]); c->h_pose[k] = nullptr; }
             HIP_TRY(hipMalloc(&c->d_pose[k], bytes));
+            HIP_TRY(hipHostMalloc((void **)&c->h_pose[k], bytes, hipHostMallocDefault));
             c->pose_cap[k] = bytes;
         }
-        HIP_TRY(hipMemcpyAsync(c->d_pose[k], src[k], bytes, hipMemcpyHostToDevice, c->stream));
-        dev[k] = c->d_pose[k];
+        memcpy(c->h_pose[k], src[k], bytes);
+        HIP_TRY(hipMemcpyAsync(c->d_pose[k], c->h_pose[k], bytes, hipMemcpyHostToDevice, c->stream));
+        dev[k] = c->d_pose[k]; staged = true;
+    }
+    if (staged) {
+        if (!c->ev_pose) HIP_TRY(hipEventCreateWithFlags(&c->ev_pose, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_pose, c->stream));
+        c->pose_copy_pending = true;
     }
     c->pose_pos = dev[0]; c->pose_dir = dev[1];
     const int rc = mcrt_trace_frames(c, frame, n_frames, e0, e1, rf_dev);
@@ -1085,25 +1113,35 @@ extern "C" int mcrt_envelope(mcrt_ctx *c, float *rf_dev, uint32_t E, uint32_t R)
     return mcrt_envelope_frames(c, rf_dev, 1, E, R);
 }
 
-// rfimage.h:183-215 create_mapping, evaluated once per geometry on the host (as the reference does in its constructor)
-static void build_maps(const mcrt_ctx *c, uint32_t E, uint32_t R, double radius_mm, double total_angle, uint32_t orows, uint32_t ocols,
-                       std::vector<float> &map_col, std::vector<float> &map_row)
+// rfimage.h:183-215 create_mapping, evaluated once per geometry on the host (as the reference does in its constructor).
+// Operand types as C++ gives them to the reference's statements (pinned by tests/golden/ref_probe.json "scan_maps_*": the same
+// statements evaluated with the reference's own unit types, compiled from its units.h):
+//   :186 ratio: `max_travel_time * speed_of_sound * 0.001f` is an unsigned product times a float = FLOAT (150.0f for 100 us x 1500);
+//        `+ radius` stays float; `- radius * cos(angle_f / 2.0)` is double; `/ rows` double; rounded once to float
+//   :189 shift_y: millimeter_t (double) * cosf(angle_f / 2.0f)
+//   :201-205 fi, fj, r: float throughout            :208 angle: atan2f, widened
+//   :211 map_x (row coordinate): float throughout, the divisor the same float depth as in :186
+//   :212 map_y (column coordinate): radian_t arithmetic in double, * (float)rf_width, rounded once
+// (Rounds 1-3 held the depth as a double -- 150.0000071 -- and divided in double: ratio 0.385048121 instead of 0.385048091.)
+extern "C" int mcrt_scan_maps(uint32_t E, uint32_t R, double radius_mm, double total_angle, uint32_t max_travel_us, uint32_t speed_of_sound,
+                              uint32_t orows, uint32_t ocols, float *map_row, float *map_col)
 {
+    if (!map_row || !map_col || E == 0 || R == 0 || orows == 0 || ocols == 0 || !(total_angle > 0.0)) return set_error(MCRT_ERR_INVALID, "mcrt_scan_maps: bad arguments");
     const float radius_f = (float)radius_mm, ta_f = (float)total_angle;
-    const double depth_um = c->c.max_travel_us * (double)c->p.speed_of_sound;
-    const float ratio = (float)((depth_um * 0.001f + radius_f - radius_f * std::cos(ta_f / 2.0)) / (double)orows);
+    const float depth_mm_f = (float)(uint32_t)(max_travel_us * speed_of_sound) * 0.001f;
+    const float ratio = (float)(((double)(depth_mm_f + radius_f) - (double)radius_f * std::cos((double)ta_f / 2.0)) / (double)(int)orows);
     const double shift_y = radius_mm * (double)std::cos(ta_f / 2.0f);
-    const float half_width = (float)ocols / 2.0f;
-    map_col.resize((size_t)orows * ocols); map_row.resize((size_t)orows * ocols);
+    const float half_width = (float)(int)ocols / 2.0f;
     for (uint32_t j = 0; j < ocols; j++)
         for (uint32_t i = 0; i < orows; i++) {
-            const float fi = (float)i + (float)shift_y / ratio;
-            const float fj = (float)j - half_width;
+            const float fi = (float)(int)i + (float)shift_y / ratio;
+            const float fj = (float)(int)j - half_width;
             const float r = std::sqrt(fi * fi + fj * fj);
             const double angle = (double)std::atan2(fj, fi);
-            map_row[(size_t)i * ocols + j] = (float)((double)(r * ratio - radius_f) / (depth_um * 0.001f) * (double)(float)R);
+            map_row[(size_t)i * ocols + j] = (r * ratio - radius_f) / depth_mm_f * (float)R;
             map_col[(size_t)i * ocols + j] = (float)(((angle - (-total_angle / 2)) / total_angle) * (double)(float)E);
         }
+    return MCRT_OK;
 }
 
 extern "C" int mcrt_scan_convert_frames(mcrt_ctx *c, const float *rf_dev, uint32_t n_frames, uint32_t E, uint32_t R, double radius_mm, double total_angle,
@@ -1115,8 +1153,9 @@ extern "C" int mcrt_scan_convert_frames(mcrt_ctx *c, const float *rf_dev, uint32
     const uint32_t key[6] = { E, R, orows, ocols, c->p.speed_of_sound, 1u };
     const double keyd[2] = { radius_mm * 1e6 + total_angle, c->c.max_travel_us };
     if (memcmp(key, c->map_key, sizeof key) || memcmp(keyd, c->map_keyd, sizeof keyd)) {
-        std::vector<float> mc, mr;
-        build_maps(c, E, R, radius_mm, total_angle, orows, ocols, mc, mr);
+        std::vector<float> mc((size_t)orows * ocols), mr((size_t)orows * ocols);
+        // (the rf_image template parameter is max_travel_time.to<unsigned int>(), main.cpp:36 -- the same truncation as max_rows uses)
+        { int rc = mcrt_scan_maps(E, R, radius_mm, total_angle, (uint32_t)c->c.max_travel_us, c->p.speed_of_sound, orows, ocols, mr.data(), mc.data()); if (rc) return rc; }
         HIP_TRY(hipStreamSynchronize(c->stream));
         hipFree(c->d_map_col); hipFree(c->d_map_row); c->d_map_col = c->d_map_row = nullptr;
         HIP_TRY(hipMalloc(&c->d_map_col, mc.size() * 4)); HIP_TRY(hipMalloc(&c->d_map_row, mr.size() * 4));
@@ -1212,6 +1251,7 @@ extern "C" int mcrt_debug_fast_paths(mcrt_ctx *c, uint32_t out[4])
 extern "C" int mcrt_debug_set_error(mcrt_ctx *c, uint32_t bits)
 {
     CTX_TRY(c);
+    if (!c->knobs.test_hooks) return set_error(MCRT_ERR_INVALID, "mcrt_debug_set_error is a test hook: create the context with MCRT_TEST_HOOKS set in the environment");
     uint32_t e = 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(&e, c->d_error, 4, hipMemcpyDeviceToHost));

@@ -1029,38 +1029,73 @@ void orc_envelope(float *img, uint32_t rows, uint32_t cols)
 #undef AT
 }
 
-/* rfimage.h:183-215 (create_mapping) + :139 cv::remap(src,dst,map_y,map_x,LINEAR,BORDER_CONSTANT 0).
+/* rfimage.h:183-215 (create_mapping).  map_row = the reference's map_x (ROW coordinate in the RF image), map_col = its map_y
+ * (COLUMN coordinate) -- cv::remap(src, dst, map_y, map_x) at rfimage.h:139 swaps them back.  [out_rows][out_cols], row-major.
+ *
+ * Operand types, expression by expression (rfimage.h line -> what C++ makes of it; pinned by oracle/ref_probe.cpp, which evaluates
+ * the same statements with the reference's own units.h types -> tests/golden/ref_probe.json "scan_maps_*"):
+ *   :186 ratio   = (max_travel_time * speed_of_sound * 0.001f      unsigned * unsigned (wraps mod 2^32) -> float * float: 150.0f
+ *                   + radius.to<float>()                           float + float = float (180.0f)
+ *                   - radius.to<float>() * std::cos(ta_f / 2.0))   float / double -> cos(double) -> float * double = double; float - double = double
+ *                  / scan_converted.rows                           double / int = double, rounded ONCE to float by the declaration
+ *   :189 shift_y = radius * std::cos(ta_f / 2.0f)                  float / float -> std::cos(float) = cosf; millimeter_t (double) * float = double
+ *   :192 half_width = (float)cols / 2.0f                           float
+ *   :201 fi      = (float)i + shift_y.to<float>() / ratio          float throughout
+ *   :202 fj      = (float)j - half_width                           float
+ *   :205 r       = std::sqrt(std::pow(fi,2.0f) + std::pow(fj,2.0f))  float overloads.  GCC expands pow(x, 2.0f) to x * x from -O1 on; at -O0 (the reference's
+ *                                                                  CMakeLists.txt sets no optimisation level) glibc's powf is called: the probe built
+ *                                                                  at -O0 and at -O1 prints identical maps for all three golden shapes (checked when
+ *                                                                  the fixture was generated), so x * x it is
+ *   :208 angle   = radian_t(std::atan2(fj, fi))                    atan2f, widened to double
+ *   :211 map_x   = (r*ratio - radius.to<float>()) / (max_travel_time*speed_of_sound*0.001f) * (float)rf_height       float throughout
+ *   :212 map_y   = ((angle - (-total_angle/2)) / total_angle) * (float)rf_width   radian_t arithmetic in double, * float -> double, rounded once by the store
+ * (Rounds 1-3 carried the depth of :186/:211 as a double, `depth_um * 0.001f` = 150.0000071, and divided in double: ratio 0.385048121
+ * instead of 0.385048091, 72 % of the row coordinates off by up to 9e-5 -- found by the round-3 review.) */
+void orc_scan_maps(uint32_t rows, uint32_t cols, double radius_mm, double total_angle, uint32_t max_travel_us, uint32_t sos,
+                   uint32_t out_rows, uint32_t out_cols, float *map_row, float *map_col)
+{
+    const float radius_f = (float)radius_mm, ta_f = (float)total_angle;
+    const float depth_mm_f = (float)(uint32_t)(max_travel_us * sos) * 0.001f;          /* unsigned product, then float */
+    const float ratio = (float)(((double)(depth_mm_f + radius_f) - (double)radius_f * cos((double)ta_f / 2.0)) / (double)(int)out_rows);
+    const double shift_y = radius_mm * (double)cosf(ta_f / 2.0f);
+    const float half_width = (float)(int)out_cols / 2.0f;
+    for (uint32_t j = 0; j < out_cols; j++)
+        for (uint32_t i = 0; i < out_rows; i++) {
+            const float fi = (float)(int)i + (float)shift_y / ratio;
+            const float fj = (float)(int)j - half_width;
+            const float r = sqrtf(fi * fi + fj * fj);
+            const double angle = (double)atan2f(fj, fi);
+            map_row[(size_t)i * out_cols + j] = (r * ratio - radius_f) / depth_mm_f * (float)rows;
+            map_col[(size_t)i * out_cols + j] = (float)(((angle - (-total_angle / 2)) / total_angle) * (double)(float)cols);
+        }
+}
+
+/* rfimage.h:125-140 postprocess: cv::remap(src, dst, map_y, map_x, INTER_LINEAR, BORDER_CONSTANT 0) over the maps above.
  * OpenCV is absent: the bilinear kernel is restated as EXACT bilinear in float (OpenCV
- * quantises fractions to 1/32) -- parity unpinned for this function. */
+ * quantises fractions to 1/32) -- parity unpinned for the interpolation; the maps are pinned (above).
+ * max_travel_us / sos are the rf_image template parameters (unsigned int: main.cpp:36 hands over max_travel_time.to<unsigned int>()). */
 void orc_scan_convert(const float *img, uint32_t rows, uint32_t cols, double radius_mm, double total_angle,
                       double max_travel_us, double sos, float *out, uint32_t out_rows, uint32_t out_cols)
 {
-    float radius_f = (float)radius_mm, ta_f = (float)total_angle;
-    /* ratio: (max_travel_time*sos [um] * 0.001f + r - r*cos(a/2.0)) / rows  (mixed double) */
-    double depth_um = max_travel_us * sos;
-    float ratio = (float)((depth_um * 0.001f + radius_f - radius_f * cos(ta_f / 2.0)) / (double)out_rows);
-    double shift_y = radius_mm * (double)cosf(ta_f / 2.0f);
-    float half_width = (float)out_cols / 2.0f;
-    for (uint32_t j = 0; j < out_cols; j++)
-        for (uint32_t i = 0; i < out_rows; i++) {
-            float fi = (float)i + (float)shift_y / ratio;
-            float fj = (float)j - half_width;
-            float r = sqrtf(fi * fi + fj * fj);
-            double angle = (double)atan2f(fj, fi);
-            float my = (float)((double)((r * ratio - radius_f)) / (depth_um * 0.001f) * (double)(float)rows);   /* map_x: row coord */
-            float mx = (float)(((angle - (-total_angle / 2)) / total_angle) * (double)(float)cols);               /* map_y: col coord */
-            /* remap: dst(i,j) = src(y=my, x=mx) bilinear, constant 0 border */
-            float fx = floorf(mx), fy = floorf(my);
-            float ax = mx - fx, ay = my - fy;
-            long x0 = (long)fx, y0 = (long)fy;
-            float v[2][2];
-            for (int dy = 0; dy < 2; dy++)
-                for (int dx = 0; dx < 2; dx++) {
-                    long xx = x0 + dx, yy = y0 + dy;
-                    v[dy][dx] = (mx == mx && my == my && xx >= 0 && yy >= 0 && xx < (long)cols && yy < (long)rows) ? img[(size_t)yy * cols + xx] : 0.0f;
-                }
-            float top = v[0][0] * (1.0f - ax) + v[0][1] * ax;
-            float bot = v[1][0] * (1.0f - ax) + v[1][1] * ax;
-            out[(size_t)i * out_cols + j] = top * (1.0f - ay) + bot * ay;
-        }
+    const size_t n = (size_t)out_rows * out_cols;
+    float *map_row = (float *)malloc(n * sizeof(float)), *map_col = (float *)malloc(n * sizeof(float));
+    if (!map_row || !map_col) { free(map_row); free(map_col); return; }
+    orc_scan_maps(rows, cols, radius_mm, total_angle, (uint32_t)max_travel_us, (uint32_t)sos, out_rows, out_cols, map_row, map_col);
+    for (size_t p = 0; p < n; p++) {
+        const float my = map_row[p], mx = map_col[p];
+        /* remap: dst(i,j) = src(y=my, x=mx) bilinear, constant 0 border */
+        float fx = floorf(mx), fy = floorf(my);
+        float ax = mx - fx, ay = my - fy;
+        long x0 = (long)fx, y0 = (long)fy;
+        float v[2][2];
+        for (int dy = 0; dy < 2; dy++)
+            for (int dx = 0; dx < 2; dx++) {
+                long xx = x0 + dx, yy = y0 + dy;
+                v[dy][dx] = (mx == mx && my == my && xx >= 0 && yy >= 0 && xx < (long)cols && yy < (long)rows) ? img[(size_t)yy * cols + xx] : 0.0f;
+            }
+        float top = v[0][0] * (1.0f - ax) + v[0][1] * ax;
+        float bot = v[1][0] * (1.0f - ax) + v[1][1] * ax;
+        out[p] = top * (1.0f - ay) + bot * ay;
+    }
+    free(map_row); free(map_col);
 }

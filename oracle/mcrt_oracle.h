@@ -160,6 +160,10 @@ void orc_convolve(float *img, float *tmp, uint32_t rows, uint32_t cols,
                   const float *axial, uint32_t n_ax, const float *lateral, uint32_t n_lat);
 /* rfimage.h:54-91 on a row-major [R][E] image, in place */
 void orc_envelope(float *img, uint32_t rows, uint32_t cols);
+/* rfimage.h:183-215 create_mapping: map_row = the reference's map_x (row coordinate), map_col = its map_y (column coordinate);
+ * [out_rows][out_cols] row-major.  max_travel_us / sos: the rf_image template parameters (unsigned int). */
+void orc_scan_maps(uint32_t rows, uint32_t cols, double radius_mm, double total_angle_rad, uint32_t max_travel_us, uint32_t sos,
+                   uint32_t out_rows, uint32_t out_cols, float *map_row, float *map_col);
 /* rfimage.h:183-215 mapping + exact bilinear remap (BORDER_CONSTANT 0). out = [out_rows][out_cols] */
 void orc_scan_convert(const float *img, uint32_t rows, uint32_t cols, double radius_mm, double total_angle_rad,
                       double max_travel_us, double sos, float *out, uint32_t out_rows, uint32_t out_cols);

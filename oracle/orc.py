@@ -257,3 +257,11 @@ def scan_convert(img, radius_mm=30.0, total_angle=1.0471975511965976, max_travel
     lib().orc_scan_convert(_p(img), C.c_uint32(img.shape[0]), C.c_uint32(img.shape[1]), C.c_double(radius_mm), C.c_double(total_angle),
                            C.c_double(max_travel_us), C.c_double(sos), _p(out), C.c_uint32(out_rows), C.c_uint32(out_cols))
     return out
+
+
+def scan_maps(rows, cols, radius_mm=30.0, total_angle=1.0471975511965976, max_travel_us=100, sos=1500, out_rows=400, out_cols=500):
+    """rfimage.h:183-215 create_mapping -> (map_row = the reference's map_x, map_col = its map_y), each [out_rows][out_cols]"""
+    mr = np.zeros((out_rows, out_cols), np.float32); mc = np.zeros((out_rows, out_cols), np.float32)
+    lib().orc_scan_maps(C.c_uint32(rows), C.c_uint32(cols), C.c_double(radius_mm), C.c_double(total_angle), C.c_uint32(max_travel_us), C.c_uint32(sos),
+                        C.c_uint32(out_rows), C.c_uint32(out_cols), _p(mr), _p(mc))
+    return mr, mc

@@ -5,7 +5,8 @@
 // values the oracle is pinned against as JSON:
 //   src/psf.h            -> PSF taps                         (main.cpp:54 parameters)
 //   src/volume.h         -> tissue texture (hash, sums, samples, get_scattering probes)
-//   include/units/units.h-> the unit arithmetic of main.cpp:23-37,114-139 and rfimage.h:33-51,178-180
+//   include/units/units.h-> the unit arithmetic of main.cpp:23-37,114-139 and rfimage.h:33-51,178-180, and the scan-conversion maps
+//                           of rfimage.h:183-215 (create_mapping) evaluated with the reference's own unit types
 //   include/nlohmann/json.hpp + examples/**/*.scene -> the fields scene::parse_config (scene.cpp:185-247) and main.cpp:62-72 read,
 //                           converted as the reference converts them (json number -> float), for every scene file that loads
 // Built by oracle/Makefile into oracle/_ref/ref_probe (git-ignored); run by oracle/gen_golden.py,
@@ -55,6 +56,56 @@ struct rf_axis {
 };
 template <unsigned int a, unsigned int s> constexpr meters_per_second_t rf_axis<a, s>::speed_of_sound_;
 template <unsigned int a, unsigned int s> constexpr micrometer_t rf_axis<a, s>::axial_resolution_;
+
+// rfimage.h:183-215 create_mapping with the reference's template parameters and unit types; cv::Mat (absent here) is replaced by
+// plain float arrays, `scan_converted.rows / .cols` by ints as cv::Mat's are.  Every expression keeps the reference's operand types:
+// max_travel_time, speed_of_sound and rf_height / rf_width are `unsigned int`, radius a millimeter_t, total_angle a radian_t.
+template <unsigned int max_travel_time_, unsigned int speed_of_sound_>
+struct scan_maps {
+    int rows, cols;
+    std::vector<float> map_x, map_y;
+    float ratio_out; double shift_y_out;
+    scan_maps(millimeter_t radius, radian_t total_angle, unsigned int rf_width, unsigned int rf_height, int out_rows, int out_cols)
+        : rows(out_rows), cols(out_cols), map_x((size_t)out_rows * out_cols), map_y((size_t)out_rows * out_cols)
+    {
+        constexpr unsigned int max_travel_time = max_travel_time_, speed_of_sound = speed_of_sound_;
+        float ratio = (max_travel_time * speed_of_sound * 0.001f + radius.to<float>() - radius.to<float>() * std::cos(total_angle.to<float>()/2.0)) / rows;
+        millimeter_t shift_y = radius * std::cos(total_angle.to<float>() / 2.0f);
+        float half_width = (float)cols / 2.0f;
+        ratio_out = ratio; shift_y_out = shift_y();
+        for (int j = 0; j < cols; j++)
+            for (int i = 0; i < rows; i++) {
+                float fi = static_cast<float>(i)+shift_y.to<float>()/ratio;
+                float fj = static_cast<float>(j)-half_width;
+                float r = std::sqrt(std::pow(fi,2.0f) + std::pow(fj,2.0f));
+                radian_t angle = radian_t(std::atan2(fj, fi));
+                map_x[(size_t)i * cols + j] = (r*ratio-radius.to<float>())/(max_travel_time*speed_of_sound*0.001f) * (float)rf_height;
+                map_y[(size_t)i * cols + j] = ((angle - (-total_angle/2)) / (total_angle)) * (float)rf_width;
+            }
+    }
+};
+static uint64_t fnv_floats(const std::vector<float> &v)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (float f : v) { uint32_t b = fbits(f); for (int k = 0; k < 4; k++) { h ^= (b >> (8 * k)) & 0xff; h *= 1099511628211ull; } }
+    return h;
+}
+template <unsigned int T, unsigned int S>
+static void dump_maps(const char *name, millimeter_t radius, radian_t total_angle, unsigned int rf_width, unsigned int rf_height, int out_rows, int out_cols)
+{
+    const scan_maps<T, S> m(radius, total_angle, rf_width, rf_height, out_rows, out_cols);
+    printf("\"%s\": {\"max_travel_time\":%u,\"speed_of_sound\":%u,\"radius_mm\":%.17g,\"total_angle\":%.17g,\"rf_width\":%u,\"rf_height\":%u,\"rows\":%d,\"cols\":%d,",
+           name, T, S, radius(), total_angle(), rf_width, rf_height, out_rows, out_cols);
+    printf("\"ratio_bits\":%u,\"shift_y\":%.17g,\"map_x_fnv1a64\":\"%016llx\",\"map_y_fnv1a64\":\"%016llx\",\"samples\":[",
+           fbits(m.ratio_out), m.shift_y_out, (unsigned long long)fnv_floats(m.map_x), (unsigned long long)fnv_floats(m.map_y));
+    uint64_t s = 0xD1B54A32D192ED03ull;
+    for (int k = 0; k < 24; k++) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const int i = k == 0 ? 0 : k == 1 ? out_rows - 1 : (int)(s % (uint64_t)out_rows), j = k == 0 ? 0 : k == 1 ? out_cols - 1 : (int)((s >> 32) % (uint64_t)out_cols);
+        printf("%s[%d,%d,%u,%u]", k ? "," : "", i, j, fbits(m.map_x[(size_t)i * out_cols + j]), fbits(m.map_y[(size_t)i * out_cols + j]));
+    }
+    printf("]},\n");
+}
 
 // the fields scene::parse_config (scene.cpp:185-247) and main.cpp:62-72 read from a .scene file, in the reference's own conversions
 // (float x = json number), as one JSON object; floats as bit patterns.  A file the reference could not load (json.at throws, e.g.
@@ -161,6 +212,13 @@ int main(int argc, char **argv)
         printf("\"deg2rad\": [");
         for (int i = 0; i < 6; i++) { degree_t d(degs[i]); radian_t r{ d }; printf("%s[%u,%.17g,%u]", i ? "," : "", fbits(degs[i]), r(), fbits(r.to<float>())); }
         printf("],\n");
+    }
+    // ---- scan-conversion maps: rfimage.h:183-215 as main.cpp:56 instantiates it (rf_image<512, 100, 322>{3_cm, 60_deg}, 400 x 500),
+    //      and two other shapes (the 128-column headline image; other template constants and a non-integral depth product) ----
+    {
+        dump_maps<100, 1500>("scan_maps_reference", transducer_radius, transducer_amplitude, 512, 465, 400, 500);
+        dump_maps<100, 1500>("scan_maps_headline", transducer_radius, transducer_amplitude, 128, 465, 400, 500);
+        dump_maps<133, 1540>("scan_maps_other", millimeter_t(41.5), radian_t(degree_t(75.0f)), 192, 777, 333, 257);
     }
     // ---- time axis: main.cpp:114-118,139 + rfimage.h:33-40 on a sweep of inputs ----
     {

@@ -404,10 +404,17 @@ def test_passes_replayed_as_hip_graphs(mcrt, sphere, tex256, monkeypatch):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-def test_abandoned_launch_poisons_frames_until_asked(mcrt, sphere, tex256):
+def test_abandoned_launch_poisons_frames_until_asked(mcrt, sphere, tex256, monkeypatch):
     """a launch abandoned by a kernel watchdog sets the context's device error word: every image finalised from then on is NaN
-    throughout, mcrt_synchronize reports MCRT_ERR_LIMIT once and clears it, the next frame is the frame again"""
+    throughout, mcrt_synchronize reports MCRT_ERR_LIMIT once and clears it, the next frame is the frame again.  (The hook that sets
+    the word by hand is refused unless the context was created with MCRT_TEST_HOOKS in the environment.)"""
     cfg, sd = sphere
+    monkeypatch.delenv("MCRT_TEST_HOOKS", raising=False)
+    tr, sim = _sim(mcrt, cfg, sd, 16, 64, texture=tex256)
+    with pytest.raises(mcrt.McrtError, match="test hook"):
+        sim.ctx.debug_set_error(2)
+    sim.close()
+    monkeypatch.setenv("MCRT_TEST_HOOKS", "1")
     tr, sim = _sim(mcrt, cfg, sd, 16, 64, texture=tex256)
     good = sim.frame(3, convolve=False).copy()
     assert np.isfinite(good).all() and np.abs(good).sum() > 0
