@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define MCRT_VERSION 104   /* round 3: + mcrt_trace_frames_poses, mcrt_envelope_frames, mcrt_scan_convert_frames; the slab rule of the closest-hit contract is one fma per plane;
-                              104: + the test hooks mcrt_debug_set_error, mcrt_debug_fast_paths; RF images are NaN while the device error word is set */
+#define MCRT_VERSION 105   /* round 3: + mcrt_trace_frames_poses, mcrt_envelope_frames, mcrt_scan_convert_frames; the slab rule of the closest-hit contract is one fma per plane;
+                              104: + the test hooks mcrt_debug_set_error, mcrt_debug_fast_paths; RF images are NaN while the device error word is set;
+                              105 (round 4): + mcrt_group_* (several GPUs behind one call), mcrt_scan_maps; the scan-conversion maps follow the reference's float promotions */
 
 typedef enum {
     MCRT_OK = 0,
@@ -209,6 +210,48 @@ int mcrt_export_rf(mcrt_ctx *ctx, const float *rf_dev, uint32_t n_elements, uint
 /* host [R][E] row-major (the cv::Mat layout)  ->  device [E][R]: the inverse of mcrt_export_rf, for callers that deposit
  * echoes on the host (rf_image::add_echo, rfimage.h:33-40) and post-process on the GPU; synchronous */
 int mcrt_import_rf(mcrt_ctx *ctx, const float *host_rows_by_cols, uint32_t n_elements, uint32_t n_rows, float *rf_dev);
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Several GPUs of one node behind the same calls (the reference's frame loop main.cpp:92-152 is one GPU-less thread).
+ * Paths are independent and deposit only into their own scan-line's column (main.cpp:128,139 use ray_i as the column), so the
+ * scan-lines are cut into contiguous shards -- rank g of G traces [g*E/G, (g+1)*E/G), the first E % G ranks one more -- with scene,
+ * texture and transducer replicated; every rank's [F][E_g][R] block then crosses xGMI once (hipMemcpyPeerAsync on the rank's own copy
+ * stream) into GPU devices[0], where one kernel lays the blocks out as the [F][E][R] frames a single context would have produced, bit
+ * for bit (RF bins are integer sums: no partition changes them).  PSF, envelope and scan conversion need neighbouring columns
+ * (rfimage.h:113-118) and run on the gathered frames: call mcrt_convolve_frames / mcrt_envelope_frames / mcrt_scan_convert_frames on
+ * mcrt_group_root().
+ * A group owns one tracing context per listed device (each driven by its own host thread, so G GPUs are fed in parallel) and a root
+ * context on devices[0] for the gathered frames.  A device may be listed more than once: its contexts then share that GPU (how the
+ * one-GPU test box runs a two-rank group).  Passes are DOUBLE-BUFFERED: mcrt_group_trace_frames returns once everything is enqueued,
+ * the ranks' next pass does not wait for the root's stream, so post-processing pass k on the root overlaps the trace of pass k+1
+ * (alternate two rf_dev buffers to use it).  Errors: the first failing rank's status, its message prefixed with "rank r:". */
+typedef struct mcrt_group mcrt_group;
+int mcrt_group_create(const int *devices, uint32_t n_devices, mcrt_group **out);
+int mcrt_group_destroy(mcrt_group *grp);
+int mcrt_group_size(const mcrt_group *grp);                        /* ranks (0 for NULL) */
+mcrt_ctx *mcrt_group_root(mcrt_group *grp);                        /* context on devices[0] that owns the gathered frames: post-processing, mcrt_alloc, exports */
+mcrt_ctx *mcrt_group_member(mcrt_group *grp, uint32_t rank);       /* the rank's tracing context (statistics, timing, mcrt_cast_rays on one shard) */
+/* the contiguous scan-line shard of `rank` when n_elements are cut over n_ranks (no group needed) */
+int mcrt_group_shard(uint32_t rank, uint32_t n_ranks, uint32_t n_elements, uint32_t *e_begin, uint32_t *e_end);
+/* the replicated set-up calls: the single-context call of the same name on every rank (concurrently), params also on the root */
+int mcrt_group_set_params(mcrt_group *grp, const mcrt_params *p);
+int mcrt_group_set_bvh_builder(mcrt_group *grp, int builder);
+int mcrt_group_upload_scene(mcrt_group *grp, const float *tri_xyz, const uint32_t *tri_mesh, uint32_t n_tri, const mcrt_mesh *meshes, uint32_t n_mesh,
+                            const float *materials, uint32_t n_mat, uint32_t start_mat, const float spacing[3]);
+int mcrt_group_update_triangles(mcrt_group *grp, const float *tri_xyz_host, uint32_t n_tri);      /* host pointers only: a device pointer belongs to one GPU */
+int mcrt_group_refit_triangles(mcrt_group *grp, const float *tri_xyz_host, uint32_t n_tri);
+int mcrt_group_upload_texture(mcrt_group *grp, const float *voxels, uint32_t n);                  /* NULL: the reference's texture, generated once */
+int mcrt_group_set_transducer(mcrt_group *grp, const float *pos, const float *dir, uint32_t n_elements);   /* all E elements */
+/* mcrt_trace_frames over the whole group: rf_dev is a device buffer [n_frames][E][R] ON devices[0]; asynchronous -- the frames are
+ * complete on the ROOT context's stream (anything enqueued on mcrt_group_root() afterwards sees them; mcrt_group_synchronize waits). */
+int mcrt_group_trace_frames(mcrt_group *grp, uint32_t frame_id, uint32_t n_frames, float *rf_dev);
+/* ... with a probe pose per frame (mcrt_trace_frames_poses); pos / dir: HOST tables [n_frames][E][3], copied before the call returns */
+int mcrt_group_trace_frames_poses(mcrt_group *grp, uint32_t frame_id, uint32_t n_frames, const float *pos, const float *dir, float *rf_dev);
+/* waits for every rank and the root; reports a rank's device error word as mcrt_synchronize does */
+int mcrt_group_synchronize(mcrt_group *grp);
+/* per rank, the device time of its last mcrt_group_trace_frames* pass: trace (k_init .. k_finalize) and its block's peer copy, in ms
+ * (HIP events on the rank's streams; synchronises).  trace_ms / copy_ms: [mcrt_group_size()] each, either may be NULL */
+int mcrt_group_last_pass_ms(mcrt_group *grp, float *trace_ms, float *copy_ms);
 
 /* device memory helpers for callers without their own allocator */
 int mcrt_alloc(mcrt_ctx *ctx, size_t bytes, void **dev);

@@ -113,17 +113,22 @@ class Psf:
 
 # ------------------------------------------------------------------ C-ABI context
 class Context:
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
         self.L = load_library()
-        h = C.c_void_p()
-        check(self.L.mcrt_create(device, C.byref(h)))
+        self.owned = _borrowed is None
+        if self.owned:
+            h = C.c_void_p()
+            check(self.L.mcrt_create(device, C.byref(h)))
+        else:                                   # a context that belongs to a Group (root / member): not destroyed here
+            h = C.c_void_p(_borrowed)
         self.h = h
         self.params = Params()
         check(self.L.mcrt_default_params(C.byref(self.params)))
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.mcrt_destroy(self.h)
+            if self.owned:
+                self.L.mcrt_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -322,6 +327,98 @@ class Context:
         c = np.asarray(ctr, np.uint32); k = np.asarray(key, np.uint32); o = np.zeros(4, np.uint32)
         check(self.L.mcrt_debug_philox(self.h, ptr(c), ptr(k), ptr(o)))
         return o
+
+
+# ------------------------------------------------------------------ several GPUs behind one call (mcrt_group_*)
+def shard_range(rank, n_ranks, n_elements):
+    """the contiguous scan-line block of `rank` (mcrt_group_shard; dist.shard_range is the same rule in Python)"""
+    b = C.c_uint32(); e = C.c_uint32()
+    check(load_library().mcrt_group_shard(rank, n_ranks, n_elements, C.byref(b), C.byref(e)))
+    return int(b.value), int(e.value)
+
+
+class Group:
+    """mcrt_group: one tracing context per listed device (a device may repeat), scan-lines cut into contiguous shards, the blocks
+    gathered on devices[0].  `root` is the context that owns the gathered frames (post-processing, alloc, exports)."""
+
+    def __init__(self, devices):
+        self.L = load_library()
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        check(self.L.mcrt_group_create(C.cast(devs, C.c_void_p), len(devices), C.byref(h)))
+        self.h = h
+        self.size = int(self.L.mcrt_group_size(self.h))
+        self.root = Context(_borrowed=self.L.mcrt_group_root(self.h))
+        self.members = [Context(_borrowed=self.L.mcrt_group_member(self.h, r)) for r in range(self.size)]
+        self.params = Params()
+        check(self.L.mcrt_default_params(C.byref(self.params)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mcrt_group_destroy(self.h)
+            self.h = None
+            self.root.h = None
+            for m in self.members:
+                m.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.params, k):
+                raise AttributeError(k)
+            setattr(self.params, k, v)
+        check(self.L.mcrt_group_set_params(self.h, C.byref(self.params)))
+        for c in [self.root] + self.members:
+            check(self.L.mcrt_get_params(c.h, C.byref(c.params)))
+
+    def set_bvh_builder(self, builder):
+        kind = {"sah": 0, "lbvh": 1}[builder] if isinstance(builder, str) else int(builder)
+        check(self.L.mcrt_group_set_bvh_builder(self.h, kind))
+
+    def upload_scene(self, sd):
+        meshes = (MeshRec * len(sd.meshes))(*[MeshRec(a, b, c, 0) for a, b, c in sd.meshes])
+        sp = np.asarray(sd.spacing, np.float32)
+        check(self.L.mcrt_group_upload_scene(self.h, ptr(sd.tri), ptr(sd.tri_mesh), sd.n_tri, C.cast(meshes, C.c_void_p), len(sd.meshes),
+                                             ptr(sd.materials), sd.materials.shape[0], sd.start_mat, ptr(sp)))
+
+    def update_triangles(self, tri):
+        tri = np.ascontiguousarray(tri, np.float32).reshape(-1, 9)
+        check(self.L.mcrt_group_update_triangles(self.h, ptr(tri), tri.shape[0]))
+
+    def refit_triangles(self, tri):
+        tri = np.ascontiguousarray(tri, np.float32).reshape(-1, 9)
+        check(self.L.mcrt_group_refit_triangles(self.h, ptr(tri), tri.shape[0]))
+
+    def upload_texture(self, vox=None, n=256):
+        if vox is not None:
+            vox = np.ascontiguousarray(vox, np.float32)
+        check(self.L.mcrt_group_upload_texture(self.h, ptr(vox), n))
+
+    def set_transducer(self, pos, d):
+        pos = np.ascontiguousarray(pos, np.float32); d = np.ascontiguousarray(d, np.float32)
+        check(self.L.mcrt_group_set_transducer(self.h, ptr(pos), ptr(d), pos.shape[0]))
+
+    def trace_frames(self, frame_id, n_frames, rf_dev):
+        """rf_dev: [n_frames][E][R] on devices[0]; complete on the root context's stream"""
+        check(self.L.mcrt_group_trace_frames(self.h, frame_id, n_frames, ptr(rf_dev)))
+
+    def trace_frames_poses(self, frame_id, pos, dirs, rf_dev):
+        pos = np.ascontiguousarray(pos, np.float32); dirs = np.ascontiguousarray(dirs, np.float32)
+        assert tuple(pos.shape) == (pos.shape[0], self.params.n_elements, 3) and tuple(dirs.shape) == tuple(pos.shape)
+        check(self.L.mcrt_group_trace_frames_poses(self.h, frame_id, pos.shape[0], ptr(pos), ptr(dirs), ptr(rf_dev)))
+
+    def synchronize(self):
+        check(self.L.mcrt_group_synchronize(self.h))
+
+    def last_pass_ms(self):
+        t = np.zeros(self.size, np.float32); c = np.zeros(self.size, np.float32)
+        check(self.L.mcrt_group_last_pass_ms(self.h, ptr(t), ptr(c)))
+        return t, c
 
 
 # ------------------------------------------------------------------ frame-level mirror of main.cpp:92-152

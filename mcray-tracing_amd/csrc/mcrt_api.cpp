@@ -364,6 +364,7 @@ extern "C" int mcrt_destroy(mcrt_ctx *c)
     return MCRT_OK;
 }
 
+namespace mcrt { hipStream_t ctx_stream(mcrt_ctx *c) { return c->stream; } }   // (mcrt_group.cpp: the root context's stream)
 extern "C" int mcrt_set_stream(mcrt_ctx *c, void *s) { CTX_TRY(c); c->stream = s ? (hipStream_t)s : c->own_stream; return MCRT_OK; }
 static int check_device_error(mcrt_ctx *c)
 {

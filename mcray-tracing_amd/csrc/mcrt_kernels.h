@@ -58,6 +58,7 @@ hipError_t launch_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t 
 hipError_t launch_convolve(float *img, float *tmp, uint32_t n_img, uint32_t E, uint32_t R, const ConvTaps &taps, hipStream_t st);
 hipError_t launch_envelope(float *img, uint32_t E, uint32_t R, hipStream_t st);
 hipError_t launch_remap(const float *img, uint32_t n_img, uint32_t E, uint32_t R, const float *map_col, const float *map_row, float *out, uint32_t n, hipStream_t st);
+hipError_t launch_blocks_to_frames(const float *blocks, float *frames, uint32_t F, uint32_t E, uint32_t R, uint32_t G, const uint32_t *off /*[G+1]*/, hipStream_t st);   // at most 64 ranks
 hipError_t launch_transpose(const float *in, float *out, uint32_t E, uint32_t R, hipStream_t st);
 hipError_t launch_math_probe(int op, const double *x, const double *y, double *out, uint32_t n, hipStream_t st);
 hipError_t launch_verify_div(float res, float rcp, unsigned long long *bad, hipStream_t st);

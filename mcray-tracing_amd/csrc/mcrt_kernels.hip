@@ -1528,6 +1528,22 @@ __global__ void k_transpose(const float *in, float *out, uint32_t E, uint32_t R)
     }
 }
 
+// The ranks' blocks, as they arrive from the other GPUs -- rank g's [F][ne_g][R] one after the other -- laid out as the frames
+// [F][E][R] a single context would have written (mcrt_group_trace_frames): one float4 per lane where R allows, else scalars.
+// off[g] = first scan-line of rank g (off[G] = E); the block of rank g starts at float offset F * off[g] * R of `blocks`.
+struct GroupOffsets { uint32_t off[65]; };
+template <typename V>
+__global__ void k_blocks_to_frames(const V *blocks, V *frames, uint32_t F, uint32_t E, uint32_t Rv, uint32_t G, GroupOffsets o)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // element of `frames`
+    if (i >= (size_t)F * E * Rv) return;
+    const uint32_t r = (uint32_t)(i % Rv), e = (uint32_t)((i / Rv) % E), f = (uint32_t)(i / ((size_t)Rv * E));
+    uint32_t g = 0;
+    while (g + 1u < G && e >= o.off[g + 1u]) g++;
+    const uint32_t ne = o.off[g + 1u] - o.off[g];
+    frames[i] = blocks[((size_t)F * o.off[g] + (size_t)f * ne + (e - o.off[g])) * Rv + r];
+}
+
 __global__ void k_math_probe(int op, const double *x, const double *y, double *out, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1695,6 +1711,18 @@ hipError_t launch_envelope(float *img, uint32_t E, uint32_t R, hipStream_t st)
 hipError_t launch_remap(const float *img, uint32_t n_img, uint32_t E, uint32_t R, const float *map_col, const float *map_row, float *out, uint32_t n, hipStream_t st)
 {
     hipLaunchKernelGGL(k_remap, dim3((n + 255) / 256, n_img), dim3(256), 0, st, img, E, R, map_col, map_row, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_blocks_to_frames(const float *blocks, float *frames, uint32_t F, uint32_t E, uint32_t R, uint32_t G, const uint32_t *off, hipStream_t st)
+{
+    GroupOffsets o;
+    for (uint32_t g = 0; g <= G && g < 65u; g++) o.off[g] = off[g];
+    const bool vec = (R % 4u) == 0u && ((uintptr_t)blocks % 16u) == 0u && ((uintptr_t)frames % 16u) == 0u;
+    const uint32_t Rv = vec ? R / 4u : R;
+    const size_t n = (size_t)F * E * Rv;
+    if (vec) hipLaunchKernelGGL((k_blocks_to_frames<float4>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float4 *)blocks, (float4 *)frames, F, E, Rv, G, o);
+    else hipLaunchKernelGGL((k_blocks_to_frames<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, blocks, frames, F, E, Rv, G, o);
     return hipGetLastError();
 }
 

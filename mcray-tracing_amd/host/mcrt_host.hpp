@@ -243,11 +243,35 @@ public:
 };
 
 // ---------------------------------------------------------------- GPU context shared by scene and rf_image
+// One GPU (mcrt_ctx), or several behind the same objects (mcrt_group: scan-line shards, blocks gathered on the first device; a
+// device may be listed more than once).  `ctx` is the context the images live on -- the group's root -- in either case.
 struct device {
     explicit device(int id = 0) { check(mcrt_create(id, &ctx), "mcrt_create"); }
-    ~device() { mcrt_destroy(ctx); }
+    explicit device(const std::vector<int> &ids)
+    {
+        if (ids.size() == 1) { check(mcrt_create(ids[0], &ctx), "mcrt_create"); return; }
+        check(mcrt_group_create(ids.data(), (uint32_t)ids.size(), &group), "mcrt_group_create");
+        ctx = mcrt_group_root(group);
+    }
+    ~device() { if (group) mcrt_group_destroy(group); else mcrt_destroy(ctx); }
     device(const device &) = delete; device &operator=(const device &) = delete;
+    mcrt_ctx *tracer() const { return group ? mcrt_group_member(group, 0) : ctx; }      // for calls on one shard (scene::cast_rays)
+    // the set-up and trace calls, on the one context or on every rank of the group
+    int set_params(const mcrt_params *p) { return group ? mcrt_group_set_params(group, p) : mcrt_set_params(ctx, p); }
+    int upload_scene(const float *tri, const uint32_t *tri_mesh, uint32_t n_tri, const mcrt_mesh *meshes, uint32_t n_mesh, const float *mats, uint32_t n_mat, uint32_t start_mat, const float *spacing)
+    {
+        return group ? mcrt_group_upload_scene(group, tri, tri_mesh, n_tri, meshes, n_mesh, mats, n_mat, start_mat, spacing)
+                     : mcrt_upload_scene(ctx, tri, tri_mesh, n_tri, meshes, n_mesh, mats, n_mat, start_mat, spacing);
+    }
+    int upload_texture(const float *vox, uint32_t n) { return group ? mcrt_group_upload_texture(group, vox, n) : mcrt_upload_texture(ctx, vox, n); }
+    int set_transducer(const float *pos, const float *dir, uint32_t n) { return group ? mcrt_group_set_transducer(group, pos, dir, n) : mcrt_set_transducer(ctx, pos, dir, n); }
+    int trace_frames(uint32_t frame, uint32_t n_frames, uint32_t columns, float *rf_dev)
+    {
+        return group ? mcrt_group_trace_frames(group, frame, n_frames, rf_dev) : mcrt_trace_frames(ctx, frame, n_frames, 0, columns, rf_dev);
+    }
+    int synchronize() { return group ? mcrt_group_synchronize(group) : mcrt_synchronize(ctx); }
     mcrt_ctx *ctx = nullptr;
+    mcrt_group *group = nullptr;
 };
 // the reference's objects take no device argument: they share this process-wide one (GPU 0), created on first use
 inline std::shared_ptr<device> default_device()
@@ -295,14 +319,14 @@ public:
         catch (const std::exception &ex) { throw std::runtime_error{ "Error while loading scene: " + std::string{ ex.what() } }; }
         mcrt_params p; mcrt_default_params(&p);
         p.n_elements = (uint32_t)N; p.n_samples = samples; p.frequency = t.frequency; p.seed = seed;
-        check(mcrt_set_params(this->dev->ctx, &p), "mcrt_set_params");
+        check(this->dev->set_params(&p), "mcrt_set_params");
         params = p;
         init();
-        check(mcrt_upload_texture(this->dev->ctx, nullptr, p.tex_n), "mcrt_upload_texture");     // static volume_ texture_volume (main.cpp:52)
+        check(this->dev->upload_texture(nullptr, p.tex_n), "mcrt_upload_texture");     // static volume_ texture_volume (main.cpp:52)
         set_transducer(t);
     }
 
-    template <size_t N> void set_transducer(const transducer<N> &t) { check(mcrt_set_transducer(dev->ctx, t.pos.data(), t.dir.data(), (uint32_t)N), "mcrt_set_transducer"); }
+    template <size_t N> void set_transducer(const transducer<N> &t) { check(dev->set_transducer(t.pos.data(), t.dir.data(), (uint32_t)N), "mcrt_set_transducer"); }
 
     // scene::cast_rays<sample_count, ray_count>(transducer) (scene.h:29-30, scene.cpp:50-183): the segments of every
     // (element, sample) path, traced on the GPU.  The reference draws fresh random numbers on every call (random_device);
@@ -314,12 +338,12 @@ public:
         if (params.n_samples != sample_count || params.n_elements != ray_count) {
             check(mcrt_get_params(dev->ctx, &params), "mcrt_get_params");
             params.n_samples = sample_count; params.n_elements = ray_count;
-            check(mcrt_set_params(dev->ctx, &params), "mcrt_set_params");
+            check(dev->set_params(&params), "mcrt_set_params");
         }
         set_transducer(t);
         const size_t B = params.max_depth;
         std::vector<mcrt_segment> flat((size_t)ray_count * sample_count * B); std::vector<uint32_t> cnt((size_t)ray_count * sample_count);
-        check(mcrt_cast_rays(dev->ctx, frame_id++, 0, ray_count, flat.data(), cnt.data(), nullptr), "mcrt_cast_rays");
+        check(mcrt_cast_rays(dev->tracer(), frame_id++, 0, ray_count, flat.data(), cnt.data(), nullptr), "mcrt_cast_rays");
         std::array<std::array<std::vector<ray_physics::segment>, sample_count>, ray_count> out;
         for (size_t e = 0; e < ray_count; e++)
             for (size_t s = 0; s < sample_count; s++) {
@@ -339,7 +363,7 @@ public:
     {
         const size_t E = params.n_elements, S = params.n_samples, B = params.max_depth;
         std::vector<mcrt_segment> flat(E * S * B); std::vector<uint32_t> cnt(E * S);
-        check(mcrt_cast_rays(dev->ctx, frame, 0, (uint32_t)E, flat.data(), cnt.data(), nullptr), "mcrt_cast_rays");
+        check(mcrt_cast_rays(dev->tracer(), frame, 0, (uint32_t)E, flat.data(), cnt.data(), nullptr), "mcrt_cast_rays");
         std::vector<std::vector<std::vector<mcrt_segment>>> out(E, std::vector<std::vector<mcrt_segment>>(S));
         for (size_t e = 0; e < E; e++)
             for (size_t s = 0; s < S; s++) {
@@ -407,7 +431,7 @@ private:
             tri_mesh.insert(tri_mesh.end(), t9.size() / 9, (uint32_t)mi);
             recs.push_back(mcrt_mesh{ m.material_inside, m.material_outside, m.is_vascular ? 1u : 0u, 0u });
         }
-        check(mcrt_upload_scene(dev->ctx, tri.data(), tri_mesh.data(), (uint32_t)(tri.size() / 9), recs.data(), (uint32_t)recs.size(),
+        check(dev->upload_scene(tri.data(), tri_mesh.data(), (uint32_t)(tri.size() / 9), recs.data(), (uint32_t)recs.size(),
                                 &materials[0].impedance, (uint32_t)materials.size(), material_index(starting_material), spacing.data()), "mcrt_upload_scene");
     }
 };
@@ -456,9 +480,9 @@ public:
         mcrt_params p; check(mcrt_get_params(dev->ctx, &p), "mcrt_get_params");
         if (p.n_rows != max_rows || p.n_elements != columns) {       // the image's shape is the kernel's: rows from THIS image's template arguments
             p.n_rows = max_rows; p.n_elements = columns; p.speed_of_sound = speed_of_sound;
-            check(mcrt_set_params(dev->ctx, &p), "mcrt_set_params");
+            check(dev->set_params(&p), "mcrt_set_params");
         }
-        check(mcrt_trace_frame(dev->ctx, frame_id, 0, columns, rf_dev), "mcrt_trace_frame");
+        check(dev->trace_frames(frame_id, 1, columns, rf_dev), "mcrt_trace_frame");       // (every GPU of a group traces its scan-line shard)
         where = on_device;
     }
     template <typename psf_> void convolve(const psf_ &p)

@@ -453,6 +453,12 @@ def test_cpp_host_cli_matches_oracle(mcrt, orc, tex256, tmp_path):
     ax, lat = orc.psf()
     ref = orc.envelope(orc.convolve(o["rf"], ax, lat))
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # the same program over a GROUP (mcrt_group_*: here three ranks sharing GPU 0, 171 + 171 + 170 scan-lines): the same image and B-mode file
+    r3 = subprocess.run([exe, str(tmp_path / "sphere.scene"), "3", "5", str(tmp_path / "bmode3.pgm"), str(tmp_path / "rf3.bin"), "--devices", "0,0,0"],
+                        capture_output=True, text=True, timeout=240)
+    assert r3.returncode == 0 and "3 GPU context(s)" in r3.stdout, r3.stdout + r3.stderr
+    assert np.array_equal(np.fromfile(str(tmp_path / "rf3.bin"), np.uint32), got.view(np.uint32).ravel())
+    assert (tmp_path / "bmode3.pgm").read_bytes() == (tmp_path / "bmode.pgm").read_bytes()
     bad = subprocess.run([exe, str(tmp_path / "missing.scene")], capture_output=True, text=True)
     assert bad.returncode == 1 and "The program found an error" in bad.stdout
 

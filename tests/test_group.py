@@ -1,0 +1,130 @@
+"""mcrt_group_*: several GPUs of one node behind the C-ABI (the frame loop main.cpp:92-152 sharded by scan-line).
+On the one-GPU box a group lists device 0 several times: its ranks then share the GPU, every code path of the real thing runs
+(the ranks' host threads, shard ranges, block buffers, peer copies, the interleaving kernel, the double buffering) except the
+xGMI hop itself."""
+import ctypes as C
+import numpy as np
+import pytest
+
+
+def test_shard_rule_and_argument_errors(mcrt):
+    """mcrt_group_shard == dist.shard_range (contiguous blocks, the first E % G ranks one more); bad arguments are refused; without
+    a GPU the group fails as loudly as a context"""
+    from mcray_tracing_amd.dist import shard_range
+    for E in (1, 7, 128, 512, 1000):
+        for G in (1, 2, 3, 8, 64):
+            cover = []
+            for r in range(G):
+                assert mcrt.shard_range(r, G, E) == shard_range(r, G, E)
+                cover += list(range(*mcrt.shard_range(r, G, E)))
+            assert cover == list(range(E))
+    L = mcrt.load_library()
+    b = C.c_uint32(); e = C.c_uint32()
+    assert L.mcrt_group_shard(3, 3, 10, C.byref(b), C.byref(e)) == -1
+    assert L.mcrt_group_shard(0, 0, 10, C.byref(b), C.byref(e)) == -1
+    h = C.c_void_p()
+    assert L.mcrt_group_create(None, 2, C.byref(h)) == -1 and h.value is None
+    assert L.mcrt_group_size(None) == 0 and L.mcrt_group_root(None) is None
+    assert L.mcrt_group_trace_frames(None, 0, 1, None) == -1 and b"null group" in L.mcrt_last_error()
+    assert L.mcrt_group_synchronize(None) == -1 and L.mcrt_group_destroy(None) == 0
+    if L.mcrt_device_count() == 0:
+        with pytest.raises(mcrt.McrtError) as ex:
+            mcrt.Group([0, 0])
+        assert ex.value.code == -4 and "no CPU fallback" in str(ex.value)
+
+
+def _setup(obj, mcrt, sd, tr, S, tex, **params):
+    obj.set_params(n_elements=tr.n_elements, n_samples=S, frequency=tr.frequency, **params)
+    obj.upload_scene(sd)
+    obj.upload_texture(tex, 256)
+    obj.set_transducer(tr.pos, tr.dir)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,E", [(2, 16), (3, 16), (1, 8)])
+def test_group_equals_single_context(mcrt, sphere, tex256, ranks, E):
+    """a group of `ranks` contexts on GPU 0 (even and ragged shards, and the one-rank group) == one context, bit for bit: one frame,
+    the frames of a pass, successive passes on alternating buffers (the double buffering), a pass with a probe pose per frame, and
+    the whole B-mode frame post-processed on the root context"""
+    cfg, sd = sphere
+    S = 64
+    tr = mcrt.Transducer(E, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
+    one = mcrt.Context(0); _setup(one, mcrt, sd, tr, S, tex256)
+    grp = mcrt.Group([0] * ranks); _setup(grp, mcrt, sd, tr, S, tex256)
+    assert grp.size == ranks
+    R = one.params.n_rows
+    psf = mcrt.Psf(freq=tr.frequency)
+    F = 3
+    ref_dev = one.alloc(F * E * R * 4)
+    bufs = [grp.root.alloc(F * E * R * 4) for _ in range(2)]
+    img_one, img_grp = one.alloc(F * 400 * 500 * 4), grp.root.alloc(F * 400 * 500 * 4)
+
+    def single(frame, nf):
+        one.trace_frames(frame, nf, ref_dev)
+        return one.d2h(ref_dev, (nf, E, R))
+
+    # one frame (blocks land in place), then passes of 3 on alternating buffers WITHOUT synchronising in between
+    grp.trace_frames(7, 1, bufs[0]); grp.synchronize()
+    assert np.array_equal(grp.root.d2h(bufs[0], (1, E, R)).view(np.uint32), single(7, 1).view(np.uint32))
+    want = [single(10 + 3 * k, F) for k in range(4)]
+    got = []
+    for k in range(4):
+        grp.trace_frames(10 + 3 * k, F, bufs[k & 1])
+        if k >= 1:      # the previous pass's frames, read on the ROOT's stream while this pass is in flight
+            got.append(grp.root.d2h(bufs[(k - 1) & 1], (F, E, R)))
+    grp.synchronize()
+    got.append(grp.root.d2h(bufs[1], (F, E, R)))
+    for k in range(4):
+        assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), k
+    assert np.abs(want[0]).sum() > 0 and not np.array_equal(want[0], want[1])
+    t_ms, c_ms = grp.last_pass_ms()
+    assert (t_ms > 0).all() and (c_ms >= 0).all()
+
+    # the whole B-mode frame: PSF, envelope, scan conversion of the gathered frames on the root context
+    for ctx, dev, img in ((one, ref_dev, img_one), (grp.root, bufs[0], img_grp)):
+        if ctx is one:
+            one.trace_frames(30, F, dev)
+        else:
+            grp.trace_frames(30, F, dev)
+        ctx.convolve_frames(dev, F, E, R, psf.axial_kernel, psf.lateral_kernel)
+        ctx.envelope_frames(dev, F, E, R)
+        ctx.scan_convert_frames(dev, F, E, R, img)
+    grp.synchronize(); one.synchronize()
+    a, b = one.d2h(img_one, (F, 400, 500)), grp.root.d2h(img_grp, (F, 400, 500))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.abs(a).sum() > 0
+
+    # a probe pose per frame of the pass
+    poses = [mcrt.Transducer(E, position=np.asarray(cfg["transducerPosition"], np.float64) + np.array([0.0, 0.2 * f, 0.0]),
+                             angles_deg=np.asarray(cfg["transducerAngles"], np.float64) + np.array([2.0 * f, 0.0, -1.0 * f])) for f in range(F)]
+    pos = np.stack([t.pos for t in poses]); dirs = np.stack([t.dir for t in poses])
+    one.trace_frames_poses(50, pos, dirs, ref_dev)
+    grp.trace_frames_poses(50, pos, dirs, bufs[1]); grp.synchronize()
+    assert np.array_equal(one.d2h(ref_dev, (F, E, R)).view(np.uint32), grp.root.d2h(bufs[1], (F, E, R)).view(np.uint32))
+
+    # a rank's error comes back with its rank: a transducer of the wrong size
+    with pytest.raises(mcrt.McrtError, match="rank 0"):
+        grp.set_transducer(tr.pos[:4], tr.dir[:4])
+    for d in bufs + [img_grp]:
+        grp.root.free(d)
+    one.free(ref_dev); one.free(img_one)
+    grp.close(); one.close()
+
+
+@pytest.mark.gpu
+def test_group_moving_geometry_and_device_builder(mcrt, sphere, tex256):
+    """mcrt_group_set_bvh_builder / _update_triangles / _refit_triangles reach every rank: frames equal a single context's"""
+    cfg, sd = sphere
+    E, S, F = 12, 32, 2
+    tr = mcrt.Transducer(E, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
+    one = mcrt.Context(0); one.set_bvh_builder("lbvh"); _setup(one, mcrt, sd, tr, S, tex256)
+    grp = mcrt.Group([0, 0]); grp.set_bvh_builder("lbvh"); _setup(grp, mcrt, sd, tr, S, tex256)
+    R = one.params.n_rows
+    a_dev, b_dev = one.alloc(F * E * R * 4), grp.root.alloc(F * E * R * 4)
+    moved = sd.tri.reshape(-1, 9) + np.float32(0.05)
+    for step, (f1, fg) in enumerate(((None, None), (one.refit_triangles, grp.refit_triangles), (one.update_triangles, grp.update_triangles))):
+        if f1:
+            f1(moved * np.float32(1.0 + 0.01 * step)); fg(moved * np.float32(1.0 + 0.01 * step))
+        one.trace_frames(3, F, a_dev); grp.trace_frames(3, F, b_dev); grp.synchronize()
+        assert np.array_equal(one.d2h(a_dev, (F, E, R)).view(np.uint32), grp.root.d2h(b_dev, (F, E, R)).view(np.uint32)), step
+    one.free(a_dev); grp.root.free(b_dev)
+    grp.close(); one.close()
