@@ -54,13 +54,13 @@ TRACE_KERNELS = ("k_trace_lane<false",)   # the walk kernel of the timed build
 def build_workload(m, name):
     if name == "random1m":
         cfg, meshes = m.synth.random_scene(1_000_000, 8, 12345)
-        label = "synthetic 1M random triangles (8 meshes, PCG64 seed 12345)"
+        label = "1M random triangles (8 meshes, PCG64 12345)"
     elif name == "sphere":
         cfg, meshes = m.synth.sphere_scene(5)
-        label = "examples/sphere (generated icosphere 20480 tris + box)"
+        label = "examples/sphere (icosphere 20480 tris + box)"
     elif name == "liver":
         cfg, meshes = m.synth.liver_scene(5)
-        label = "ircad11-like synthetic liver scene (11 procedural organs, ~225k tris)"
+        label = "ircad11-like liver (11 organs, ~225k tris)"
     else:
         raise SystemExit("unknown workload " + name)
     return cfg, m.scene_io.build_scene(cfg, meshes), label
@@ -151,9 +151,9 @@ class Pipeline:
         self.ev_traced[i].record(self.s_trace)
         self.s_post.wait_event(self.ev_traced[i])
         with torch.cuda.stream(self.s_post):
-            # ONE collective per pass (RCCL all-gather over xGMI of the [nf][E/N][R] blocks), then the rest of the B-mode frames on rank 0
+            # ONE collective per pass (RCCL gather over xGMI of the [nf][E/N][R] blocks to rank 0), then the rest of the B-mode frames there
             if ev: ev[2].record(self.s_post)
-            frames = self.gather_rf(rf[:nf], self.E, self.R, self.dist if self.world > 1 else None)
+            frames = self.gather_rf(rf[:nf], self.E, self.R, self.dist if self.world > 1 else None, root=0 if self.world > 1 else None)   # to rank 0 only: it alone post-processes
             if ev: ev[3].record(self.s_post)
             if self.rank == 0:
                 self.ctx.set_stream(self.s_post.cuda_stream)
@@ -173,11 +173,16 @@ class Pipeline:
             f += nf
 
     def sync(self):
+        """barrier + synchronize: the bracket around a timed region.  At its END the clock is read after `drain()` and BEFORE this
+        (the maximum over the ranks is taken afterwards, so the barrier's own latency is not part of anybody's time)."""
         self.torch.cuda.synchronize()
         if self.world > 1:
             self.dist.barrier()
         self.torch.cuda.synchronize()
         self.ctx.synchronize()          # (raises if a persistent kernel's watchdog abandoned a launch: a number must not come from a broken frame)
+
+    def drain(self):
+        self.torch.cuda.synchronize()   # everything this rank enqueued -- its passes, the gather, rank 0's post-processing -- has finished
 
     def times(self, steps):
         """ms per step of this rank's trace / gather / post-processing over the passes recorded since `timing` was switched on"""
@@ -236,6 +241,10 @@ def main():
     psf = m.Psf(freq=tr.frequency)
     F = max(1, min(args.frames_in_flight, 256))
     K, W = args.steps, args.warmup
+    if world > 1 and K >= 2:
+        # N > 1: a timed region is cut into at least TWO passes, so that the gather + post-processing of a pass really run beside the
+        # next pass's trace inside the clock (with K <= frames in flight the region would be one pass with its gather and post exposed)
+        F = min(F, -(-K // 2))
     pipe = Pipeline(torch, dist, ctx, psf, rank, world, E, e0, e1, R, F, args.backend, not args.no_overlap)
 
     if args.pmc_child:
@@ -277,8 +286,9 @@ def main():
         pipe.sync()
         t0 = time.perf_counter()
         pipe.run_steps(0, K)
-        pipe.sync()
+        pipe.drain()
         dt = time.perf_counter() - t0
+        pipe.sync()
         dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)       # MAX over ranks (every rank then takes the same loop decisions)
@@ -324,9 +334,9 @@ def main():
             "value": rays / dt, "unit": "rays/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "frames_per_sec": K / dt, "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s; %d scan-lines x %d rays per GPU, %d RF rows, max depth 10" % (label, E_local, S, R),
+            "config": {"workload": "%s: %dx%d rays/GPU, depth 10, %d rows" % (label, E_local, S, R),
                        "scan_lines_total": E, "rays_per_scan_line": S, "triangles": int(sd.n_tri), "parallelism": "scanline-shard x%d" % world,
-                       "frames_in_flight": F, "passes_per_timed_region": pass_sizes, "timed_region_repeats": n_rep,
+                       "frames_in_flight": F, "passes_per_timed_region": pass_sizes, "gather": "none (one GPU)" if world == 1 else "RCCL gather of the scan-line blocks to rank 0, one per pass, double-buffered against the next pass's trace", "timed_region_repeats": n_rep,
                        "timed_seconds_total": total, "repeat_ms_per_step_min_median_max": [min(reps) / K * 1e3, dt / K * 1e3, max(reps) / K * 1e3], "slowest_repeat": reps.index(max(reps)),
                        "overlap_gather_psf_with_next_trace": not args.no_overlap, "bvh_builder": args.bvh, "bvh_build_s": round(t_bvh, 3),
                        "warmup_steps_run": W_run, "step": "clear, trace, accumulate, [all-gather], PSF, envelope, scan conversion to %dx%d" % (pipe.OUT_ROWS, pipe.OUT_COLS)},
@@ -594,8 +604,7 @@ def cpu_baseline(m, sd, tr, ctx, S, R, rf0):
     dt1 = time.perf_counter() - t1
     base = {"value": E * S * frames / dt, "unit": "rays/s", "cores": cores, "kind": "port", "host": core_info, "cores_kept_busy": round(busy, 1),
             "single_thread": {"value": n1 * S / dt1, "unit": "rays/s", "cores": 1, "sample": "%d scan-lines x %d rays, one thread" % (n1, S), "seconds": dt1},
-            "sample": "%d whole frame(s) of %d scan-lines x %d rays of the same workload, OpenMP over (scan-line x sample-block) tasks on %d threads "
-                      "(trace + RF accumulation, no PSF)" % (frames, E, S, cores),
+            "sample": "%d whole frame(s) of %dx%d rays, same workload, %d OpenMP threads (trace + accumulate, no PSF)" % (frames, E, S, cores),
             "seconds": dt}
     return base, parity
 

@@ -12,15 +12,18 @@ def shard_range(rank, world, n_elements):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def gather_rf(rf_local, n_elements, n_rows, dist=None, group=None):
+def gather_rf(rf_local, n_elements, n_rows, dist=None, group=None, root=None):
     """rf_local: this rank's scan-line block, [ne_local][R] for one frame or [F][ne_local][R] for the F frames of a pass
-    (tensor on the backend's device).  Returns the full image(s), [E][R] or [F][E][R], on every rank -- ONE collective
-    whatever F is.  The collective is enqueued on the CURRENT torch stream."""
+    (tensor on the backend's device).  Returns the full image(s), [E][R] or [F][E][R] -- ONE collective whatever F is, enqueued on
+    the CURRENT torch stream.  root=None: an all-gather, every rank gets the frames; root=r: a gather to rank r only (what the
+    B-mode pipeline needs: one rank post-processes), the other ranks get None and send their block once instead of receiving
+    world - 1 of them."""
     if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return rf_local
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "gloo" and rf_local.is_cuda:      # plumbing checks only: stage through the host
-        return gather_rf(rf_local.cpu(), n_elements, n_rows, dist, group).to(rf_local.device)
+        full = gather_rf(rf_local.cpu(), n_elements, n_rows, dist, group, root)
+        return None if full is None else full.to(rf_local.device)
     batched = rf_local.dim() == 3
     loc = rf_local if batched else rf_local.unsqueeze(0)            # [F][ne][R]
     F = loc.shape[0]
@@ -31,9 +34,17 @@ def gather_rf(rf_local, n_elements, n_rows, dist=None, group=None):
     else:                                                           # ragged shards: pad to the largest block
         mine = torch.zeros((F, ne_max, n_rows), dtype=loc.dtype, device=loc.device)
         mine[:, : loc.shape[1]] = loc
-    flat = torch.empty((world * F, ne_max, n_rows), dtype=loc.dtype, device=loc.device)      # rank blocks concatenated along dim 0
-    dist.all_gather_into_tensor(flat, mine, group=group)
-    stacked = flat.view(world, F, ne_max, n_rows)
+    if root is None:
+        flat = torch.empty((world * F, ne_max, n_rows), dtype=loc.dtype, device=loc.device)      # rank blocks concatenated along dim 0
+        dist.all_gather_into_tensor(flat, mine, group=group)
+        stacked = flat.view(world, F, ne_max, n_rows)
+    else:
+        me = dist.get_rank(group)
+        flat = torch.empty((world, F, ne_max, n_rows), dtype=loc.dtype, device=loc.device) if me == root else None
+        dist.gather(mine, list(flat.unbind(0)) if me == root else None, dst=dist.get_global_rank(group, root) if group is not None else root, group=group)
+        if me != root:
+            return None
+        stacked = flat
     if n_elements % world == 0:
         full = stacked.permute(1, 0, 2, 3).reshape(F, n_elements, n_rows)      # frame-major, rank blocks concatenated (a copy)
     else:

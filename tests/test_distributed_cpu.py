@@ -32,6 +32,12 @@ def _worker(rank, world, port, E, S, out_path):
     o3 = osc.trace_frame(p, tr.pos, tr.dir, tex, frame_id=3, e_begin=e0, e_end=e1, want_hits=False, want_ref=False)
     both = gather_rf(torch.stack([local, torch.from_numpy(np.ascontiguousarray(o3["rf"].T))]), E, p.n_rows, dist)
     assert both.shape == (2, E, p.n_rows) and torch.equal(both[0], full)
+    # gathered to ONE rank (what bench.py does for N > 1: only rank 0 post-processes): the same frames there, nothing elsewhere
+    for root in (0, 1):
+        at_root = gather_rf(torch.stack([local, torch.from_numpy(np.ascontiguousarray(o3["rf"].T))]), E, p.n_rows, dist, root=root)
+        assert (at_root is None) == (rank != root)
+        if rank == root:
+            assert torch.equal(at_root, both)
     if rank == 0:
         np.save(out_path, full.numpy())
         np.save(out_path + ".f3.npy", both[1].numpy())

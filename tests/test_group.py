@@ -101,9 +101,13 @@ def test_group_equals_single_context(mcrt, sphere, tex256, ranks, E):
     grp.trace_frames_poses(50, pos, dirs, bufs[1]); grp.synchronize()
     assert np.array_equal(one.d2h(ref_dev, (F, E, R)).view(np.uint32), grp.root.d2h(bufs[1], (F, E, R)).view(np.uint32))
 
-    # a rank's error comes back with its rank: a transducer of the wrong size
-    with pytest.raises(mcrt.McrtError, match="rank 0"):
-        grp.set_transducer(tr.pos[:4], tr.dir[:4])
+    # a rank's error comes back with its rank: a transducer of the wrong size is refused when the pass is traced
+    grp.set_transducer(tr.pos[:4], tr.dir[:4])
+    with pytest.raises(mcrt.McrtError, match=r"rank 0: transducer has 4 elements"):
+        grp.trace_frames(0, 1, bufs[0])
+    grp.set_transducer(tr.pos, tr.dir)
+    grp.trace_frames(7, 1, bufs[0]); grp.synchronize()
+    assert np.array_equal(grp.root.d2h(bufs[0], (1, E, R)).view(np.uint32), single(7, 1).view(np.uint32))
     for d in bufs + [img_grp]:
         grp.root.free(d)
     one.free(ref_dev); one.free(img_one)
