@@ -55,7 +55,7 @@ static Consts derive_consts(const mcrt_params &p)
 struct Work {
     hipStream_t stream = nullptr, side[MCRT_SIDE_STREAMS] = {};   // k_march of bounce b runs on side[b % n] (n = 1 unless MCRT_MARCH_STREAMS says otherwise)
     hipEvent_t ev_bounce[MCRT_MAX_BOUNCES] = {}, ev_join[MCRT_SIDE_STREAMS] = {}, ev_done = nullptr;
-    float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr, *d_ray0 = nullptr, *d_ray1 = nullptr;
+    float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr;
     unsigned long long *d_key0 = nullptr, *d_key1 = nullptr;
     int *d_stack_ovf = nullptr; size_t ovf_cap = 0;            // traversal-stack overflow of THIS work set's walk (its launches run beside the other groups')
     uint32_t *d_q = nullptr, *d_counts = nullptr, *d_seg_count = nullptr, *d_cursors = nullptr;
@@ -238,9 +238,9 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
 
 static void free_work_buffers(Work &w)
 {
-    hipFree(w.d_st0); hipFree(w.d_st1); hipFree(w.d_st2); hipFree(w.d_ray0); hipFree(w.d_ray1); hipFree(w.d_key0); hipFree(w.d_key1);
+    hipFree(w.d_st0); hipFree(w.d_st1); hipFree(w.d_st2); hipFree(w.d_key0); hipFree(w.d_key1);
     hipFree(w.d_q); hipFree(w.d_counts); hipFree(w.d_seg_count); hipFree(w.d_cursors); w.d_cursors = nullptr; hipFree(w.d_segs); hipFree(w.d_hits); hipFree(w.d_mrec);
-    w.d_st0 = w.d_st1 = w.d_st2 = w.d_ray0 = w.d_ray1 = nullptr; w.d_key0 = w.d_key1 = nullptr; w.d_q = w.d_counts = w.d_seg_count = nullptr;
+    w.d_st0 = w.d_st1 = w.d_st2 = nullptr; w.d_key0 = w.d_key1 = nullptr; w.d_q = w.d_counts = w.d_seg_count = nullptr;
     w.d_segs = nullptr; w.segs_cap = 0; w.d_hits = nullptr; w.hits_cap = 0; w.d_mrec = nullptr; w.paths = 0; w.depth = 0;
 }
 
@@ -731,7 +731,7 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne_frame, uint32_t n_frame
         w.d_segs = sg; w.segs_cap = sc; w.d_hits = ht; w.hits_cap = hc;
     }
     HIP_TRY(hipMalloc(&w.d_st0, 32 * np)); HIP_TRY(hipMalloc(&w.d_st1, 32 * np)); HIP_TRY(hipMalloc(&w.d_st2, 32 * np));   // two halves: bounce parity
-    HIP_TRY(hipMalloc(&w.d_ray0, 32 * np)); HIP_TRY(hipMalloc(&w.d_ray1, 32 * np)); HIP_TRY(hipMalloc(&w.d_key0, 8 * np)); HIP_TRY(hipMalloc(&w.d_key1, 8 * np));
+    HIP_TRY(hipMalloc(&w.d_key0, 8 * np)); HIP_TRY(hipMalloc(&w.d_key1, 8 * np));
     HIP_TRY(hipMalloc(&w.d_q, 8 * np)); HIP_TRY(hipMalloc(&w.d_seg_count, 4 * np));
     HIP_TRY(hipMalloc(&w.d_counts, 4 * (MCRT_MAX_BOUNCES + 1)));
     HIP_TRY(hipMalloc(&w.d_cursors, 4 * (size_t)MCRT_MAX_BOUNCES * MCRT_XCDS * MCRT_CURSOR_STRIDE));
@@ -750,7 +750,7 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     a.acc = c->d_acc; a.flags = c->d_flags;                 // the frame block [n_frames][acc_ne][R]; this group owns columns e0-acc_e0 ...
     a.acc_stride = acc_ne; a.acc_off = e0 - acc_e0;
     a.st0 = w.d_st0; a.st1 = w.d_st1; a.st2 = w.d_st2; a.queue = w.d_q;
-    a.ray0 = w.d_ray0; a.ray1 = w.d_ray1; a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.cursors = w.d_cursors; a.segs = w.d_segs; a.hits = w.d_hits; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
+    a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.cursors = w.d_cursors; a.segs = w.d_segs; a.hits = w.d_hits; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
     a.stats = c->d_stats; a.error_flag = c->d_error; a.stamps = c->d_stats + 8;
     a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
     a.e_begin = e0; a.ne_frame = e1 - e0; a.ne = (e1 - e0) * n_frames;   // n_frames consecutive frame ids traced as one pass

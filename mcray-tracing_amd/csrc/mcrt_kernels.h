@@ -19,9 +19,9 @@ struct FrameArgs {
     const double *row_thr;     // [R+1] row thresholds (see row_of)
     const uint32_t *frame_dev; // a device word ADDED to `frame`: 0 for direct launches; the frame number itself when the pass is replayed as a HIP graph (frame = 0 then)
     // per-frame work buffers; np = ne * S paths
-    float4 *st0, *st1, *st2;   // [2][np] path state in queue order, two halves by bounce parity: from,intensity | dir,media | distance_traveled(f64),outside,-
+    float4 *st0, *st1, *st2;   // [2][np] path state in queue order, two halves by bounce parity: from, ray length factor | dir, media | distance_traveled(f64), outside, intensity
+                               //         (the walk reads st0 + st1 and rebuilds the ray from them: ray_of)
     uint32_t *queue;           // [2][np] live path ids of bounce b in buffer b & 1
-    float4 *ray0, *ray1;       // [np][2] f2.xyz,to.x | to.yz, 1/d.x, 1/d.y   (d = to - f2; indexed by queue position), ping-pong
     unsigned long long *key0, *key1;   // [np] closest hit per ray: fraction bits << 32 | triangle id (atomicMin), ping-pong by bounce parity
     const uint32_t *tri_slot;  // [T] triangle id -> position in the leaf-order triangle array
     uint32_t *counts;          // [MAX_BOUNCES+1] live rays per bounce

@@ -324,11 +324,18 @@ MCRT_DEV uint32_t ksplit(uint32_t n, uint32_t limit)
     return k;
 }
 
-// max_ray_length (ray.cpp:110-113) + enlarge (scene.cpp:292-298) + the 0.1 start offset (scene.cpp:115)
-MCRT_DEV Ray make_ray(f3 from, f3 dir, float intensity, float att, const FrameArgs &a)
+// max_ray_length (ray.cpp:110-113) + enlarge (scene.cpp:292-298) + the 0.1 start offset (scene.cpp:115).
+// The segment a ray is tested on is a pure function of the path state -- origin, direction and the length factor L / 100 -- so the
+// state carries that ONE float (ray_len, evaluated once per bounce where intensity and medium are at hand) and both the walk and
+// k_shade rebuild the end points from it with the same expressions (ray_of): rounds 1-3 wrote a 32-byte ray record per ray and
+// bounce in k_shade and read it back twice.
+MCRT_DEV float ray_len(float intensity, float att, const FrameArgs &a)
 {
     const float L = 10.f * det_logf(a.eps / intensity) / -att * a.freq;
-    const float Ls = L / 100.0f;
+    return L / 100.0f;
+}
+MCRT_DEV Ray ray_of(f3 from, f3 dir, float Ls, const FrameArgs &a)
+{
     Ray r;
     r.to = mk(from.x + Ls * (a.sx * dir.x), from.y + Ls * (a.sy * dir.y), from.z + Ls * (a.sz * dir.z));
     r.f2 = mk(from.x + a.offs * dir.x, from.y + a.offs * dir.y, from.z + a.offs * dir.z);
@@ -354,15 +361,12 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
     const f3 from = mk(a.el_pos[3 * pe], a.el_pos[3 * pe + 1], a.el_pos[3 * pe + 2]);
     const f3 dir = mk(a.el_dir[3 * pe], a.el_dir[3 * pe + 1], a.el_dir[3 * pe + 2]);
     const float intensity = a.I0 / (float)a.S;
-    a.st0[pos] = make_float4(from.x, from.y, from.z, intensity);
+    a.st0[pos] = make_float4(from.x, from.y, from.z, ray_len(intensity, a.mats[2 * a.start_mat].y, a));   // origin | length factor of the ray (ray_of)
     a.st1[pos] = make_float4(dir.x, dir.y, dir.z, __int_as_float((int)a.start_mat));
-    a.st2[pos] = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), 0.0f);      // distance_traveled (double) | outside | -
+    a.st2[pos] = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), intensity);  // distance_traveled (double) | outside | intensity
     a.queue[pos] = pid;                                  // queue of bounce 0 (buffer 0 of two)
     a.seg_count[pid] = 0u;
     if (pos < a.ne) a.key0[pos] = MCRT_KEY_MISS;          // bounce 0: one closest-hit word per queued (scan-line, frame)
-    const Ray r = make_ray(from, dir, intensity, a.mats[2 * a.start_mat].y, a);
-    a.ray0[2 * pos] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
-    a.ray0[2 * pos + 1] = make_float4(r.to.y, r.to.z, rcp_dir(r.to.x - r.f2.x), rcp_dir(r.to.y - r.f2.y));   // + two of the three reciprocals the walk needs
 }
 
 // =============================================================================================================
@@ -400,9 +404,10 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 #define MCRT_WATCHDOG_DECL() const unsigned long long wd_start = wall_clock64(); uint32_t wd_iter = 0;
 #define MCRT_WATCHDOG_CHECK() { if ((++wd_iter & 4095u) == 0u && wall_clock64() - wd_start > (unsigned long long)MCRT_WATCHDOG_SECONDS * 100000000ull) { \
         if ((threadIdx.x & 63) == 0) atomicOr(a.error_flag, 2u); break; } }
-#ifndef MCRT_LANE_WAVES
-#define MCRT_LANE_WAVES 5            // waves per SIMD the register budget of k_trace_lane is set for
-#endif
+#ifndef MCRT_LANE_VGPRS
+#define MCRT_LANE_VGPRS 104          // register budget of k_trace_lane: four of its wavefronts per SIMD (1024 persistent workgroups, 4 per CU) take 416 of the
+#endif                               // SIMD's 512 registers and leave 96 for a k_march wavefront (80) beside them; at 96 (five wavefronts' worth, rounds 2-3)
+                                     // the refill that rebuilds the ray from the path state spilled four registers
 #ifndef MCRT_LANE_REFILL
 #define MCRT_LANE_REFILL 16          // fetch and set up new rays once this many of a wavefront's 64 lanes are without one
 #endif
@@ -661,7 +666,7 @@ MCRT_DEV int nth_set_bit(unsigned long long m, uint32_t r)
 }
 
 template <bool STATS>
-__global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a, uint32_t b)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_VGPRS))) k_trace_lane(FrameArgs a, uint32_t b)
 {
     __shared__ int stack[MCRT_LANE_STACK * 256];      // [entry][thread]: entry sp of thread t at sp*256 + t -> conflict-free
     const int tid = threadIdx.x, lane = tid & 63;
@@ -674,7 +679,8 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
     // word, so the result is exactly the single-walk answer.
     const uint32_t K = ksplit(n_rays, a.ksplit_limit);
     const uint32_t n = n_rays * K;
-    const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;           // rays and closest-hit words in queue order, ping-pong by bounce parity
+    const size_t st_half = (size_t)(b & 1u) * a.ne * a.S;      // path state and closest-hit words in queue order, ping-pong by bounce parity
+    const float4 *st0 = a.st0 + st_half, *st1 = a.st1 + st_half;   // (the ray is rebuilt from origin | length factor and direction: ray_of)
     const uint32_t ray_stride = (b == 0u) ? a.S : 1u;          // bounce 0: the first sample of each queued scan-line stands for all
     unsigned long long *keys = (b & 1u) ? a.key1 : a.key0;
 #define MCRT_KEYP(p) (&keys[p])
@@ -774,10 +780,11 @@ __global__ void __launch_bounds__(256, MCRT_LANE_WAVES) k_trace_lane(FrameArgs a
                     uint32_t piece = 0u;                                 // the pieces of one ray land in different wavefronts
                     if (K == 1u) ray_id = i;                             // (no division on the common path)
                     else { piece = i / n_rays; ray_id = i - piece * n_rays; }
-                    const float4 r0 = rays[2 * (size_t)ray_id * ray_stride], r1 = rays[2 * (size_t)ray_id * ray_stride + 1];
-                    f2 = mk(r0.x, r0.y, r0.z); to = mk(r0.w, r1.x, r1.y);
+                    const float4 s0 = st0[(size_t)ray_id * ray_stride], s1 = st1[(size_t)ray_id * ray_stride];
+                    const Ray ry = ray_of(mk(s0.x, s0.y, s0.z), mk(s1.x, s1.y, s1.z), s0.w, a);
+                    f2 = ry.f2; to = ry.to;
                     const f3 d = to - f2;
-                    inv = mk(r1.z, r1.w, rcp_dir(d.z));
+                    inv = mk(rcp_dir(d.x), rcp_dir(d.y), rcp_dir(d.z));
                     t_lo = 0.0f;
                     float t_hi = 1.0f;
                     if (K > 1u) {
@@ -1092,8 +1099,6 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
     // two queue buffers, ping-pong by bounce parity (like the path state)
     const uint32_t *q_in = a.queue + (size_t)(b & 1u) * a.ne * a.S;
     uint32_t *q_out = a.queue + (size_t)((b + 1u) & 1u) * a.ne * a.S;
-    const float4 *rays = (b & 1u) ? a.ray1 : a.ray0;
-    float4 *rays_out = (b & 1u) ? a.ray0 : a.ray1;
     const bool valid = i < n;
     bool alive = false, reflected = false;
     uint32_t pid = 0;
@@ -1104,12 +1109,12 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
         // path state lives in queue order (ping-pong halves by bounce parity), so a wavefront reads and writes it coalesced
         const size_t sin = (size_t)(b & 1u) * a.ne * a.S + i;
         const float4 s0 = a.st0[sin], s1 = a.st1[sin], s2 = a.st2[sin];
-        ps.from = mk(s0.x, s0.y, s0.z); ps.intensity = s0.w;
+        ps.from = mk(s0.x, s0.y, s0.z); ps.intensity = s2.w;
         ps.dir = mk(s1.x, s1.y, s1.z); ps.media = __float_as_int(s1.w);
         ps.dist_mm = __hiloint2double(__float_as_int(s2.y), __float_as_int(s2.x));
         ps.outside = __float_as_int(s2.z);
-        const float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
-        const f3 f2 = mk(r0.x, r0.y, r0.z), to = mk(r0.w, r1.x, r1.y);
+        const Ray ry = ray_of(ps.from, ps.dir, s0.w, a);          // the segment the walk tested (same expressions, same bits)
+        const f3 f2 = ry.f2, to = ry.to;
         const size_t hi = (b == 0u) ? (size_t)(i / a.S) : (size_t)i;            // bounce 0: one walk per queued (scan-line, frame) (see k_trace_lane, k_init)
         const unsigned long long key = ((b & 1u) ? a.key1 : a.key0)[hi];
         alive = shade_path<STATS>(a, b, pid, ps, f2, to, key, reflected, st_seg, st_hits);
@@ -1141,12 +1146,9 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
             q_out[pos] = pid;
             ((b & 1u) ? a.key0 : a.key1)[pos] = MCRT_KEY_MISS;            // the next bounce's closest-hit word of this ray
             const size_t so = (size_t)((b + 1u) & 1u) * a.ne * a.S + pos;
-            a.st0[so] = make_float4(from.x, from.y, from.z, intensity);
+            a.st0[so] = make_float4(from.x, from.y, from.z, ray_len(intensity, a.mats[2 * media].y, a));   // origin | the next ray's length factor
             a.st1[so] = make_float4(dir.x, dir.y, dir.z, __int_as_float(media));
-            a.st2[so] = make_float4(__int_as_float(__double2loint(dist_mm)), __int_as_float(__double2hiint(dist_mm)), __int_as_float(outside), 0.0f);
-            const Ray r = make_ray(from, dir, intensity, a.mats[2 * media].y, a);
-            rays_out[2 * (size_t)pos] = make_float4(r.f2.x, r.f2.y, r.f2.z, r.to.x);
-            rays_out[2 * (size_t)pos + 1] = make_float4(r.to.y, r.to.z, rcp_dir(r.to.x - r.f2.x), rcp_dir(r.to.y - r.f2.y));   // (one lane divides here, once per ray)
+            a.st2[so] = make_float4(__int_as_float(__double2loint(dist_mm)), __int_as_float(__double2hiint(dist_mm)), __int_as_float(outside), intensity);
         }
     }
     if (STATS) {

@@ -1099,3 +1099,140 @@ void orc_scan_convert(const float *img, uint32_t rows, uint32_t cols, double rad
     }
     free(map_row); free(map_col);
 }
+
+/* ===================================================================================== */
+/*  ANALYSIS (tools/bvh_width.py): the same closest-hit queries walked over the product's  */
+/*  BVH2 collapsed to W-wide nodes, W = 2..16, counted.  Not part of any parity path.      */
+/* ===================================================================================== */
+typedef struct { float lo[3], hi[3]; int32_t ref; } wide_child;
+struct orc_wide { uint32_t W, n_nodes; wide_child *c; };
+
+static float wc_harea(const wide_child *s) { float dx = s->hi[0] - s->lo[0], dy = s->hi[1] - s->lo[1], dz = s->hi[2] - s->lo[2]; return dx * dy + dy * dz + dz * dx; }
+static void wc_kids(const orc_bvh_node *n, wide_child *a, wide_child *b)
+{
+    a->ref = n->c0; b->ref = n->c1;
+    for (int i = 0; i < 3; i++) { a->lo[i] = n->lo0[i]; a->hi[i] = n->hi0[i]; b->lo[i] = n->lo1[i]; b->hi[i] = n->hi1[i]; }
+}
+/* the product's collapse rule (csrc/mcrt_host.cpp, Collapser::build), for any width: the inner child with the largest half area is
+ * replaced by its two children until the node is full.  quant: 0 = float boxes; 8 = the children's boxes snapped OUTWARDS to a
+ * 256-step grid spanning the node's own box per axis (what an 8-bit node in the parent's frame could store) */
+static uint32_t wide_build(struct orc_wide *w, const orc_scene *sc, int32_t n2, int quant, uint32_t *cap)
+{
+    wide_child s[16]; uint32_t k = 2;
+    wc_kids(&sc->nodes[n2], &s[0], &s[1]);
+    if (s[0].ref == s[1].ref && s[0].ref < 0) k = 1;
+    while (k < w->W) {
+        int pick = -1; float best = -1.f;
+        for (uint32_t i = 0; i < k; i++) if (s[i].ref >= 0) { float a = wc_harea(&s[i]); if (a > best) { best = a; pick = (int)i; } }
+        if (pick < 0) break;
+        wide_child a, b; wc_kids(&sc->nodes[s[pick].ref], &a, &b);
+        s[pick] = a; s[k++] = b;
+    }
+    if (quant == 8) {
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (uint32_t i = 0; i < k; i++) for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], s[i].lo[a]); hi[a] = fmaxf(hi[a], s[i].hi[a]); }
+        for (int a = 0; a < 3; a++) {
+            const float step = (hi[a] - lo[a]) / 255.0f;
+            if (!(step > 0.0f)) continue;
+            for (uint32_t i = 0; i < k; i++) {
+                float ql = floorf((s[i].lo[a] - lo[a]) / step), qh = ceilf((s[i].hi[a] - lo[a]) / step);
+                float nl = lo[a] + ql * step, nh = lo[a] + qh * step;
+                while (nl > s[i].lo[a]) { ql -= 1.0f; nl = lo[a] + ql * step; }
+                while (nh < s[i].hi[a]) { qh += 1.0f; nh = lo[a] + qh * step; }
+                s[i].lo[a] = nl; s[i].hi[a] = nh;
+            }
+        }
+    }
+    if (w->n_nodes == *cap) { *cap *= 2; w->c = (wide_child *)realloc(w->c, sizeof(wide_child) * (size_t)*cap * w->W); }
+    const uint32_t me = w->n_nodes++;
+    for (uint32_t i = 0; i < w->W; i++) {
+        wide_child c;
+        if (i < k) {
+            c = s[i];
+            if (c.ref >= 0) c.ref = (int32_t)wide_build(w, sc, c.ref, quant, cap);
+        } else { c.lo[0] = c.lo[1] = c.lo[2] = INFINITY; c.hi[0] = c.hi[1] = c.hi[2] = -INFINITY; c.ref = ORC_BVH4_EMPTY; }
+        w->c[(size_t)me * w->W + i] = c;
+    }
+    return me;
+}
+
+struct orc_wide *orc_wide_build(const orc_scene *sc, uint32_t W, int quant)
+{
+    if (!sc || !sc->nodes || sc->n_nodes == 0 || W < 2 || W > 16) return NULL;
+    struct orc_wide *w = (struct orc_wide *)calloc(1, sizeof *w);
+    uint32_t cap = sc->n_nodes / (W - 1) + 16;
+    w->W = W; w->c = (wide_child *)malloc(sizeof(wide_child) * (size_t)cap * W);
+    wide_build(w, sc, 0, quant, &cap);
+    return w;
+}
+void orc_wide_free(struct orc_wide *w) { if (w) { free(w->c); free(w); } }
+uint32_t orc_wide_nodes(const struct orc_wide *w) { return w ? w->n_nodes : 0; }
+
+/* one query: nearest hit child first (key = t_near bits with the slot in the low 4 bits), the others stacked in slot order;
+ * returns the triangle; *steps = inner nodes + leaves visited (the ray's chain of dependent fetches), *nn / *nt nodes and triangles */
+static int32_t wide_walk(const struct orc_wide *w, const orc_scene *sc, v3 from, v3 to, uint32_t *nn_o, uint32_t *nt_o, uint32_t *nl_o, uint32_t *maxsp_o)
+{
+    hit_t best; best.frac = 1.0f; best.tri = -1; best.n = V(0, 0, 0); best.da = 0;
+    v3 d = vsub(to, from);
+    v3 inv = V(rcp_dir(d.x), rcp_dir(d.y), rcp_dir(d.z));
+    const v3 rc = ray_c(from, inv);
+    int32_t stack[256]; int sp = 0, maxsp = 0;
+    int32_t cur = 0;
+    uint32_t nn = 0, nt = 0, nl = 0;
+    const uint32_t W = w->W;
+    for (;;) {
+        if (cur >= 0) {
+            const wide_child *N = w->c + (size_t)cur * W;
+            nn++;
+            uint32_t key[16]; int nh = 0;
+            const float tcap = fminf(1.0f, best.frac);
+            for (uint32_t k = 0; k < W; k++) {
+                float tn;
+                const int h = N[k].ref != ORC_BVH4_EMPTY && slab_node(N[k].lo, N[k].hi, rc, inv, tcap, &tn);
+                key[k] = h ? ((f2u(tn) & ~15u) | k) : 0xffffffffu; nh += h;
+            }
+            if (nh > 0) {
+                int jn = -1;
+                for (uint32_t k = 0; k < W; k++) if (key[k] != 0xffffffffu && (jn < 0 || key[k] < key[jn])) jn = (int)k;
+                for (uint32_t k = 0; k < W; k++) { if (key[k] == 0xffffffffu || (int)k == jn) continue; if (sp < 256) stack[sp++] = N[k].ref; }
+                if (sp > maxsp) maxsp = sp;
+                cur = N[jn].ref;
+                continue;
+            }
+        } else {
+            const uint32_t v = (uint32_t)~cur, first = v >> 3, cnt = (v & 7u) + 1u;
+            nl++;
+            for (uint32_t i = 0; i < cnt; i++) {
+                const float *t = sc->bvh_tri + (size_t)(first + i) * 12;
+                float t9[9] = { t[0], t[1], t[2], t[4], t[5], t[6], t[8], t[9], t[10] };
+                tri_test(t9, (int32_t)f2u(t[3]), from, to, inv, rc, sc->pad_abs, &best);
+                nt++;
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    *nn_o = nn; *nt_o = nt; *nl_o = nl; *maxsp_o = (uint32_t)maxsp;
+    return best.tri;
+}
+
+/* the closest-hit queries of `n` segments (from, dir, the intensity and attenuation they started with: what orc_trace_frame returns),
+ * rebuilt as trace_path builds them, walked over `w`.  out[q] = { inner nodes, leaves, triangles, deepest stack } of query q;
+ * tri[q] = the triangle found (to be compared with the segment's own). */
+void orc_wide_count(const struct orc_wide *w, const orc_scene *sc, const orc_params *prm, const orc_segment *segs, uint64_t n,
+                    uint32_t *out /*[n][4]*/, int32_t *tri /*[n]*/, int n_threads)
+{
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t q = 0; q < (int64_t)n; q++) {
+        const orc_segment *sg = &segs[q];
+        const v3 from = V(sg->from[0], sg->from[1], sg->from[2]), dir = V(sg->dir[0], sg->dir[1], sg->dir[2]);
+        const float L = 10.f * orc_logf(prm->intensity_epsilon / sg->initial_intensity) / -sg->attenuation * prm->frequency;
+        const float Ls = L / 100.0f;
+        const v3 to = V(from.x + Ls * (sc->spacing[0] * dir.x), from.y + Ls * (sc->spacing[1] * dir.y), from.z + Ls * (sc->spacing[2] * dir.z));
+        const v3 f2 = V(from.x + prm->ray_start_offset * dir.x, from.y + prm->ray_start_offset * dir.y, from.z + prm->ray_start_offset * dir.z);
+        uint32_t nn, nt, nl, ms;
+        tri[q] = wide_walk(w, sc, f2, to, &nn, &nt, &nl, &ms);
+        out[4 * q] = nn; out[4 * q + 1] = nl; out[4 * q + 2] = nt; out[4 * q + 3] = ms;
+    }
+}

@@ -168,6 +168,16 @@ void orc_scan_maps(uint32_t rows, uint32_t cols, double radius_mm, double total_
 void orc_scan_convert(const float *img, uint32_t rows, uint32_t cols, double radius_mm, double total_angle_rad,
                       double max_travel_us, double sos, float *out, uint32_t out_rows, uint32_t out_cols);
 
+/* ANALYSIS (tools/bvh_width.py), no parity path uses it: the scene's BVH2 collapsed to W-wide nodes (2..16; quant 8 = boxes snapped
+ * outwards to a 256-step grid in the node's own frame), and the closest-hit queries of traced segments counted on it:
+ * out[q] = { inner nodes, leaves, triangles, deepest stack }, tri[q] the triangle found */
+struct orc_wide;
+struct orc_wide *orc_wide_build(const orc_scene *sc, uint32_t W, int quant);
+void orc_wide_free(struct orc_wide *w);
+uint32_t orc_wide_nodes(const struct orc_wide *w);
+void orc_wide_count(const struct orc_wide *w, const orc_scene *sc, const orc_params *prm, const orc_segment *segs, uint64_t n,
+                    uint32_t *out, int32_t *tri, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif
