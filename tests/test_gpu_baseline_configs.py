@@ -62,7 +62,7 @@ def _setup(mcrt, orc, cfg, sd, E, S, tex, **kw):
 def _blocks(E, width, n, seed):
     """n disjoint scan-line blocks of `width`, seeded; always includes the first and the last block of the frame"""
     starts = list(range(0, E - width + 1, width))
-    if os.environ.get("MCRT_FULL_ORACLE"):                       # (a one-off: the oracle on EVERY scan-line of C4 / C5, ~1 min of 16 cores)
+    if n is None or os.environ.get("MCRT_FULL_ORACLE"):          # the oracle on EVERY scan-line (C4 always: ~16 s of 16 cores; C5 with MCRT_FULL_ORACLE=1: ~75 s)
         return [(s0, s0 + width) for s0 in starts]
     rng = np.random.default_rng(seed)
     pick = {0, len(starts) - 1}
@@ -166,7 +166,7 @@ def test_c3_liver_128x4096(mcrt, orc, tex256):
 
 def test_c4_1m_triangles_256x8192(mcrt, orc, tex256):
     """BASELINE config 4: 1 M random triangles, 256 scan-lines x 8192 rays (2.1 M paths) -- GPU traces the full frame, the
-    oracle checks six seeded blocks of 16 scan-lines (786 432 paths)"""
+    oracle checks EVERY scan-line (round 4: the whole frame by default, in blocks of 16 scan-lines)"""
     cfg, meshes = mcrt.synth.random_scene(1_000_000, 8, 12345)
     sd = mcrt.scene_io.build_scene(cfg, meshes)
     E, S, frame = 256, 8192, 1
@@ -175,7 +175,7 @@ def test_c4_1m_triangles_256x8192(mcrt, orc, tex256):
     hits, _, _ = sim.ctx.trace_frame_debug(frame, sim.rf_dev)
     rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
     p = orc.default_params(n_elements=E, n_samples=S)
-    _check_blocks(orc, osc, tr, tex256, hits, rf, p, frame, _blocks(E, 16, 6, seed=4), threads)
+    _check_blocks(orc, osc, tr, tex256, hits, rf, p, frame, _blocks(E, 16, None, seed=4), threads)
     # scan-line shards (what 2/4/8 GPUs would each trace) reproduce the full frame bit for bit
     full = sim.ctx.d2h(sim.rf_dev, (E, sim.R))
     for g in (1, 6):                                              # two of the eight shards
@@ -187,7 +187,8 @@ def test_c4_1m_triangles_256x8192(mcrt, orc, tex256):
 
 def test_c5_liver_512x16384_psf(mcrt, orc, tex256):
     """BASELINE config 5: liver-like scene, 512 scan-lines x 16384 rays (8.4 M paths) + PSF convolution -- GPU traces and
-    convolves the full frame; the oracle checks four seeded blocks of 32 scan-lines, and the convolution of the block
+    convolves the full frame; the oracle checks eight seeded blocks of 32 scan-lines (half the frame, 4.2 M paths; MCRT_FULL_ORACLE=1: all
+    sixteen, run by hand once per round on the final binary), and the convolution of the block
     interiors (the lateral pass reads 12 columns to the right, rfimage.h:113-118)"""
     cfg, meshes = mcrt.synth.liver_scene(5)
     sd = mcrt.scene_io.build_scene(cfg, meshes)
@@ -197,7 +198,7 @@ def test_c5_liver_512x16384_psf(mcrt, orc, tex256):
     hits, _, _ = sim.ctx.trace_frame_debug(frame, sim.rf_dev)
     rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
     p = orc.default_params(n_elements=E, n_samples=S)
-    blocks = _blocks(E, 32, 4, seed=5)
+    blocks = _blocks(E, 32, 8, seed=5)
     _check_blocks(orc, osc, tr, tex256, hits, rf, p, frame, blocks, threads)
     del hits
     # PSF convolution of the whole frame on the GPU == the oracle's convolution of the GPU's (verified) raw image

@@ -70,21 +70,41 @@ def test_pow_forms(orc):
     assert d.max() <= 1 and (d != 0).mean() < 1e-3
 
 
-def test_libm_mode_changes_images_only_within_tolerance(orc, mcrt):
-    """the contract math vs the reference's libm calls, end to end on a small frame: same hit indices, RF within 1e-4"""
-    cfg, meshes = mcrt.synth.sphere_scene(3)
+import pytest
+
+
+@pytest.mark.parametrize("name,E,S", [("random1m", 128, 1024), ("liver", 128, 4096)])
+def test_contract_math_vs_libm_at_benchmark_size(orc, mcrt, name, E, S):
+    """north_star's "within 1e-4 of the CPU reference" is about the image the reference's LIBM calls produce (std::exp / log / pow / sin /
+    cos: ray.cpp:102,112,158-160,186,222; scene.cpp:135; main.cpp:135); the contract replaces them by its own polynomials.  The distance
+    between the two, measured where the benchmark runs -- the headline workload (1 M triangles, 128 x 1024) and BASELINE C3 (liver, 128 x
+    4096) -- with the oracle switched to libm (orc.set_math_mode(1)) against the contract, whole frames, CPU only:
+        hit indices      every query of every bounce identical (816 k / 2.63 M queries)            measured: agreement 1.0
+        float RF image   max |difference| / peak, reference summation order                        measured: 4.7e-10 / 1.8e-9
+    Bars (no escape hatch): agreement >= 0.9999 of the queries, RF within 1e-6 of the peak element-wise -- two orders inside the 1e-4 bar."""
+    if name == "random1m":
+        cfg, meshes = mcrt.synth.random_scene(1_000_000, 8, 12345)
+    else:
+        cfg, meshes = mcrt.synth.liver_scene(5)
     sd = mcrt.scene_io.build_scene(cfg, meshes)
-    tr = mcrt.Transducer(8, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
-    tex = orc.texture(32)
-    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
-    p = orc.default_params(n_elements=8, n_samples=32, tex_n=32)
-    a = osc.trace_frame(p, tr.pos, tr.dir, tex)
+    tr = mcrt.Transducer(E, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
+    nodes, btri, _ = mcrt.host_build_bvh(sd.tri, sd.tri_mesh)
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
+    tex = orc.texture(256)
+    p = orc.default_params(n_elements=E, n_samples=S)
+    a = osc.trace_frame(p, tr.pos, tr.dir, tex, use_bvh=1, n_threads=8)
     orc.set_math_mode(1)
     try:
-        b = osc.trace_frame(p, tr.pos, tr.dir, tex)
+        b = osc.trace_frame(p, tr.pos, tr.dir, tex, use_bvh=1, n_threads=8)
     finally:
         orc.set_math_mode(0)
-    same = (a["hits"] == b["hits"]).mean()
-    assert same > 0.999
-    m = ~np.isnan(a["rf_ref"]) & ~np.isnan(b["rf_ref"])
-    assert np.abs(a["rf_ref"][m] - b["rf_ref"][m]).max() <= 1e-4 * np.abs(a["rf_ref"][m]).max() or same < 1.0
+    asked = (a["hits"] != -2) | (b["hits"] != -2)
+    assert asked.sum() > 5 * E * S
+    agreement = (a["hits"] == b["hits"])[asked].mean()
+    assert agreement >= 0.9999, agreement
+    for key in ("rf_ref", "rf"):                       # the reference-order float image, and the contract's fixed-point image
+        x, y = a[key].astype(np.float64), b[key].astype(np.float64)
+        assert np.array_equal(np.isnan(x), np.isnan(y))
+        m = ~np.isnan(x)
+        peak = np.abs(y[m]).max()
+        assert peak > 0.1 and np.abs(x[m] - y[m]).max() <= 1e-6 * peak, (key, np.abs(x[m] - y[m]).max() / peak)
