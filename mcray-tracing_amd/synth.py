@@ -141,8 +141,10 @@ def liver_scene(subdiv=5, seed=11):
     return cfg, meshes
 
 
-def random_scene(n_tri=1_000_000, n_mesh=8, seed=12345):
-    """n_mesh meshes of n_tri/n_mesh random triangles in front of the probe at (-13.5,0,0)."""
+def random_scene(n_tri=1_000_000, n_mesh=8, seed=12345, edge=0.1):
+    """n_mesh meshes of n_tri/n_mesh random triangles in front of the probe at (-13.5,0,0).
+    edge: half-range of the edge vectors in cm (0.1 = the 1 M-triangle scene of SURVEY 8(d); the 16 M-triangle streaming scene uses
+    0.025, the same total area, so a ray crosses as much tissue before it meets a triangle and walks a tree two levels deeper)."""
     cyc = [("LIVER", "GEL", False), ("FAT", "LIVER", False), ("KIDNEY", "FAT", False), ("BONE", "LIVER", False),
            ("BLOOD", "LIVER", True), ("GALLBLADDER", "FAT", False), ("SKIN", "GEL", False), ("VESSEL", "LIVER", True)]
     cfg = {"transducerPosition": [-13.5, 0.0, 0.0], "transducerAngles": [0.0, 0.0, -90.0], "materials": materials(), "meshes": [],
@@ -152,7 +154,7 @@ def random_scene(n_tri=1_000_000, n_mesh=8, seed=12345):
     for i in range(n_mesh):
         n = per if i < n_mesh - 1 else n_tri - per * (n_mesh - 1)
         f = "random_%d.obj" % i
-        meshes[f] = random_triangles(n, seed + i)
+        meshes[f] = random_triangles(n, seed + i, edge=edge)
         mat, out, vasc = cyc[i % len(cyc)]
         cfg["meshes"].append(_mesh(f, mat, out, vasc))
     return cfg, meshes

@@ -213,3 +213,38 @@ def test_c5_liver_512x16384_psf(mcrt, orc, tex256):
         lo, hi = 6, (b1 - b0) - 13
         assert np.array_equal(rfc[:, b0 + lo:b0 + hi].view(np.uint32), ob[:, lo:hi].view(np.uint32))
     sim.close()
+
+
+def test_random16m_streaming_scene(mcrt, orc, tex256):
+    """The streaming regime bench.py --workload random16m measures: 16 M random triangles (1.5 GB of triangle records,
+    ~0.5 GB of walked nodes: past the 256 MiB Infinity Cache; inside the walk's 2^25-triangle / 32-bit-offset limits), indexed by the
+    DEVICE builder.  A seeded block of scan-lines against the oracle walking the product's own tree (hits, fixed-point RF, visit counts),
+    every triangle id once in the leaf array, and ~500 closest-hit queries of every bounce against BRUTE FORCE over all 16 M triangles."""
+    cfg, meshes = mcrt.synth.random_scene(16_000_000, 8, 12345, edge=0.025)
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    del meshes
+    assert sd.n_tri == 16_000_000
+    E, S, frame = 16, 256, 3
+    threads = os.cpu_count() or 8
+    tr, sim, osc = _setup(mcrt, orc, cfg, sd, E, S, tex256, bvh_builder="lbvh")
+    hits, _, _ = sim.ctx.trace_frame_debug(frame, sim.rf_dev)
+    rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+    p_kw = dict(n_elements=E, n_samples=S)
+    p = orc.default_params(**p_kw)
+    o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, use_bvh=2, n_threads=threads, want_ref64=True)
+    assert np.array_equal(hits, o["hits"])
+    assert (hits >= 0).sum() > 2 * E * S
+    assert_rf(rf, o)
+    _visit_counts(mcrt, orc, sim, osc, tr, tex256, p_kw, frame, S, o["stats"], threads)
+    _, btri, _ = sim.ctx.get_bvh()
+    assert np.array_equal(np.sort(btri.view(np.uint32)[:, 3]), np.arange(sd.n_tri, dtype=np.uint32))
+    del btri
+    # brute force over all 16 M triangles: one scan-line x 64 samples of a fresh small frame on the same tree
+    sim.close()
+    E2, S2 = 4, 64
+    tr2, sim2, osc2 = _setup(mcrt, orc, cfg, sd, E2, S2, tex256, bvh_builder="lbvh")
+    hits2, _, _ = sim2.ctx.trace_frame_debug(5, sim2.rf_dev)
+    p2 = orc.default_params(n_elements=E2, n_samples=S2)
+    brute = osc2.trace_frame(p2, tr2.pos, tr2.dir, tex256, frame_id=5, e_begin=1, e_end=2, use_bvh=0, n_threads=threads, want_ref=False, want_fix=False)
+    assert np.array_equal(brute["hits"][0], hits2[1]) and brute["stats"]["queries"] >= 300
+    sim2.close()
