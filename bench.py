@@ -349,7 +349,7 @@ def main():
                        "warmup_steps_run": W_run, "step": "clear, trace, accumulate, [all-gather], PSF, envelope, scan conversion to %dx%d" % (pipe.OUT_ROWS, pipe.OUT_COLS)},
             "ranks_seen": world, "per_rank": per_rank,
         }
-        roof = {"kernel": "k_trace_lane<false>", "kernel_ms": k_ms, "launches": k_n, "launches_per_frame": launches_per_frame,
+        roof = {"frac_vs_architectural": None, "kernel": "k_trace_lane<false>", "kernel_ms": k_ms, "launches": k_n, "launches_per_frame": launches_per_frame,
                 "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps_cache_served": alg_gbs, "node_bytes": node_bytes,
                 "trace_bytes_per_frame": trace_bytes_frame, "other_stage_bytes_per_frame": other_bytes_frame,
                 "per_frame": {k: v / K for k, v in st.items()}}
@@ -402,64 +402,75 @@ def main():
 
 # ------------------------------------------------------------------------------------------------ roofline
 def valu_calibration():
-    """profiles/round2/valu_roof.json (tools/valu_roof.hip on the MI355X; the tool and the chip have not changed since): the VALU issue ceiling in wave-instructions per
-    cycle and SIMD.  It depends on the instruction class (0.24-0.29 for fp32 fma / min3 / packed / DPP / compare-select streams,
-    0.45 for plain integer adds), so the roof the walk is priced against is the one measured for ITS mix: the register-only part of
-    a BVH4 node step (packed subtract/multiply, min/max/min3/max3, compares, selects, integer key work) at the walk's occupancy
-    of 5 wavefronts per SIMD, with the clock the chip held during that measurement."""
+    """profiles/round4/valu_roof.json (tools/valu_roof.hip on the MI355X, round 4): the VALU issue ceiling in wave-instructions per cycle and
+    SIMD.  It depends on the instruction class (0.25-0.28 for fp32 fma / min3 / compare-select streams, 0.40-0.43 for plain integer adds),
+    so the roof the walk is priced against is the one measured for ITS mix: a register-only replica of the node step the kernel runs TODAY
+    (12 v_cndmask plane picks, 24 v_fma_mix_f32, 4 x max / max3 / min / min3 / compare, key build and ranking, branch-free push offsets,
+    child pick, address: 91 instructions) at the walk's occupancy of 4 wavefronts per SIMD, with the clock the chip held meanwhile."""
     try:
-        with open(os.path.join(ROOT, "profiles", "round2", "valu_roof.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "round4", "valu_roof.json")) as f:
             d = json.load(f)
-        mix = [r for r in d["results"] if r["class"].startswith("BVH4 node-step mix") and r["waves_per_simd"] == 5][0]
+        mix = [r for r in d["results"] if r["class"].startswith("BVH4 LANE node-step mix") and r["waves_per_simd"] == 4][0]
         best = max(r["simd_ipc"] for r in d["results"] if not r["class"].startswith("node fetch"))
-        return {"ipc_per_simd": mix["simd_ipc"], "clock_ghz": mix["clock_ghz"], "class": mix["class"], "waves_per_simd": 5,
-                "best_class_ipc_per_simd": best, "source": "profiles/round2/valu_roof.json"}
+        return {"ipc_per_simd": mix["simd_ipc"], "clock_ghz": mix["clock_ghz"], "class": mix["class"], "waves_per_simd": 4,
+                "best_class_ipc_per_simd": best, "source": "profiles/round4/valu_roof.json"}
     except Exception:
         # MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles on the SIMD-32 once >= 2 waves share a SIMD; 2.4 GHz max clock
         return {"ipc_per_simd": 0.5, "clock_ghz": 2.4, "source": "MI355X_MICROARCH.md (no calibration file)"}
 
 
+def tcp_access_cost():
+    """profiles/round4/tcp_access_cost.json: cycles of a CU's vector memory pipe per access TCP_TOTAL_CACHE_ACCESSES counts (one per lane; a
+    uniform adjacent quad counts once), measured for every sharing pattern -- the CHEAPEST pattern is the floor of what an access costs"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round4", "tcp_access_cost.json")) as f:
+            return float(json.load(f)["min_cycles_per_counted_access"]), "profiles/round4/tcp_access_cost.json"
+    except Exception:
+        return 1.32, "default (no calibration file)"
+
+
 def roofline_from(pmc, k_ms, alg_gbs):
-    """k_trace against the roof that binds it.  The BVH is served from L1/L2/Infinity Cache (fabric traffic is a few per cent of
-    the HBM peak), so the binding roof is VALU issue: achieved = wave-level VALU instructions per second (SQ_INSTS_VALU of the
-    launch / its duration), peak = 1024 SIMDs x calibrated instructions per cycle x calibrated clock."""
+    """k_trace against the roofs that bind it.  The BVH is served from L1 / L2 / Infinity Cache (fabric traffic is a few per cent of the
+    HBM peak at 1 M triangles), so the binding roofs are on the CU: VALU issue -- achieved = wave-level VALU instructions per second
+    (SQ_INSTS_VALU of the launch / its duration), peak = 1024 SIMDs x calibrated instructions per cycle x calibrated clock -- and the vector
+    memory pipe (second_roof: the time the launch's counted cache accesses need at the cheapest measured cost per access, over its duration)."""
     cal = valu_calibration()
     peak = N_SIMD * cal["ipc_per_simd"] * cal["clock_ghz"]            # G wave-instructions / s
-    r = {"bound": "valu", "unit": "Ginstr/s", "peak": peak, "peak_source": cal,
-         "peak_is": "the issue rate of a register-only replica of this kernel's node step (tools/valu_roof.hip), NOT the architectural rate: see frac_vs_*",
+    r = {"frac_vs_architectural": None, "bound": "valu", "unit": "Ginstr/s", "peak": peak, "peak_source": cal,
+         "peak_is": "the issue rate of a register-only replica of this kernel's CURRENT node step (tools/valu_roof.hip, round 4), NOT the architectural rate: see frac_vs_architectural",
+         "kernel_ms_is": "HIP-event time of the walk's launches on the stream they run on, with k_march running beside them on its side stream (contention included)",
          "hbm_peak_GBps": HBM_PEAK_GBS, "algorithmic_over_hbm_peak": alg_gbs / HBM_PEAK_GBS}
     if pmc and pmc.get("valu_instructions_per_launch") and k_ms > 0:
         ach = pmc["valu_instructions_per_launch"] / (k_ms * 1e-3) / 1e9
         r.update({"achieved": ach, "frac": ach / peak, "frac_of_calibrated_mix": ach / peak,
-                  "frac_vs_best_class": ach / (N_SIMD * cal.get("best_class_ipc_per_simd", 0.449) * cal["clock_ghz"]),        # plain integer adds: the best class measured
+                  "frac_vs_best_class": ach / (N_SIMD * cal.get("best_class_ipc_per_simd", 0.43) * cal["clock_ghz"]),        # plain integer adds: the best class measured
                   "frac_vs_architectural": ach / (N_SIMD * 0.5 * cal["clock_ghz"]),                                       # MI355X_MICROARCH.md: 2 cycles per wave64 instruction
                   "derived": bool(pmc.get("derived"))})
         if pmc.get("lane_utilisation") is not None:
             r["valu_lane_utilisation"] = pmc["lane_utilisation"]
     else:
         r.update({"achieved": None, "frac": None})
-    if pmc and pmc.get("tcp_lane_accesses_per_launch") and pmc.get("busy_cu_cycles_per_launch"):
-        # the OTHER roof of the walk (DESIGN.md 5.2): the CU's vector memory pipe, in lane-accesses per cycle and CU, against the rate
-        # tools/fetch_roof.hip measured for scattered 16-byte-per-lane loads (profiles/round2/fetch_roof.json); counters of the walk alone
-        tcp_peak = 0.75
-        try:
-            fr = json.load(open(os.path.join(ROOT, "profiles", "round2", "fetch_roof.json")))
-            row = [x for x in fr["results"] if x["lanes_per_run"] == 1 and x["bytes_per_lane"] == 16 and x["table"].startswith("16 KiB")][0]
-            tcp_peak = 64.0 / row["cycles_per_wave_load_per_cu"]
-        except Exception:
-            pass
-        ach = pmc["tcp_lane_accesses_per_launch"] / 256.0 / pmc["busy_cu_cycles_per_launch"]
-        r["second_roof"] = {"what": "vector memory pipe (TCP) of a CU: lane-accesses per cycle, scattered 16-byte-per-lane loads", "achieved": ach, "peak": tcp_peak,
-                            "frac": ach / tcp_peak, "source": "SQ/TCP counters of the walk's launches; peak: profiles/round2/fetch_roof.json"}
+    if pmc and pmc.get("tcp_lane_accesses_per_launch") and k_ms > 0:
+        # the OTHER roof of the walk (DESIGN.md 5.2): the CU's vector memory pipe.  Cost model (round 4, fetch_roof_same under --pmc): every
+        # access the counter counts costs at least `cost` cycles of its CU's pipe, whatever the sharing pattern; the launch cannot be shorter
+        # than its accesses x cost / (256 CUs x clock).  frac = that time / the launch's duration: it cannot exceed 1 (up to the clock).
+        cost, src = tcp_access_cost()
+        t_ms = pmc["tcp_lane_accesses_per_launch"] * cost / 256.0 / (cal["clock_ghz"] * 1e6)
+        r["second_roof"] = {"what": "vector memory pipe (TCP) of the CUs: time the launch's counted cache accesses need at the cheapest measured cost per access",
+                            "accesses_per_launch": pmc["tcp_lane_accesses_per_launch"], "cycles_per_access_floor": cost, "clock_ghz": cal["clock_ghz"],
+                            "pipe_ms": t_ms, "kernel_ms": k_ms, "frac": t_ms / k_ms, "source": "TCP_TOTAL_CACHE_ACCESSES of the walk's launches; cost: " + src}
         if r.get("frac") is not None:
-            # which of the walk's two pipes is the fuller one (a fraction above 1 on the second roof: part of the lanes share lines)
-            r["binding_roof"] = "vector memory pipe (second_roof)" if ach / tcp_peak > r["frac"] else "valu issue (frac)"
-            r["note"] = ("an instruction-RATE fraction falls when instructions are removed from the same work: round 3 cut the walk's VALU instructions per "
-                         "launch by 12 % (1579 M -> 1386 M at 128 frames in flight); kernel_ms and value are the figures of merit")
+            r["binding_roof"] = "vector memory pipe (second_roof)" if t_ms / k_ms > r["frac"] else "valu issue (frac)"
     if pmc and pmc.get("traffic_bytes_per_launch") is not None and k_ms > 0:
         r["traffic"] = pmc["traffic_bytes_per_launch"]
         r["hbm_measured_GBps"] = pmc["traffic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9
         r["hbm_measured_frac"] = r["hbm_measured_GBps"] / HBM_PEAK_GBS
+        if pmc.get("fetch_size_kib") is not None:
+            # profiles/round4/fetch_size_calibration.json: the walk's scattered 64-byte node reads are ONE fabric request each, counted as 64 bytes;
+            # the guide's doubling (right for coalesced 128-byte requests) is an upper bound for them.  Both readings are reported.
+            one = (pmc["fetch_size_kib"] + pmc["write_size_kib"]) * 1024.0
+            r["traffic_one_unit_per_request"] = one
+            r["hbm_measured_frac_one_unit_per_request"] = one / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     else:
         r["traffic"] = None; r["hbm_measured_frac"] = None
     r["pmc"] = pmc

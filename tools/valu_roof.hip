@@ -23,16 +23,18 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum Kind { FMA_IND, FMA_DEP, PKMUL_IND, PKMUL_DEP, MIN3_IND, MIN3_DEP, DPP_IND, DPP_DEP, CMP_CND, INT_ADD, FMA64_IND, ADD64_DEP, MUL64_IND, WALK_MIX, VALU_SALU, FETCH_AOS, FETCH_SPLIT, FETCH_LANE, N_KINDS };
+enum Kind { FMA_IND, FMA_DEP, PKMUL_IND, PKMUL_DEP, MIN3_IND, MIN3_DEP, DPP_IND, DPP_DEP, CMP_CND, INT_ADD, FMA64_IND, ADD64_DEP, MUL64_IND, WALK_MIX, WALK_MIX_LANE, VALU_SALU, FETCH_AOS, FETCH_SPLIT, FETCH_LANE, N_KINDS };
 static const char *kind_name[N_KINDS] = { "v_fma_f32 independent", "v_fma_f32 dependent", "v_pk_mul_f32 independent", "v_pk_mul_f32 dependent",
     "v_min3_f32 independent", "v_min3_f32 dependent", "v_mov_b32 dpp quad_perm independent", "v_mov_b32 dpp quad_perm dependent",
     "v_cmp_lt_f32 + v_cndmask_b32 pairs", "v_add_u32 independent", "v_fma_f64 independent", "v_add_f64 dependent", "v_mul_f64 independent",
-    "BVH4 node-step mix (pk sub/mul, min/max/min3/max3, dpp, cmp, cndmask, integer)", "v_fma_f32 + s_add_u32 interleaved 1:1 (VALU count only)",
+    "BVH4 node-step mix (pk sub/mul, min/max/min3/max3, dpp, cmp, cndmask, integer)",
+    "BVH4 LANE node-step mix, rounds 3-4 (12 cndmask plane picks, 24 v_fma_mix_f32, 4 x max/max3/min/min3/cmp, keys, ranking, branch-free push offsets, child pick, address)",
+    "v_fma_f32 + s_add_u32 interleaved 1:1 (VALU count only)",
     "node fetch, quad reads one 128-B node, lane j bytes [32j,32j+32) as 2 x dwordx4 (k_trace round 1); counts wave-level loads",
     "node fetch, quad reads one 128-B node, lane j bytes [16j,16j+16) and [64+16j,..) (half-line contiguous); counts wave-level loads",
     "node fetch, every LANE reads its own 128-B node as 8 x dwordx4 (one lane per ray); counts wave-level loads" };
 // VALU instructions per unrolled body (the loop runs `iters` bodies)
-static const int kind_body[N_KINDS] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 64, 16, 16, 16 };
+static const int kind_body[N_KINDS] = { 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 48, 91, 64, 16, 16, 16 };
 
 struct Stamp { unsigned long long t0, t1, r0, r1; unsigned hw_id, xcc_id, pad0, pad1; };
 
@@ -52,6 +54,8 @@ __global__ void __launch_bounds__(256) k_roof(Stamp *out, int iters, float seed,
     v2f p0 = { a0, a1 }, p1 = { a2, a3 }, p2 = { a4, a5 }, p3 = { a6, a7 }, px = { x, x };
     double d0 = a0, d1 = a1, d2 = a2, d3 = a3, dx = 1.0000000001, dy = 1e-12;
     unsigned u0 = threadIdx.x, u1 = u0 + 1, u2 = u0 + 2, u3 = u0 + 3;
+    unsigned q4 = u0 * 3u, q5 = u0 * 5u, q6 = u0 * 7u, q7 = u0 * 11u, q8 = u0 * 13u, q9 = u0 * 17u, q10 = 256u, q11 = u0 * 19u;
+    asm volatile("" : "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7), "+v"(q8), "+v"(q9), "+v"(q10), "+v"(q11));
     unsigned s0 = 1;
     asm volatile("" : "+v"(x), "+v"(y), "+v"(px), "+v"(dx), "+v"(dy));
     __syncthreads();
@@ -123,6 +127,63 @@ __global__ void __launch_bounds__(256) k_roof(Stamp *out, int iters, float seed,
                 "v_cndmask_b32 %10, %10, %11, vcc\n v_cndmask_b32 %11, %11, %12, vcc\n v_add_u32 %10, %10, %6\n v_or_b32 %11, 1, %11\n"
                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(a3), "+v"(px), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a4), "+v"(a5), "+v"(u0), "+v"(u1), "+v"(u2)
                 : "v"(x), "v"(y), "v"(a6), "v"(a7) : "vcc", "s10", "s11");
+        } else if constexpr (KIND == WALK_MIX_LANE) {
+            // the register-only part of lane_node_step (mcrt_kernels.hip) as rounds 3-4 compile it, in its dependency structure -- 91 VALU:
+            // 12 v_cndmask (near / far packed plane words by the sign of the reciprocal direction), 24 v_fma_mix_f32 (plane distances from the
+            // half operands), per child v_max / v_max3 / v_min / v_min3 / v_cmp_le (20), per child key = v_and_or + v_cndmask (8), 3 v_min_u32
+            // (nearest key), v_cmp_eq (no hit child), 4 v_cmp_ne (children to push), 3 v_cndmask + 2 v_add (store offsets of the branch-free
+            // pushes), v_lshrrev + v_cndmask + 2 v_add (stack pointer), v_and + 3 v_cmp_eq + 3 v_cndmask (next node), v_lshlrev + v_add_co +
+            // v_addc_co (its address).  (The 4 LDS stores and 4 global loads of the step are not VALU instructions.)
+            unsigned long long m0 = 0x5555aaaa3333ccccull, m1 = 0x0f0ff0f0ff0000ffull;
+            asm volatile("" : "+s"(m0), "+s"(m1));
+            unsigned n0, n1, n2, n3, n4, n5, n6, n7, n8, n9, n10, n11;
+            float t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15, t16, t17, t18, t19, t20, t21, t22, t23;
+            unsigned k0, k1, k2, k3;
+            // near / far packed plane words picked by the sign of the reciprocal direction (per axis: 4 selects)
+            asm volatile("v_cndmask_b32 %0, %12, %15, %24\n v_cndmask_b32 %1, %13, %16, %24\n v_cndmask_b32 %2, %15, %12, %24\n v_cndmask_b32 %3, %16, %13, %24\n"
+                         "v_cndmask_b32 %4, %14, %17, %25\n v_cndmask_b32 %5, %18, %19, %25\n v_cndmask_b32 %6, %17, %14, %25\n v_cndmask_b32 %7, %19, %18, %25\n"
+                         "v_cndmask_b32 %8, %20, %22, %24\n v_cndmask_b32 %9, %21, %23, %24\n v_cndmask_b32 %10, %22, %20, %24\n v_cndmask_b32 %11, %23, %21, %24\n"
+                         : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "=&v"(n4), "=&v"(n5), "=&v"(n6), "=&v"(n7), "=&v"(n8), "=&v"(n9), "=&v"(n10), "=&v"(n11)
+                         : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(q4), "v"(q5), "v"(q6), "v"(q7), "v"(q8), "v"(q9), "v"(q10), "v"(q11), "s"(m0), "s"(m1));
+            // 24 plane distances: one mixed-precision fma per plane, the half operand read from the packed word
+            asm volatile("v_fma_mix_f32 %0, %12, %18, %19 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %12, %18, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                         "v_fma_mix_f32 %2, %13, %18, %19 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %13, %18, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                         "v_fma_mix_f32 %4, %14, %18, %19 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %14, %18, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                         "v_fma_mix_f32 %6, %15, %18, %19 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %15, %18, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                         "v_fma_mix_f32 %8, %16, %18, %19 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %9, %16, %18, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                         "v_fma_mix_f32 %10, %17, %18, %19 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %11, %17, %18, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(t8), "=&v"(t9), "=&v"(t10), "=&v"(t11)
+                         : "v"(n0), "v"(n1), "v"(n2), "v"(n3), "v"(n4), "v"(n5), "v"(x), "v"(y));
+            asm volatile("v_fma_mix_f32 %0, %12, %18, %19 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %12, %18, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                         "v_fma_mix_f32 %2, %13, %18, %19 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %13, %18, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                         "v_fma_mix_f32 %4, %14, %18, %19 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %14, %18, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                         "v_fma_mix_f32 %6, %15, %18, %19 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %15, %18, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                         "v_fma_mix_f32 %8, %16, %18, %19 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %9, %16, %18, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                         "v_fma_mix_f32 %10, %17, %18, %19 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %11, %17, %18, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                         : "=&v"(t12), "=&v"(t13), "=&v"(t14), "=&v"(t15), "=&v"(t16), "=&v"(t17), "=&v"(t18), "=&v"(t19), "=&v"(t20), "=&v"(t21), "=&v"(t22), "=&v"(t23)
+                         : "v"(n6), "v"(n7), "v"(n8), "v"(n9), "v"(n10), "v"(n11), "v"(x), "v"(y));
+            // per child: tmin = max3(nx, ny, max(nz, tlow)), tmax = min3(fx, fy, min(fz, tcap)), hit = tmin <= tmax; key = (bits(tmin) & ~3) | slot, -1 when missed
+            asm volatile("v_max_f32 %2, %2, %14\n v_max3_f32 %2, %4, %6, %2\n v_min_f32 %8, %8, %15\n v_min3_f32 %8, %10, %12, %8\n v_cmp_le_f32 s[10:11], %2, %8\n"
+                         "v_max_f32 %3, %3, %14\n v_max3_f32 %3, %5, %7, %3\n v_min_f32 %9, %9, %15\n v_min3_f32 %9, %11, %13, %9\n v_cmp_le_f32 s[12:13], %3, %9\n"
+                         "v_and_or_b32 %0, %2, -4, 0\n v_cndmask_b32 %0, -1, %0, s[10:11]\n v_and_or_b32 %1, %3, -4, 1\n v_cndmask_b32 %1, -1, %1, s[12:13]\n"
+                         : "=&v"(k0), "=&v"(k1), "+v"(t8), "+v"(t9), "+v"(t20), "+v"(t21)
+                         : "v"(t0), "v"(t1), "v"(t4), "v"(t5), "v"(t12), "v"(t13), "v"(t16), "v"(t17), "v"(y), "v"(x) : "s10", "s11", "s12", "s13");
+            asm volatile("v_max_f32 %2, %2, %14\n v_max3_f32 %2, %4, %6, %2\n v_min_f32 %8, %8, %15\n v_min3_f32 %8, %10, %12, %8\n v_cmp_le_f32 s[10:11], %2, %8\n"
+                         "v_max_f32 %3, %3, %14\n v_max3_f32 %3, %5, %7, %3\n v_min_f32 %9, %9, %15\n v_min3_f32 %9, %11, %13, %9\n v_cmp_le_f32 s[12:13], %3, %9\n"
+                         "v_and_or_b32 %0, %2, -4, 2\n v_cndmask_b32 %0, -1, %0, s[10:11]\n v_and_or_b32 %1, %3, -4, 3\n v_cndmask_b32 %1, -1, %1, s[12:13]\n"
+                         : "=&v"(k2), "=&v"(k3), "+v"(t10), "+v"(t11), "+v"(t22), "+v"(t23)
+                         : "v"(t2), "v"(t3), "v"(t6), "v"(t7), "v"(t14), "v"(t15), "v"(t18), "v"(t19), "v"(y), "v"(x) : "s10", "s11", "s12", "s13");
+            // nearest key; children to push and the store offsets of the branch-free pushes; stack pointer; next node and its address
+            asm volatile("v_min_u32 %4, %0, %1\n v_min_u32 %5, %2, %3\n v_min_u32 %4, %4, %5\n v_cmp_eq_u32 vcc, -1, %4\n"
+                         "v_cmp_ne_u32 s[10:11], %0, %4\n v_cmp_ne_u32 s[12:13], %1, %4\n v_cmp_ne_u32 s[14:15], %2, %4\n v_cmp_ne_u32 s[16:17], %3, %4\n"
+                         "v_cndmask_b32 %5, 0, %10, s[10:11]\n v_cndmask_b32 %6, 0, %10, s[12:13]\n v_cndmask_b32 %7, 0, %10, s[14:15]\n v_add_u32 %6, %5, %6\n v_add_u32 %7, %6, %7\n"
+                         "v_lshrrev_b32 %5, 8, %7\n v_cndmask_b32 %6, 0, 1, s[16:17]\n v_add_u32 %5, %5, %6\n v_add_u32 %8, %8, %5\n"
+                         "v_and_b32 %5, 3, %4\n v_cmp_eq_u32 s[10:11], 0, %5\n v_cmp_eq_u32 s[12:13], 1, %5\n v_cmp_eq_u32 s[14:15], 2, %5\n"
+                         "v_cndmask_b32 %6, %14, %13, s[14:15]\n v_cndmask_b32 %6, %6, %12, s[12:13]\n v_cndmask_b32 %6, %6, %11, s[10:11]\n"
+                         "v_lshlrev_b32 %6, 6, %6\n v_add_co_u32 %9, vcc, %9, %6\n v_addc_co_u32 %8, vcc, 0, %8, vcc\n"
+                         : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3), "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "+v"(q4), "+v"(q5)
+                         : "v"(q6), "v"(q7), "v"(q8), "v"(q9), "v"(q10) : "vcc", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17");
+            u0 ^= n2; a0 += t8 + t9 + t10 + t11;      // (outside the counted 91: keeps the chains alive across iterations)
         } else if constexpr (KIND == FETCH_AOS || KIND == FETCH_SPLIT || KIND == FETCH_LANE) {
             // 16 wave-level dwordx4 loads in flight, addresses from a per-quad (or per-lane) hash: rays of a wavefront sit on different nodes
             float4 r[16];
@@ -156,7 +217,7 @@ __global__ void __launch_bounds__(256) k_roof(Stamp *out, int iters, float seed,
         out[blockIdx.x * 4 + (threadIdx.x >> 6)] = s;
     }
     // keep every chain alive
-    const float keep = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + (float)(d0 + d1 + d2 + d3) + (float)(u0 + u1 + u2 + u3);
+    const float keep = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y + (float)(d0 + d1 + d2 + d3) + (float)(u0 + u1 + u2 + u3) + (float)(q4 + q5);
     if (keep == 12345.678f) lds_[0] = 1;
     if (keep == 12345.678f && lds_[threadIdx.x] == 77) out[0].t0 = 0;
 }
@@ -231,7 +292,7 @@ int main(int argc, char **argv)
     Stamp *d_out = nullptr;
     CHECK(hipMalloc(&d_out, sizeof(Stamp) * (size_t)n_cu * 8 * 4));
     std::vector<Stamp> h;
-    const std::vector<int> Ws = quick ? std::vector<int>{ 1, 2, 5 } : std::vector<int>{ 1, 2, 4, 5, 8 };
+    const std::vector<int> Ws = quick ? std::vector<int>{ 1, 2, 4, 5 } : std::vector<int>{ 1, 2, 4, 5, 8 };
     printf("{\"device\": \"%s\", \"compute_units\": %d, \"simds\": %d, \"instructions_per_wave\": %d, \"results\": [", prop.gcnArchName, n_cu, n_cu * 4, iters * 64);
     bool first = true;
     sweep<FMA_IND>(first, Ws, iters, n_cu, d_out, h);
@@ -248,6 +309,7 @@ int main(int argc, char **argv)
     sweep<ADD64_DEP>(first, Ws, iters, n_cu, d_out, h);
     sweep<MUL64_IND>(first, Ws, iters, n_cu, d_out, h);
     sweep<WALK_MIX>(first, Ws, iters, n_cu, d_out, h);
+    sweep<WALK_MIX_LANE>(first, Ws, iters, n_cu, d_out, h);
     sweep<VALU_SALU>(first, Ws, iters, n_cu, d_out, h);
     // node-fetch patterns on tables of three sizes: 16 KiB (vector L1), 2 MiB (one XCD's L2), 64 MiB (Infinity Cache: the size of the 1 M-triangle BVH)
     {
