@@ -48,6 +48,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMD = 1024           # 256 CUs x 4 SIMD-32
+MIN_SPLIT_PASS = 48     # N > 1: a timed region is cut into two passes (gather + post of the first hidden behind the second) only if each has this many frames
 TRACE_KERNELS = ("k_trace_lane<false",)   # the walk kernel of the timed build
 
 
@@ -91,6 +92,7 @@ def parse_args():
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the extra one-frame-at-a-time and moving-probe measurements (profiling runs)")
     ap.add_argument("--no-pmc", action="store_true", help="do not take the live rocprofv3 PMC passes (HBM traffic, VALU instructions of k_trace)")
     ap.add_argument("--no-overlap", action="store_true", help="gather + PSF on the trace stream (no double buffering)")
+    ap.add_argument("--no-split", action="store_true", help="N > 1: never cut a timed region into two passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the process rocprofv3 profiles: warm-up + one K-step region, nothing else
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for plumbing checks")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing check on a 1-GPU box: every rank uses GPU 0")
@@ -248,9 +250,12 @@ def main():
     psf = m.Psf(freq=tr.frequency)
     F = max(1, min(args.frames_in_flight, 256))
     K, W = args.steps, args.warmup
-    if world > 1 and K >= 2:
-        # N > 1: a timed region is cut into at least TWO passes, so that the gather + post-processing of a pass really run beside the
-        # next pass's trace inside the clock (with K <= frames in flight the region would be one pass with its gather and post exposed)
+    if world > 1 and not args.no_split and K >= 2 * MIN_SPLIT_PASS:
+        # N > 1: a timed region of ONE pass has its gather + rank-0 post-processing exposed at the end (nothing to overlap them with).  Cutting
+        # the region into two passes hides them behind the second pass's trace -- but smaller passes pay more in launch tails: measured on
+        # one MI355X (profiles/round4/exp_pass_split.txt), 20 steps as 10 + 10 cost 0.500 ms per step against 0.415 as one pass (+20 %), 64 as
+        # 32 + 32 0.388 against 0.366 (+6 %), while the exposed gather + post of a 20-frame pass of 8 x 128 scan-lines is ~4 % of it
+        # (33 MB over seven xGMI links, three memory-bound kernels).  So the region is cut only where a half still fills the GPU.
         F = min(F, -(-K // 2))
     pipe = Pipeline(torch, dist, ctx, psf, rank, world, E, e0, e1, R, F, args.backend, not args.no_overlap)
 
@@ -343,7 +348,7 @@ def main():
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%d rays/GPU, depth 10, %d rows" % (label, E_local, S, R),
                        "scan_lines_total": E, "rays_per_scan_line": S, "triangles": int(sd.n_tri), "parallelism": "scanline-shard x%d" % world,
-                       "frames_in_flight": F, "passes_per_timed_region": pass_sizes, "gather": "none (one GPU)" if world == 1 else "RCCL gather of the scan-line blocks to rank 0, one per pass, double-buffered against the next pass's trace", "timed_region_repeats": n_rep,
+                       "frames_in_flight": F, "passes_per_timed_region": pass_sizes, "last_pass_gather_and_post_exposed": world > 1, "gather": "none (one GPU)" if world == 1 else "RCCL gather of the scan-line blocks to rank 0, one per pass, double-buffered against the next pass's trace", "timed_region_repeats": n_rep,
                        "timed_seconds_total": total, "repeat_ms_per_step_min_median_max": [min(reps) / K * 1e3, dt / K * 1e3, max(reps) / K * 1e3], "slowest_repeat": reps.index(max(reps)),
                        "overlap_gather_psf_with_next_trace": not args.no_overlap, "bvh_builder": args.bvh, "bvh_build_s": round(t_bvh, 3),
                        "warmup_steps_run": W_run, "step": "clear, trace, accumulate, [all-gather], PSF, envelope, scan conversion to %dx%d" % (pipe.OUT_ROWS, pipe.OUT_COLS)},

@@ -62,15 +62,12 @@ for kernel, name in (("k_trace_lane<false", "pmc_k_trace_lane.json"), ("k_march<
     pmc[name] = der
 
 # ---- README
-roofs = os.path.join(root, "profiles", "round2")       # the two roofs were calibrated in round 2 (same tool, same chip)
-cal = json.load(open(os.path.join(roofs, "valu_roof.json")))
-mix5 = [r for r in cal["results"] if r["class"].startswith("BVH4 node-step mix") and r["waves_per_simd"] == 5][0]
-fet = json.load(open(os.path.join(roofs, "fetch_roof.json")))
-
-
-def fr(lanes, nbytes, table):
-    return [r for r in fet["results"] if r["lanes_per_run"] == lanes and r["bytes_per_lane"] == nbytes and r["table"].startswith(table)][0]
-
+rnd = os.path.basename(os.path.normpath(dst))
+cal = json.load(open(os.path.join(root, "profiles", "round4", "valu_roof.json")))      # re-measured in round 4 on the node step the walk runs today
+mix = [r for r in cal["results"] if r["class"].startswith("BVH4 LANE node-step mix") and r["waves_per_simd"] == 4][0]
+old_mix = [r for r in cal["results"] if r["class"].startswith("BVH4 node-step mix") and r["waves_per_simd"] == 5][0]
+tcp = json.load(open(os.path.join(root, "profiles", "round4", "tcp_access_cost.json")))
+cost = tcp["min_cycles_per_counted_access"]
 
 ks = {}
 for row in csv.DictReader(open(os.path.join(dst, "kernel_stats.csv"))):
@@ -82,7 +79,19 @@ for line in open(os.path.join(dst, "kernels_standalone.txt")):
             alone[k] = float(line.split(" avg ")[1].split()[0])
 r = bench["roofline"]; t = pmc["pmc_k_trace_lane.json"]; m = pmc["pmc_k_march.json"]; s = pmc["pmc_k_shade.json"]
 cb = bench["cpu_baseline"]
-txt = """# profiles/round3 -- MI355X (gfx950), ROCm 7.2
+
+
+def pipe_ms(d):          # the time a launch's counted cache accesses need at the cheapest measured cost per access
+    return d["tcp_lane_accesses_per_cycle_per_cu"] * d["kernel_busy_cycles_per_cu"] * cost / (mix["clock_ghz"] * 1e6)
+
+
+def krow(name, key, d, over):
+    return "| `%s` | %.0f us | %.0f us | %.0f M | %.3f (%.0f %%) | %.0f %% | %.0f %% | %.0f M = %.2f ms of the pipe | %.0f MB |" % (
+        name, alone.get(key, 0), over, d["valu_instructions"] / 1e6, d["valu_ipc_per_simd"], 100 * d["valu_ipc_per_simd"] / mix["simd_ipc"], 100 * d["valu_lane_utilisation"],
+        100 * d["wave_time_waiting_on_memory"], d["tcp_lane_accesses_per_cycle_per_cu"] * d["kernel_busy_cycles_per_cu"] * 256 / 1e6, pipe_ms(d), d["fabric_bytes_per_launch"] / 1e6)
+
+
+txt = """# profiles/@RND@ -- MI355X (gfx950), ROCm 7.2
 
 Workload of every file unless it says otherwise: `bench.py` defaults = synthetic 1 M random triangles, 128 scan-lines x 1024 sample
 paths per frame, 465 RF rows, max depth 10, one GPU, @FIF@ frames in flight per pass.  Produced by `tools/profile_round.sh` on a gpurun
@@ -90,9 +99,14 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 
 | file | what |
 |---|---|
-| `../round2/valu_roof.json`, `valu_roof_pmc.json`, `fetch_roof.json` | the two calibrated roofs (`tools/valu_roof.hip`, `tools/fetch_roof.hip`), measured in round 2 on the same chip with the same tools: not repeated |
-| `exp_*` | this round's experiments, copied in by hand (DESIGN.md 5.5): queues sorted into ray bundles against the order-preserving compaction (`exp_sorted_bundles_*`, `exp_unsorted_*`: per-bounce PMC of the walk, stamp-build lane statistics, refill / leaf-batch thresholds with sorted queues), kernels with path state in place by path id (`exp_records_kernels_standalone.txt`), CU-masked streams (`exp_cu_masks.txt`) |
-| `fetch_roof_same.json` | `tools/fetch_roof_same.hip` on the box: what lanes on ONE address cost the vector memory pipe (only whole adjacent quads are cheaper: 0.3 of four), and inactive lanes (nothing) |
+| `valu_roof.json` | `tools/valu_roof.hip --quick`, round 4: the VALU issue ceiling per instruction class, now with a register-only replica of the node step the walk runs TODAY (`BVH4 LANE node-step mix`: 12 `v_cndmask`, 24 `v_fma_mix_f32`, min / max / min3 / max3, keys, ranking, branch-free pushes: 91 instructions) beside round 2's mix |
+| `fetch_roof_same.json`, `tcp_access_cost.json` | `tools/fetch_roof_same.hip` alone and under `rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum SQ_INSTS_VMEM_RD`: what the counter counts (one access per lane, a uniform adjacent quad once) and what a counted access costs a CU's vector memory pipe in every sharing pattern -- the cheapest, %.3f cycles, is the floor `bench.py`'s `second_roof` uses |
+| `fetch_size_calibration.json` | `tools/fetch_calib.hip` under `--pmc FETCH_SIZE` / `TCC_EA0_RDREQ` / `TCC_MISS`: FETCH_SIZE against KNOWN byte counts in the walk's access shapes (a coalesced stream reads 1/2, as the guide says; a scattered 64-byte node is one request counted at 64 bytes: 1.00) |
+| `bvh_width.json` | `tools/bvh_width.py` (CPU): the headline frame's 816 k closest-hit queries walked over the product's BVH2 collapsed to 2 / 4 / 8 / 16-wide nodes, float and 8-bit boxes -- visits, chains, 16-byte pieces (DESIGN.md 5.6: rules 8-wide nodes out) |
+| `exp_refill_threshold.txt` | the walk's refill threshold at 4 / 8 / 16 idle lanes, timed and with the stamp build: more lanes step per iteration, every iteration costs proportionally more (the walk is bound by the vector memory pipe, not by idle lanes) |
+| `exp_pass_split.txt` | what cutting a timed region into smaller passes costs (decides `bench.py`'s N > 1 rule) |
+| `bench_random16m.json` | `python bench.py --workload random16m`: the STREAMING regime (16 M triangles, 2 GB of BVH past the Infinity Cache), with live PMC, CPU baseline and parity check |
+| `group_bench.json` | `tools/group_bench.py 0,0`: whole B-mode frames through `mcrt_group_*` (two ranks sharing the GPU) against one context |
 | `bench_unprofiled.json` | `python bench.py`: the JSON line (live PMC passes in child processes, CPU baseline, inline parity check) |
 | `bench_driver_cmd.json` | `python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command: one 20-frame pass per timed region) |
 | `pmc_bench.json` | the PMC block of `bench_unprofiled.json`, the labelled fall-back `bench.py` reads when it cannot profile itself |
@@ -104,56 +118,49 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 
 ## The two roofs (calibrated, not assumed)
 
-**VALU issue.**  A wave64 VALU instruction costs the SIMD about FOUR cycles for the instruction classes the kernels are made of, however
-many wavefronts share the SIMD: `v_fma_f32` independent streams reach %.3f instructions per cycle and SIMD at 8 waves, `v_min3_f32`,
-`v_pk_mul_f32`, DPP moves and compare/select pairs 0.24-0.26, `v_fma_f64` / `v_mul_f64` 0.24; only plain integer adds (0.45) and
-dependent `v_fma_f32` chains of many waves (0.44) come near the 2-cycle figure of the micro-architecture guide.  The register-only
-part of a BVH4 node step (as it was in round 2: packed subtract / multiply, min / max / min3 / max3, compares, selects, key arithmetic) issues at
-**%.3f instructions per cycle and SIMD at 5 waves per SIMD, clock %.2f GHz** -- the roof `bench.py` prices the walk against
-(1024 SIMDs x %.3f x %.2f GHz = %.0f G wave-instructions per second).
+**VALU issue.**  The register-only part of the node step the walk runs today issues at **%.3f instructions per cycle and SIMD at 4 wavefronts per
+SIMD, clock %.2f GHz** (round 2's step, the one `bench.py` priced against until round 3: %.3f at 5 wavefronts): 1024 SIMDs x %.3f x %.2f GHz =
+**%.0f G wave-instructions per second** is the ceiling of `roofline.frac`; the guide's two cycles per wave64 instruction (0.5) is
+`frac_vs_architectural`, which leads the block.
 
-**Vector memory pipe.**  A scattered wave-level `global_load_dwordx4` (every lane its own 128-byte line) costs a CU %.0f cycles
-when the data is in L1 (%.2f lanes per cycle), the same from L2, and %.0f cycles from the Infinity Cache; eight lanes reading one whole
-line cost %.0f cycles per wave-load (%.1f B/cycle/CU) -- the TCP moves ~24 B per cycle and CU through `dwordx4` loads however they
-are shaped, twice that through `dword` / `dwordx2` loads of contiguous lanes.  What the walk pays per node is therefore the number of
-16-byte pieces a lane fetches: 7 with the 128-byte nodes of round 1, 4 with the 64-byte half-float nodes.
-`bench.py` also reports the walk against the best class measured (`frac_vs_best_class`, 0.449) and against the guide's two cycles per
-instruction (`frac_vs_architectural`, 0.5).
+**Vector memory pipe.**  Every access `TCP_TOTAL_CACHE_ACCESSES` counts costs a CU at least %.3f cycles, whatever lanes share (a uniform
+adjacent quad counts once and costs 1.6; scattered lanes count one each at 1.35).  A launch cannot be shorter than its accesses x %.3f /
+(256 CUs x clock): `second_roof.frac` = that time over the launch's duration, at most 1 by construction.
 
 ## What the kernels do with them (per launch = one bounce of a @FIF@-frame pass)
 
-| kernel | alone | overlapped | VALU instr. | IPC / SIMD (of %.3f) | lanes active | waiting on memory | TCP lane-accesses / cycle / CU | fabric bytes |
+| kernel | alone | overlapped | VALU instr. | IPC / SIMD (of %.3f) | lanes active | waiting on memory | cache accesses | fabric bytes |
 |---|---|---|---|---|---|---|---|---|
-| `k_trace_lane` | %.0f us | %.0f us | %.0f M | %.3f (%.0f %%) | %.0f %% | %.0f %% | %.2f | %.0f MB |
-| `k_march` | %.0f us | %.0f us | %.0f M | %.3f (%.0f %%) | %.0f %% | %.0f %% | %.2f | %.0f MB |
-| `k_shade` | %.0f us | %.0f us | %.0f M | %.3f (%.0f %%) | %.0f %% | %.0f %% | %.2f | %.0f MB |
+%s
+%s
+%s
 
-The walk (`k_trace_lane`) issues at %.0f %% of the calibrated VALU ceiling with %.0f %% of its lanes active, and its %.1f M wave-level
-loads per launch keep the TCP at %.2f lane-accesses per cycle (the scattered-`dwordx4` rate measured above is %.2f): with 64-byte nodes
-both pipes are loaded to about the same degree.  The BVH is served on-die: L1 hit rate %.0f %%, L2 %.0f %% of the rest, fabric traffic
-%.0f MB per launch -- `bench.py` reports it as `hbm_measured_frac` = %.3f of the 8 TB/s HBM figure (the algorithmic bytes, %.1f GB per
-launch, flow at %.1f TB/s from the caches).
+The walk alone lasts %.0f us and its counted cache accesses need %.0f us of the CUs' vector memory pipes at the cheapest measured cost: it runs
+ON that roof (DESIGN.md 5.6), at %.0f %% of the calibrated VALU ceiling with %.0f %% of its lanes active.  The BVH is served on-die: L1 hit rate
+%.0f %%, L2 %.0f %% of the rest, fabric traffic %.0f MB per launch -- `hbm_measured_frac` = %.3f of the 8 TB/s HBM figure (the algorithmic
+bytes, %.1f GB per launch, flow at %.1f TB/s from the caches).
 
 `bench_unprofiled.json` (a step is a WHOLE B-mode frame: trace, accumulate, PSF, envelope, scan conversion): **%.1f M rays/s, %.3f ms per frame (%.0f frames/s)**, timed region repeated %d times (min / median / max
-%.3f / %.3f / %.3f ms per frame); one frame at a time %.2f ms per frame; roofline `frac` = %.2f of the VALU ceiling
-(%.0f of %.0f G wave-instructions per second, wall time of the launches, tails and the concurrently running `k_march` included);
+%.3f / %.3f / %.3f ms per frame); one frame at a time %.2f ms per frame; roofline `frac` = %.2f of the VALU ceiling, `frac_vs_architectural` %.2f,
+`second_roof.frac` %.2f (wall time of the launches with `k_march` running beside them);
 `parity_check.rf_bit_exact` = %s on %d scan-lines.  CPU baseline (the oracle, %d usable cores of %d hardware threads, %.1f kept busy):
 %.2f M rays/s, one thread %.1f k rays/s.  `bench_driver_cmd.json` (one 20-frame pass): %.1f M rays/s, %.3f ms per frame; the same pass with a
 different probe pose in every frame (`sweep`): %.3f ms per frame.
 """ % (
-    max(x["simd_ipc"] for x in cal["results"] if x["class"] == "v_fma_f32 independent"), mix5["simd_ipc"], mix5["clock_ghz"], mix5["simd_ipc"], mix5["clock_ghz"], 1024 * mix5["simd_ipc"] * mix5["clock_ghz"],
-    fr(1, 16, "16 KiB")["cycles_per_wave_load_per_cu"], 64 / fr(1, 16, "16 KiB")["cycles_per_wave_load_per_cu"], fr(1, 16, "64 MiB")["cycles_per_wave_load_per_cu"],
-    fr(8, 16, "16 KiB")["cycles_per_wave_load_per_cu"], fr(8, 16, "16 KiB")["bytes_per_cycle_per_cu"],
-    mix5["simd_ipc"],
-    alone.get("k_trace_lane<false>", 0), float(ks["k_trace_lane<false>"]["AverageNs"]) / 1e3, t["valu_instructions"] / 1e6, t["valu_ipc_per_simd"], 100 * t["valu_ipc_per_simd"] / mix5["simd_ipc"], 100 * t["valu_lane_utilisation"], 100 * t["wave_time_waiting_on_memory"], t["tcp_lane_accesses_per_cycle_per_cu"], t["fabric_bytes_per_launch"] / 1e6,
-    alone.get("k_march<false", 0), float(next(v for k, v in ks.items() if k.startswith("k_march<false, 2"))["AverageNs"]) / 1e3, m["valu_instructions"] / 1e6, m["valu_ipc_per_simd"], 100 * m["valu_ipc_per_simd"] / mix5["simd_ipc"], 100 * m["valu_lane_utilisation"], 100 * m["wave_time_waiting_on_memory"], m["tcp_lane_accesses_per_cycle_per_cu"], m["fabric_bytes_per_launch"] / 1e6,
-    alone.get("k_shade<false>", 0), float(ks["k_shade<false>"]["AverageNs"]) / 1e3, s["valu_instructions"] / 1e6, s["valu_ipc_per_simd"], 100 * s["valu_ipc_per_simd"] / mix5["simd_ipc"], 100 * s["valu_lane_utilisation"], 100 * s["wave_time_waiting_on_memory"], s["tcp_lane_accesses_per_cycle_per_cu"], s["fabric_bytes_per_launch"] / 1e6,
-    100 * t["valu_ipc_per_simd"] / mix5["simd_ipc"], 100 * t["valu_lane_utilisation"], t["vmem_read_instructions"] / 1e6, t["tcp_lane_accesses_per_cycle_per_cu"], 64 / fr(1, 16, "16 KiB")["cycles_per_wave_load_per_cu"],
+    cost, mix["simd_ipc"], mix["clock_ghz"], old_mix["simd_ipc"], mix["simd_ipc"], mix["clock_ghz"], 1024 * mix["simd_ipc"] * mix["clock_ghz"], cost, cost,
+    mix["simd_ipc"],
+    krow("k_trace_lane", "k_trace_lane<false>", t, float(ks["k_trace_lane<false>"]["AverageNs"]) / 1e3),
+    krow("k_march", "k_march<false", m, float(next(v for k, v in ks.items() if k.startswith("k_march<false, 2"))["AverageNs"]) / 1e3),
+    krow("k_shade", "k_shade<false>", s, float(ks["k_shade<false>"]["AverageNs"]) / 1e3),
+    alone.get("k_trace_lane<false>", 0), 1e3 * pipe_ms(t), 100 * t["valu_ipc_per_simd"] / mix["simd_ipc"], 100 * t["valu_lane_utilisation"],
     100 * t["l1_hit_rate"], 100 * t["l2_hit_rate"], t["fabric_bytes_per_launch"] / 1e6, r.get("hbm_measured_frac") or 0.0, r["algorithmic_bytes_per_launch"] / 1e9, r["algorithmic_GBps_cache_served"] / 1e3,
     bench["value"] / 1e6, bench["ms_per_step"], bench["frames_per_sec"], bench["config"]["timed_region_repeats"], *bench["config"]["repeat_ms_per_step_min_median_max"],
-    bench["one_frame_at_a_time"]["ms_per_step"], r.get("frac") or 0.0, r.get("achieved") or 0.0, r["peak"],
+    bench["one_frame_at_a_time"]["ms_per_step"], r.get("frac") or 0.0, r.get("frac_vs_architectural") or 0.0, (r.get("second_roof") or {}).get("frac") or 0.0,
     bench["parity_check"]["rf_bit_exact"], bench["parity_check"]["scan_lines"], cb["cores"], cb["host"]["cpu_count"], cb["cores_kept_busy"], cb["value"] / 1e6, cb["single_thread"]["value"] / 1e3,
     drv["value"] / 1e6, drv["ms_per_step"], drv["sweep"]["ms_per_step"])
-txt = txt.replace("@FIF@", str(FIF))
+txt = txt.replace("@FIF@", str(FIF)).replace("@RND@", rnd)
 open(os.path.join(dst, "README.md"), "w").write(txt)
+for extra in ("bench_random16m.json", "group_bench.json"):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(dst, extra))
 print(txt)

@@ -10,4 +10,6 @@ MCRT_NO_OVERLAP=1 bash tools/kstats.sh ${tag}_alone > $O/kernels_standalone.txt 
 bash tools/timeline.sh $tag > $O/frame_timeline.txt 2>&1
 BENCH_ARGS="--frames-in-flight 1" bash tools/timeline.sh ${tag}_f1 > $O/frame_timeline_one_frame.txt 2>&1
 bash tools/configs.sh > $O/configs.txt 2>&1
+( time timeout 900 python bench.py --workload random16m ) > $O/bench_random16m.json 2> $O/bench_random16m.err
+timeout 600 python tools/group_bench.py 0,0 32 8 > $O/group_bench.json 2> $O/group_bench.err
 tail -3 $O/bench.err; cat $O/configs.txt; head -5 $O/kernels_standalone.txt
