@@ -400,8 +400,8 @@ extern "C" int mcrt_get_params(mcrt_ctx *c, mcrt_params *out)
 // builds the BVH over tri[n_tri][9] (host or device pointer) with the context's builder and installs it on the device
 static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
 {
-    // k_trace addresses nodes (128 B) and triangle records (96 B) with 32-bit byte offsets
-    if (n_tri >= (1u << 25)) return set_error(MCRT_ERR_LIMIT, "%u triangles: the walk addresses at most 2^25 (4 GB of 96-byte records)", n_tri);
+    // k_trace addresses nodes (64 B as walked) and triangle records (64 B) with 32-bit byte offsets
+    if (n_tri >= (1u << 25)) return set_error(MCRT_ERR_LIMIT, "%u triangles: the walk addresses at most 2^25 (32-bit byte offsets into 64-byte nodes and records)", n_tri);
     hipFree(c->d_nodes); hipFree(c->d_tris); hipFree(c->d_tri_slot); c->d_nodes = c->d_tris = nullptr; c->d_tri_slot = nullptr;
     mcrt_free_bvh(&c->bvh); mcrt_free_bvh4(&c->bvh4);
     c->host_bvh_stale = false;
@@ -418,8 +418,8 @@ static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
         hipFree(d_tri); hipFree(d_mesh);
         if (rc) return rc;
         c->d_nodes = r.d_nodes; c->d_tri_slot = r.d_tri_slot;
-        {   // the walk's 96-byte records from the builder's 48-byte leaf-order array
-            hipError_t e = hipMalloc(&c->d_tris, 96 * (size_t)n_tri);
+        {   // the walk's 64-byte records from the builder's 48-byte leaf-order array
+            hipError_t e = hipMalloc(&c->d_tris, 64 * (size_t)n_tri);
             if (e == hipSuccess) e = mcrt::launch_expand_tris(r.d_tris, n_tri, r.pad_abs, c->d_tris, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             hipFree(r.d_tris);
@@ -459,10 +459,10 @@ static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
     if (c->bvh4.n_nodes >= (1u << 25)) return set_error(MCRT_ERR_LIMIT, "%u BVH4 nodes: the walk addresses at most 2^25", c->bvh4.n_nodes);
     HIP_TRY(hipMalloc(&c->d_nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes));
     HIP_TRY(hipMemcpy(c->d_nodes, c->bvh4.nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes, hipMemcpyHostToDevice));
-    {   // the walk's 96-byte records from the builder's 48-byte leaf-order array
+    {   // the walk's 64-byte records from the builder's 48-byte leaf-order array
         float4 *d_in = nullptr;
         HIP_TRY(hipMalloc(&d_in, 48 * (size_t)n_tri));
-        hipError_t e = hipMalloc(&c->d_tris, 96 * (size_t)n_tri);
+        hipError_t e = hipMalloc(&c->d_tris, 64 * (size_t)n_tri);
         if (e == hipSuccess) e = hipMemcpy(d_in, c->bvh.tri, 48 * (size_t)n_tri, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = mcrt::launch_expand_tris(d_in, n_tri, c->bvh.pad_abs, c->d_tris, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -486,14 +486,13 @@ static int download_bvh(mcrt_ctx *c)
     c->bvh.tri = (float *)malloc(48 * (size_t)c->bvh.n_tri);
     c->bvh4.nodes = (mcrt_bvh4_node *)malloc(sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes);
     if (!c->bvh.tri || !c->bvh4.nodes) return set_error(MCRT_ERR_NOMEM, "out of memory");
-    {   // back from the walk's 96-byte records to the ABI's 48-byte layout (v0|id, v1|mesh, v2|0)
-        std::vector<float> rec((size_t)c->bvh.n_tri * 24);
-        HIP_TRY(hipMemcpy(rec.data(), c->d_tris, 96 * (size_t)c->bvh.n_tri, hipMemcpyDeviceToHost));
+    {   // back from the walk's 64-byte records to the ABI's 48-byte layout (v0|id, v1|mesh, v2|0)
+        std::vector<float> rec((size_t)c->bvh.n_tri * 16);
+        HIP_TRY(hipMemcpy(rec.data(), c->d_tris, 64 * (size_t)c->bvh.n_tri, hipMemcpyDeviceToHost));
         for (size_t t = 0; t < c->bvh.n_tri; t++) {
-            const float *r = &rec[t * 24]; float *o = &c->bvh.tri[t * 12];
-            o[0] = r[12]; o[1] = r[13]; o[2] = r[14]; o[3] = r[7];      // v0 | id   (id rides with the padded lo)
-            o[4] = r[16]; o[5] = r[17]; o[6] = r[18]; o[7] = r[11];     // v1 | mesh (mesh with the padded hi)
-            o[8] = r[20]; o[9] = r[21]; o[10] = r[22]; o[11] = 0.0f;
+            const float *r = &rec[t * 16]; float *o = &c->bvh.tri[t * 12];
+            memcpy(o, r + 4, 32);                                       // v0 | id, v1 | mesh
+            o[8] = r[12]; o[9] = r[13]; o[10] = r[14]; o[11] = 0.0f;    // v2 | 0 (the record keeps the edge tolerance there)
         }
     }
     HIP_TRY(hipMemcpy(c->bvh4.nodes, c->d_nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes, hipMemcpyDeviceToHost));

@@ -85,13 +85,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // the walk only needs (fraction, triangle): k_shade looks the plane of the winner up again
 struct Best { float frac; int tri; };
 
-// The walk's triangle record, 6 x float4 = 96 B, from the 48-byte (v0|id, v1|mesh, v2|-) leaf-order array:
+// The walk's triangle record, 4 x float4 = 64 B, from the 48-byte (v0|id, v1|mesh, v2|-) leaf-order array:
 //   n.xyz | dot(v0,n)      plane of Bullet's processTriangle: n = (v1-v0) x (v2-v0)
-//   lo.xyz - pad | id      the triangle's own padded bounds (contract: pad = 2e-4 * largest extent + pad_abs),
-//   hi.xyz + pad | mesh    bit for bit what the builders put around the leaves
-//   v0 | v1 | v2           for the edge tests, each with the edge tolerance -1e-4 |n|^2 in .w
-// Every expression is the contract's (as in mcrt_build_bvh), evaluated once per triangle here instead of once
-// per test.
+//   v0 | id, v1 | mesh     the vertices (edge tests; the triangle's own padded bounds are rebuilt from them: tri_padded_bounds)
+//   v2 | -1e-4 |n|^2       ... and processTriangle's edge tolerance
+// Rounds 1-3 also stored the padded bounds (96 bytes, six 16-byte pieces per triangle tested): the walk is bound by the cache
+// accesses it makes, and the bounds are 19 register instructions from the vertices -- the contract's own expressions,
+// evaluated only for the triangles that pass the plane-side and fraction tests -- against two accesses for EVERY triangle tested.
 __global__ void k_expand_tris(const float4 *in, uint32_t n_tri, float pad_abs, float4 *out)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,18 +101,23 @@ __global__ void k_expand_tris(const float4 *in, uint32_t n_tri, float pad_abs, f
     const f3 v10 = v1 - v0, v20 = v2 - v0;
     const f3 n = cross(v10, v20);
     const float dist = dot(v0, n);
-    f3 lo = mk(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)));
-    f3 hi = mk(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)));
+    float4 *o = out + 4 * (size_t)t;
+    o[0] = make_float4(n.x, n.y, n.z, dist);
+    o[1] = make_float4(v0.x, v0.y, v0.z, t0.w);
+    o[2] = make_float4(v1.x, v1.y, v1.z, t1.w);
+    o[3] = make_float4(v2.x, v2.y, v2.z, dot(n, n) * -0.0001f);           // processTriangle's edge tolerance, -1e-4 |n|^2
+    (void)pad_abs;
+}
+// the triangle's own padded bounds (contract: pad = 2e-4 * largest extent + pad_abs), bit for bit what the builders put around the
+// leaves (mcrt_build_bvh, k_prims): min / max are exact, the three roundings (extent, pad, the six sums) are the builders' own
+MCRT_DEV void tri_padded_bounds(f3 v0, f3 v1, f3 v2, float pad_abs, f3 &lo_o, f3 &hi_o)
+{
+    const f3 lo = mk(fminf(v0.x, fminf(v1.x, v2.x)), fminf(v0.y, fminf(v1.y, v2.y)), fminf(v0.z, fminf(v1.z, v2.z)));
+    const f3 hi = mk(fmaxf(v0.x, fmaxf(v1.x, v2.x)), fmaxf(v0.y, fmaxf(v1.y, v2.y)), fmaxf(v0.z, fmaxf(v1.z, v2.z)));
     const float ext = fmaxf(fmaxf(fmaxf(0.0f, hi.x - lo.x), hi.y - lo.y), hi.z - lo.z);
     const float pad = 2e-4f * ext + pad_abs;
-    float4 *o = out + 6 * (size_t)t;
-    o[0] = make_float4(n.x, n.y, n.z, dist);
-    o[1] = make_float4(lo.x - pad, lo.y - pad, lo.z - pad, t0.w);
-    o[2] = make_float4(hi.x + pad, hi.y + pad, hi.z + pad, t1.w);
-    const float edge_tol = dot(n, n) * -0.0001f;              // processTriangle's edge tolerance, -1e-4 |n|^2
-    o[3] = make_float4(v0.x, v0.y, v0.z, edge_tol);
-    o[4] = make_float4(v1.x, v1.y, v1.z, edge_tol);
-    o[5] = make_float4(v2.x, v2.y, v2.z, edge_tol);
+    lo_o = mk(lo.x - pad, lo.y - pad, lo.z - pad);
+    hi_o = mk(hi.x + pad, hi.y + pad, hi.z + pad);
 }
 
 struct Rng { uint32_t k0, k1, element, sample, bounce; };
@@ -427,8 +432,8 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 #define MCRT_LANE_ADOPT_STEPS 4      // while idle lanes wait for a subtree, the inner-node phase returns to the hand-over after this many steps
 #endif
 #ifndef MCRT_LEAF_PREFETCH
-#define MCRT_LEAF_PREFETCH 2         // pieces of a triangle record fetched ahead of the tests that need them: 0 = none, 1 = plane + padded bounds, 2 = all six
-                                     // (measured per leaf phase: 5833 / 4597 / 4153 cycles; frame 0.512 / 0.506 / 0.505 ms)
+#define MCRT_LEAF_PREFETCH 1         // pieces of a triangle record fetched ahead of the tests that need them: 0 = the plane only, 1 = all four
+                                     // (round 2, 96-byte records, none / three / all six: 5833 / 4597 / 4153 cycles per leaf phase; frame 0.512 / 0.506 / 0.505 ms)
 #endif
 #ifndef MCRT_LANE_FETCH
 #define MCRT_LANE_FETCH 128          // queue positions a wavefront claims per atomic in a LARGE launch (>= MCRT_LANE_FETCH_FROM items), 64 below: measured
@@ -602,16 +607,12 @@ MCRT_DEV uint32_t lane_leaf_test(const FrameArgs &a, const LaneStack &S, f3 f2, 
     const uint32_t v = (uint32_t)~cur;
     const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
     for (uint32_t k = 0; k < cnt; k++) {
-        const float4 *T = (const float4 *)((const char *)a.tris + (first + k) * 96u);
+        const float4 *T = (const float4 *)((const char *)a.tris + ((first + k) << 6));
 #if MCRT_LEAF_PREFETCH >= 1
-        // the record's pieces are fetched TOGETHER, not stage by stage behind the early exits: a leaf phase then costs one
-        // memory round trip instead of three (the pieces of a rejected triangle are wasted loads; the walk has TCP headroom)
-        float4 P = T[0], PL = T[1], PH = T[2];
-        asm volatile("" : "+v"(PL.x), "+v"(PL.y), "+v"(PL.z), "+v"(PL.w), "+v"(PH.x), "+v"(PH.y), "+v"(PH.z));
-#if MCRT_LEAF_PREFETCH >= 2
-        float4 V0 = T[3], V1 = T[4], V2 = T[5];
-        asm volatile("" : "+v"(V0.x), "+v"(V0.y), "+v"(V0.z), "+v"(V0.w), "+v"(V1.x), "+v"(V1.y), "+v"(V1.z), "+v"(V2.x), "+v"(V2.y), "+v"(V2.z));
-#endif
+        // the record's four pieces are fetched TOGETHER, not stage by stage behind the early exits: a leaf phase then costs one
+        // memory round trip (the pieces of a rejected triangle are wasted loads)
+        float4 P = T[0], V0 = T[1], V1 = T[2], V2 = T[3];
+        asm volatile("" : "+v"(V0.x), "+v"(V0.y), "+v"(V0.z), "+v"(V0.w), "+v"(V1.x), "+v"(V1.y), "+v"(V1.z), "+v"(V2.x), "+v"(V2.y), "+v"(V2.z), "+v"(V2.w));
 #else
         const float4 P = T[0];
 #endif
@@ -620,18 +621,17 @@ MCRT_DEV uint32_t lane_leaf_test(const FrameArgs &a, const LaneStack &S, f3 f2, 
         const float db = dot(nrm, to) - P.w;
         if (da * db >= 0.0f) continue;
 #if MCRT_LEAF_PREFETCH < 1
-        const float4 PL = T[1], PH = T[2];
+        const float4 V0 = T[1], V1 = T[2], V2 = T[3];
 #endif
-        const int id = __float_as_int(PL.w);
+        const int id = __float_as_int(V0.w);
         const float proj = da - db;
         const float frac = da / proj;
         if (!(frac < best.frac || (frac == best.frac && (id < best.tri || (helper && best.tri < 0)))) || !(frac >= t_lo)) continue;
         float tmin, tmax;
-        if (!(slab_c(xyz(PL), xyz(PH), rc, inv, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax)) continue;
-#if MCRT_LEAF_PREFETCH < 2
-        const float4 V0 = T[3], V1 = T[4], V2 = T[5];
-#endif
-        const float edge_tol = V0.w;
+        f3 plo, phi;
+        tri_padded_bounds(xyz(V0), xyz(V1), xyz(V2), a.pad_abs, plo, phi);
+        if (!(slab_c(plo, phi, rc, inv, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax)) continue;
+        const float edge_tol = V2.w;
         const float s = 1.0f - frac;
         const f3 p = mk(s * f2.x + frac * to.x, s * f2.y + frac * to.y, s * f2.z + frac * to.z);
         const f3 p0 = xyz(V0) - p, p1 = xyz(V1) - p, p2 = xyz(V2) - p;
@@ -958,8 +958,8 @@ MCRT_DEV bool shade_path(const FrameArgs &a, uint32_t b, uint32_t pid, PathState
         Hit best; best.frac = __uint_as_float((uint32_t)(key >> 32)); best.tri = (int)(uint32_t)key; best.da = 0.0f; best.mesh = 0; best.n = mk(0, 0, 0);
         if (best.tri >= 0) {
             // plane normal, mesh and the origin-side value of the winning triangle, as the walk's test evaluated them
-            const float4 *T = a.tris + 6 * (size_t)a.tri_slot[best.tri];
-            const float4 P = T[0], t2 = T[2];
+            const float4 *T = a.tris + 4 * (size_t)a.tri_slot[best.tri];
+            const float4 P = T[0], t2 = T[2];                          // plane | (v1, mesh)
             best.n = xyz(P);
             best.da = dot(best.n, f2) - P.w;
             best.mesh = __float_as_int(t2.w);
@@ -1746,9 +1746,9 @@ hipError_t launch_verify_div(float res, float rcp, unsigned long long *bad, hipS
     return hipGetLastError();
 }
 
-hipError_t launch_expand_tris(const float4 *in48, uint32_t n_tri, float pad_abs, float4 *out96, hipStream_t st)
+hipError_t launch_expand_tris(const float4 *in48, uint32_t n_tri, float pad_abs, float4 *out64, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_expand_tris, dim3((n_tri + 255u) / 256u), dim3(256), 0, st, in48, n_tri, pad_abs, out96);
+    hipLaunchKernelGGL(k_expand_tris, dim3((n_tri + 255u) / 256u), dim3(256), 0, st, in48, n_tri, pad_abs, out64);
     return hipGetLastError();
 }
 

@@ -271,7 +271,7 @@ __global__ void k_stack(const int *parent_int, const uint32_t *is4, const uint8_
 // box is recomputed bottom-up from the triangles' new padded bounds -- exact unions again, so the closest-hit contract holds and
 // frames equal those of a freshly built tree.  For deformations that keep the spatial order roughly intact this is ~10x cheaper
 // than a rebuild and keeps the quality of a host SAH tree.
-//   k_refit_records   the walk's 96-byte triangle record of every leaf-order slot from the new vertices (as k_expand_tris)
+//   k_refit_records   the walk's 64-byte triangle record of every leaf-order slot from the new vertices (as k_expand_tris)
 //   k_refit_links     parent node and slot of every BVH4 node, number of inner children per node
 //   k_refit_nodes     per node: boxes of its leaf children from the records; then the LAST arrival at a node (its own thread and
 //                     the threads coming up from its inner children) computes the node's union and carries it to the parent
@@ -279,7 +279,7 @@ __global__ void k_refit_records(const float *tri, const float4 *old_rec, uint32_
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_tri) return;
-    const float4 id_rec = old_rec[6 * (size_t)slot + 1], mesh_rec = old_rec[6 * (size_t)slot + 2];
+    const float4 id_rec = old_rec[4 * (size_t)slot + 1], mesh_rec = old_rec[4 * (size_t)slot + 2];
     const uint32_t id = __float_as_uint(id_rec.w);
     const float *v = tri + (size_t)id * 9;
     const float v0x = v[0], v0y = v[1], v0z = v[2], v1x = v[3], v1y = v[4], v1z = v[5], v2x = v[6], v2y = v[7], v2z = v[8];
@@ -287,18 +287,13 @@ __global__ void k_refit_records(const float *tri, const float4 *old_rec, uint32_
     const float ax = v1x - v0x, ay = v1y - v0y, az = v1z - v0z, bx = v2x - v0x, by = v2y - v0y, bz = v2z - v0z;
     const float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
     const float dist = v0x * nx + v0y * ny + v0z * nz;
-    const float lx = fminf(v0x, fminf(v1x, v2x)), ly = fminf(v0y, fminf(v1y, v2y)), lz = fminf(v0z, fminf(v1z, v2z));
-    const float hx = fmaxf(v0x, fmaxf(v1x, v2x)), hy = fmaxf(v0y, fmaxf(v1y, v2y)), hz = fmaxf(v0z, fmaxf(v1z, v2z));
-    const float ext = fmaxf(fmaxf(fmaxf(0.0f, hx - lx), hy - ly), hz - lz);
-    const float pad = 2e-4f * ext + s->pad_abs;
     const float edge_tol = (nx * nx + ny * ny + nz * nz) * -0.0001f;
-    float4 *o = rec + 6 * (size_t)slot;
+    float4 *o = rec + 4 * (size_t)slot;
     o[0] = make_float4(nx, ny, nz, dist);
-    o[1] = make_float4(lx - pad, ly - pad, lz - pad, id_rec.w);
-    o[2] = make_float4(hx + pad, hy + pad, hz + pad, mesh_rec.w);
-    o[3] = make_float4(v0x, v0y, v0z, edge_tol);
-    o[4] = make_float4(v1x, v1y, v1z, edge_tol);
-    o[5] = make_float4(v2x, v2y, v2z, edge_tol);
+    o[1] = make_float4(v0x, v0y, v0z, id_rec.w);
+    o[2] = make_float4(v1x, v1y, v1z, mesh_rec.w);
+    o[3] = make_float4(v2x, v2y, v2z, edge_tol);
+    (void)s;
 }
 
 __global__ void k_refit_links(const float4 *nodes, uint32_t n4, int *parent, uint32_t *inner, uint32_t *arrived)
@@ -314,7 +309,7 @@ __global__ void k_refit_links(const float4 *nodes, uint32_t n4, int *parent, uin
     if (i == 0) parent[0] = -1;
 }
 
-__global__ void k_refit_nodes(float4 *nodes, uint32_t n4, const float4 *rec, const int *parent, const uint32_t *inner, uint32_t *arrived, float4 *root_box)
+__global__ void k_refit_nodes(float4 *nodes, uint32_t n4, const float4 *rec, const Scal *s, const int *parent, const uint32_t *inner, uint32_t *arrived, float4 *root_box)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
@@ -324,9 +319,16 @@ __global__ void k_refit_nodes(float4 *nodes, uint32_t n4, const float4 *rec, con
         const uint32_t v = (uint32_t)~ref, first = v >> 3, cnt = (v & 7u) + 1u;
         float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
         for (uint32_t t = 0; t < cnt; t++) {
-            const float4 l = rec[6 * (size_t)(first + t) + 1], h = rec[6 * (size_t)(first + t) + 2];
-            lo[0] = fminf(lo[0], l.x); lo[1] = fminf(lo[1], l.y); lo[2] = fminf(lo[2], l.z);
-            hi[0] = fmaxf(hi[0], h.x); hi[1] = fmaxf(hi[1], h.y); hi[2] = fmaxf(hi[2], h.z);
+            // the triangle's own padded bounds from its record's vertices -- bit for bit what k_prims / mcrt_build_bvh / the walk compute
+            const float4 a0 = rec[4 * (size_t)(first + t) + 1], a1 = rec[4 * (size_t)(first + t) + 2], a2 = rec[4 * (size_t)(first + t) + 3];
+            const float v[9] = { a0.x, a0.y, a0.z, a1.x, a1.y, a1.z, a2.x, a2.y, a2.z };
+            float l[3], h[3], ext = 0.0f;
+            for (int a = 0; a < 3; a++) {
+                l[a] = fminf(v[a], fminf(v[3 + a], v[6 + a])); h[a] = fmaxf(v[a], fmaxf(v[3 + a], v[6 + a]));
+                ext = fmaxf(ext, h[a] - l[a]);
+            }
+            const float pad = 2e-4f * ext + s->pad_abs;
+            for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], l[a] - pad); hi[a] = fmaxf(hi[a], h[a] + pad); }
         }
         nodes[8 * (size_t)i + 2 * k] = make_float4(lo[0], lo[1], lo[2], hi[0]);
         nodes[8 * (size_t)i + 2 * k + 1] = make_float4(hi[1], hi[2], __int_as_float(ref), 0.0f);
@@ -435,16 +437,16 @@ int bvh_refit(const float *tri_dev, uint32_t n_tri, float4 *d_nodes, uint32_t n_
     if (n_tri == 0 || n_nodes4 == 0) return set_error(MCRT_ERR_INVALID, "refit: no tree");
     Temp tmp;
     Scal *s = nullptr; float4 *new_rec = nullptr, *root = nullptr; int *parent = nullptr; uint32_t *inner = nullptr, *arrived = nullptr;
-    LB_TRY(tmp.get(&s, 1)); LB_TRY(tmp.get(&new_rec, 6 * (size_t)n_tri)); LB_TRY(tmp.get(&root, 2));
+    LB_TRY(tmp.get(&s, 1)); LB_TRY(tmp.get(&new_rec, 4 * (size_t)n_tri)); LB_TRY(tmp.get(&root, 2));
     LB_TRY(tmp.get(&parent, n_nodes4)); LB_TRY(tmp.get(&inner, n_nodes4)); LB_TRY(tmp.get(&arrived, n_nodes4));
     const dim3 blk(256), grid_t((n_tri + 255u) / 256u), grid_n((n_nodes4 + 255u) / 256u);
     hipLaunchKernelGGL(k_scal_init, dim3(1), dim3(1), 0, st, s);
     hipLaunchKernelGGL(k_scale, dim3(1024), blk, 0, st, tri_dev, (size_t)n_tri * 9, s);
     hipLaunchKernelGGL(k_pad, dim3(1), dim3(1), 0, st, s);
     hipLaunchKernelGGL(k_refit_records, grid_t, blk, 0, st, tri_dev, (const float4 *)d_recs, n_tri, (const Scal *)s, new_rec);
-    LB_TRY(hipMemcpyAsync(d_recs, new_rec, 96 * (size_t)n_tri, hipMemcpyDeviceToDevice, st));
+    LB_TRY(hipMemcpyAsync(d_recs, new_rec, 64 * (size_t)n_tri, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_refit_links, grid_n, blk, 0, st, (const float4 *)d_nodes, n_nodes4, parent, inner, arrived);
-    hipLaunchKernelGGL(k_refit_nodes, grid_n, blk, 0, st, d_nodes, n_nodes4, (const float4 *)d_recs, (const int *)parent, (const uint32_t *)inner, arrived, root);
+    hipLaunchKernelGGL(k_refit_nodes, grid_n, blk, 0, st, d_nodes, n_nodes4, (const float4 *)d_recs, (const Scal *)s, (const int *)parent, (const uint32_t *)inner, arrived, root);
     Scal hs; float4 rb[2];
     LB_TRY(hipMemcpyAsync(&hs, s, sizeof hs, hipMemcpyDeviceToHost, st));
     LB_TRY(hipMemcpyAsync(rb, root, sizeof rb, hipMemcpyDeviceToHost, st));
