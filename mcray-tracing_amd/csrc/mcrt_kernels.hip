@@ -428,6 +428,12 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 #ifndef MCRT_MARCH_TILE
 #define MCRT_MARCH_TILE 256          // slots a wavefront of k_march sorts by segment length at a time (a multiple of 64, at most 256: one byte per slot)
 #endif
+#ifndef MCRT_MARCH_LDS_TABLES
+#define MCRT_MARCH_LDS_TABLES 1      // k_march keeps the per-material table and a tile's length classes in LDS (0: rounds 2-3, both re-read through the vector memory pipe)
+#endif
+#ifndef MCRT_MARCH_MTAB
+#define MCRT_MARCH_MTAB 32           // rows of the per-material table k_march keeps in LDS (scenes with more materials read it from memory)
+#endif
 #ifndef MCRT_LANE_ADOPT_STEPS
 #define MCRT_LANE_ADOPT_STEPS 4      // while idle lanes wait for a subtree, the inner-node phase returns to the hand-over after this many steps
 #endif
@@ -1197,10 +1203,17 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
     RowBin *rb = (RowBin *)smem;
     uint32_t *lflags = (uint32_t *)(rb + nrt);
     uint32_t *sort_cnt = lflags + ((nf + 3u) & ~3u) + wv * 64;                              // this wavefront's 64 length classes ...
-    unsigned char *sort_list = (unsigned char *)(lflags + ((nf + 3u) & ~3u) + 4 * 64) + wv * MCRT_MARCH_TILE;   // ... and its tile's slots, longest first
+    unsigned char *sort_list = (unsigned char *)(lflags + ((nf + 3u) & ~3u) + 4 * 64) + wv * MCRT_MARCH_TILE;   // ... its tile's slots, longest first ...
+    unsigned char *sort_cls = (unsigned char *)(lflags + ((nf + 3u) & ~3u) + 4 * 64) + 4 * MCRT_MARCH_TILE + wv * MCRT_MARCH_TILE;   // ... and their classes (worked out once)
+    // the per-material table (a few 16-byte rows) in LDS: the tile sort and every segment load look it up -- as reads of the vector memory pipe
+    // they were a tenth of this kernel's cache accesses, and the frame is bound by the sum of its kernels' accesses
+    float4 *mtab_l = (float4 *)((unsigned char *)(lflags + ((nf + 3u) & ~3u) + 4 * 64) + 8 * MCRT_MARCH_TILE);
+    const bool mtab_in_lds = MCRT_MARCH_LDS_TABLES && a.n_mat <= (uint32_t)MCRT_MARCH_MTAB;
     for (uint32_t r = tid; r < nrt; r += nthr) { rb[r].thr = r <= R ? a.row_thr[r] : -__builtin_inf(); rb[r].bin = 0; }
     for (uint32_t r = tid; r < nf; r += nthr) lflags[r] = 0u;
+    if (mtab_in_lds) for (uint32_t r = tid; r < a.n_mat; r += nthr) mtab_l[r] = a.mtab[r];
     __syncthreads();
+#define MCRT_MTAB(m) (mtab_in_lds ? mtab_l[m] : a.mtab[m])
 
     // XCD-aware numbering: workgroup w runs on XCD w % 8; give every XCD a CONTIGUOUS range of scan-lines, so that the texture
     // cells its segments touch (neighbouring scan-lines cross the same tissue) are shared in ITS L2
@@ -1238,7 +1251,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
 #define MCRT_LOAD_SEGMENT() { \
         const float4 *mr = a.mrec + 3 * ((size_t)seg_b * a.ne * a.S + seg_pid); \
         const float4 g0 = mr[0], g1 = mr[1], g2 = mr[2]; \
-        const float4 mt = a.mtab[__float_as_int(g2.w)]; \
+        const float4 mt = MCRT_MTAB(__float_as_int(g2.w)); \
         point = mk(g0.x, g0.y, g0.z); seg_refl = g0.w; \
         delta = mk(g1.x, g1.y, g1.z); inten = g1.w; \
         t_start = __hiloint2double(__float_as_int(g2.y), __float_as_int(g2.x)); \
@@ -1283,7 +1296,8 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
                     const uint32_t t1 = min(s_end, tile0 + (uint32_t)MCRT_MARCH_TILE);
                     sort_cnt[lane] = 0u;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                    // (the class of a slot is worked out twice -- once to count, once to place -- rather than kept in registers)
+                    // (the class of a slot is worked out once, while counting, and kept in LDS for the placing pass: worked out twice -- rounds 2-3 --
+                    //  it cost the placing pass the same three global reads per slot again)
                     auto slot_class = [&](uint32_t slot) -> uint32_t {
                         if (slot >= t1) return 0xffffffffu;
                         const uint32_t sn = a.seg_count[pid0 + slot], sb0 = all_b ? 0u : b;
@@ -1291,7 +1305,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
                         uint32_t its = 0u;
                         if (!all_b) {
                             const float4 g2 = a.mrec[3 * ((size_t)sb0 * a.ne * a.S + pid0 + slot) + 2];
-                            const float4 mt = a.mtab[__float_as_int(g2.w)];
+                            const float4 mt = MCRT_MTAB(__float_as_int(g2.w));
                             const bool silent = a.tex_finite && mt.x == 0.0f && mt.z == 0.0f;
                             its = silent ? 0u : (__float_as_uint(g2.z) + 7u) >> 3;
                         }
@@ -1299,6 +1313,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
                     };
                     for (int k = 0; k < MCRT_MARCH_TILE / 64; k++) {
                         const uint32_t c = slot_class(tile0 + (uint32_t)(k * 64 + lane));
+                        sort_cls[k * 64 + lane] = (unsigned char)c;                      // (0xff: no live segment in this slot)
                         if (c != 0xffffffffu) atomicAdd(&sort_cnt[c], 1u);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -1310,8 +1325,8 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
                     sort_cnt[lane] = incl - mine_cnt;                            // now the class's next free position in the list
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
                     for (int k = 0; k < MCRT_MARCH_TILE / 64; k++) {
-                        const uint32_t c = slot_class(tile0 + (uint32_t)(k * 64 + lane));
-                        if (c != 0xffffffffu) sort_list[atomicAdd(&sort_cnt[c], 1u)] = (unsigned char)(k * 64 + lane);
+                        const uint32_t c = MCRT_MARCH_LDS_TABLES ? (uint32_t)sort_cls[k * 64 + lane] : (slot_class(tile0 + (uint32_t)(k * 64 + lane)) & 0xffu);
+                        if (c != 0xffu) sort_list[atomicAdd(&sort_cnt[c], 1u)] = (unsigned char)(k * 64 + lane);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
                     list_n = (uint32_t)__shfl((int)incl, 63, 64); list_pos = 0u;
@@ -1381,6 +1396,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
     }
 #undef MCRT_ADVANCE
 #undef MCRT_LOAD_SEGMENT
+#undef MCRT_MTAB
 #ifdef MCRT_STAMP
     if (lane == 0) { atomicAdd(&a.stamps[120], mt_hand); atomicAdd(&a.stamps[121], mt_adv); atomicAdd(&a.stamps[122], mt_vox); atomicAdd(&a.stamps[123], mt_acc); atomicAdd(&a.stamps[124], __builtin_readcyclecounter() - mt_begin); }
     if (lane == 0) { atomicAdd(&a.stamps[9], mc_iter); atomicAdd(&a.stamps[10], mc_step_it); atomicAdd(&a.stamps[11], mc_step_quads); atomicAdd(&a.stamps[12], mc_fin_it); atomicAdd(&a.stamps[13], mc_refill); atomicAdd(&a.stamps[14], 1ull); }
@@ -1614,7 +1630,7 @@ __global__ void k_philox_probe(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c
 size_t march_lds_bytes(uint32_t R, uint32_t rows)               // rows: entries of the { threshold, bin } image (R + 1, or FrameArgs::march_rows)
 {
     const size_t img = (size_t)rows * 16, flg = (size_t)((((R + 31u) >> 5) + 3u) & ~3u) * 4;
-    return img + flg + 4 * (64 * 4 + MCRT_MARCH_TILE);        // + per wavefront: 64 length-class counters, one tile of slot numbers
+    return img + flg + 4 * (64 * 4 + 2 * MCRT_MARCH_TILE) + 16 * MCRT_MARCH_MTAB;        // + per wavefront: 64 length-class counters, one tile of slot numbers and of their classes; + the material table
 }
 
 hipError_t launch_init(const FrameArgs &a, hipStream_t st)
