@@ -419,7 +419,7 @@ static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
         if (rc) return rc;
         c->d_nodes = r.d_nodes; c->d_tri_slot = r.d_tri_slot;
         {   // the walk's 64-byte records from the builder's 48-byte leaf-order array
-            hipError_t e = hipMalloc(&c->d_tris, 64 * (size_t)n_tri);
+            hipError_t e = hipMalloc(&c->d_tris, 16 * MCRT_TRI_PIECES * (size_t)n_tri);
             if (e == hipSuccess) e = mcrt::launch_expand_tris(r.d_tris, n_tri, r.pad_abs, c->d_tris, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             hipFree(r.d_tris);
@@ -462,7 +462,7 @@ static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
     {   // the walk's 64-byte records from the builder's 48-byte leaf-order array
         float4 *d_in = nullptr;
         HIP_TRY(hipMalloc(&d_in, 48 * (size_t)n_tri));
-        hipError_t e = hipMalloc(&c->d_tris, 64 * (size_t)n_tri);
+        hipError_t e = hipMalloc(&c->d_tris, 16 * MCRT_TRI_PIECES * (size_t)n_tri);
         if (e == hipSuccess) e = hipMemcpy(d_in, c->bvh.tri, 48 * (size_t)n_tri, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = mcrt::launch_expand_tris(d_in, n_tri, c->bvh.pad_abs, c->d_tris, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -486,13 +486,14 @@ static int download_bvh(mcrt_ctx *c)
     c->bvh.tri = (float *)malloc(48 * (size_t)c->bvh.n_tri);
     c->bvh4.nodes = (mcrt_bvh4_node *)malloc(sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes);
     if (!c->bvh.tri || !c->bvh4.nodes) return set_error(MCRT_ERR_NOMEM, "out of memory");
-    {   // back from the walk's 64-byte records to the ABI's 48-byte layout (v0|id, v1|mesh, v2|0)
-        std::vector<float> rec((size_t)c->bvh.n_tri * 16);
-        HIP_TRY(hipMemcpy(rec.data(), c->d_tris, 64 * (size_t)c->bvh.n_tri, hipMemcpyDeviceToHost));
+    {   // back from the walk's records to the ABI's 48-byte layout (v0|id, v1|mesh, v2|0)
+        const size_t W = 4 * MCRT_TRI_PIECES, V = 4 * (MCRT_TRI_PIECES - 3);      // floats per record, first float of v0
+        std::vector<float> rec((size_t)c->bvh.n_tri * W);
+        HIP_TRY(hipMemcpy(rec.data(), c->d_tris, 4 * W * (size_t)c->bvh.n_tri, hipMemcpyDeviceToHost));
         for (size_t t = 0; t < c->bvh.n_tri; t++) {
-            const float *r = &rec[t * 16]; float *o = &c->bvh.tri[t * 12];
-            memcpy(o, r + 4, 32);                                       // v0 | id, v1 | mesh
-            o[8] = r[12]; o[9] = r[13]; o[10] = r[14]; o[11] = 0.0f;    // v2 | 0 (the record keeps the edge tolerance there)
+            const float *r = &rec[t * W + V]; float *o = &c->bvh.tri[t * 12];
+            memcpy(o, r, 32);                                          // v0 | id, v1 | mesh
+            o[8] = r[8]; o[9] = r[9]; o[10] = r[10]; o[11] = 0.0f;      // v2 | 0 (the record keeps the edge tolerance there)
         }
     }
     HIP_TRY(hipMemcpy(c->bvh4.nodes, c->d_nodes, sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes, hipMemcpyDeviceToHost));

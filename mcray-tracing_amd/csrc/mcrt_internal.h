@@ -16,6 +16,10 @@
 #define MCRT_MAX_ROWS 2048
 #define MCRT_MAX_BOUNCES 16
 
+#ifndef MCRT_TRI_PIECES
+#define MCRT_TRI_PIECES 3             // 16-byte pieces of the walk's triangle record: 3 = v0|id, v1|mesh, v2|edge tolerance (48 B, the plane rebuilt from the vertices);
+#endif                                // 4 = plane first (64 B).  Round 1-3's records also carried the padded bounds (96 B)
+
 namespace mcrt {
 int set_error(int code, const char *fmt, ...);
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/mcrt.h"
+#include "mcrt_internal.h"
 
 namespace mcrt {
 
@@ -10,7 +11,7 @@ struct FrameArgs {
     // scene (HBM-resident, read-only)
     const uint4 *nodes_walk;   // [n_nodes][4]  the walk's 64-byte nodes: child-transposed half-float boxes (rounded outwards) + refs
     int *stack_ovf;            // [max_stack - MCRT_LANE_STACK][trace_blocks * 256] traversal-stack entries beyond the LDS part (this work set's own)
-    const float4 *tris;        // [T][4]        64-B triangle records, leaf order: n|dist, v0|id, v1|mesh, v2|edge tolerance
+    const float4 *tris;        // [T][MCRT_TRI_PIECES]  48-B triangle records, leaf order: v0|id, v1|mesh, v2|edge tolerance (64-B form: n|dist first)
     const uint4 *meshes;       // [n_mesh]      mat_inside, mat_outside, vascular, -
     const float4 *mats;        // [n_mat][2]    imp, att, mu0, mu1 | sigma, spec, shine, thick
     const float2 *tex;         // [n^3]         texture_noise, scattering_probability

@@ -85,13 +85,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // the walk only needs (fraction, triangle): k_shade looks the plane of the winner up again
 struct Best { float frac; int tri; };
 
-// The walk's triangle record, 4 x float4 = 64 B, from the 48-byte (v0|id, v1|mesh, v2|-) leaf-order array:
-//   n.xyz | dot(v0,n)      plane of Bullet's processTriangle: n = (v1-v0) x (v2-v0)
+// The walk's triangle record, from the 48-byte (v0|id, v1|mesh, v2|-) leaf-order array -- MCRT_TRI_PIECES x 16 bytes:
+//   [n.xyz | dot(v0,n)]    plane of Bullet's processTriangle, n = (v1-v0) x (v2-v0): only in the 4-piece record; the 3-piece record
+//                          leaves it out and tri_plane() rebuilds it (20 register instructions per triangle tested)
 //   v0 | id, v1 | mesh     the vertices (edge tests; the triangle's own padded bounds are rebuilt from them: tri_padded_bounds)
 //   v2 | -1e-4 |n|^2       ... and processTriangle's edge tolerance
-// Rounds 1-3 also stored the padded bounds (96 bytes, six 16-byte pieces per triangle tested): the walk is bound by the cache
-// accesses it makes, and the bounds are 19 register instructions from the vertices -- the contract's own expressions,
-// evaluated only for the triangles that pass the plane-side and fraction tests -- against two accesses for EVERY triangle tested.
+// Rounds 1-3 stored plane AND padded bounds (96 bytes, six 16-byte pieces per triangle tested).  The walk is bound by the cache accesses
+// it makes: what a few register instructions rebuild -- with the contract's own expressions, so bit for bit -- is not
+// fetched.
+constexpr int TRI_V0 = MCRT_TRI_PIECES - 3;          // index of the v0 piece in a record
 __global__ void k_expand_tris(const float4 *in, uint32_t n_tri, float pad_abs, float4 *out)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,12 +103,18 @@ __global__ void k_expand_tris(const float4 *in, uint32_t n_tri, float pad_abs, f
     const f3 v10 = v1 - v0, v20 = v2 - v0;
     const f3 n = cross(v10, v20);
     const float dist = dot(v0, n);
-    float4 *o = out + 4 * (size_t)t;
-    o[0] = make_float4(n.x, n.y, n.z, dist);
-    o[1] = make_float4(v0.x, v0.y, v0.z, t0.w);
-    o[2] = make_float4(v1.x, v1.y, v1.z, t1.w);
-    o[3] = make_float4(v2.x, v2.y, v2.z, dot(n, n) * -0.0001f);           // processTriangle's edge tolerance, -1e-4 |n|^2
+    float4 *o = out + MCRT_TRI_PIECES * (size_t)t;
+    if (TRI_V0 == 1) o[0] = make_float4(n.x, n.y, n.z, dist);
+    o[TRI_V0] = make_float4(v0.x, v0.y, v0.z, t0.w);
+    o[TRI_V0 + 1] = make_float4(v1.x, v1.y, v1.z, t1.w);
+    o[TRI_V0 + 2] = make_float4(v2.x, v2.y, v2.z, dot(n, n) * -0.0001f);           // processTriangle's edge tolerance, -1e-4 |n|^2
     (void)pad_abs;
+}
+// the plane of a triangle, n = (v1 - v0) x (v2 - v0) and dot(v0, n): k_expand_tris' expressions (what the 4-piece record stores)
+MCRT_DEV float4 tri_plane(f3 v0, f3 v1, f3 v2)
+{
+    const f3 n = cross(v1 - v0, v2 - v0);
+    return make_float4(n.x, n.y, n.z, dot(v0, n));
 }
 // the triangle's own padded bounds (contract: pad = 2e-4 * largest extent + pad_abs), bit for bit what the builders put around the
 // leaves (mcrt_build_bvh, k_prims): min / max are exact, the three roundings (extent, pad, the six sums) are the builders' own
@@ -613,12 +621,13 @@ MCRT_DEV uint32_t lane_leaf_test(const FrameArgs &a, const LaneStack &S, f3 f2, 
     const uint32_t v = (uint32_t)~cur;
     const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
     for (uint32_t k = 0; k < cnt; k++) {
-        const float4 *T = (const float4 *)((const char *)a.tris + ((first + k) << 6));
-#if MCRT_LEAF_PREFETCH >= 1
-        // the record's four pieces are fetched TOGETHER, not stage by stage behind the early exits: a leaf phase then costs one
-        // memory round trip (the pieces of a rejected triangle are wasted loads)
-        float4 P = T[0], V0 = T[1], V1 = T[2], V2 = T[3];
+        const float4 *T = (const float4 *)((const char *)a.tris + (first + k) * (uint32_t)(16 * MCRT_TRI_PIECES));
+#if MCRT_LEAF_PREFETCH >= 1 || MCRT_TRI_PIECES == 3
+        // the record's pieces are fetched TOGETHER, not stage by stage behind the early exits: a leaf phase then costs one
+        // memory round trip (the pieces of a rejected triangle are wasted loads; staged: 0.349 against 0.343 ms per frame, round 4)
+        float4 V0 = T[TRI_V0], V1 = T[TRI_V0 + 1], V2 = T[TRI_V0 + 2];
         asm volatile("" : "+v"(V0.x), "+v"(V0.y), "+v"(V0.z), "+v"(V0.w), "+v"(V1.x), "+v"(V1.y), "+v"(V1.z), "+v"(V2.x), "+v"(V2.y), "+v"(V2.z), "+v"(V2.w));
+        const float4 P = MCRT_TRI_PIECES == 3 ? tri_plane(xyz(V0), xyz(V1), xyz(V2)) : T[0];
 #else
         const float4 P = T[0];
 #endif
@@ -626,7 +635,7 @@ MCRT_DEV uint32_t lane_leaf_test(const FrameArgs &a, const LaneStack &S, f3 f2, 
         const float da = dot(nrm, f2) - P.w;
         const float db = dot(nrm, to) - P.w;
         if (da * db >= 0.0f) continue;
-#if MCRT_LEAF_PREFETCH < 1
+#if MCRT_LEAF_PREFETCH < 1 && MCRT_TRI_PIECES == 4
         const float4 V0 = T[1], V1 = T[2], V2 = T[3];
 #endif
         const int id = __float_as_int(V0.w);
@@ -964,8 +973,9 @@ MCRT_DEV bool shade_path(const FrameArgs &a, uint32_t b, uint32_t pid, PathState
         Hit best; best.frac = __uint_as_float((uint32_t)(key >> 32)); best.tri = (int)(uint32_t)key; best.da = 0.0f; best.mesh = 0; best.n = mk(0, 0, 0);
         if (best.tri >= 0) {
             // plane normal, mesh and the origin-side value of the winning triangle, as the walk's test evaluated them
-            const float4 *T = a.tris + 4 * (size_t)a.tri_slot[best.tri];
-            const float4 P = T[0], t2 = T[2];                          // plane | (v1, mesh)
+            const float4 *T = a.tris + MCRT_TRI_PIECES * (size_t)a.tri_slot[best.tri];
+            const float4 t2 = T[TRI_V0 + 1];                            // (v1, mesh)
+            const float4 P = MCRT_TRI_PIECES == 3 ? tri_plane(xyz(T[0]), xyz(t2), xyz(T[2])) : T[0];
             best.n = xyz(P);
             best.da = dot(best.n, f2) - P.w;
             best.mesh = __float_as_int(t2.w);

@@ -18,7 +18,7 @@ struct LbvhResult {
 // Runs on stream st and synchronises it.  Returns an mcrt_status.
 int lbvh_build(const float *tri_dev, const uint32_t *mesh_dev, uint32_t n_tri, hipStream_t st, LbvhResult *out);
 
-// New vertex positions for an existing tree (either builder): rewrites the 64-byte triangle records d_recs in place and refits
+// New vertex positions for an existing tree (either builder): rewrites the walk's triangle records d_recs (MCRT_TRI_PIECES x 16 bytes each) in place and refits
 // every box of d_nodes bottom-up; returns the new absolute pad and the tree's bounds.  Runs on st and synchronises it.
 int bvh_refit(const float *tri_dev, uint32_t n_tri, float4 *d_nodes, uint32_t n_nodes4, float4 *d_recs, hipStream_t st, float *pad_abs, float lo[3], float hi[3]);
 

@@ -271,7 +271,7 @@ __global__ void k_stack(const int *parent_int, const uint32_t *is4, const uint8_
 // box is recomputed bottom-up from the triangles' new padded bounds -- exact unions again, so the closest-hit contract holds and
 // frames equal those of a freshly built tree.  For deformations that keep the spatial order roughly intact this is ~10x cheaper
 // than a rebuild and keeps the quality of a host SAH tree.
-//   k_refit_records   the walk's 64-byte triangle record of every leaf-order slot from the new vertices (as k_expand_tris)
+//   k_refit_records   the walk's triangle record of every leaf-order slot from the new vertices (as k_expand_tris)
 //   k_refit_links     parent node and slot of every BVH4 node, number of inner children per node
 //   k_refit_nodes     per node: boxes of its leaf children from the records; then the LAST arrival at a node (its own thread and
 //                     the threads coming up from its inner children) computes the node's union and carries it to the parent
@@ -279,7 +279,8 @@ __global__ void k_refit_records(const float *tri, const float4 *old_rec, uint32_
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_tri) return;
-    const float4 id_rec = old_rec[4 * (size_t)slot + 1], mesh_rec = old_rec[4 * (size_t)slot + 2];
+    constexpr int V0 = MCRT_TRI_PIECES - 3;
+    const float4 id_rec = old_rec[MCRT_TRI_PIECES * (size_t)slot + V0], mesh_rec = old_rec[MCRT_TRI_PIECES * (size_t)slot + V0 + 1];
     const uint32_t id = __float_as_uint(id_rec.w);
     const float *v = tri + (size_t)id * 9;
     const float v0x = v[0], v0y = v[1], v0z = v[2], v1x = v[3], v1y = v[4], v1z = v[5], v2x = v[6], v2y = v[7], v2z = v[8];
@@ -288,11 +289,12 @@ __global__ void k_refit_records(const float *tri, const float4 *old_rec, uint32_
     const float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
     const float dist = v0x * nx + v0y * ny + v0z * nz;
     const float edge_tol = (nx * nx + ny * ny + nz * nz) * -0.0001f;
-    float4 *o = rec + 4 * (size_t)slot;
-    o[0] = make_float4(nx, ny, nz, dist);
-    o[1] = make_float4(v0x, v0y, v0z, id_rec.w);
-    o[2] = make_float4(v1x, v1y, v1z, mesh_rec.w);
-    o[3] = make_float4(v2x, v2y, v2z, edge_tol);
+    float4 *o = rec + MCRT_TRI_PIECES * (size_t)slot;
+    if (V0 == 1) o[0] = make_float4(nx, ny, nz, dist);
+    o[V0] = make_float4(v0x, v0y, v0z, id_rec.w);
+    o[V0 + 1] = make_float4(v1x, v1y, v1z, mesh_rec.w);
+    o[V0 + 2] = make_float4(v2x, v2y, v2z, edge_tol);
+    (void)dist;
     (void)s;
 }
 
@@ -320,7 +322,8 @@ __global__ void k_refit_nodes(float4 *nodes, uint32_t n4, const float4 *rec, con
         float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
         for (uint32_t t = 0; t < cnt; t++) {
             // the triangle's own padded bounds from its record's vertices -- bit for bit what k_prims / mcrt_build_bvh / the walk compute
-            const float4 a0 = rec[4 * (size_t)(first + t) + 1], a1 = rec[4 * (size_t)(first + t) + 2], a2 = rec[4 * (size_t)(first + t) + 3];
+            const float4 *rp = rec + MCRT_TRI_PIECES * (size_t)(first + t) + (MCRT_TRI_PIECES - 3);
+            const float4 a0 = rp[0], a1 = rp[1], a2 = rp[2];
             const float v[9] = { a0.x, a0.y, a0.z, a1.x, a1.y, a1.z, a2.x, a2.y, a2.z };
             float l[3], h[3], ext = 0.0f;
             for (int a = 0; a < 3; a++) {
@@ -437,14 +440,14 @@ int bvh_refit(const float *tri_dev, uint32_t n_tri, float4 *d_nodes, uint32_t n_
     if (n_tri == 0 || n_nodes4 == 0) return set_error(MCRT_ERR_INVALID, "refit: no tree");
     Temp tmp;
     Scal *s = nullptr; float4 *new_rec = nullptr, *root = nullptr; int *parent = nullptr; uint32_t *inner = nullptr, *arrived = nullptr;
-    LB_TRY(tmp.get(&s, 1)); LB_TRY(tmp.get(&new_rec, 4 * (size_t)n_tri)); LB_TRY(tmp.get(&root, 2));
+    LB_TRY(tmp.get(&s, 1)); LB_TRY(tmp.get(&new_rec, MCRT_TRI_PIECES * (size_t)n_tri)); LB_TRY(tmp.get(&root, 2));
     LB_TRY(tmp.get(&parent, n_nodes4)); LB_TRY(tmp.get(&inner, n_nodes4)); LB_TRY(tmp.get(&arrived, n_nodes4));
     const dim3 blk(256), grid_t((n_tri + 255u) / 256u), grid_n((n_nodes4 + 255u) / 256u);
     hipLaunchKernelGGL(k_scal_init, dim3(1), dim3(1), 0, st, s);
     hipLaunchKernelGGL(k_scale, dim3(1024), blk, 0, st, tri_dev, (size_t)n_tri * 9, s);
     hipLaunchKernelGGL(k_pad, dim3(1), dim3(1), 0, st, s);
     hipLaunchKernelGGL(k_refit_records, grid_t, blk, 0, st, tri_dev, (const float4 *)d_recs, n_tri, (const Scal *)s, new_rec);
-    LB_TRY(hipMemcpyAsync(d_recs, new_rec, 64 * (size_t)n_tri, hipMemcpyDeviceToDevice, st));
+    LB_TRY(hipMemcpyAsync(d_recs, new_rec, 16 * MCRT_TRI_PIECES * (size_t)n_tri, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_refit_links, grid_n, blk, 0, st, (const float4 *)d_nodes, n_nodes4, parent, inner, arrived);
     hipLaunchKernelGGL(k_refit_nodes, grid_n, blk, 0, st, d_nodes, n_nodes4, (const float4 *)d_recs, (const Scal *)s, (const int *)parent, (const uint32_t *)inner, arrived, root);
     Scal hs; float4 rb[2];
