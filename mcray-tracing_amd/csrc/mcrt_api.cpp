@@ -752,7 +752,7 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     a.st0 = w.d_st0; a.st1 = w.d_st1; a.st2 = w.d_st2; a.queue = w.d_q;
     a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.cursors = w.d_cursors; a.segs = w.d_segs; a.hits = w.d_hits; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
     a.stats = c->d_stats; a.error_flag = c->d_error; a.stamps = c->d_stats + 8;
-    a.n_mat = c->n_mat; a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
+    a.n_mat = c->n_mat; a.n_mesh = c->n_mesh; a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
     a.e_begin = e0; a.ne_frame = e1 - e0; a.ne = (e1 - e0) * n_frames;   // n_frames consecutive frame ids traced as one pass
     a.ksplit_limit = c->knobs.ksplit_limit;   // bounces with fewer rays than this are cut into pieces (see k_trace)
     if (c->stats_on) a.ksplit_limit = 0;   // counting mode = one walk per ray, so the counts are those of a plain closest-hit walk

@@ -436,6 +436,9 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 #ifndef MCRT_MARCH_TILE
 #define MCRT_MARCH_TILE 256          // slots a wavefront of k_march sorts by segment length at a time (a multiple of 64, at most 256: one byte per slot)
 #endif
+#ifndef MCRT_SHADE_TABLE
+#define MCRT_SHADE_TABLE 32          // rows of the material / mesh tables k_shade keeps in LDS (larger scenes read them from memory)
+#endif
 #ifndef MCRT_MARCH_LDS_TABLES
 #define MCRT_MARCH_LDS_TABLES 1      // k_march keeps the per-material table and a tile's length classes in LDS (0: rounds 2-3, both re-read through the vector memory pipe)
 #endif
@@ -961,8 +964,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_
 // the path goes on.
 struct PathState { f3 from, dir; float intensity; int media, outside; double dist_mm; };
 
+// the scene's material and mesh tables as k_shade reads them: its LDS copies when they fit (MCRT_SHADE_TABLE rows each), else memory.
+// (`lds` is wave-uniform: a scalar branch picks the load, so the LDS side compiles to ds_read, not to a flat load)
+struct ShadeTables {
+    const float4 *mats_g; const uint4 *meshes_g; const float4 *mats_l; const uint4 *meshes_l; bool lds;
+    // (the empty asm keeps the two sides different instructions: otherwise the compiler merges them into ONE load through a selected flat pointer)
+    MCRT_DEV float4 mat(uint32_t r) const { float4 v; if (lds) { v = mats_l[r]; asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); } else v = mats_g[r]; return v; }
+    MCRT_DEV uint4 mesh(uint32_t r) const { uint4 v; if (lds) { v = meshes_l[r]; asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); } else v = meshes_g[r]; return v; }
+};
 template <bool STATS>
-MCRT_DEV bool shade_path(const FrameArgs &a, uint32_t b, uint32_t pid, PathState &ps, f3 f2, f3 to, unsigned long long key, bool &reflected,
+MCRT_DEV bool shade_path(const FrameArgs &a, const ShadeTables &tb, uint32_t b, uint32_t pid, PathState &ps, f3 f2, f3 to, unsigned long long key, bool &reflected,
                          unsigned long long &st_seg, unsigned long long &st_hits)
 {
     bool alive = false;
@@ -983,7 +994,7 @@ MCRT_DEV bool shade_path(const FrameArgs &a, uint32_t b, uint32_t pid, PathState
         const uint32_t line = pid / a.S, fr = line / a.ne_frame;      // (two divisions; the remainders by multiply-subtract)
         const uint32_t e_abs = a.e_begin + (line - fr * a.ne_frame);
         Rng g; g.k0 = a.seed; g.k1 = a.frame + *a.frame_dev + fr; g.element = e_abs; g.sample = pid - line * a.S; g.bounce = b;
-        const float4 m0 = a.mats[2 * media];   // imp, att, mu0, mu1  (second half: sigma, spec, shine, thick)
+        const float4 m0 = tb.mat(2 * media);   // imp, att, mu0, mu1  (second half: sigma, spec, shine, thick)
         const float att = m0.y;
 
         f3 seg_to = to;
@@ -995,9 +1006,9 @@ MCRT_DEV bool shade_path(const FrameArgs &a, uint32_t b, uint32_t pid, PathState
             if (best.da <= 0.0f) nn = neg(nn);
             const float sfr = 1.0f - best.frac;
             const f3 hp = mk(sfr * f2.x + best.frac * to.x, sfr * f2.y + best.frac * to.y, sfr * f2.z + best.frac * to.z);
-            const uint4 organ = a.meshes[best.mesh];   // mat_inside, mat_outside, vascular
+            const uint4 organ = tb.mesh(best.mesh);   // mat_inside, mat_outside, vascular
             // thickness penetration scene.cpp:132-139 (Box-Muller on block 0)
-            const float sigma_t = a.mats[2 * organ.x + 1].w;
+            const float sigma_t = tb.mat(2 * organ.x + 1).w;
             float qpen = 0.0f;
             if (sigma_t != 0.0f) {
                 double n1, n2, sn, cs;
@@ -1022,7 +1033,7 @@ MCRT_DEV bool shade_path(const FrameArgs &a, uint32_t b, uint32_t pid, PathState
                 if (organ.z) { after_vasc = OUT_SELF; mat_after = (int)organ.x; }
                 else { after_vasc = OUT_NONE; mat_after = (int)organ.x; }
             }
-            const float4 a0 = a.mats[2 * mat_after], a1 = a.mats[2 * mat_after + 1];
+            const float4 a0 = tb.mat(2 * mat_after), a1 = tb.mat(2 * mat_after + 1);
             double u_pc, u_x;
             rng_block(g, 1u, u_pc, u_x);
             // power_cosine_variate ray.cpp:213-224
@@ -1112,6 +1123,17 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x * blockDim.x >= n) return;
     const int lane = threadIdx.x & 63;
+    // the scene's material and mesh tables in LDS when they fit (they nearly always do: the reference's scenes have 9 materials and <= 11 meshes):
+    // a ray looks up five material rows and one mesh row -- a quarter of this kernel's cache accesses, and the frame is bound by their sum
+    __shared__ float4 mats_l[2 * MCRT_SHADE_TABLE];
+    __shared__ uint4 meshes_l[MCRT_SHADE_TABLE];
+    const bool tables_in_lds = a.n_mat <= (uint32_t)MCRT_SHADE_TABLE && a.n_mesh <= (uint32_t)MCRT_SHADE_TABLE;
+    if (tables_in_lds) {
+        for (uint32_t r = threadIdx.x; r < 2u * a.n_mat; r += blockDim.x) mats_l[r] = a.mats[r];
+        for (uint32_t r = threadIdx.x; r < a.n_mesh; r += blockDim.x) meshes_l[r] = a.meshes[r];
+        __syncthreads();
+    }
+    const ShadeTables tb = { a.mats, a.meshes, mats_l, meshes_l, tables_in_lds };
     // two queue buffers, ping-pong by bounce parity (like the path state)
     const uint32_t *q_in = a.queue + (size_t)(b & 1u) * a.ne * a.S;
     uint32_t *q_out = a.queue + (size_t)((b + 1u) & 1u) * a.ne * a.S;
@@ -1133,7 +1155,7 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
         const f3 f2 = ry.f2, to = ry.to;
         const size_t hi = (b == 0u) ? (size_t)(i / a.S) : (size_t)i;            // bounce 0: one walk per queued (scan-line, frame) (see k_trace_lane, k_init)
         const unsigned long long key = ((b & 1u) ? a.key1 : a.key0)[hi];
-        alive = shade_path<STATS>(a, b, pid, ps, f2, to, key, reflected, st_seg, st_hits);
+        alive = shade_path<STATS>(a, tb, b, pid, ps, f2, to, key, reflected, st_seg, st_hits);
     }
     const f3 from = ps.from, dir = ps.dir; const float intensity = ps.intensity; const int media = ps.media, outside = ps.outside; const double dist_mm = ps.dist_mm;
 
@@ -1162,7 +1184,7 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
             q_out[pos] = pid;
             ((b & 1u) ? a.key0 : a.key1)[pos] = MCRT_KEY_MISS;            // the next bounce's closest-hit word of this ray
             const size_t so = (size_t)((b + 1u) & 1u) * a.ne * a.S + pos;
-            a.st0[so] = make_float4(from.x, from.y, from.z, ray_len(intensity, a.mats[2 * media].y, a));   // origin | the next ray's length factor
+            a.st0[so] = make_float4(from.x, from.y, from.z, ray_len(intensity, tb.mat(2 * media).y, a));   // origin | the next ray's length factor
             a.st1[so] = make_float4(dir.x, dir.y, dir.z, __int_as_float(media));
             a.st2[so] = make_float4(__int_as_float(__double2loint(dist_mm)), __int_as_float(__double2hiint(dist_mm)), __int_as_float(outside), intensity);
         }
@@ -1223,7 +1245,9 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
     for (uint32_t r = tid; r < nf; r += nthr) lflags[r] = 0u;
     if (mtab_in_lds) for (uint32_t r = tid; r < a.n_mat; r += nthr) mtab_l[r] = a.mtab[r];
     __syncthreads();
-#define MCRT_MTAB(m) (mtab_in_lds ? mtab_l[m] : a.mtab[m])
+    // (a scalar branch picks the load; the empty asm keeps the LDS side a ds_read -- merged, the compiler emits ONE flat load through a selected pointer)
+    auto mtab_row = [&](int m) -> float4 { float4 v; if (mtab_in_lds) { v = mtab_l[m]; asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); } else v = a.mtab[m]; return v; };
+#define MCRT_MTAB(m) mtab_row(m)
 
     // XCD-aware numbering: workgroup w runs on XCD w % 8; give every XCD a CONTIGUOUS range of scan-lines, so that the texture
     // cells its segments touch (neighbouring scan-lines cross the same tissue) are shared in ITS L2
