@@ -546,17 +546,17 @@ def committed_pmc(args, pass_sizes, queries_per_launch):
     match; otherwise the walk's VALU instructions are DERIVED as the committed instructions per closest-hit query x the queries this
     run counted per launch (labelled `derived`), and the fabric bytes are left out."""
     try:
-        with open(os.path.join(ROOT, "profiles", "round3", "pmc_bench.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "round4", "pmc_bench.json")) as f:
             d = json.load(f)
         key = d.get("config_key")
         if key[:1] != [args.workload] or key[4] != args.rows:            # (the instructions per query are the scene's, to a few per cent whatever the ray count)
             return None
         p = dict(d["pmc"])
         if key == [args.workload, args.scanlines, args.scanlines_total, args.rays, args.rows, args.gpus, pass_sizes]:
-            p["source"] = "file: profiles/round3/pmc_bench.json (%s)" % d.get("taken_at", "?")
+            p["source"] = "file: profiles/round4/pmc_bench.json (%s)" % d.get("taken_at", "?")
             return p
         per_query = d["valu_instructions_per_query"]
-        return {"source": "derived: profiles/round3/pmc_bench.json instructions per closest-hit query (%.1f, N = 1) x the %.0f queries per launch counted in this run" % (per_query, queries_per_launch),
+        return {"source": "derived: profiles/round4/pmc_bench.json instructions per closest-hit query (%.1f, N = 1) x the %.0f queries per launch counted in this run" % (per_query, queries_per_launch),
                 "derived": True, "kernel": p.get("kernel"), "valu_instructions_per_launch": per_query * queries_per_launch,
                 "lane_utilisation": p.get("lane_utilisation"), "traffic_bytes_per_launch": None}
     except Exception:

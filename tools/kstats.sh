@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-kernel totals of one bench run under rocprofv3 --kernel-trace --stats (kernels overlap as in production unless MCRT_NO_OVERLAP=1)
-out=gpurun_out/kstats_$1; mkdir -p $out; export TMPDIR=/tmp
+out=gpurun_out/kstats_$1; rm -rf $out; mkdir -p $out; export TMPDIR=/tmp
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/s -- python3 bench.py --steps 128 --warmup 128 --no-cpu-baseline --no-latency-leg --no-pmc ${BENCH_ARGS} > $out/bench.log 2>&1
 python3 - $out <<'PY'
 import csv, glob, sys

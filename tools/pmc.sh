@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes for one kernel (PMC_KERNEL, default k_trace_lane<false>): separate rocprofv3 runs per counter group, as the pool requires
-out=gpurun_out/pmc_$1; mkdir -p $out; export TMPDIR=/tmp
+out=gpurun_out/pmc_$1; rm -rf $out; mkdir -p $out; export TMPDIR=/tmp      # (a fresh directory: rocprofv3 names its files by process id, an older run's would be summarised too)
 B="python3 bench.py --steps 128 --warmup 128 --no-cpu-baseline --no-latency-leg --no-pmc ${BENCH_ARGS}"
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 128 --warmup 128 --no-cpu-baseline --no-latency-leg --no-pmc ${BENCH_ARGS} > $out/stats.log 2>&1
 timeout -s KILL 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --output-format csv -d $out/sq1 -- $B > $out/sq1.log 2>&1

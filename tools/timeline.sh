@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-launch kernel durations of the last benchmark frame (rocprofv3 kernel trace)
-out=gpurun_out/timeline_$1; mkdir -p $out; export TMPDIR=/tmp
+out=gpurun_out/timeline_$1; rm -rf $out; mkdir -p $out; export TMPDIR=/tmp
 timeout -s KILL 400 rocprofv3 --kernel-trace --output-format csv -d $out/kt -- python3 bench.py --no-cpu-baseline --no-latency-leg --no-pmc ${BENCH_ARGS:---steps 128 --warmup 128} > $out/bench.log 2>&1
 python3 - $out <<'PY'
 import csv, glob, sys
