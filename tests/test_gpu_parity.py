@@ -997,3 +997,42 @@ def test_whole_bmode_frames_of_a_pass(mcrt, orc, sphere, tex256):
     for d in (dev, out, one):
         sim.ctx.free(d)
     sim.close()
+
+
+def test_scene_with_more_tables_than_fit_in_lds(mcrt, orc, tex256):
+    """k_shade and k_march keep the material / mesh tables in LDS when they have at most 32 rows (round 4); a scene with 40 materials and
+    36 meshes takes the other path -- the tables read from memory -- and must give the oracle's frame bit for bit as well; the same
+    scene cut down to tables that fit gives its own oracle frame (both sides of the switch in one test)"""
+    rng = np.random.default_rng(77)
+    base = mcrt.synth.materials()
+    for n_extra, n_mesh in ((31, 36), (0, 6)):
+        mats = [dict(m) for m in base]
+        for k in range(n_extra):            # copies of the tissue rows under new names, slightly different impedance / attenuation: every row is used
+            m = dict(base[1 + k % (len(base) - 1)]); m["name"] = "X%d" % k
+            m["impedance"] = float(m["impedance"]) * (1.0 + 0.01 * (k + 1)); m["attenuation"] = float(m["attenuation"]) * (1.0 + 0.02 * k)
+            mats.append(m)
+        names = [m["name"] for m in mats if m["name"] != "GEL"]
+        cfg = {"transducerPosition": [-13.5, 0.0, 0.0], "transducerAngles": [0.0, 0.0, -90.0], "materials": mats, "meshes": [],
+               "origin": [0.0, 0.0, 0.0], "spacing": [1.0, 1.0, 1.0], "scaling": 1.0, "startingMaterial": "GEL"}
+        meshes = {}
+        for i in range(n_mesh):
+            f = "soup_%d.obj" % i
+            meshes[f] = mcrt.synth.random_triangles(400, 900 + i, lo=(-10.0, -4.0, -4.0), hi=(2.0, 4.0, 4.0), edge=0.6)
+            cfg["meshes"].append({"file": f, "rigid": True, "vascular": bool(i % 5 == 4), "deltas": [0.0, 0.0, 0.0],
+                                  "material": names[(7 * i + 3) % len(names)], "outsideMaterial": names[(5 * i) % len(names)], "outsideNormals": True})
+        sd = mcrt.scene_io.build_scene(cfg, meshes)
+        assert sd.materials.shape[0] == len(base) + n_extra and len(sd.meshes) == n_mesh
+        E, S = 12, 96
+        tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256)
+        hits, _, _ = sim.ctx.trace_frame_debug(4, sim.rf_dev)
+        rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
+        osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
+        o = osc.trace_frame(orc.default_params(n_elements=E, n_samples=S), tr.pos, tr.dir, tex256, frame_id=4, use_bvh=False, n_threads=8)
+        assert np.array_equal(hits, o["hits"]) and (hits >= 0).sum() > E * S
+        assert np.array_equal(rf.view(np.uint32), o["rf"].view(np.uint32)) and np.isnan(rf).any()       # (AIR interfaces: total internal reflection, NaN bins included)
+        # the frames of a pass too (k_march's pair variant and its tile sort)
+        dev = sim.ctx.alloc(2 * E * sim.R * 4)
+        sim.ctx.trace_frames(4, 2, dev)
+        assert np.array_equal(sim.ctx.d2h(dev, (2, E, sim.R))[0].T.view(np.uint32), o["rf"].view(np.uint32))
+        sim.ctx.free(dev)
+        sim.close()
