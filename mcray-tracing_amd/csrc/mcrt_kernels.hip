@@ -775,7 +775,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_
                     const uint32_t hi = MCRT_SUB_LO(cur_x + 1u);
                     const unsigned long long start = (unsigned long long)MCRT_SUB_LO(cur_x) + MCRT_SUB_STATIC(cur_x) + base;
                     if (start < hi) { pool_next = (uint32_t)start; pool_end = min((uint32_t)start + fetch, hi); }
-                    else if (++visited >= X) queue_empty = true;
+                    else if (++visited >= X) {
+                        queue_empty = true;
+                        // the launch has entered its TAIL: from here on it only finishes the rays in flight, at falling occupancy.  The word tells the
+                        // accumulation's stream (hipStreamWaitValue32 in run_bounce) that the CUs' memory pipes are free for k_march of the previous bounce
+                        if (a.tail_flag && lane == 0) atomicMax(a.tail_flag, a.tail_base + b + 1u);
+                    }
                     else cur_x = (cur_x + 1u) & (X - 1u);
 #if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
                     if (queue_empty) { wc_empty = wall_clock64(); if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 1], ~wc_empty); }
@@ -1121,6 +1126,7 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
 {
     const uint32_t n = a.counts[b];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.tail_flag && i == 0u) atomicMax(a.tail_flag, a.tail_base + b + 1u);      // (the walk of bounce b is over: the safety net of its own signal, see k_trace_lane)
     if (blockIdx.x * blockDim.x >= n) return;
     const int lane = threadIdx.x & 63;
     // the scene's material and mesh tables in LDS when they fit (they nearly always do: the reference's scenes have 9 materials and <= 11 meshes):
