@@ -765,6 +765,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_
                 }
                 fresh = true; shared = false; helper = false; i = 0xffffffffu;
             }
+            // (Publishing finished rays WHILE the launch runs -- so that k_shade could start on them in the launch's tail -- needs a device-scope
+            //  release here: the XCDs' L2s are not coherent with each other inside a launch.  Measured, round 4: __threadfence() + one atomic per
+            //  refill round make a launch of the 20-frame pass 3.11 ms instead of 0.67, of a 128-frame pass 13.6 instead of 3.08.  Not done.)
             const bool need = fresh && !exhausted;
             const unsigned long long dynm = __ballot(need && i == 0xffffffffu);
             if (dynm) {
