@@ -26,7 +26,8 @@ struct FrameArgs {
     unsigned long long *key0, *key1;   // [np] closest hit per ray: fraction bits << 32 | triangle id (atomicMin), ping-pong by bounce parity
     const uint32_t *tri_slot;  // [T] triangle id -> position in the leaf-order triangle array
     uint32_t *counts;          // [MAX_BOUNCES+1] live rays per bounce
-    uint32_t *cursors;         // [MAX_BOUNCES][MCRT_XCDS][MCRT_CURSOR_STRIDE] queue cursors of the persistent walk, one per XCD sub-queue
+    uint32_t *cursors;         // [MAX_BOUNCES][MCRT_XCDS][MCRT_CURSOR_STRIDE] queue cursors of the persistent walk, one per XCD sub-queue; word MCRT_TAIL_WORD of a
+                               // bounce's first cursor: raised to 1 when that bounce's walk has claimed its last ray (the accumulation's stream waits for it)
     mcrt_segment *segs;        // [np][B]   written only when want_segs (mcrt_cast_rays / mcrt_trace_frame_debug with a segment buffer)
     int32_t *hits;             // [np][B]   triangle hit at the end of each segment (-1 none); null unless the caller asked for hit indices
     float4 *mrec;              // [B][np][3] what k_march needs of a segment: from,refl | delta,intensity | t_start(f64),steps,media
@@ -36,10 +37,9 @@ struct FrameArgs {
     uint32_t *flags;           // [ne][(R+31)/32] non-finite flags
     unsigned long long *stats; // [6]
     uint32_t *error_flag;      // device word, bit 0: traversal stack overflow
-    uint32_t *tail_flag;       // device word the walk of bounce b raises to tail_base + b + 1 when its queue has run dry (the accumulation's stream waits for it), or null
     unsigned long long *stamps; // [80] diagnostic build (-DMCRT_STAMP) only
     // sizes / parameters
-    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, pose_stride, acc_stride, acc_off, trace_blocks, march_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift, march_rows, n_mat, n_mesh, tail_base;   // march_rows: entries of k_march's padded LDS image when its fast variant applies, else 0
+    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, pose_stride, acc_stride, acc_off, trace_blocks, march_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift, march_rows, n_mat, n_mesh;   // march_rows: entries of k_march's padded LDS image when its fast variant applies, else 0
     float scene_lo[3], scene_hi[3];   // bounds of the whole BVH
     float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs, tex_rcp, lean_bound;
     double axial_res_mm, time_step, row_dt, max_travel, sos_d, inv_row_dt;
