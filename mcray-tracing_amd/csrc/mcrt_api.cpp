@@ -67,7 +67,7 @@ struct Work {
 // tuning knobs from the environment, read ONCE at mcrt_create (never on the frame path)
 struct Knobs {
     uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 0;   // march_blocks 0: launch_march picks
-    bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false, graph = false, march_tail = false;
+    bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false, graph = false;
     uint32_t march_cus = 0;                    // CUs the accumulation's side stream is confined to (0 = no mask); the mask's bit order is the driver's
     bool main_mask = false;                    // with march_cus: the walk / shade chain runs on its own stream confined to the OTHER CUs
     bool test_hooks = false;                   // MCRT_TEST_HOOKS: mcrt_debug_set_error may poison the context (tests only)
@@ -82,7 +82,6 @@ static Knobs read_knobs()
     if (const char *e = getenv("MCRT_MARCH_BLOCKS")) { int v = atoi(e); if (v >= 1) k.march_blocks = (uint32_t)v; }
     k.no_overlap = getenv("MCRT_NO_OVERLAP") != nullptr; k.no_priority = getenv("MCRT_NO_PRIORITY") != nullptr;
     k.no_fast_div = getenv("MCRT_NO_FAST_DIV") != nullptr; k.no_lean = getenv("MCRT_NO_LEAN") != nullptr;
-    k.march_tail = getenv("MCRT_MARCH_TAIL") != nullptr;   // the accumulation of bounce b waits for the TAIL of the next walk instead of starting with it (measured slower; hangs under rocprofv3 --pmc: see run_bounce)
     k.graph = getenv("MCRT_GRAPH") != nullptr;   // passes replayed as HIP graphs (measured slower on ROCm 7.2: see trace_frames_graph)
     if (const char *e = getenv("MCRT_MARCH_CUS")) { int v = atoi(e); if (v >= 0 && v <= 248) k.march_cus = (uint32_t)v; }
     k.main_mask = getenv("MCRT_MAIN_MASK") != nullptr;
@@ -794,34 +793,10 @@ static int timing_events(mcrt_ctx *c, hipEvent_t *e0, hipEvent_t *e1);
 
 // one bounce of one group: k_trace_lane + k_shade on the group's stream, k_march of the finished segments on its side stream.
 // With timing enabled every k_trace launch (the dominant kernel) is bracketed by HIP events on the stream it is launched on.
-// k_march of bounce b in the TAIL of the walk of bounce b+1 (round 4; a knob, MCRT_MARCH_TAIL, OFF by default).  A launch of the walk ends long
-// after its queue has run dry (the rays in flight finish at falling occupancy: half of a launch of the driver's 20-frame pass), while k_march --
-// which shares both of the walk's roofs -- starts WITH that walk and slows its body down.  The walk raises a device word when its queue runs dry
-// (next to the bounce's first cursor; k_shade of the same bounce raises it too: a walk without rays raises nothing) and the accumulation's stream
-// can wait for it (hipStreamWaitValue32: the command processor polls the word, released ~1 us after the kernel's store -- probed on the MI355X).
-// MEASURED (back to back, the kernels at their 96 registers): 0.360 against 0.343 ms per frame at 128 frames in flight, 0.414 against 0.405 on the
-// driver's 20-frame pass -- SLOWER: held back, k_march no longer fills the gaps around k_shade and the next walk's start, and its own tail lands on
-// the critical chain.  And a run under `rocprofv3 --pmc` hangs in this mode (the profiler's queue interception and the wait packet).  Hence the knob.
-// (A first measurement had shown -2.8 %: the two extra kernel arguments of that version spilled a scalar register in the walk, the spill took a
-// vector register, 96 became 105 -- allocated as 112 -- and k_march no longer fitted beside four walk wavefronts: BOTH modes were slow, the early
-// one more.  tests/test_abi.py now holds the walk to its register budget.)
-static bool march_in_tail(const mcrt_ctx *c, bool accumulate, bool overlap)
-{
-    return accumulate && overlap && c->knobs.march_tail && !c->stats_on && side_streams(c) == 1u;
-}
-// the accumulation of bounce b on the side stream: behind the event that says its segments are final, and -- in tail mode -- behind the word
-// the walk of bounce b+1 raises
-static int enqueue_march(mcrt_ctx *c, Work &w, const mcrt::FrameArgs &a, uint32_t b, bool wait_for_tail)
-{
-    hipStream_t side;
-    { int rc = side_stream(c, w, b % side_streams(c), &side); if (rc) return rc; }
-    HIP_TRY(hipStreamWaitEvent(side, w.ev_bounce[b], 0));
-    if (wait_for_tail)      // the NEXT walk's queue has run dry (its word: zeroed by k_init of this pass, which precedes the event just waited for)
-        HIP_TRY(hipStreamWaitValue32(side, a.cursors + (size_t)(b + 1u) * MCRT_XCDS * MCRT_CURSOR_STRIDE + MCRT_TAIL_WORD, 1u, hipStreamWaitValueGte, 0xffffffffu));
-    HIP_TRY(mcrt::launch_march(a, b, c->stats_on, side));
-    return MCRT_OK;
-}
-static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArgs &a, uint32_t b, bool accumulate, bool overlap, bool tail)
+// (Round 4 tried holding k_march of bounce b back until the walk of bounce b+1 had claimed its last ray -- a device word raised by the walk, waited
+//  for with hipStreamWaitValue32, which the command processor releases ~1 us after the store --: 0.360 against 0.343 ms per frame at 128 frames in
+//  flight, 0.414 against 0.405 on the driver's pass, and a hang under `rocprofv3 --pmc`.  Removed; DESIGN.md 5.6, profiles/round4/exp_round4_kernels.txt.)
+static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArgs &a, uint32_t b, bool accumulate, bool overlap)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     { int rc = timing_events(c, &e0, &e1); if (rc) return rc; }
@@ -831,15 +806,10 @@ static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArg
     HIP_TRY(mcrt::launch_shade(a, b, c->stats_on, st));
     if (accumulate && overlap) {   // the segments of bounce b are final: accumulate them beside the next bounce's walk
         HIP_TRY(hipEventRecord(w.ev_bounce[b], st));
-        if (!tail) { int rc = enqueue_march(c, w, a, b, false); if (rc) return rc; }
-        else {
-            // Tail mode: k_march of bounce b-1 waits for the word THIS bounce's walk raises.  Its packets are enqueued only now, behind the walk and
-            // the k_shade that raise the word: whatever serialises the device's work in the order it was submitted (rocprofv3 --pmc runs one kernel at
-            // a time; a runtime that feeds several streams into one hardware queue) then finds the word already raised.  Enqueued BEFORE them -- the
-            // first version -- the wait sat in front of the kernels it waited for: a profiled run hung until its time limit.
-            if (b > 0u) { int rc = enqueue_march(c, w, a, b - 1u, true); if (rc) return rc; }
-            if (b + 1u == a.B) { int rc = enqueue_march(c, w, a, b, false); if (rc) return rc; }      // the last bounce: nothing to wait for
-        }
+        hipStream_t side;
+        { int rc = side_stream(c, w, b % side_streams(c), &side); if (rc) return rc; }
+        HIP_TRY(hipStreamWaitEvent(side, w.ev_bounce[b], 0));
+        HIP_TRY(mcrt::launch_march(a, b, c->stats_on, side));
     } else if (accumulate) {
         HIP_TRY(mcrt::launch_march(a, b, c->stats_on, st));
     }
@@ -883,11 +853,10 @@ static int prepare_frame(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_
     return MCRT_OK;
 }
 
-static int enqueue_frame(mcrt_ctx *c, const std::vector<mcrt::FrameArgs> &args, const std::vector<Work *> &ws, bool accumulate, bool capturing = false)
+static int enqueue_frame(mcrt_ctx *c, const std::vector<mcrt::FrameArgs> &args, const std::vector<Work *> &ws, bool accumulate)
 {
     const uint32_t groups = (uint32_t)args.size();
     const bool overlap = !c->knobs.no_overlap;
-    const bool tail = march_in_tail(c, accumulate, overlap) && !capturing;          // (a captured graph cannot hold the stream memory operation)
     std::vector<hipStream_t> gst(groups);
     for (uint32_t g = 0; g < groups; g++) { int rc = work_stream(c, *ws[g], g == 0, &gst[g]); if (rc) return rc; }
     if (c->scene_pending && c->scene_stream != c->stream) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_scene, 0));   // a scene update issued on another stream
@@ -898,7 +867,7 @@ static int enqueue_frame(mcrt_ctx *c, const std::vector<mcrt::FrameArgs> &args, 
     }
     for (uint32_t b = 0; b < c->p.max_depth; b++)
         for (uint32_t g = 0; g < groups; g++) {
-            int rc = run_bounce(c, *ws[g], gst[g], args[g], b, accumulate, overlap, tail); if (rc) return rc;
+            int rc = run_bounce(c, *ws[g], gst[g], args[g], b, accumulate, overlap); if (rc) return rc;
         }
     for (uint32_t g = 0; g < groups; g++) {
         if (accumulate && overlap) {
@@ -970,7 +939,7 @@ static int trace_frames_graph(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, ui
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
         bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
-            const int rq = enqueue_frame(c, args, ws, true, true);
+            const int rq = enqueue_frame(c, args, ws, true);
             const hipError_t ef = rq ? hipSuccess : mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, lines, c->p.n_rows, c->d_error, c->stream);
             const hipError_t ee = hipStreamEndCapture(c->stream, &graph);            // (always: the stream must leave capture mode)
             ok = rq == 0 && ef == hipSuccess && ee == hipSuccess && graph != nullptr;

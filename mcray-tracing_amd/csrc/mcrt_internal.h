@@ -12,7 +12,6 @@
 #define MCRT_LBVH_LEAF 1             // device builder: triangles per leaf (1..4); measured best at 1, like the SAH builder's own leaves
 #define MCRT_XCDS 8                   // XCDs of the MI355X = sub-queues of a bounce's ray queue (see k_trace)
 #define MCRT_CURSOR_STRIDE 64         // uint32 between two queue cursors: 256 B, so they sit in different L2 lines / channels
-#define MCRT_TAIL_WORD 1               // word of a bounce's first queue cursor that the walk raises when its queue has run dry
 #define MCRT_XCD_MIN_ITEMS 262144     // bounces with fewer work items use a single queue
 #define MCRT_MAX_ROWS 2048
 #define MCRT_MAX_BOUNCES 16

@@ -361,7 +361,6 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
     const uint32_t np = a.ne * a.S;
     if (pos == 0) { a.counts[0] = np; for (uint32_t b = 1; b <= a.B; b++) a.counts[b] = 0u; }
     if (pos < MCRT_MAX_BOUNCES * MCRT_XCDS) a.cursors[(size_t)pos * MCRT_CURSOR_STRIDE] = 0u;   // k_trace_lane's queue cursors (relative, see there)
-    if (pos < MCRT_MAX_BOUNCES) a.cursors[(size_t)pos * MCRT_XCDS * MCRT_CURSOR_STRIDE + MCRT_TAIL_WORD] = 0u;   // ... and each bounce's "the walk's queue has run dry" word
     if (pos >= np) return;
     // Queue position -> path.  Paths are numbered frame-major (pid = (frame * ne_frame + scan-line) * S + sample) but QUEUED
     // scan-line-major: the F frames of a scan-line sit next to each other.  The queue is swept in order, so the rays in flight
@@ -779,14 +778,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_
                     const uint32_t hi = MCRT_SUB_LO(cur_x + 1u);
                     const unsigned long long start = (unsigned long long)MCRT_SUB_LO(cur_x) + MCRT_SUB_STATIC(cur_x) + base;
                     if (start < hi) { pool_next = (uint32_t)start; pool_end = min((uint32_t)start + fetch, hi); }
-                    else if (++visited >= X) {
-                        queue_empty = true;
-                        // the launch has entered its TAIL: from here on it only finishes the rays in flight, at falling occupancy.  The word (next to this
-                        // bounce's first cursor, zeroed by k_init) says so to whoever waits for it (MCRT_MARCH_TAIL: hipStreamWaitValue32 in run_bounce;
-                        // off by default).  Through the cursors' pointer, which this loop holds anyway, and with no state of its own: one more scalar
-                        // register spills here, and a spilled scalar costs the kernel a vector register and with it its 104-register budget.
-                        if (lane == 0) atomicMax(&cursors[MCRT_TAIL_WORD], 1u);
-                    }
+                    else if (++visited >= X) queue_empty = true;      // (the launch enters its TAIL: it only finishes the rays in flight from here on.  Round 4 let the
+                                                                      //  accumulation's stream wait for this moment -- a device word + hipStreamWaitValue32 --: slower)
                     else cur_x = (cur_x + 1u) & (X - 1u);
 #if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
                     if (queue_empty) { wc_empty = wall_clock64(); if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 1], ~wc_empty); }
@@ -1132,7 +1125,6 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
 {
     const uint32_t n = a.counts[b];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0u) atomicMax(&a.cursors[(size_t)b * MCRT_XCDS * MCRT_CURSOR_STRIDE + MCRT_TAIL_WORD], 1u);      // (the walk of bounce b is over: the safety net of its own signal, see k_trace_lane)
     if (blockIdx.x * blockDim.x >= n) return;
     const int lane = threadIdx.x & 63;
     // the scene's material and mesh tables in LDS when they fit (they nearly always do: the reference's scenes have 9 materials and <= 11 meshes):
