@@ -31,7 +31,7 @@ if pm:
               open(os.path.join(dst, "pmc_bench.json"), "w"), indent=1)
 
 # ---- kernel statistics (overlapped = production; standalone = MCRT_NO_OVERLAP=1)
-shutil.copy(glob.glob(os.path.join(out, "pmc_" + tag, "stats", "*", "*kernel_stats.csv"))[0], os.path.join(dst, "kernel_stats.csv"))
+shutil.copy(sorted(glob.glob(os.path.join(out, "pmc_" + tag, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1], os.path.join(dst, "kernel_stats.csv"))   # (the newest run: gpurun merges into the local directory)
 shutil.copy(os.path.join(src, "kernels_standalone.txt"), os.path.join(dst, "kernels_standalone.txt"))
 shutil.copy(os.path.join(src, "frame_timeline.txt"), os.path.join(dst, "frame_timeline.txt"))
 shutil.copy(os.path.join(src, "frame_timeline_one_frame.txt"), os.path.join(dst, "frame_timeline_one_frame.txt"))

@@ -4,12 +4,19 @@ import csv, glob, json, os, sys, collections
 KERNEL = os.environ.get("PMC_KERNEL", "k_trace_lane<false>")   # substring of the kernel the counters are reported for
 out = sys.argv[1]
 res = {"kernel_stats": [], "pmc": {}}
-for f in glob.glob(out + "/stats/*/*kernel_stats.csv"):
+
+
+def newest_only(paths):
+    """rocprofv3 names its files by process id, and gpurun MERGES a run's outputs into the local copy of the directory: keep the newest run's file"""
+    paths = sorted(paths, key=os.path.getmtime)
+    return paths[-1:]
+
+for f in newest_only(glob.glob(out + "/stats/*/*kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
         if float(r["Percentage"]) > 0.05:
             res["kernel_stats"].append({k: r[k] for k in ("Name", "Calls", "AverageNs", "Percentage", "MinNs", "MaxNs")})
 for d in sorted(glob.glob(out + "/*/")):
-    for f in glob.glob(d + "*/*counter_collection.csv"):
+    for f in newest_only(glob.glob(d + "*/*counter_collection.csv")):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
