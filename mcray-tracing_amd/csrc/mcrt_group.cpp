@@ -363,7 +363,7 @@ extern "C" int mcrt_group_last_pass_ms(mcrt_group *g, float *trace_ms, float *co
         Member &m = g->mem[r];
         if (trace_ms) trace_ms[r] = 0.0f;
         if (copy_ms) copy_ms[r] = 0.0f;
-        if (m.last_slot < 0) continue;
+        if (m.last_slot < 0 || !m.used[m.last_slot]) continue;      // (no pass yet, or its events were never recorded: a pass that failed on this rank)
         const int i = m.last_slot;
         G_HIP(hipSetDevice(m.device));
         G_HIP(hipEventSynchronize(m.ev_copied[i]));
