@@ -161,7 +161,7 @@ int mcrt_trace_frame(mcrt_ctx *ctx, uint32_t frame_id, uint32_t e_begin, uint32_
  * stage of the pipeline then runs over n_frames times the rays, which is what fills the GPU when a single frame is small.
  * rf_dev: device float [n_frames][(e_end-e_begin)][R].  Each image is bit-identical to the one mcrt_trace_frame produces.
  * Limits (MCRT_ERR_LIMIT beyond them): n_frames <= 1024 and n_frames x scan-lines x samples <= 2^27 paths per pass (a path takes
- * about 700 bytes of work buffers). */
+ * about 600 bytes of work buffers). */
 int mcrt_trace_frames(mcrt_ctx *ctx, uint32_t frame_id, uint32_t n_frames, uint32_t e_begin, uint32_t e_end, float *rf_dev);
 /* The same pass with a probe pose PER FRAME: pos / dir are [n_frames][E][3] tables (host or device memory), frame f of the pass is
  * traced from the elements pos[f], dir[f] -- the moving probe the reference's loop is built for (transducer<N>::update(),

@@ -967,7 +967,7 @@ extern "C" int mcrt_trace_frames(mcrt_ctx *c, uint32_t frame, uint32_t n_frames,
     int rc = check_ready(c, e0, e1); if (rc) return rc;
     if (!rf_dev) return set_error(MCRT_ERR_INVALID, "null rf_dev");
     if (n_frames == 0 || n_frames > 1024) return set_error(MCRT_ERR_LIMIT, "n_frames must be 1..1024");
-    if ((uint64_t)(e1 - e0) * n_frames * c->p.n_samples > (1ull << 27))        // (~700 bytes of work buffers per path)
+    if ((uint64_t)(e1 - e0) * n_frames * c->p.n_samples > (1ull << 27))        // (~600 bytes of work buffers per path)
         return set_error(MCRT_ERR_LIMIT, "%u frames x %u scan-lines x %u samples: more than 2^27 paths in one pass", n_frames, e1 - e0, c->p.n_samples);
     const uint32_t lines = (e1 - e0) * n_frames;
     rc = ensure_acc(c, lines); if (rc) return rc;
