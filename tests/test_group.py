@@ -132,3 +132,41 @@ def test_group_moving_geometry_and_device_builder(mcrt, sphere, tex256):
         assert np.array_equal(one.d2h(a_dev, (F, E, R)).view(np.uint32), grp.root.d2h(b_dev, (F, E, R)).view(np.uint32)), step
     one.free(a_dev); grp.root.free(b_dev)
     grp.close(); one.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,E,S,ranks", [("random1m", 256, 8192, 8), ("liver", 512, 16384, 8)])
+def test_group_baseline_shapes_c4_c5(mcrt, tex256, name, E, S, ranks):
+    """BASELINE C4 ("1 M random triangles, 256 x 8192 rays, scan-lines sharded across 2/4/8 GPUs with a gather") and C5 ("512 x 16384 rays + PSF
+    convolution at 8 GPUs") as a SYSTEM: an eight-rank mcrt_group -- eight tracing contexts with their own scene copies and work buffers, eight
+    host threads, eight peer copies, the root's post-processing; the ranks share the one GPU of the test box -- against one context tracing the
+    whole frame: RF image and the PSF-convolved, enveloped, scan-converted B-mode frame bit for bit.  (That the single context's frame is the
+    oracle's: tests/test_gpu_baseline_configs.py.)"""
+    cfg, meshes = (mcrt.synth.random_scene(1_000_000, 8, 12345) if name == "random1m" else mcrt.synth.liver_scene(5))
+    sd = mcrt.scene_io.build_scene(cfg, meshes)
+    tr = mcrt.Transducer(E, position=cfg["transducerPosition"], angles_deg=cfg["transducerAngles"])
+    psf = mcrt.Psf(freq=tr.frequency)
+    frame = 1 if name == "random1m" else 7
+    out = {}
+    for who in ("one", "group"):
+        obj = mcrt.Context(0) if who == "one" else mcrt.Group([0] * ranks)
+        _setup(obj, mcrt, sd, tr, S, tex256)
+        root = obj if who == "one" else obj.root
+        R = root.params.n_rows
+        dev, img = root.alloc(E * R * 4), root.alloc(400 * 500 * 4)
+        if who == "one":
+            obj.trace_frames(frame, 1, dev)
+        else:
+            obj.trace_frames(frame, 1, dev)
+            assert [mcrt.shard_range(r, ranks, E) for r in range(ranks)][-1][1] == E
+        obj.synchronize()
+        rf = root.d2h(dev, (E, R)).copy()
+        root.convolve_frames(dev, 1, E, R, psf.axial_kernel, psf.lateral_kernel)
+        root.envelope_frames(dev, 1, E, R)
+        root.scan_convert_frames(dev, 1, E, R, img)
+        obj.synchronize()
+        out[who] = (rf, root.d2h(img, (400, 500)).copy())
+        root.free(dev); root.free(img)
+        obj.close()
+    assert np.array_equal(out["one"][0].view(np.uint32), out["group"][0].view(np.uint32)) and np.nansum(np.abs(out["one"][0])) > 0
+    assert np.array_equal(out["one"][1].view(np.uint32), out["group"][1].view(np.uint32)) and np.nansum(np.abs(out["one"][1])) > 0
