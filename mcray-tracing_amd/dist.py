@@ -4,6 +4,8 @@ rank g traces the contiguous block [g*E/G, (g+1)*E/G) with the scene replicated,
 pass needs 12 columns of halo (rfimage.h:113-118), so convolution runs on the gathered image."""
 import torch
 
+_GATHER_TO_ROOT_OK = True      # cleared when the backend refuses dist.gather (every rank then falls back to the all-gather, in the same call)
+
 
 def shard_range(rank, world, n_elements):
     """contiguous scan-line block of `rank`; the last ranks take one fewer when E % world != 0"""
@@ -34,17 +36,28 @@ def gather_rf(rf_local, n_elements, n_rows, dist=None, group=None, root=None):
     else:                                                           # ragged shards: pad to the largest block
         mine = torch.zeros((F, ne_max, n_rows), dtype=loc.dtype, device=loc.device)
         mine[:, : loc.shape[1]] = loc
-    if root is None:
+    global _GATHER_TO_ROOT_OK
+    stacked = None
+    if root is not None and _GATHER_TO_ROOT_OK:
+        me = dist.get_rank(group)
+        flat = torch.empty((world, F, ne_max, n_rows), dtype=loc.dtype, device=loc.device) if me == root else None
+        try:
+            dist.gather(mine, list(flat.unbind(0)) if me == root else None, dst=dist.get_global_rank(group, root) if group is not None else root, group=group)
+        except (RuntimeError, NotImplementedError, ValueError) as ex:
+            # a backend without gather raises on EVERY rank before anything is sent: all of them take the all-gather below, now and from here on
+            _GATHER_TO_ROOT_OK = False
+            import sys
+            sys.stderr.write("mcray_tracing_amd.dist: dist.gather refused (%s): falling back to all_gather_into_tensor\n" % str(ex).splitlines()[0])
+        else:
+            if me != root:
+                return None
+            stacked = flat
+    if stacked is None:
         flat = torch.empty((world * F, ne_max, n_rows), dtype=loc.dtype, device=loc.device)      # rank blocks concatenated along dim 0
         dist.all_gather_into_tensor(flat, mine, group=group)
         stacked = flat.view(world, F, ne_max, n_rows)
-    else:
-        me = dist.get_rank(group)
-        flat = torch.empty((world, F, ne_max, n_rows), dtype=loc.dtype, device=loc.device) if me == root else None
-        dist.gather(mine, list(flat.unbind(0)) if me == root else None, dst=dist.get_global_rank(group, root) if group is not None else root, group=group)
-        if me != root:
+        if root is not None and dist.get_rank(group) != root:
             return None
-        stacked = flat
     if n_elements % world == 0:
         full = stacked.permute(1, 0, 2, 3).reshape(F, n_elements, n_rows)      # frame-major, rank blocks concatenated (a copy)
     else:
