@@ -104,6 +104,7 @@ struct mcrt_ctx {
     float4 *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr;
     mcrt_bvh4_node *walked_nodes = nullptr; bool walked_stale = true;   // host copy of the tree as the lane walk sees it (mcrt_get_bvh4)
     uint4 *d_nodes_walk = nullptr; uint32_t nodes_walk_cap = 0;   // the walk's child-transposed half-float nodes
+    uint32_t *d_top_list = nullptr; uint4 *d_top_table = nullptr;  // the walk's top-of-tree table: its nodes [slots] + their count [1]; the table [4][slots] (k_pick_top)
     uint4 *d_meshes = nullptr;
     uint32_t *d_tri_slot = nullptr;
     uint32_t n_mesh = 0, n_mat = 0, start_mat = 0, n_cu = 256;
@@ -312,7 +313,7 @@ static int side_stream(mcrt_ctx *c, Work &w, uint32_t i, hipStream_t *out)
 // allocation HERE; mcrt_refit_triangles itself still frees its staging copy of the vertices, which synchronises the device).
 // Nothing here waits: the rebuild is ordered on the stream it was issued on, and an event recorded behind it orders a trace that
 // is issued on ANOTHER stream after mcrt_set_stream (enqueue_frame waits for it).
-static int refresh_soa(mcrt_ctx *c)
+static int refresh_soa(mcrt_ctx *c, bool new_tree)
 {
     c->walked_stale = true;
     if (c->bvh4.n_nodes == 0) { hipFree(c->d_nodes_walk); c->d_nodes_walk = nullptr; c->nodes_walk_cap = 0; return MCRT_OK; }
@@ -322,7 +323,14 @@ static int refresh_soa(mcrt_ctx *c)
         HIP_TRY(hipMalloc(&c->d_nodes_walk, 64 * (size_t)c->bvh4.n_nodes));
         c->nodes_walk_cap = c->bvh4.n_nodes;
     }
-    HIP_TRY(mcrt::launch_nodes_walk(c->d_nodes, c->bvh4.n_nodes, c->d_nodes_walk, c->stream));
+    const uint32_t slots = mcrt::lane_top_slots();
+    if (slots && !c->d_top_list) {
+        HIP_TRY(hipMalloc(&c->d_top_list, 4 * ((size_t)slots + 1)));
+        HIP_TRY(hipMalloc(&c->d_top_table, 80 * (size_t)slots));
+        HIP_TRY(hipMemsetAsync(c->d_top_table, 0, 80 * (size_t)slots, c->stream));
+        new_tree = true;
+    }
+    HIP_TRY(mcrt::launch_nodes_walk(c->d_nodes, c->bvh4.n_nodes, c->d_nodes_walk, c->d_top_list, c->d_top_table, new_tree, c->stream));
     if (!c->ev_scene) HIP_TRY(hipEventCreateWithFlags(&c->ev_scene, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c->ev_scene, c->stream));
     c->scene_stream = c->stream; c->scene_pending = true;
@@ -348,7 +356,7 @@ extern "C" int mcrt_destroy(mcrt_ctx *c)
     free_scene(c);
     free_work(c);
     free(c->walked_nodes); c->walked_nodes = nullptr;
-    hipFree(c->d_pose[0]); hipFree(c->d_pose[1]);
+    hipFree(c->d_pose[0]); hipFree(c->d_pose[1]); hipFree(c->d_top_list); hipFree(c->d_top_table);
     if (c->h_pose[0]) hipHostFree(c->h_pose[0]);
     if (c->h_pose[1]) hipHostFree(c->h_pose[1]);
     if (c->ev_pose) hipEventDestroy(c->ev_pose);
@@ -518,7 +526,7 @@ extern "C" int mcrt_update_triangles(mcrt_ctx *c, const float *tri, uint32_t n_t
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_scene = false;                           // a failed rebuild leaves no scene
     int rc = index_triangles(c, tri, n_tri); if (rc) return rc;
-    rc = refresh_soa(c); if (rc) return rc;
+    rc = refresh_soa(c, true); if (rc) return rc;
     c->have_scene = true;
     return MCRT_OK;
 }
@@ -537,7 +545,7 @@ extern "C" int mcrt_refit_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tr
     float pad = 0.0f, lo[3], hi[3];
     if (!rc) rc = mcrt::bvh_refit(d_tri, n_tri, c->d_nodes, c->bvh4.n_nodes, c->d_tris, c->stream, &pad, lo, hi);
     hipFree(d_tri);
-    if (!rc) rc = refresh_soa(c);
+    if (!rc) rc = refresh_soa(c, false);                    // (same topology: the top-of-tree table keeps its nodes, with their new boxes)
     if (rc) { c->have_scene = false; return rc; }           // a failed refit leaves no scene
     c->bvh.pad_abs = pad;
     for (int i = 0; i < 3; i++) { c->scene_lo[i] = lo[i]; c->scene_hi[i] = hi[i]; }
@@ -566,7 +574,7 @@ extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *
     if (n_tri) {
         c->tri_mesh.assign(tri_mesh, tri_mesh + n_tri);
         int rc = index_triangles(c, tri, n_tri); if (rc) return rc;
-        rc = refresh_soa(c); if (rc) return rc;
+        rc = refresh_soa(c, true); if (rc) return rc;
     }
     HIP_TRY(hipMalloc(&c->d_mats, 32 * (size_t)n_mat));
     HIP_TRY(hipMemcpy(c->d_mats, mats, 32 * (size_t)n_mat, hipMemcpyHostToDevice));
@@ -598,7 +606,7 @@ extern "C" int mcrt_get_bvh4(mcrt_ctx *c, mcrt_bvh4 *out)
             const size_t bytes = sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes;
             float4 *d_tmp = nullptr;
             HIP_TRY(hipMalloc(&d_tmp, bytes));
-            hipError_t e = mcrt::launch_nodes_walk_decode(c->d_nodes_walk, c->bvh4.n_nodes, d_tmp, c->stream);
+            hipError_t e = mcrt::launch_nodes_walk_decode(c->d_nodes_walk, c->bvh4.n_nodes, d_tmp, c->d_top_list, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             free(c->walked_nodes);
             c->walked_nodes = (mcrt_bvh4_node *)malloc(bytes);
@@ -744,7 +752,7 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne_frame, uint32_t n_frame
 static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, uint32_t acc_e0, uint32_t acc_ne)
 {
     memset(&a, 0, sizeof a);
-    a.nodes_walk = c->d_nodes_walk; a.stack_ovf = w.d_stack_ovf; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
+    a.nodes_walk = c->d_nodes_walk; a.top_nodes = c->d_top_table; a.stack_ovf = w.d_stack_ovf; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
     a.el_pos = c->pose_pos ? c->pose_pos : c->d_pos; a.el_dir = c->pose_pos ? c->pose_dir : c->d_dir; a.pose_stride = c->pose_pos ? c->p.n_elements : 0u;
     a.row_thr = c->d_row_thr;
     a.acc = c->d_acc; a.flags = c->d_flags;                 // the frame block [n_frames][acc_ne][R]; this group owns columns e0-acc_e0 ...

@@ -10,6 +10,7 @@ namespace mcrt {
 struct FrameArgs {
     // scene (HBM-resident, read-only)
     const uint4 *nodes_walk;   // [n_nodes][4]  the walk's 64-byte nodes: child-transposed half-float boxes (rounded outwards) + refs
+    const uint4 *top_nodes;    // [4][MCRT_LANE_TOP] the walk's top-of-tree table, piece-major (k_pick_top / k_top_table); every workgroup copies it to LDS
     int *stack_ovf;            // [max_stack - MCRT_LANE_STACK][trace_blocks * 256] traversal-stack entries beyond the LDS part (this work set's own)
     const float4 *tris;        // [T][MCRT_TRI_PIECES]  48-B triangle records, leaf order: v0|id, v1|mesh, v2|edge tolerance (64-B form: n|dist first)
     const uint4 *meshes;       // [n_mesh]      mat_inside, mat_outside, vascular, -
@@ -50,8 +51,9 @@ struct ConvTaps { float ax[16]; float lat[32]; uint32_t n_ax, n_lat; };
 
 hipError_t launch_init(const FrameArgs &a, hipStream_t st);
 hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
-hipError_t launch_nodes_walk(const float4 *nodes, uint32_t n_nodes, uint4 *out, hipStream_t st);
-hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 *out, hipStream_t st);
+hipError_t launch_nodes_walk(const float4 *nodes, uint32_t n_nodes, uint4 *out, uint32_t *top_list, uint4 *top_table, bool pick, hipStream_t st);
+hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 *out, const uint32_t *top_list, hipStream_t st);
+uint32_t lane_top_slots();
 uint32_t lane_stack_entries();
 hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
 hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);

@@ -405,9 +405,21 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 // Traversal stacks: MCRT_LANE_STACK entries per lane in LDS ([entry][thread], conflict-free); deeper entries (only reachable on
 // degenerate paths of deep trees) go to a global overflow array.
 // =============================================================================================================
+#ifndef MCRT_LANE_TOP
+#define MCRT_LANE_TOP 0              // nodes of the TOP-OF-TREE TABLE each workgroup of the walk keeps in LDS (see k_pick_top).  OFF: built and measured in round 4
+#endif                               // (64 / 128 / 192 / 256 nodes, with 28 / 24 / 20 / 16 stack entries: every GPU parity test green, 14-19 % of the node visits served
+                                     // from LDS -- and the walk 3.31-3.33 ms per launch against 3.20-3.21, the frame 0.348-0.351 against 0.342-0.345 ms: the vector
+                                     // memory pipe's saving does not shorten a step that ends with its last lane; the flat-load form the same; profiles/round4/exp_top_of_tree.txt)
 #ifndef MCRT_LANE_STACK
-#define MCRT_LANE_STACK 32
+#define MCRT_LANE_STACK (MCRT_LANE_TOP ? 24 : 32)     // (the headline workload's deepest walk stacks 16 entries, 14 at the 99.9th percentile: profiles/round4/bvh_width.json)
 #endif
+#ifndef MCRT_LANE_TOP_FLAT
+#define MCRT_LANE_TOP_FLAT 0         // 1: the table node-major with an 80-byte pitch and ONE flat load per piece for both kinds of lanes (the address picks LDS or memory)
+#endif
+#define MCRT_TOP_PITCH (MCRT_LANE_TOP_FLAT ? 5 : 1)                       // 16-byte units from slot to slot ...
+#define MCRT_TOP_PIECE (MCRT_LANE_TOP_FLAT ? 1 : MCRT_LANE_TOP)           // ... and from piece to piece
+#define MCRT_TOP_UNITS (MCRT_LANE_TOP_FLAT ? 5 * MCRT_LANE_TOP : 4 * MCRT_LANE_TOP)
+#define MCRT_TOP_FLAG 0x40000000     // a child reference with this bit names slot (ref & 0xffff) of the table instead of a node (node numbers stay below 2^25)
 // Persistent kernels carry a WATCHDOG: every 4096 iterations of its outer loop a wavefront compares the 100 MHz wall clock
 // with its start, and a kernel that is still running after MCRT_WATCHDOG_SECONDS sets bit 1 of the device error word and leaves
 // -- a logic error then surfaces as MCRT_ERR_LIMIT from the next synchronising call instead of a hung GPU.
@@ -483,7 +495,14 @@ MCRT_DEV uint32_t half_towards(float x, bool up)
 MCRT_DEV float half_bits_to_float(uint32_t b) { return __half2float(__ushort_as_half((unsigned short)b)); }
 
 // the walk's 64-byte nodes from the builders' 128-byte ones
-__global__ void k_nodes_walk(const float4 *in, uint32_t n_nodes, uint4 *out)
+// slot of node `ref` in the sorted list of table nodes, or -1
+MCRT_DEV int top_slot(const uint32_t *top_list, uint32_t n_top, uint32_t ref)
+{
+    uint32_t lo = 0, hi = n_top;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (top_list[mid] < ref) lo = mid + 1; else hi = mid; }
+    return (lo < n_top && top_list[lo] == ref) ? (int)lo : -1;
+}
+__global__ void k_nodes_walk(const float4 *in, uint32_t n_nodes, uint4 *out, const uint32_t *top_list, const uint32_t *n_top_p)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
@@ -493,6 +512,7 @@ __global__ void k_nodes_walk(const float4 *in, uint32_t n_nodes, uint4 *out)
         const float4 A = in[8 * (size_t)i + 2 * c], B = in[8 * (size_t)i + 2 * c + 1];
         ref[c] = __float_as_int(B.z);
         const bool empty = ref[c] == MCRT_BVH4_EMPTY;
+        if (ref[c] >= 0 && top_list) { const int slot = top_slot(top_list, *n_top_p, (uint32_t)ref[c]); if (slot >= 0) ref[c] = MCRT_TOP_FLAG | slot; }
         const float l[3] = { A.x, A.y, A.z }, h[3] = { A.w, B.x, B.y };
 #pragma unroll
         for (int k = 0; k < 3; k++) { lo[k][c] = empty ? 0x7c00u : half_towards(l[k], false); hi[k][c] = empty ? 0x7c00u : half_towards(h[k], true); }
@@ -506,16 +526,76 @@ __global__ void k_nodes_walk(const float4 *in, uint32_t n_nodes, uint4 *out)
 #undef MCRT_PACK4
 }
 // ... and back: the tree as the walk sees it, in the builders' layout (for mcrt_get_bvh4)
-__global__ void k_nodes_walk_decode(const uint4 *in, uint32_t n_nodes, float4 *out)
+// THE TOP-OF-TREE TABLE.  The walk is bound by the compute units' vector memory pipe (1.3 cycles per lane and 16-byte piece, four pieces
+// per node: profiles/round4/tcp_access_cost.json), and nine of ten pieces it fetches are nodes -- but LDS is a different pipe.  The N nodes
+// a ray is most likely to visit are therefore kept in LDS by every workgroup of the walk (child-transposed like the nodes, piece-major so
+// that lanes on different slots spread over the banks), and a child reference that names one of them carries MCRT_TOP_FLAG | slot: which
+// copy of a node a lane reads changes nothing about the walk (same boxes, same order, same counts).
+// k_pick_top chooses them without looking at rays: from the root, always the pending inner node with the LARGEST BOX next (the chance
+// that a random line meets a convex box is proportional to its area).  One workgroup, n_top rounds of an argmax over the frontier in LDS;
+// the list comes out sorted by node number (slot 0 = the root).
+__global__ void __launch_bounds__(256) k_pick_top(const float4 *nodes, uint32_t n_nodes, uint32_t want, uint32_t *top_list, uint32_t *n_top_p)
+{
+    constexpr int CAP = 3 * 1024 + 4;                 // the frontier grows by at most three entries per round
+    __shared__ float f_area[CAP]; __shared__ uint32_t f_node[CAP];
+    __shared__ float r_area[256]; __shared__ int r_idx[256];
+    __shared__ uint32_t picked[1024]; __shared__ int n_front, n_pick;
+    const int tid = threadIdx.x;
+    if (want > 1024u) want = 1024u;
+    if (tid == 0) { n_front = 0; n_pick = 0; if (n_nodes) { f_area[0] = INFINITY; f_node[0] = 0u; n_front = 1; } }
+    __syncthreads();
+    while (n_pick < (int)want && n_front > 0) {
+        float best = -1.0f; int bi = -1;
+        for (int i = tid; i < n_front; i += 256) if (f_area[i] > best) { best = f_area[i]; bi = i; }      // (strict: the earliest entry wins a tie)
+        r_area[tid] = best; r_idx[tid] = bi;
+        __syncthreads();
+        for (int w = 128; w >= 1; w >>= 1) {
+            if (tid < w) { const float o = r_area[tid + w]; const int oi = r_idx[tid + w];
+                           if (oi >= 0 && (r_idx[tid] < 0 || o > r_area[tid] || (o == r_area[tid] && oi < r_idx[tid]))) { r_area[tid] = o; r_idx[tid] = oi; } }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const int at = r_idx[0];
+            const uint32_t me = f_node[at];
+            f_area[at] = f_area[n_front - 1]; f_node[at] = f_node[n_front - 1]; n_front--;
+            picked[n_pick++] = me;
+            for (int c = 0; c < 4; c++) {
+                const float4 A = nodes[8 * (size_t)me + 2 * c], B = nodes[8 * (size_t)me + 2 * c + 1];
+                const int ref = __float_as_int(B.z);
+                if (ref < 0) continue;                 // a leaf or an unused slot
+                const float dx = A.w - A.x, dy = B.x - A.y, dz = B.y - A.z;
+                f_area[n_front] = dx * dy + dy * dz + dz * dx; f_node[n_front] = (uint32_t)ref; n_front++;
+            }
+        }
+        __syncthreads();
+    }
+    const int np = n_pick;
+    for (int i = tid; i < np; i += 256) {             // rank sort by node number (distinct)
+        const uint32_t v = picked[i]; int rank = 0;
+        for (int j = 0; j < np; j++) rank += picked[j] < v;
+        top_list[rank] = v;
+    }
+    if (tid == 0) *n_top_p = (uint32_t)np;
+}
+// the table itself: pieces of the walk's nodes, piece-major ([4][MCRT_LANE_TOP])
+__global__ void k_top_table(const uint4 *walk, const uint32_t *top_list, const uint32_t *n_top_p, uint4 *table, uint32_t slots)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4u * slots) return;
+    const uint32_t piece = i / slots, slot = i - piece * slots;
+    table[slot * MCRT_TOP_PITCH + piece * MCRT_TOP_PIECE] = slot < *n_top_p ? walk[4 * (size_t)top_list[slot] + piece] : make_uint4(0x7c007c00u, 0x7c007c00u, 0x7c007c00u, 0x7c007c00u);
+}
+__global__ void k_nodes_walk_decode(const uint4 *in, uint32_t n_nodes, float4 *out, const uint32_t *top_list)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     const uint4 q0 = in[4 * (size_t)i], q1 = in[4 * (size_t)i + 1], q2 = in[4 * (size_t)i + 2], q3 = in[4 * (size_t)i + 3];
     const uint32_t w[12] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w };      // lo.x lo.y lo.z hi.x hi.y hi.z, two words each
-    const uint32_t ref[4] = { q3.x, q3.y, q3.z, q3.w };
+    uint32_t ref[4] = { q3.x, q3.y, q3.z, q3.w };
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         float v[6];
+        if ((int)ref[c] >= 0 && (ref[c] & MCRT_TOP_FLAG)) ref[c] = top_list[ref[c] & 0xffffu];     // a table slot: back to the node it stands for
 #pragma unroll
         for (int k = 0; k < 6; k++) v[k] = half_bits_to_float((w[2 * k + (c >> 1)] >> ((c & 1) * 16)) & 0xffffu);
         const bool empty = (int)ref[c] == MCRT_BVH4_EMPTY;
@@ -541,7 +621,7 @@ MCRT_DEV Planes4 planes4(uint32_t w01, uint32_t w23, float c, float inv)
 // ---- the lane-per-ray walk's two steps ---------------------------------------------------------------------------------
 // A lane's traversal stack: entries [sb, sp), entry e of thread t at lds[e * 256 + t] while e < MCRT_LANE_STACK, beyond that in the
 // global overflow array (only reachable on degenerate paths of deep trees).
-struct LaneStack { int *lds; int *ovf; size_t ovf_stride; int tid; };
+struct LaneStack { int *lds; int *ovf; size_t ovf_stride; int tid; const uint4 *top; };     // top: the top-of-tree table in LDS
 constexpr int CUR_IDLE = (int)0x80000000;      // walk state: cur >= 0 inner node, cur < 0 ~(leaf descriptor), CUR_IDLE = no walk in progress
 MCRT_DEV void lane_pop(const LaneStack &S, int &cur, int &sp, int sb)
 {
@@ -570,8 +650,18 @@ MCRT_DEV bool slab_near_far(float nx, float ny, float nz, float fx, float fy, fl
 // one inner node: the four children's slab tests, the nearest hit child next, the other hit children stacked in slot order
 MCRT_DEV void lane_node_step(const FrameArgs &a, const LaneStack &S, const LaneRay &r, float t_lo, float tcap, int &cur, int &sp, int sb)
 {
-    const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
-    const uint4 Q0 = N[0], Q1 = N[1], Q2 = N[2], RF = N[3];     // (as eight 8-byte pieces instead: 0.492 vs 0.427 ms per frame, round 3)
+    uint4 Q0, Q1, Q2, RF;
+    if (MCRT_LANE_TOP && MCRT_LANE_TOP_FLAT) {                  // one generic address per lane: flat loads go to LDS or to memory lane by lane
+        const uint4 *N = (cur & MCRT_TOP_FLAG) ? S.top + 5 * (cur & 0xffff) : (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
+        Q0 = N[0]; Q1 = N[1]; Q2 = N[2]; RF = N[3];
+    } else if (MCRT_LANE_TOP && (cur & MCRT_TOP_FLAG)) {        // one of the table's nodes: four LDS reads instead of four trips through the vector memory pipe
+        const uint4 *T = S.top + (cur & 0xffff);
+        Q0 = T[0]; Q1 = T[MCRT_LANE_TOP]; Q2 = T[2 * MCRT_LANE_TOP]; RF = T[3 * MCRT_LANE_TOP];
+        asm volatile("" : "+v"(Q0.x), "+v"(Q1.x), "+v"(Q2.x), "+v"(RF.x));      // (keeps the two sides apart: merged, they become flat loads)
+    } else {
+        const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
+        Q0 = N[0]; Q1 = N[1]; Q2 = N[2]; RF = N[3];            // (as eight 8-byte pieces instead: 0.492 vs 0.427 ms per frame, round 3)
+    }
     // six plane distances of the four children
     // Which plane of a slab the ray meets first follows from the SIGN of the reciprocal direction (low plane for a positive one):
     // the packed words of the near and far planes are picked per axis (12 selects) instead of ordering the 24 distances afterwards
@@ -687,7 +777,12 @@ template <bool STATS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_VGPRS))) k_trace_lane(FrameArgs a, uint32_t b)
 {
     __shared__ int stack[MCRT_LANE_STACK * 256];      // [entry][thread]: entry sp of thread t at sp*256 + t -> conflict-free
+    __shared__ uint4 top[MCRT_LANE_TOP ? MCRT_TOP_UNITS : 1];      // the top-of-tree table (k_pick_top), piece-major
     const int tid = threadIdx.x, lane = tid & 63;
+    if (MCRT_LANE_TOP && a.n_nodes != 0u) {
+        for (int k = tid; k < MCRT_TOP_UNITS; k += 256) top[k] = a.top_nodes[k];
+        __syncthreads();
+    }
     // Bounce 0 is special: every sample path of a scan-line starts as a copy of the same first_ray (scene.cpp:83-101), so only
     // ONE ray per (frame, scan-line) is walked -- the first sample's -- and k_shade hands its hit to all S samples.
     const uint32_t n_rays = (b == 0u) ? a.ne : a.counts[b];
@@ -704,7 +799,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_
 #define MCRT_KEYP(p) (&keys[p])
     unsigned long long st_nodes = 0, st_tris = 0, st_q = 0;
     // (overflow entries of this lane: [entry - MCRT_LANE_STACK][grid thread])
-    const LaneStack S = { stack, a.stack_ovf + ((size_t)blockIdx.x * 256 + tid), (size_t)gridDim.x * 256, tid };
+    const LaneStack S = { stack, a.stack_ovf + ((size_t)blockIdx.x * 256 + tid), (size_t)gridDim.x * 256, tid, top };
 
     // WORK DISTRIBUTION, XCD-aware.  Workgroups are dealt round-robin to the 8 XCDs (workgroup w runs on XCD w % 8), each with
     // its own L2.  The queue is cut into 8 contiguous sub-queues, one per XCD, each with its own cursor: an XCD sweeps ITS part
@@ -818,7 +913,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_
                         } else if (piece > 0u) t_hi = 0.0f;
                     }
                     best.frac = t_hi; best.tri = -1;
-                    sp = 0; sb = 0; shared = false; helper = false; cur = (a.n_nodes != 0u && t_lo < t_hi) ? 0 : CUR_IDLE; fresh = false;
+                    sp = 0; sb = 0; shared = false; helper = false; cur = (a.n_nodes != 0u && t_lo < t_hi) ? (MCRT_LANE_TOP ? MCRT_TOP_FLAG : 0) : CUR_IDLE; fresh = false;   // (the root is slot 0 of the table)
                     if (STATS && piece == 0u) st_q++;
                 } else exhausted = true;
             }
@@ -1678,14 +1773,20 @@ hipError_t launch_init(const FrameArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_nodes_walk(const float4 *nodes, uint32_t n_nodes, uint4 *out, hipStream_t st)
+uint32_t lane_top_slots() { return MCRT_LANE_TOP; }
+// top (MCRT_LANE_TOP > 0): {list of the table's nodes [MCRT_LANE_TOP], their count [1]} and the table [4][MCRT_LANE_TOP]; pick = choose the nodes again
+// (a new tree), otherwise the list is kept (a refit: same topology, new boxes)
+hipError_t launch_nodes_walk(const float4 *nodes, uint32_t n_nodes, uint4 *out, uint32_t *top_list, uint4 *top_table, bool pick, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_nodes_walk, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, nodes, n_nodes, out);
+    uint32_t *n_top = top_list ? top_list + MCRT_LANE_TOP : nullptr;
+    if (top_list && pick) hipLaunchKernelGGL(k_pick_top, dim3(1), dim3(256), 0, st, nodes, n_nodes, (uint32_t)MCRT_LANE_TOP, top_list, n_top);
+    hipLaunchKernelGGL(k_nodes_walk, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, nodes, n_nodes, out, (const uint32_t *)top_list, (const uint32_t *)n_top);
+    if (top_list) hipLaunchKernelGGL(k_top_table, dim3((4u * MCRT_LANE_TOP + 255u) / 256u), dim3(256), 0, st, (const uint4 *)out, (const uint32_t *)top_list, (const uint32_t *)n_top, top_table, (uint32_t)MCRT_LANE_TOP);
     return hipGetLastError();
 }
-hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 *out, hipStream_t st)
+hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 *out, const uint32_t *top_list, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_nodes_walk_decode, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, walk, n_nodes, out);
+    hipLaunchKernelGGL(k_nodes_walk_decode, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, walk, n_nodes, out, top_list);
     return hipGetLastError();
 }
 

@@ -1105,7 +1105,7 @@ void orc_scan_convert(const float *img, uint32_t rows, uint32_t cols, double rad
 /*  BVH2 collapsed to W-wide nodes, W = 2..16, counted.  Not part of any parity path.      */
 /* ===================================================================================== */
 typedef struct { float lo[3], hi[3]; int32_t ref; } wide_child;
-struct orc_wide { uint32_t W, n_nodes; wide_child *c; };
+struct orc_wide { uint32_t W, n_nodes; wide_child *c; uint32_t *visits; /* optional: visits per node (orc_wide_visits) */ };
 
 static float wc_harea(const wide_child *s) { float dx = s->hi[0] - s->lo[0], dy = s->hi[1] - s->lo[1], dz = s->hi[2] - s->lo[2]; return dx * dy + dy * dz + dz * dx; }
 static void wc_kids(const orc_bvh_node *n, wide_child *a, wide_child *b)
@@ -1167,6 +1167,41 @@ struct orc_wide *orc_wide_build(const orc_scene *sc, uint32_t W, int quant)
 }
 void orc_wide_free(struct orc_wide *w) { if (w) { free(w->c); free(w); } }
 uint32_t orc_wide_nodes(const struct orc_wide *w) { return w ? w->n_nodes : 0; }
+/* visits[node] is incremented for every inner-node visit of the following orc_wide_count calls (NULL: off) */
+void orc_wide_visits(struct orc_wide *w, uint32_t *visits) { if (w) w->visits = visits; }
+
+/* an order of the inner nodes, root first, in which a node always comes after its parent: mode 0 = breadth first (by depth), mode 1 =
+ * always the pending node with the largest box area next (a ray-independent guess at "most visited").  order[k] = node; returns the count */
+uint32_t orc_wide_order(const struct orc_wide *w, int mode, uint32_t *order)
+{
+    typedef struct { float key; uint32_t node; } item;
+    item *heap = (item *)malloc(sizeof(item) * ((size_t)w->n_nodes + 1));
+    uint32_t hn = 0, n = 0, seq = 0;
+#define HEAP_PUSH(K, N) { uint32_t i_ = hn++; heap[i_].key = (K); heap[i_].node = (N); \
+        while (i_ > 0 && heap[(i_ - 1) / 2].key < heap[i_].key) { item t_ = heap[i_]; heap[i_] = heap[(i_ - 1) / 2]; heap[(i_ - 1) / 2] = t_; i_ = (i_ - 1) / 2; } }
+    HEAP_PUSH(INFINITY, 0u)
+    while (hn > 0) {
+        const uint32_t me = heap[0].node;
+        heap[0] = heap[--hn];
+        for (uint32_t i = 0;;) {
+            uint32_t l = 2 * i + 1, r = l + 1, m = i;
+            if (l < hn && heap[l].key > heap[m].key) m = l;
+            if (r < hn && heap[r].key > heap[m].key) m = r;
+            if (m == i) break;
+            item t = heap[i]; heap[i] = heap[m]; heap[m] = t; i = m;
+        }
+        order[n++] = me;
+        for (uint32_t k = 0; k < w->W; k++) {
+            const wide_child *c = &w->c[(size_t)me * w->W + k];
+            if (c->ref < 0) continue;                       /* leaf or empty */
+            seq++;
+            HEAP_PUSH(mode == 0 ? -(float)seq : wc_harea(c), (uint32_t)c->ref)
+        }
+    }
+#undef HEAP_PUSH
+    free(heap);
+    return n;
+}
 
 /* one query: nearest hit child first (key = t_near bits with the slot in the low 4 bits), the others stacked in slot order;
  * returns the triangle; *steps = inner nodes + leaves visited (the ray's chain of dependent fetches), *nn / *nt nodes and triangles */
@@ -1184,6 +1219,7 @@ static int32_t wide_walk(const struct orc_wide *w, const orc_scene *sc, v3 from,
         if (cur >= 0) {
             const wide_child *N = w->c + (size_t)cur * W;
             nn++;
+            if (w->visits) __atomic_fetch_add(&w->visits[cur], 1u, __ATOMIC_RELAXED);
             uint32_t key[16]; int nh = 0;
             const float tcap = fminf(1.0f, best.frac);
             for (uint32_t k = 0; k < W; k++) {

@@ -175,6 +175,8 @@ struct orc_wide;
 struct orc_wide *orc_wide_build(const orc_scene *sc, uint32_t W, int quant);
 void orc_wide_free(struct orc_wide *w);
 uint32_t orc_wide_nodes(const struct orc_wide *w);
+uint32_t orc_wide_order(const struct orc_wide *w, int mode /*0 breadth first, 1 largest box area first*/, uint32_t *order /*[nodes]*/);
+void orc_wide_visits(struct orc_wide *w, uint32_t *visits /*[nodes] or NULL*/);
 void orc_wide_count(const struct orc_wide *w, const orc_scene *sc, const orc_params *prm, const orc_segment *segs, uint64_t n,
                     uint32_t *out, int32_t *tri, int n_threads);
 
