@@ -410,8 +410,14 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 #endif                               // (64 / 128 / 192 / 256 nodes, with 28 / 24 / 20 / 16 stack entries: every GPU parity test green, 14-19 % of the node visits served
                                      // from LDS -- and the walk 3.31-3.33 ms per launch against 3.20-3.21, the frame 0.348-0.351 against 0.342-0.345 ms: the vector
                                      // memory pipe's saving does not shorten a step that ends with its last lane; the flat-load form the same; profiles/round4/exp_top_of_tree.txt)
+#ifndef MCRT_LANE_QUAD
+#define MCRT_LANE_QUAD 0             // 1: nodes are fetched a QUAD of lanes at a time, whole 64-byte lines straight into LDS (lane_node_fetch_quad).  OFF: parity green,
+                                     // 2.4x / 1.2x on a bare dependent fetch chain (tools/quad_line.hip), the walk 3.35-3.38 ms per launch against 3.20-3.21
+                                     // (profiles/round4/exp_quad_fetch.txt: the instructions it adds weigh more than the pipe time it saves)
+#endif
+#define MCRT_QUAD_PITCH 1040         // bytes between the LDS images of a wavefront's four quad loads (1 KiB + 16: the four lanes of a quad read their nodes from different banks)
 #ifndef MCRT_LANE_STACK
-#define MCRT_LANE_STACK (MCRT_LANE_TOP ? 24 : 32)     // (the headline workload's deepest walk stacks 16 entries, 14 at the 99.9th percentile: profiles/round4/bvh_width.json)
+#define MCRT_LANE_STACK (MCRT_LANE_QUAD ? 20 : MCRT_LANE_TOP ? 24 : 32)     // (the headline workload's deepest walk stacks 16 entries, 14 at the 99.9th percentile: profiles/round4/bvh_width.json)
 #endif
 #ifndef MCRT_LANE_TOP_FLAT
 #define MCRT_LANE_TOP_FLAT 0         // 1: the table node-major with an 80-byte pitch and ONE flat load per piece for both kinds of lanes (the address picks LDS or memory)
@@ -648,6 +654,7 @@ MCRT_DEV bool slab_near_far(float nx, float ny, float nz, float fx, float fy, fl
 }
 
 // one inner node: the four children's slab tests, the nearest hit child next, the other hit children stacked in slot order
+MCRT_DEV void lane_node_compute(const LaneStack &S, const LaneRay &r, float t_lo, float tcap, const uint4 Q0, const uint4 Q1, const uint4 Q2, const uint4 RF, int &cur, int &sp, int sb);
 MCRT_DEV void lane_node_step(const FrameArgs &a, const LaneStack &S, const LaneRay &r, float t_lo, float tcap, int &cur, int &sp, int sb)
 {
     uint4 Q0, Q1, Q2, RF;
@@ -662,6 +669,37 @@ MCRT_DEV void lane_node_step(const FrameArgs &a, const LaneStack &S, const LaneR
         const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
         Q0 = N[0]; Q1 = N[1]; Q2 = N[2]; RF = N[3];            // (as eight 8-byte pieces instead: 0.492 vs 0.427 ms per frame, round 3)
     }
+    lane_node_compute(S, r, t_lo, tcap, Q0, Q1, Q2, RF, cur, sp, sb);
+}
+
+// THE QUAD FETCH (MCRT_LANE_QUAD).  The vector memory pipe works through a 16-byte-per-lane load a quad of lanes at a time, and a lane that
+// reads the four pieces of ITS OWN node makes every quad of each of the four loads touch four different lines.  Here load k (k = 0..3) is
+// issued for the node of the quad's k-th lane BY ALL FOUR lanes of the quad, lane j reading piece j: a quad reads one whole line per load, and
+// the load is an LDS-DMA (global_load_lds_dwordx4: destination = image k + lane x 16), so the line lands in LDS as the contiguous node of
+// lane 4q+k, which then reads it with four ds_read_b128.  tools/quad_line.hip, dependent fetches, 16 wavefronts per CU: 490 against 1178 ns
+// per step from L1-resident nodes, 988 against 1199 ns from L2 (either half alone -- quad lines into registers, or own pieces through LDS
+// -- gains nothing).  Runs for ALL lanes of the wavefront (a lane not on an inner node stands in with the root's line for its slot).
+MCRT_DEV void lane_node_fetch_quad(const FrameArgs &a, int cur, uint32_t stage_wave /*LDS address of the wavefront's images, wave-uniform*/, uint32_t piece_off /*(lane & 3) * 16*/)
+{
+    // byte offset of piece j of the node of the quad's k-th lane: max(cur of lane k, 0) << 6 | j * 16 -- the quad broadcast and the clamp in one
+    // DPP instruction each
+    int m0, m1, m2, m3; const int zero = 0;
+    asm("v_max_i32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "=v"(m0) : "v"(cur), "v"(zero));
+    asm("v_max_i32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "=v"(m1) : "v"(cur), "v"(zero));
+    asm("v_max_i32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "=v"(m2) : "v"(cur), "v"(zero));
+    asm("v_max_i32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "=v"(m3) : "v"(cur), "v"(zero));
+    const uint32_t o0 = ((uint32_t)m0 << 6) | piece_off, o1 = ((uint32_t)m1 << 6) | piece_off, o2 = ((uint32_t)m2 << 6) | piece_off, o3 = ((uint32_t)m3 << 6) | piece_off;
+    // (M0 = LDS address of the image; one wait state between writing M0 and the LDS-DMA that reads it)
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %5\n\t"
+                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 :: "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(stage_wave), "s"(a.nodes_walk), "n"(MCRT_QUAD_PITCH) : "memory", "m0", "scc");
+}
+
+MCRT_DEV void lane_node_compute(const LaneStack &S, const LaneRay &r, float t_lo, float tcap, const uint4 Q0, const uint4 Q1, const uint4 Q2, const uint4 RF, int &cur, int &sp, int sb)
+{
     // six plane distances of the four children
     // Which plane of a slab the ray meets first follows from the SIGN of the reciprocal direction (low plane for a positive one):
     // the packed words of the near and far planes are picked per axis (12 selects) instead of ordering the 24 distances afterwards
@@ -778,6 +816,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_
 {
     __shared__ int stack[MCRT_LANE_STACK * 256];      // [entry][thread]: entry sp of thread t at sp*256 + t -> conflict-free
     __shared__ uint4 top[MCRT_LANE_TOP ? MCRT_TOP_UNITS : 1];      // the top-of-tree table (k_pick_top), piece-major
+    __shared__ __attribute__((aligned(16))) char quad_stage[MCRT_LANE_QUAD ? 4 * 4 * MCRT_QUAD_PITCH : 16];      // [wavefront][load][lane x 16]: the quad fetch's landing area
+    static_assert(!(MCRT_LANE_QUAD && MCRT_LANE_TOP), "the quad fetch and the top-of-tree table are alternatives");
     const int tid = threadIdx.x, lane = tid & 63;
     if (MCRT_LANE_TOP && a.n_nodes != 0u) {
         for (int k = tid; k < MCRT_TOP_UNITS; k += 256) top[k] = a.top_nodes[k];
@@ -800,6 +840,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_
     unsigned long long st_nodes = 0, st_tris = 0, st_q = 0;
     // (overflow entries of this lane: [entry - MCRT_LANE_STACK][grid thread])
     const LaneStack S = { stack, a.stack_ovf + ((size_t)blockIdx.x * 256 + tid), (size_t)gridDim.x * 256, tid, top };
+    const uint32_t quad_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)quad_stage + (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) * (4u * MCRT_QUAD_PITCH);   // LDS address of this wavefront's four images
+    const uint4 *quad_node = (const uint4 *)(quad_stage + (tid >> 6) * (4 * MCRT_QUAD_PITCH) + (lane & 3) * MCRT_QUAD_PITCH + (lane >> 2) * 64);      // where this lane's node lands
+    const uint32_t quad_piece = (uint32_t)(lane & 3) * 16u;
 
     // WORK DISTRIBUTION, XCD-aware.  Workgroups are dealt round-robin to the 8 XCDs (workgroup w runs on XCD w % 8), each with
     // its own L2.  The queue is cut into 8 contiguous sub-queues, one per XCD, each with its own cursor: an XCD sweeps ITS part
@@ -988,7 +1031,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_
                 sc_dist++;
             }
 #endif
-            if (cur >= 0) {
+            if (MCRT_LANE_QUAD) {
+                lane_node_fetch_quad(a, cur, quad_wave, quad_piece);
+                if (cur >= 0) {
+                    if (STATS) st_nodes++;
+                    const uint4 Q0 = quad_node[0], Q1 = quad_node[1], Q2 = quad_node[2], RF = quad_node[3];
+                    lane_node_compute(S, lr, t_lo, tcap, Q0, Q1, Q2, RF, cur, sp, sb);
+                }
+            } else if (cur >= 0) {
                 if (STATS) st_nodes++;
                 lane_node_step(a, S, lr, t_lo, tcap, cur, sp, sb);
             }
