@@ -669,6 +669,21 @@ MCRT_DEV void lane_node_step(const FrameArgs &a, const LaneStack &S, const LaneR
         const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
         Q0 = N[0]; Q1 = N[1]; Q2 = N[2]; RF = N[3];            // (as eight 8-byte pieces instead: 0.492 vs 0.427 ms per frame, round 3)
     }
+#if defined(MCRT_SENS_LOAD)
+    // SENSITIVITY build (make variant DEFS=-DMCRT_SENS_LOAD=n): n more loads per node step and lane (4 bytes of the node's own line through a pointer the
+    // compiler cannot see through, so they are neither merged nor dropped; ordinary cached loads), folded into a word that cannot change the walk --
+    // what does one more lane access cost the launch?
+    { uint32_t off = (uint32_t)(cur & ~MCRT_TOP_FLAG) << 6; asm volatile("" : "+v"(off)); uint32_t sink = 0;
+      const uint32_t *E = (const uint32_t *)((const char *)a.nodes_walk + off);
+      for (int e = 0; e < MCRT_SENS_LOAD; e++) sink |= E[4 * (e & 3) + 1];
+      asm volatile("" : "+v"(sink)); RF.x |= sink & 0u; }
+#endif
+#if defined(MCRT_SENS_VALU)
+    // ... and n more VALU instructions per node step (a dependent chain of integer adds on a dead value)
+    { uint32_t d = Q0.x;
+      for (int e = 0; e < MCRT_SENS_VALU; e++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(d) : "v"(Q1.x));
+      asm volatile("" :: "v"(d)); }
+#endif
     lane_node_compute(S, r, t_lo, tcap, Q0, Q1, Q2, RF, cur, sp, sb);
 }
 

@@ -105,6 +105,12 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 | `bvh_width.json` | `tools/bvh_width.py` (CPU): the headline frame's 816 k closest-hit queries walked over the product's BVH2 collapsed to 2 / 4 / 8 / 16-wide nodes, float and 8-bit boxes -- visits, chains, 16-byte pieces (rules 8-wide nodes out) |
 | `exp_refill_threshold.txt` | the walk's refill threshold at 4 / 8 / 16 idle lanes, timed and with the stamp build: more lanes step per iteration, every iteration costs proportionally more (the walk is bound by the vector memory pipe, not by idle lanes) |
 | `exp_pass_split.txt` | what cutting a timed region into smaller passes costs (decides `bench.py`'s N > 1 rule) |
+| `exp_round4_kernels.txt` | round 4's kernel changes one by one (triangle records, LDS tables, the held-back accumulation, the register trap) |
+| `exp_pass20.txt` | the driver's 20-frame pass on its own: launch timeline, the walk's tails, the schedule knobs (already at the optimum) |
+| `top_of_tree.json`, `exp_top_of_tree.txt` | a top-of-tree table in LDS for the walk: what a static table can serve (`tools/top_of_tree.py`, CPU) and what it did on the GPU (parity green, 3 % slower: off) |
+| `quad_line.json`, `exp_quad_fetch.txt` | the node fetch a quad of lanes at a time through LDS-DMA: 2.4 x on a bare dependent fetch chain (`tools/quad_line.hip`), 4-5 % slower in the walk (parity green: off) |
+| `exp_sensitivity.txt` | what one more load, and ten more instructions, per node step cost the walk: 3 % and 2 % -- neither pipe is the wall alone |
+| `bench_random16m_sah.json` | the 16 M scene with the host's SAH builder instead of the device LBVH: 9 % faster frames for a 70 x longer build |
 | `bench_random16m.json` | `python bench.py --workload random16m`: the STREAMING regime (16 M triangles, 2 GB of BVH past the Infinity Cache), with live PMC, CPU baseline and parity check |
 | `group_bench.json` | `tools/group_bench.py 0,0`: whole B-mode frames through `mcrt_group_*` (two ranks sharing the GPU) against one context |
 | `bench_unprofiled.json` | `python bench.py`: the JSON line (live PMC passes in child processes, CPU baseline, inline parity check) |
