@@ -32,10 +32,10 @@ struct Box {
     }
 };
 
-constexpr int kLeafMax = 4;
+static int kLeafMax = 4;              // (both tunable through MCRT_SAH_LEAF_MAX / MCRT_SAH_COST_TRI for experiments: tools/tune.sh)
 constexpr int kBins = 16;
 constexpr int kMaxDepth = MCRT_BVH_MAX_DEPTH;   // deepest leaf; the traversal stack holds this many entries
-constexpr float kCostNode = 1.0f, kCostTri = 1.2f;
+constexpr float kCostNode = 1.0f; static float kCostTri = 1.2f;
 
 struct Builder {
     std::vector<Prim> prims;
@@ -122,6 +122,8 @@ extern "C" int mcrt_build_bvh(const float *tri, const uint32_t *tri_mesh, uint32
 {
     if (!tri || !out || n_tri == 0) return mcrt::set_error(MCRT_ERR_INVALID, "mcrt_build_bvh: no triangles");
     if (n_tri >= (1u << 28)) return mcrt::set_error(MCRT_ERR_LIMIT, "mcrt_build_bvh: more than 2^28 triangles");
+    if (const char *e = getenv("MCRT_SAH_LEAF_MAX")) { int v = atoi(e); if (v >= 1 && v <= 8) kLeafMax = v; }
+    if (const char *e = getenv("MCRT_SAH_COST_TRI")) { float v = (float)atof(e); if (v > 0.0f) kCostTri = v; }
     Builder b;
     b.prims.resize(n_tri);
     // Padding (DESIGN.md "Closest hit"): Bullet's triangle test accepts points up to 1e-4 of the triangle's
