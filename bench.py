@@ -49,7 +49,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMD = 1024           # 256 CUs x 4 SIMD-32
 MIN_SPLIT_PASS = 48     # N > 1: a timed region is cut into two passes (gather + post of the first hidden behind the second) only if each has this many frames
-TRACE_KERNELS = ("k_trace_lane<false",)   # the walk kernel of the timed build
+TRACE_KERNELS = ("k_trace_lane<false", "k_trace_lane_wide")   # the walk of the timed build: its four- and five-wavefront forms (large launches take the second), pooled
 
 
 def build_workload(m, name):
@@ -354,7 +354,7 @@ def main():
                        "warmup_steps_run": W_run, "step": "clear, trace, accumulate, [all-gather], PSF, envelope, scan conversion to %dx%d" % (pipe.OUT_ROWS, pipe.OUT_COLS)},
             "ranks_seen": world, "per_rank": per_rank,
         }
-        roof = {"frac_vs_architectural": None, "kernel": "k_trace_lane<false>", "kernel_ms": k_ms, "launches": k_n, "launches_per_frame": launches_per_frame,
+        roof = {"frac_vs_architectural": None, "kernel": "k_trace_lane<false> / k_trace_lane_wide (the walk: launches of >= 4 Mi rays take the five-wavefront form)", "kernel_ms": k_ms, "launches": k_n, "launches_per_frame": launches_per_frame,
                 "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps_cache_served": alg_gbs, "node_bytes": node_bytes,
                 "trace_bytes_per_frame": trace_bytes_frame, "other_stage_bytes_per_frame": other_bytes_frame,
                 "per_frame": {k: v / K for k, v in st.items()}}
@@ -483,18 +483,15 @@ def roofline_from(pmc, k_ms, alg_gbs):
 
 
 def _pmc_rows(d):
-    """counter values of the walk kernel's launches (the kernel with the most launches among the candidates), per counter"""
+    """counter values of the walk's launches (both of its kernels), per counter"""
     per = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            for k in TRACE_KERNELS:
-                if k in row["Kernel_Name"]:
-                    per.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-                    break
+            if any(k in row["Kernel_Name"] for k in TRACE_KERNELS):
+                per.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     if not per:
         return {}, None
-    name = max(per, key=lambda k: max(len(v) for v in per[k].values()))
-    return per[name], name
+    return per, "k_trace_lane<false> + k_trace_lane_wide"
 
 
 def live_pmc(args):

@@ -66,7 +66,7 @@ struct Work {
 
 // tuning knobs from the environment, read ONCE at mcrt_create (never on the frame path)
 struct Knobs {
-    uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 0;   // march_blocks 0: launch_march picks
+    uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, trace_blocks_wide = 0, wide_from = 0 /* 0: the kernels' own default */, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 0;   // march_blocks 0: launch_march picks
     bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false, graph = false;
     uint32_t march_cus = 0;                    // CUs the accumulation's side stream is confined to (0 = no mask); the mask's bit order is the driver's
     bool main_mask = false;                    // with march_cus: the walk / shade chain runs on its own stream confined to the OTHER CUs
@@ -77,6 +77,8 @@ static Knobs read_knobs()
     Knobs k;
     if (const char *e = getenv("MCRT_KSPLIT_LIMIT")) { long v = atol(e); if (v >= 0 && v <= MCRT_KSPLIT_MAX) k.ksplit_limit = (uint32_t)v; }   // 0 = off
     if (const char *e = getenv("MCRT_TRACE_BLOCKS")) { int v = atoi(e); if (v >= 1) k.trace_blocks = (uint32_t)v; }
+    if (const char *e = getenv("MCRT_TRACE_BLOCKS_WIDE")) { int v = atoi(e); if (v >= 1) k.trace_blocks_wide = (uint32_t)v; }
+    if (const char *e = getenv("MCRT_WIDE_FROM")) { long long v = atoll(e); if (v >= 1 && v <= 0xffffffffll) k.wide_from = (uint32_t)v; }   // rays in a launch from which the walk takes its five-wavefront form (1: always; 4294967295: never)
     if (const char *e = getenv("MCRT_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 16) k.groups = (uint32_t)v; }
     if (const char *e = getenv("MCRT_MARCH_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= MCRT_SIDE_STREAMS) k.march_streams = (uint32_t)v; }
     if (const char *e = getenv("MCRT_MARCH_BLOCKS")) { int v = atoi(e); if (v >= 1) k.march_blocks = (uint32_t)v; }
@@ -721,7 +723,7 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne_frame, uint32_t n_frame
     }
     {   // traversal-stack entries beyond the LDS part, one slot per thread of THIS work set's walk launches
         const uint32_t lds_part = mcrt::lane_stack_entries();
-        const uint32_t blocks = c->knobs.trace_blocks ? c->knobs.trace_blocks : c->n_cu * 5u;
+        const uint32_t blocks = std::max(std::max(c->knobs.trace_blocks, c->knobs.trace_blocks_wide), c->n_cu * 5u);      // (the larger of the walk's two forms)
         const size_t need = c->bvh4.max_stack > lds_part ? (size_t)(c->bvh4.max_stack - lds_part) * blocks * 256 : 0;
         if (need > w.ovf_cap) {
             HIP_TRY(hipDeviceSynchronize());
@@ -767,6 +769,9 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     for (int i = 0; i < 3; i++) { a.scene_lo[i] = c->scene_lo[i]; a.scene_hi[i] = c->scene_hi[i]; }
     a.trace_blocks = c->knobs.trace_blocks ? c->knobs.trace_blocks : (c->n_cu - (c->knobs.main_mask ? c->knobs.march_cus : 0u)) * 4u;   // persistent k_trace: 4 four-wave workgroups per CU (1024 on the MI355X's 256 CUs) of the 5 its registers and LDS allow --
                                                                                   // the fifth's registers go to a k_march wavefront beside them (since k_march's fast path: 0.446 -> 0.428 ms per frame on a 20-frame pass, 0.366 -> 0.364 at 128)
+    a.trace_blocks_wide = c->knobs.trace_blocks_wide ? c->knobs.trace_blocks_wide : c->n_cu * 5u;      // k_trace_lane_wide: five workgroups per CU
+    a.wide_from = c->knobs.wide_from ? c->knobs.wide_from : mcrt::lane_wide_from();
+    if (c->knobs.main_mask) a.trace_blocks_wide = 0;                                                   // (CU-masked streams: the four-wavefront form only)
     a.march_blocks = c->knobs.march_blocks;
     a.frame = frame; a.frame_dev = c->d_frame_words; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n; a.tex_mask = (c->tex_n & (c->tex_n - 1u)) == 0u ? c->tex_n - 1u : 0u;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;

@@ -39,7 +39,7 @@ struct FrameArgs {
     uint32_t *error_flag;      // device word, bit 0: traversal stack overflow
     unsigned long long *stamps; // [80] diagnostic build (-DMCRT_STAMP) only
     // sizes / parameters
-    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, pose_stride, acc_stride, acc_off, trace_blocks, march_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift, march_rows, n_mat, n_mesh;   // march_rows: entries of k_march's padded LDS image when its fast variant applies, else 0
+    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, pose_stride, acc_stride, acc_off, trace_blocks, trace_blocks_wide, wide_from, march_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift, march_rows, n_mat, n_mesh;   // march_rows: entries of k_march's padded LDS image when its fast variant applies, else 0
     float scene_lo[3], scene_hi[3];   // bounds of the whole BVH
     float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs, tex_rcp, lean_bound;
     double axial_res_mm, time_step, row_dt, max_travel, sos_d, inv_row_dt;
@@ -55,6 +55,7 @@ hipError_t launch_nodes_walk(const float4 *nodes, uint32_t n_nodes, uint4 *out, 
 hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 *out, const uint32_t *top_list, hipStream_t st);
 uint32_t lane_top_slots();
 uint32_t lane_stack_entries();
+uint32_t lane_wide_from();
 hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
 hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
 hipError_t launch_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t ne, uint32_t R, const uint32_t *error_flag, hipStream_t st);

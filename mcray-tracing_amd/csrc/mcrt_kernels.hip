@@ -627,16 +627,16 @@ MCRT_DEV Planes4 planes4(uint32_t w01, uint32_t w23, float c, float inv)
 // ---- the lane-per-ray walk's two steps ---------------------------------------------------------------------------------
 // A lane's traversal stack: entries [sb, sp), entry e of thread t at lds[e * 256 + t] while e < MCRT_LANE_STACK, beyond that in the
 // global overflow array (only reachable on degenerate paths of deep trees).
-struct LaneStack { int *lds; int *ovf; size_t ovf_stride; int tid; const uint4 *top; };     // top: the top-of-tree table in LDS
+template <int STACK> struct LaneStackT { int *lds; int *ovf; size_t ovf_stride; int tid; const uint4 *top; static constexpr int depth = STACK; };     // depth: entries in LDS; top: the top-of-tree table in LDS
 constexpr int CUR_IDLE = (int)0x80000000;      // walk state: cur >= 0 inner node, cur < 0 ~(leaf descriptor), CUR_IDLE = no walk in progress
-MCRT_DEV void lane_pop(const LaneStack &S, int &cur, int &sp, int sb)
+template <class LS> MCRT_DEV void lane_pop(const LS &S, int &cur, int &sp, int sb)
 {
-    if (sp > sb) { sp--; cur = (sp < MCRT_LANE_STACK) ? S.lds[sp * 256 + S.tid] : S.ovf[(size_t)(sp - MCRT_LANE_STACK) * S.ovf_stride]; }
+    if (sp > sb) { sp--; cur = (sp < LS::depth) ? S.lds[sp * 256 + S.tid] : S.ovf[(size_t)(sp - LS::depth) * S.ovf_stride]; }
     else cur = CUR_IDLE;
 }
-MCRT_DEV void lane_push(const LaneStack &S, int &sp, int v)
+template <class LS> MCRT_DEV void lane_push(const LS &S, int &sp, int v)
 {
-    if (sp < MCRT_LANE_STACK) S.lds[sp * 256 + S.tid] = v; else S.ovf[(size_t)(sp - MCRT_LANE_STACK) * S.ovf_stride] = v;
+    if (sp < LS::depth) S.lds[sp * 256 + S.tid] = v; else S.ovf[(size_t)(sp - LS::depth) * S.ovf_stride] = v;
     sp++;
 }
 struct LaneRay { float cx, cy, cz, ix, iy, iz; bool nx, ny, nz; };     // c = -(origin * reciprocal direction) and the reciprocal direction; reciprocal negative?
@@ -654,8 +654,8 @@ MCRT_DEV bool slab_near_far(float nx, float ny, float nz, float fx, float fy, fl
 }
 
 // one inner node: the four children's slab tests, the nearest hit child next, the other hit children stacked in slot order
-MCRT_DEV void lane_node_compute(const LaneStack &S, const LaneRay &r, float t_lo, float tcap, const uint4 Q0, const uint4 Q1, const uint4 Q2, const uint4 RF, int &cur, int &sp, int sb);
-MCRT_DEV void lane_node_step(const FrameArgs &a, const LaneStack &S, const LaneRay &r, float t_lo, float tcap, int &cur, int &sp, int sb)
+template <class LS> MCRT_DEV void lane_node_compute(const LS &S, const LaneRay &r, float t_lo, float tcap, const uint4 Q0, const uint4 Q1, const uint4 Q2, const uint4 RF, int &cur, int &sp, int sb);
+template <class LS> MCRT_DEV void lane_node_step(const FrameArgs &a, const LS &S, const LaneRay &r, float t_lo, float tcap, int &cur, int &sp, int sb)
 {
     uint4 Q0, Q1, Q2, RF;
     if (MCRT_LANE_TOP && MCRT_LANE_TOP_FLAT) {                  // one generic address per lane: flat loads go to LDS or to memory lane by lane
@@ -713,7 +713,7 @@ MCRT_DEV void lane_node_fetch_quad(const FrameArgs &a, int cur, uint32_t stage_w
                  :: "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(stage_wave), "s"(a.nodes_walk), "n"(MCRT_QUAD_PITCH) : "memory", "m0", "scc");
 }
 
-MCRT_DEV void lane_node_compute(const LaneStack &S, const LaneRay &r, float t_lo, float tcap, const uint4 Q0, const uint4 Q1, const uint4 Q2, const uint4 RF, int &cur, int &sp, int sb)
+template <class LS> MCRT_DEV void lane_node_compute(const LS &S, const LaneRay &r, float t_lo, float tcap, const uint4 Q0, const uint4 Q1, const uint4 Q2, const uint4 RF, int &cur, int &sp, int sb)
 {
     // six plane distances of the four children
     // Which plane of a slab the ray meets first follows from the SIGN of the reciprocal direction (low plane for a positive one):
@@ -739,7 +739,7 @@ MCRT_DEV void lane_node_compute(const LaneStack &S, const LaneRay &r, float t_lo
                                                                      //  with the references only for nodes that have a hit child 0.440 vs 0.429 ms per frame, round 3)
     if (kmin == 0xffffffffu) { lane_pop(S, cur, sp, sb); return; }
     const bool p0 = h0 && k0 != kmin, p1 = h1 && k1 != kmin, p2 = h2 && k2 != kmin, p3 = h3 && k3 != kmin;
-    if (__builtin_expect(__any(sp + 4 > MCRT_LANE_STACK), 0)) {       // (some lane may leave the LDS part: the general form)
+    if (__builtin_expect(__any(sp + 4 > LS::depth), 0)) {       // (some lane may leave the LDS part: the general form)
         if (p0) lane_push(S, sp, r0);
         if (p1) lane_push(S, sp, r1);
         if (p2) lane_push(S, sp, r2);
@@ -762,7 +762,7 @@ MCRT_DEV void lane_node_compute(const LaneStack &S, const LaneRay &r, float t_lo
 // one leaf: the contract's triangle test (btTriangleRaycastCallback::processTriangle behind the padded-bounds rule) on each of its
 // triangles, then the next stack entry.  helper: the lane walks an adopted subtree (see k_trace_lane): a triangle at exactly the
 // owner's closest fraction is a candidate.  Returns the number of triangles of the leaf.
-MCRT_DEV uint32_t lane_leaf_test(const FrameArgs &a, const LaneStack &S, f3 f2, f3 to, f3 inv, f3 rc, float t_lo, bool helper, Best &best, int &cur, int &sp, int sb)
+template <class LS> MCRT_DEV uint32_t lane_leaf_test(const FrameArgs &a, const LS &S, f3 f2, f3 to, f3 inv, f3 rc, float t_lo, bool helper, Best &best, int &cur, int &sp, int sb)
 {
     const uint32_t v = (uint32_t)~cur;
     const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
@@ -826,10 +826,9 @@ MCRT_DEV int nth_set_bit(unsigned long long m, uint32_t r)
     return base;
 }
 
-template <bool STATS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_VGPRS))) k_trace_lane(FrameArgs a, uint32_t b)
+template <bool STATS, int STACK>
+MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b, int *stack /* LDS, [STACK][256]: entry sp of thread t at sp*256 + t -> conflict-free */)
 {
-    __shared__ int stack[MCRT_LANE_STACK * 256];      // [entry][thread]: entry sp of thread t at sp*256 + t -> conflict-free
     __shared__ uint4 top[MCRT_LANE_TOP ? MCRT_TOP_UNITS : 1];      // the top-of-tree table (k_pick_top), piece-major
     __shared__ __attribute__((aligned(16))) char quad_stage[MCRT_LANE_QUAD ? 4 * 4 * MCRT_QUAD_PITCH : 16];      // [wavefront][load][lane x 16]: the quad fetch's landing area
     static_assert(!(MCRT_LANE_QUAD && MCRT_LANE_TOP), "the quad fetch and the top-of-tree table are alternatives");
@@ -854,7 +853,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_
 #define MCRT_KEYP(p) (&keys[p])
     unsigned long long st_nodes = 0, st_tris = 0, st_q = 0;
     // (overflow entries of this lane: [entry - MCRT_LANE_STACK][grid thread])
-    const LaneStack S = { stack, a.stack_ovf + ((size_t)blockIdx.x * 256 + tid), (size_t)gridDim.x * 256, tid, top };
+    const LaneStackT<STACK> S = { stack, a.stack_ovf + ((size_t)blockIdx.x * 256 + tid), (size_t)gridDim.x * 256, tid, top };
     const uint32_t quad_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)quad_stage + (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) * (4u * MCRT_QUAD_PITCH);   // LDS address of this wavefront's four images
     const uint4 *quad_node = (const uint4 *)(quad_stage + (tid >> 6) * (4 * MCRT_QUAD_PITCH) + (lane & 3) * MCRT_QUAD_PITCH + (lane >> 2) * 64);      // where this lane's node lands
     const uint32_t quad_piece = (uint32_t)(lane & 3) * 16u;
@@ -991,7 +990,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_
         // trips were added); one ray per four lanes at the start of a small launch; rays dealt out across the wavefronts.
         if (!STATS && queue_empty) {
             const bool thief = cur == CUR_IDLE && fresh;
-            const bool donor = cur != CUR_IDLE && sp > sb && sb < MCRT_LANE_STACK;
+            const bool donor = cur != CUR_IDLE && sp > sb && sb < STACK;
             const unsigned long long tm = __ballot(thief), dm = __ballot(donor);
             if (tm != 0ull && dm != 0ull) {
                 const unsigned long long below = (1ull << lane) - 1ull;
@@ -1121,6 +1120,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_
             if (lane == 0 && x) atomicAdd(&a.stats[k], (unsigned long long)x);
         }
     }
+}
+
+// The walk comes as TWO kernels around one body.  k_trace_lane is compiled for 96 registers (budget 104): four of its wavefronts per SIMD (1024
+// persistent workgroups) beside one k_march wavefront, nothing spilled -- the form for small launches, whose time is a chain of dependent
+// steps.  k_trace_lane_wide is compiled for FIVE wavefronts per SIMD beside that k_march wavefront (5 x 80 + 80 registers; 1280 workgroups;
+// MCRT_LANE_WIDE_STACK LDS stack entries so that five workgroups and k_march's LDS fit a CU): the compiler spills a dozen registers, all of them
+// in the refill, hand-over and reporting code outside the node and leaf loops.  Sensitivity builds (profiles/round4/exp_sensitivity.txt) had shown the
+// walk at the knee of its two pipes with four wavefronts to hide latency behind; the fifth is worth 3-4 % of a 128-frame pass (0.330 against
+// 0.342 ms per frame; 1.8 % at 96 frames, 1.4 % at 48, 0.5 % at 32), costs a 20-frame pass 1 % and one frame at a time 6 % -- so launch_trace
+// takes the wide form from MCRT_LANE_WIDE_FROM queued rays (32 frames of the headline workload) upwards.  (Its stack is sized at the launch: with a static LDS array the compiler caps the kernel's occupancy
+// by LDS and hands the registers back.)
+#ifndef MCRT_LANE_WIDE_STACK
+#define MCRT_LANE_WIDE_STACK 24          // (28: 0.332 against 0.3295 ms per frame; deeper walks go on in the overflow array, as in the other form)
+#endif
+#ifndef MCRT_LANE_WIDE_FROM
+#define MCRT_LANE_WIDE_FROM 4194304u
+#endif
+template <bool STATS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_VGPRS))) k_trace_lane(FrameArgs a, uint32_t b)
+{
+    __shared__ int stack[MCRT_LANE_STACK * 256];
+    trace_lane_body<STATS, MCRT_LANE_STACK>(a, b, stack);
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) k_trace_lane_wide(FrameArgs a, uint32_t b)
+{
+    extern __shared__ int stack_dyn[];
+    trace_lane_body<false, MCRT_LANE_WIDE_STACK>(a, b, stack_dyn);
 }
 
 // ---- interface interaction (scene.cpp:122-165, ray.cpp:11-97) of ONE path at bounce b, given its ray and the closest-hit
@@ -1855,7 +1881,8 @@ hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 
     return hipGetLastError();
 }
 
-uint32_t lane_stack_entries() { return MCRT_LANE_STACK; }
+uint32_t lane_stack_entries() { return MCRT_LANE_STACK < MCRT_LANE_WIDE_STACK ? MCRT_LANE_STACK : MCRT_LANE_WIDE_STACK; }   // (the smaller of the two forms' LDS parts: sizes the overflow array)
+uint32_t lane_wide_from() { return MCRT_LANE_WIDE_FROM; }
 
 hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st)
 {
@@ -1865,6 +1892,11 @@ hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
     if (np < a.ksplit_limit) np = a.ksplit_limit;          // small bounces are cut into up to ksplit_limit pieces
     const uint32_t blocks = (np + 255u) / 256u;
     const dim3 grid(blocks < a.trace_blocks ? blocks : a.trace_blocks), blk(256);
+    if (!stats && a.trace_blocks_wide != 0u && np >= a.wide_from) {          // a large launch: five wavefronts per SIMD (k_trace_lane_wide)
+        const dim3 gridw(blocks < a.trace_blocks_wide ? blocks : a.trace_blocks_wide);
+        hipLaunchKernelGGL(k_trace_lane_wide, gridw, blk, (size_t)MCRT_LANE_WIDE_STACK * 256 * sizeof(int), st, a, b);
+        return hipGetLastError();
+    }
     if (stats) hipLaunchKernelGGL((k_trace_lane<true>), grid, blk, 0, st, a, b);
     else hipLaunchKernelGGL((k_trace_lane<false>), grid, blk, 0, st, a, b);
     return hipGetLastError();

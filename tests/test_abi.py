@@ -91,5 +91,11 @@ def test_walk_kernel_keeps_its_register_budget():
     assert walk, out[-2000:]
     get = lambda key: int(re.search(key + r": (\d+)", walk[0]).group(1))
     assert get("VGPRs") <= 104 and get("VGPRs Spill") == 0 and get("SGPRs Spill") == 0 and get(r"ScratchSize \[bytes/lane\]") == 0, walk[0][:900]
+    # the five-wavefront form: 80 registers (5 x 80 + k_march's 80 <= 512), no scalar spills; what it spills of vector registers (a dozen, outside
+    # its node and leaf loops) stays under 64 bytes of scratch per lane
+    wide = [b for b in blocks if b.startswith("_ZN4mcrt17k_trace_lane_wide")]
+    assert wide, out[-2000:]
+    getw = lambda key: int(re.search(key + r": (\d+)", wide[0]).group(1))
+    assert getw("VGPRs") <= 80 and getw("SGPRs Spill") == 0 and getw(r"ScratchSize \[bytes/lane\]") <= 64, wide[0][:900]
     march = [b for b in blocks if b.startswith("_ZN4mcrt7k_marchILb0ELi2ELb1EEE")]
     assert march and int(re.search(r"VGPRs: (\d+)", march[0]).group(1)) <= 80

@@ -836,16 +836,18 @@ def test_host_shim_surface(mcrt, orc, tex256, tmp_path):
 
 def test_schedules_do_not_change_anything(mcrt, orc, tex256, monkeypatch):
     """how a pass is scheduled is free (counter-keyed RNG, integer RF bins): the default, scan-line groups on their own streams, rays
-    of small bounces cut into pieces or not, the accumulation (and the walk) confined to their own CUs, everything on one stream -- all
-    give bit-identical hits, segments, RF images and visit counts, equal to the oracle's."""
+    of small bounces cut into pieces or not, the accumulation (and the walk) confined to their own CUs, everything on one stream, the walk
+    in its five-wavefronts-per-SIMD form (k_trace_lane_wide, which large launches take by themselves) -- all give bit-identical hits,
+    segments, RF images and visit counts, equal to the oracle's."""
     cfg, meshes = mcrt.synth.random_scene(60000, 8, seed=5)
     sd = mcrt.scene_io.build_scene(cfg, meshes)
     E, S, frame = 24, 160, 11
     got = {}
     variants = (("default", {}), ("two_groups", {"MCRT_GROUPS": "2"}), ("three_groups_no_split", {"MCRT_GROUPS": "3", "MCRT_KSPLIT_LIMIT": "0"}),
-                ("masked", {"MCRT_MARCH_CUS": "64", "MCRT_MAIN_MASK": "1"}), ("march_masked", {"MCRT_MARCH_CUS": "96"}), ("no_overlap", {"MCRT_NO_OVERLAP": "1"}))
+                ("masked", {"MCRT_MARCH_CUS": "64", "MCRT_MAIN_MASK": "1"}), ("march_masked", {"MCRT_MARCH_CUS": "96"}), ("no_overlap", {"MCRT_NO_OVERLAP": "1"}),
+                ("wide_walk", {"MCRT_WIDE_FROM": "1"}), ("wide_walk_two_groups_no_split", {"MCRT_WIDE_FROM": "1", "MCRT_GROUPS": "2", "MCRT_KSPLIT_LIMIT": "0"}))
     for name, env in variants:
-        for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP"):
+        for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP", "MCRT_WIDE_FROM"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)                               # (the library reads its knobs once, at mcrt_create)
@@ -863,7 +865,7 @@ def test_schedules_do_not_change_anything(mcrt, orc, tex256, monkeypatch):
         nodes4 = sim.ctx.get_bvh4()[0]
         sim.close()
         got[name] = (hits, segs.tobytes(), cnt, rf, st, batch[1].T.copy(), nodes4)
-    for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP"):
+    for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP", "MCRT_WIDE_FROM"):
         monkeypatch.delenv(k, raising=False)
     a = got["default"]
     for name in [v[0] for v in variants[1:]]:
@@ -887,7 +889,8 @@ def test_schedules_do_not_change_anything(mcrt, orc, tex256, monkeypatch):
 
 def test_deep_tree_overflow_stacks_of_two_groups(mcrt, orc, tex256, monkeypatch):
     """a tree whose worst-case traversal stack exceeds the walk's 32 LDS entries, traced as TWO scan-line groups whose walks
-    run side by side: each group owns its overflow array, so hits stay the oracle's"""
+    run side by side: each group owns its overflow array, so hits stay the oracle's; and once more with the walk in its five-wavefront
+    form (28 LDS entries, 1280 workgroups: another split of the stack, another stride of the overflow array)"""
     rng = np.random.default_rng(77)
     # triangles at ten nested scales around a point on the probe's line of sight: the SAH tree splits the scales off one by one and
     # gets deep (worst-case stack 51 entries), and the rays through the centre cross every scale
@@ -903,8 +906,10 @@ def test_deep_tree_overflow_stacks_of_two_groups(mcrt, orc, tex256, monkeypatch)
     sd.tri = np.ascontiguousarray(tri); sd.tri_mesh = (np.arange(n) % len(sd.meshes)).astype(np.uint32)
     E, S = 16, 96
     out = {}
-    for groups in ("1", "2"):
-        monkeypatch.setenv("MCRT_GROUPS", groups)
+    for groups in ("1", "2", "2w"):
+        monkeypatch.setenv("MCRT_GROUPS", groups[0])
+        if groups == "2w":
+            monkeypatch.setenv("MCRT_WIDE_FROM", "1")
         tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256)
         _, max_stack = sim.ctx.get_bvh4()
         dev = sim.ctx.alloc(2 * E * sim.R * 4)
@@ -915,8 +920,9 @@ def test_deep_tree_overflow_stacks_of_two_groups(mcrt, orc, tex256, monkeypatch)
             hits, _, _ = sim.ctx.trace_frame_debug(5, sim.rf_dev)
             nodes4 = sim.ctx.get_bvh4()[0]; _, btri, _ = sim.ctx.get_bvh()
         sim.close()
-    monkeypatch.delenv("MCRT_GROUPS", raising=False)
+    monkeypatch.delenv("MCRT_GROUPS", raising=False); monkeypatch.delenv("MCRT_WIDE_FROM", raising=False)
     assert np.array_equal(out["1"].view(np.uint32), out["2"].view(np.uint32))
+    assert np.array_equal(out["1"].view(np.uint32), out["2w"].view(np.uint32))
     osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
     osc.set_bvh4(nodes4, btri)
     o = osc.trace_frame(orc.default_params(n_elements=E, n_samples=S), tr.pos, tr.dir, tex256, frame_id=5, use_bvh=2, n_threads=16, want_ref=False)

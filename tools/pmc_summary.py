@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 output dirs (kernel stats + PMC passes) of tools/pmc.sh into one JSON + text table."""
 import csv, glob, json, os, sys, collections
-KERNEL = os.environ.get("PMC_KERNEL", "k_trace_lane<false>")   # substring of the kernel the counters are reported for
+KERNELS = os.environ.get("PMC_KERNEL", "k_trace_lane<false>|k_trace_lane_wide").split("|")   # substrings of the kernel(s) the counters are reported for, pooled (the walk has two forms)
 out = sys.argv[1]
 res = {"kernel_stats": [], "pmc": {}}
 
@@ -20,10 +20,13 @@ for d in sorted(glob.glob(out + "/*/")):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        pooled = collections.defaultdict(list)
         for k, v in agg.items():
-            if KERNEL in k:
+            if any(name in k for name in KERNELS):
                 for c, x in v.items():
-                    res["pmc"][c] = {"avg_per_launch": sum(x) / len(x), "launches": len(x), "pass": os.path.basename(d.rstrip("/"))}
+                    pooled[c] += x
+        for c, x in pooled.items():
+            res["pmc"][c] = {"avg_per_launch": sum(x) / len(x), "launches": len(x), "pass": os.path.basename(d.rstrip("/"))}
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 for k in res["kernel_stats"]:
     print("%-90s calls %5s avg %10.1f us  %5s%%" % (k["Name"][:90], k["Calls"], float(k["AverageNs"]) / 1e3, k["Percentage"]))
