@@ -509,9 +509,13 @@ def live_pmc(args):
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         for name, ctrs in (("sq", ["SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES", "SQ_WAVES", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"]),
-                           ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("tcp", ["TCP_TOTAL_CACHE_ACCESSES_sum"])):
+                           ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("tcp", ["TCP_TOTAL_CACHE_ACCESSES_sum"]), ("tcp_all", ["TCP_TOTAL_CACHE_ACCESSES_sum"])):
             d = os.path.join(tmp, name)
-            r = subprocess.run([exe, "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+            # (the walk's ACCESSES are counted on its four-wavefront form: the five-wavefront form, which large launches take, adds the spill
+            #  traffic of its refill code -- coalesced 4-byte scratch accesses that the counter counts per lane but the pipe serves a wavefront
+            #  at a time, so the floor price per counted access does not apply to them; "tcp_all" counts that form as it runs)
+            env_pass = dict(env, MCRT_WIDE_FROM="4294967295") if name == "tcp" else env
+            r = subprocess.run([exe, "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env_pass,
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
             rows, kname = _pmc_rows(d)
             if r.returncode != 0 or not rows:
@@ -519,7 +523,7 @@ def live_pmc(args):
                 return None
             got["kernel"] = kname
             for c, v in rows.items():
-                got[c] = (sum(v) / len(v), len(v))
+                got[c + "@all" if name == "tcp_all" else c] = (sum(v) / len(v), len(v))
     except Exception:
         return None
     finally:
@@ -531,6 +535,8 @@ def live_pmc(args):
                 "vmem_read_instructions_per_launch": got["SQ_INSTS_VMEM_RD"][0], "salu_instructions_per_launch": got["SQ_INSTS_SALU"][0],
                 "lane_utilisation": got["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * got["SQ_ACTIVE_INST_VALU"][0]) if got["SQ_ACTIVE_INST_VALU"][0] else None,
                 "tcp_lane_accesses_per_launch": got["TCP_TOTAL_CACHE_ACCESSES_sum"][0],
+                "tcp_lane_accesses_counted_on": "the walk's four-wavefront form (MCRT_WIDE_FROM off for this pass): the accesses the walk needs",
+                "tcp_lane_accesses_per_launch_as_run": got.get("TCP_TOTAL_CACHE_ACCESSES_sum@all", (None, 0))[0],      # (with the five-wavefront form's coalesced spill traffic)
                 "fetch_size_kib": got["FETCH_SIZE"][0], "write_size_kib": got["WRITE_SIZE"][0],
                 "traffic_bytes_per_launch": (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0}
     except KeyError:

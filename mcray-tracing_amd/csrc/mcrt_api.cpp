@@ -66,7 +66,7 @@ struct Work {
 
 // tuning knobs from the environment, read ONCE at mcrt_create (never on the frame path)
 struct Knobs {
-    uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, trace_blocks_wide = 0, wide_from = 0 /* 0: the kernels' own default */, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 0;   // march_blocks 0: launch_march picks
+    uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, trace_blocks_wide = 0, wide_from = 0 /* 0: the kernels' own default */, wide_max_tree_mb = 128, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 0;   // march_blocks 0: launch_march picks
     bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false, graph = false;
     uint32_t march_cus = 0;                    // CUs the accumulation's side stream is confined to (0 = no mask); the mask's bit order is the driver's
     bool main_mask = false;                    // with march_cus: the walk / shade chain runs on its own stream confined to the OTHER CUs
@@ -78,6 +78,7 @@ static Knobs read_knobs()
     if (const char *e = getenv("MCRT_KSPLIT_LIMIT")) { long v = atol(e); if (v >= 0 && v <= MCRT_KSPLIT_MAX) k.ksplit_limit = (uint32_t)v; }   // 0 = off
     if (const char *e = getenv("MCRT_TRACE_BLOCKS")) { int v = atoi(e); if (v >= 1) k.trace_blocks = (uint32_t)v; }
     if (const char *e = getenv("MCRT_TRACE_BLOCKS_WIDE")) { int v = atoi(e); if (v >= 1) k.trace_blocks_wide = (uint32_t)v; }
+    if (const char *e = getenv("MCRT_WIDE_MAX_TREE_MB")) { long long v = atoll(e); if (v >= 0 && v <= 0xffffffffll) k.wide_max_tree_mb = (uint32_t)v; }
     if (const char *e = getenv("MCRT_WIDE_FROM")) { long long v = atoll(e); if (v >= 1 && v <= 0xffffffffll) k.wide_from = (uint32_t)v; }   // rays in a launch from which the walk takes its five-wavefront form (1: always; 4294967295: never)
     if (const char *e = getenv("MCRT_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 16) k.groups = (uint32_t)v; }
     if (const char *e = getenv("MCRT_MARCH_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= MCRT_SIDE_STREAMS) k.march_streams = (uint32_t)v; }
@@ -771,6 +772,9 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
                                                                                   // the fifth's registers go to a k_march wavefront beside them (since k_march's fast path: 0.446 -> 0.428 ms per frame on a 20-frame pass, 0.366 -> 0.364 at 128)
     a.trace_blocks_wide = c->knobs.trace_blocks_wide ? c->knobs.trace_blocks_wide : c->n_cu * 5u;      // k_trace_lane_wide: five workgroups per CU
     a.wide_from = c->knobs.wide_from ? c->knobs.wide_from : mcrt::lane_wide_from();
+    // ... while the tree is served from the caches: with 16 M triangles (460 MB of walked nodes, past the Infinity Cache) a fifth wavefront per SIMD only
+    // adds misses -- 0.667 against 0.638 ms per frame -- where the 1 M-triangle scene (29 MB) gains 3-4 %; the line is drawn at half the Infinity Cache
+    if ((uint64_t)c->bvh4.n_nodes * 64ull > (uint64_t)c->knobs.wide_max_tree_mb * 1048576ull) a.trace_blocks_wide = 0;
     if (c->knobs.main_mask) a.trace_blocks_wide = 0;                                                   // (CU-masked streams: the four-wavefront form only)
     a.march_blocks = c->knobs.march_blocks;
     a.frame = frame; a.frame_dev = c->d_frame_words; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n; a.tex_mask = (c->tex_n & (c->tex_n - 1u)) == 0u ? c->tex_n - 1u : 0u;

@@ -826,9 +826,13 @@ MCRT_DEV int nth_set_bit(unsigned long long m, uint32_t r)
     return base;
 }
 
-template <bool STATS, int STACK>
-MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b, int *stack /* LDS, [STACK][256]: entry sp of thread t at sp*256 + t -> conflict-free */)
+template <bool STATS, int STACK, bool DYN>
+MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
 {
+    // the traversal stacks in LDS, [STACK][256]: entry sp of thread t at sp*256 + t -> conflict-free (DYN: sized at the launch, see k_trace_lane_wide)
+    extern __shared__ int stack_dyn[];
+    __shared__ int stack_fix[DYN ? 1 : STACK * 256];
+    int *const stack = DYN ? stack_dyn : stack_fix;
     __shared__ uint4 top[MCRT_LANE_TOP ? MCRT_TOP_UNITS : 1];      // the top-of-tree table (k_pick_top), piece-major
     __shared__ __attribute__((aligned(16))) char quad_stage[MCRT_LANE_QUAD ? 4 * 4 * MCRT_QUAD_PITCH : 16];      // [wavefront][load][lane x 16]: the quad fetch's landing area
     static_assert(!(MCRT_LANE_QUAD && MCRT_LANE_TOP), "the quad fetch and the top-of-tree table are alternatives");
@@ -1129,7 +1133,7 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b, int *stack /
 // in the refill, hand-over and reporting code outside the node and leaf loops.  Sensitivity builds (profiles/round4/exp_sensitivity.txt) had shown the
 // walk at the knee of its two pipes with four wavefronts to hide latency behind; the fifth is worth 3-4 % of a 128-frame pass (0.330 against
 // 0.342 ms per frame; 1.8 % at 96 frames, 1.4 % at 48, 0.5 % at 32), costs a 20-frame pass 1 % and one frame at a time 6 % -- so launch_trace
-// takes the wide form from MCRT_LANE_WIDE_FROM queued rays (32 frames of the headline workload) upwards.  (Its stack is sized at the launch: with a static LDS array the compiler caps the kernel's occupancy
+// takes the wide form from MCRT_LANE_WIDE_FROM queued rays (32 frames of the headline workload) upwards, for trees the caches hold (mcrt_api.cpp: fill_args).  (Its stack is sized at the launch: with a static LDS array the compiler caps the kernel's occupancy
 // by LDS and hands the registers back.)
 #ifndef MCRT_LANE_WIDE_STACK
 #define MCRT_LANE_WIDE_STACK 24          // (28: 0.332 against 0.3295 ms per frame; deeper walks go on in the overflow array, as in the other form)
@@ -1140,13 +1144,11 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b, int *stack /
 template <bool STATS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_VGPRS))) k_trace_lane(FrameArgs a, uint32_t b)
 {
-    __shared__ int stack[MCRT_LANE_STACK * 256];
-    trace_lane_body<STATS, MCRT_LANE_STACK>(a, b, stack);
+    trace_lane_body<STATS, MCRT_LANE_STACK, false>(a, b);
 }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) k_trace_lane_wide(FrameArgs a, uint32_t b)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6), amdgpu_num_vgpr(80))) k_trace_lane_wide(FrameArgs a, uint32_t b)
 {
-    extern __shared__ int stack_dyn[];
-    trace_lane_body<false, MCRT_LANE_WIDE_STACK>(a, b, stack_dyn);
+    trace_lane_body<false, MCRT_LANE_WIDE_STACK, true>(a, b);
 }
 
 // ---- interface interaction (scene.cpp:122-165, ray.cpp:11-97) of ONE path at bounce b, given its ray and the closest-hit

@@ -54,7 +54,8 @@ for kernel, name in (("k_trace_lane<false|k_trace_lane_wide", "pmc_k_trace_lane.
            "valu_lane_utilisation": p["SQ_THREAD_CYCLES_VALU"] / (64 * p["SQ_ACTIVE_INST_VALU"]),
            "wave_time_waiting_on_memory": p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"], "wave_time_issue_stalled": p["SQ_WAIT_INST_ANY"] / p["SQ_WAVE_CYCLES"],
            "wave_time_issuing": p["SQ_ACTIVE_INST_ANY"] / p["SQ_WAVE_CYCLES"],
-           "tcp_lane_accesses_per_cycle_per_cu": p["TCP_TOTAL_CACHE_ACCESSES_sum"] / 256 / cu,
+           "tcp_lane_accesses_per_cycle_per_cu": p.get("TCP_TOTAL_CACHE_ACCESSES_sum@narrow", p["TCP_TOTAL_CACHE_ACCESSES_sum"]) / 256 / cu,
+           "tcp_lane_accesses_as_run": p["TCP_TOTAL_CACHE_ACCESSES_sum"], "tcp_lane_accesses_four_wavefront_form": p.get("TCP_TOTAL_CACHE_ACCESSES_sum@narrow"),
            "l1_hit_rate": 1 - p["TCP_TCC_READ_REQ_sum"] / p["TCP_TOTAL_CACHE_ACCESSES_sum"], "l2_hit_rate": p["TCC_HIT_sum"] / p["TCC_REQ_sum"],
            "fabric_bytes_per_launch": (2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024}
     d["derived"] = der
@@ -73,7 +74,7 @@ ks = {}
 for row in csv.DictReader(open(os.path.join(dst, "kernel_stats.csv"))):
     ks[row["Name"].split("(")[0].replace("void mcrt::", "")] = row
 # the walk has two forms (k_trace_lane<false>: four wavefronts per SIMD; k_trace_lane_wide: five, taken by launches of >= 4 Mi rays): one row, launch-weighted
-walk_rows = [v for k, v in ks.items() if k.startswith("k_trace_lane<false>") or k.startswith("k_trace_lane_wide")]
+walk_rows = [v for k, v in ks.items() if k.replace("mcrt::", "").startswith("k_trace_lane<false>") or k.replace("mcrt::", "").startswith("k_trace_lane_wide")]
 walk_calls = sum(int(v["Calls"]) for v in walk_rows)
 ks["k_trace_lane<false>"] = {"AverageNs": sum(int(v["Calls"]) * float(v["AverageNs"]) for v in walk_rows) / max(walk_calls, 1), "Calls": walk_calls}
 alone = {}; walk_alone = [0.0, 0]
@@ -114,10 +115,10 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 | `exp_pass_split.txt` | what cutting a timed region into smaller passes costs (decides `bench.py`'s N > 1 rule) |
 | `exp_round4_kernels.txt` | round 4's kernel changes one by one (triangle records, LDS tables, the held-back accumulation, the register trap) |
 | `exp_pass20.txt` | the driver's 20-frame pass on its own: launch timeline, the walk's tails, the schedule knobs (already at the optimum) |
-| `top_of_tree.json`, `exp_top_of_tree.txt` | a top-of-tree table in LDS for the walk: what a static table can serve (`tools/top_of_tree.py`, CPU) and what it did on the GPU (parity green, 3 % slower: off) |
-| `quad_line.json`, `exp_quad_fetch.txt` | the node fetch a quad of lanes at a time through LDS-DMA: 2.4 x on a bare dependent fetch chain (`tools/quad_line.hip`), 4-5 % slower in the walk (parity green: off) |
-| `exp_sensitivity.txt` | what one more load, and ten more instructions, per node step cost the walk: 3 % and 2 % -- neither pipe is the wall alone |
-| `bench_random16m_sah.json` | the 16 M scene with the host's SAH builder instead of the device LBVH: 9 % faster frames for a 70 x longer build |
+| `top_of_tree.json`, `exp_top_of_tree.txt` | a top-of-tree table in LDS for the walk: what a static table can serve (`tools/top_of_tree.py`, CPU) and what it did on the GPU (parity green, 3 %% slower: off) |
+| `quad_line.json`, `exp_quad_fetch.txt` | the node fetch a quad of lanes at a time through LDS-DMA: 2.4 x on a bare dependent fetch chain (`tools/quad_line.hip`), 4-5 %% slower in the walk (parity green: off) |
+| `exp_sensitivity.txt` | what one more load, and ten more instructions, per node step cost the walk: 3 %% and 2 %% -- neither pipe is the wall alone |
+| `bench_random16m_sah.json` | the 16 M scene with the host's SAH builder instead of the device LBVH: 9 %% faster frames for a 70 x longer build |
 | `bench_random16m.json` | `python bench.py --workload random16m`: the STREAMING regime (16 M triangles, 2 GB of BVH past the Infinity Cache), with live PMC, CPU baseline and parity check |
 | `group_bench.json` | `tools/group_bench.py 0,0`: whole B-mode frames through `mcrt_group_*` (two ranks sharing the GPU) against one context |
 | `bench_unprofiled.json` | `python bench.py`: the JSON line (live PMC passes in child processes, CPU baseline, inline parity check) |
@@ -136,9 +137,12 @@ SIMD, clock %.2f GHz** (round 2's step, the one `bench.py` priced against until 
 **%.0f G wave-instructions per second** is the ceiling of `roofline.frac`; the guide's two cycles per wave64 instruction (0.5) is
 `frac_vs_architectural`, which leads the block.
 
-**Vector memory pipe.**  Every access `TCP_TOTAL_CACHE_ACCESSES` counts costs a CU at least %.3f cycles, whatever lanes share (a uniform
-adjacent quad counts once and costs 1.6; scattered lanes count one each at 1.35).  A launch cannot be shorter than its accesses x %.3f /
-(256 CUs x clock): `second_roof.frac` = that time over the launch's duration, at most 1 by construction.
+**Vector memory pipe.**  Every SCATTERED access `TCP_TOTAL_CACHE_ACCESSES` counts costs a CU at least %.3f cycles, whatever lanes share (a uniform
+adjacent quad counts once and costs 1.6; scattered lanes count one each at 1.35).  A launch cannot be shorter than its scattered accesses x %.3f /
+(256 CUs x clock): `second_roof.frac` = that time over the launch's duration.  The walk's accesses are counted on its four-wavefront form
+(`k_trace_lane<false>`, `MCRT_WIDE_FROM` off for that pass): the five-wavefront form that large launches take (`k_trace_lane_wide`) adds the spill traffic of
+its refill code -- coalesced 4-byte scratch accesses, which the counter counts per lane but the pipe serves a wavefront at a time (`tcp_lane_accesses_as_run`
+in `pmc_k_trace_lane.json`).
 
 ## What the kernels do with them (per launch = one bounce of a @FIF@-frame pass)
 
@@ -148,8 +152,8 @@ adjacent quad counts once and costs 1.6; scattered lanes count one each at 1.35)
 %s
 %s
 
-The walk alone lasts %.0f us and its counted cache accesses need %.0f us of the CUs' vector memory pipes at the cheapest measured cost: it runs
-ON that roof, at %.0f %% of the calibrated VALU ceiling with %.0f %% of its lanes active.  The BVH is served on-die: L1 hit rate
+The walk alone lasts %.0f us and the cache accesses it needs cost %.0f us of the CUs' vector memory pipes at the cheapest measured price: it runs
+AT that roof and at the VALU's at once (`exp_sensitivity.txt`), at %.0f %% of the calibrated VALU ceiling with %.0f %% of its lanes active.  The BVH is served on-die: L1 hit rate
 %.0f %%, L2 %.0f %% of the rest, fabric traffic %.0f MB per launch -- `hbm_measured_frac` = %.3f of the 8 TB/s HBM figure (the algorithmic
 bytes, %.1f GB per launch, flow at %.1f TB/s from the caches).
 

@@ -9,5 +9,6 @@ timeout -s KILL 400 rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTI
 timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum --output-format csv -d $out/fetch -- $B > $out/fetch.log 2>&1
 timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum --output-format csv -d $out/write -- $B > $out/write.log 2>&1
 timeout -s KILL 400 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum --output-format csv -d $out/tcp -- $B > $out/tcp.log 2>&1
+MCRT_WIDE_FROM=4294967295 timeout -s KILL 400 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d $out/tcp_narrow -- $B > $out/tcp_narrow.log 2>&1   # the walk's accesses without the five-wavefront form's spill traffic (counters named ...@narrow)
 timeout -s KILL 400 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $out/grbm -- $B > $out/grbm.log 2>&1
 python3 tools/pmc_summary.py $out

@@ -25,7 +25,9 @@ for d in sorted(glob.glob(out + "/*/")):
             if any(name in k for name in KERNELS):
                 for c, x in v.items():
                     pooled[c] += x
+        suffix = "@narrow" if os.path.basename(d.rstrip("/")).endswith("_narrow") else ""
         for c, x in pooled.items():
+            c = c + suffix
             res["pmc"][c] = {"avg_per_launch": sum(x) / len(x), "launches": len(x), "pass": os.path.basename(d.rstrip("/"))}
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 for k in res["kernel_stats"]:
