@@ -117,6 +117,7 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 | `exp_pass20.txt` | the driver's 20-frame pass on its own: launch timeline, the walk's tails, the schedule knobs (already at the optimum) |
 | `top_of_tree.json`, `exp_top_of_tree.txt` | a top-of-tree table in LDS for the walk: what a static table can serve (`tools/top_of_tree.py`, CPU) and what it did on the GPU (parity green, 3 %% slower: off) |
 | `quad_line.json`, `exp_quad_fetch.txt` | the node fetch a quad of lanes at a time through LDS-DMA: 2.4 x on a bare dependent fetch chain (`tools/quad_line.hip`), 4-5 %% slower in the walk (parity green: off) |
+| `exp_wide_walk.txt` | the walk's five-wavefront form (`k_trace_lane_wide`): register budgets, pass sizes, the 16 M scene, constants re-swept, where it spills |
 | `exp_sensitivity.txt` | what one more load, and ten more instructions, per node step cost the walk: 3 %% and 2 %% -- neither pipe is the wall alone |
 | `bench_random16m_sah.json` | the 16 M scene with the host's SAH builder instead of the device LBVH: 9 %% faster frames for a 70 x longer build |
 | `bench_random16m.json` | `python bench.py --workload random16m`: the STREAMING regime (16 M triangles, 2 GB of BVH past the Infinity Cache), with live PMC, CPU baseline and parity check |
