@@ -32,17 +32,18 @@ struct Box {
     }
 };
 
-static int kLeafMax = 4;              // (both tunable through MCRT_SAH_LEAF_MAX / MCRT_SAH_COST_TRI for experiments: tools/tune.sh)
+constexpr int kLeafMaxDefault = 4;     // (leaf size and triangle cost can be set through MCRT_SAH_LEAF_MAX / MCRT_SAH_COST_TRI for experiments: members of the Builder)
 constexpr int kBins = 16;
 constexpr int kMaxDepth = MCRT_BVH_MAX_DEPTH;   // deepest leaf; the traversal stack holds this many entries
-constexpr float kCostNode = 1.0f; static float kCostTri = 1.2f;
+constexpr float kCostNode = 1.0f, kCostTriDefault = 1.2f;
 
 struct Builder {
+    int kLeafMax = kLeafMaxDefault; float kCostTri = kCostTriDefault;
     std::vector<Prim> prims;
     std::vector<mcrt_bvh_node> nodes;
     int deepest = 0;
 
-    static int levels_needed(uint32_t n) { int k = 0; uint64_t cap = kLeafMax; while (cap < n) { cap <<= 1; k++; } return k; }
+    int levels_needed(uint32_t n) const { int k = 0; uint64_t cap = (uint64_t)kLeafMax; while (cap < n) { cap <<= 1; k++; } return k; }
 
     static int32_t leaf_ref(uint32_t first, uint32_t cnt) { return ~(int32_t)((first << 3) | (cnt - 1)); }
 
@@ -122,9 +123,9 @@ extern "C" int mcrt_build_bvh(const float *tri, const uint32_t *tri_mesh, uint32
 {
     if (!tri || !out || n_tri == 0) return mcrt::set_error(MCRT_ERR_INVALID, "mcrt_build_bvh: no triangles");
     if (n_tri >= (1u << 28)) return mcrt::set_error(MCRT_ERR_LIMIT, "mcrt_build_bvh: more than 2^28 triangles");
-    if (const char *e = getenv("MCRT_SAH_LEAF_MAX")) { int v = atoi(e); if (v >= 1 && v <= 8) kLeafMax = v; }
-    if (const char *e = getenv("MCRT_SAH_COST_TRI")) { float v = (float)atof(e); if (v > 0.0f) kCostTri = v; }
     Builder b;
+    if (const char *e = getenv("MCRT_SAH_LEAF_MAX")) { int v = atoi(e); if (v >= 1 && v <= 8) b.kLeafMax = v; }
+    if (const char *e = getenv("MCRT_SAH_COST_TRI")) { float v = (float)atof(e); if (v > 0.0f) b.kCostTri = v; }
     b.prims.resize(n_tri);
     // Padding (DESIGN.md "Closest hit"): Bullet's triangle test accepts points up to 1e-4 of the triangle's
     // height outside an edge, and the slab arithmetic rounds; each triangle's bounds are widened accordingly.
