@@ -473,6 +473,9 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 #ifndef MCRT_LANE_FETCH
 #define MCRT_LANE_FETCH 128          // queue positions a wavefront claims per atomic in a LARGE launch (>= MCRT_LANE_FETCH_FROM items), 64 below: measured
 #endif                               // 0.434 / 0.426 / 0.426 ms per frame with 64 / 128 / 256 at 128 frames in flight (16.7 M items), 0.523 / 0.531 with 64 / 128 on
+#ifndef MCRT_LANE_FETCH_SMALL
+#define MCRT_LANE_FETCH_SMALL 64
+#endif
 #ifndef MCRT_LANE_FETCH_FROM         // a 20-frame pass (2.6 M items: what a wavefront holds back at the end of the queue weighs more there)
 #define MCRT_LANE_FETCH_FROM 4194304
 #endif
@@ -891,7 +894,7 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
 #define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)
 #define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)
     uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
-    const uint32_t fetch = n >= (uint32_t)MCRT_LANE_FETCH_FROM ? (uint32_t)MCRT_LANE_FETCH : 64u;
+    const uint32_t fetch = n >= (uint32_t)MCRT_LANE_FETCH_FROM ? (uint32_t)MCRT_LANE_FETCH : (uint32_t)MCRT_LANE_FETCH_SMALL;
     unsigned long long poll_old = 0; uint32_t poll_ray = 0; bool poll_pending = false;      // (see the end of the loop)
 #ifdef MCRT_STAMP
     // diagnostic build: cycles and lane counts per phase, summed over wavefronts (tools/stamps.py)
