@@ -5,7 +5,9 @@
 #define MCRT_BVH_MAX_DEPTH 32      // deepest leaf the builder may emit == traversal stack entries per lane
 #define MCRT_STACK 64              // BVH4 traversal stack entries per path (LDS); trees needing more are rejected at upload
 #define MCRT_KSPLIT_DEFAULT 262144 // work items a small bounce of k_trace is cut into (pieces x rays); one 128 x 1024 frame at a time is cut in two
+#ifndef MCRT_KSPLIT_MAX
 #define MCRT_KSPLIT_MAX 1048576
+#endif
 #define MCRT_GROUPS_DEFAULT 1        // independent scan-line groups a frame is traced as (their kernels overlap)
 #define MCRT_SIDE_STREAMS 4         // streams k_march launches rotate over
 #define MCRT_SIDE_STREAMS_DEFAULT 1
