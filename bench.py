@@ -466,6 +466,9 @@ def roofline_from(pmc, k_ms, alg_gbs):
                             "pipe_ms": t_ms, "kernel_ms": k_ms, "frac": t_ms / k_ms, "source": "TCP_TOTAL_CACHE_ACCESSES of the walk's launches; cost: " + src}
         if r.get("frac") is not None:
             r["binding_roof"] = "vector memory pipe (second_roof)" if t_ms / k_ms > r["frac"] else "valu issue (frac)"
+            # sensitivity builds (profiles/round4/exp_sensitivity.txt): one more load per node step costs the walk 3 %, ten more instructions 2 % -- the
+            # nearer roof is not a wall on its own, the walk sits at the knee of the two
+            r["binding_roof_note"] = "both roofs are within a few per cent of the launch; measured marginal costs in profiles/round4/exp_sensitivity.txt"
     if pmc and pmc.get("traffic_bytes_per_launch") is not None and k_ms > 0:
         r["traffic"] = pmc["traffic_bytes_per_launch"]
         r["hbm_measured_GBps"] = pmc["traffic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9
