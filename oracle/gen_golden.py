@@ -36,3 +36,14 @@ with open(out, "w") as f:
     json.dump(soup, f, separators=(",", ":"))
     f.write("\n")
 print("wrote", os.path.normpath(out), os.path.getsize(out), "bytes")
+
+# overload resolution of ray.cpp's unqualified abs(float) / sqrt(float) under the reference's own headers, with and without the
+# direct <math.h> / <stdlib.h> includes Bullet's btScalar.h contributes (oracle/ref_overload_probe.cpp)
+ov = {k: json.loads(subprocess.check_output([os.path.join(here, "_ref", "ref_overload_" + k)])) for k in ("none", "stdlib", "btscalar")}
+ov["_generated_by"] = "oracle/gen_golden.py (oracle/ref_overload_probe.cpp against /root/reference/include/units/units.h + src/mesh.h; g++ " + \
+    subprocess.check_output(["g++", "-dumpfullversion"]).decode().strip() + ")"
+out = os.path.join(here, "..", "tests", "golden", "overloads.json")
+with open(out, "w") as f:
+    json.dump(ov, f, separators=(",", ":"))
+    f.write("\n")
+print("wrote", os.path.normpath(out), os.path.getsize(out), "bytes")

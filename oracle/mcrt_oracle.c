@@ -410,6 +410,61 @@ static inline int slab_node(const float lo[3], const float hi[3], v3 c, v3 inv, 
  *   - a hit counts only if its fraction lies inside the ray's overlap with the triangle's padded bounds
  *     (float noise far from the triangle can otherwise pass the three edge tests on a 1e9-long segment);
  *   - smaller fraction wins; equal fraction -> smaller triangle id. */
+/* MEASURED ZEROS (tests/test_oracle_physics.py): while counting is on, the three additions the contract makes to the
+ * reference's behaviour are counted where they act, so that "documented and improbable" can be replaced by a number per frame:
+ *   [0] candidates the padded-bounds rule turned away that the bare processTriangle tests (plane crossing, smaller fraction, three
+ *       edge tests) accept AND whose hit point lies inside the scene's own bounds;  [1] the same without the bounds condition;
+ *   [2] echoes refused by the |e| < 1024 guard of the fixed-point bins (rfimage.h:38 would add them);
+ *   [3] random_unit_vector attempts beyond the first (ray.cpp:170-185 loops while p > 0.25);  [4] ... that gave up after 8;
+ *   [5] boundary hits with total internal reflection (ray.cpp:62), [6] NaN echoes (what they lead to, quirk 5: the reference's own
+ *       `+= NaN`) -- not additions, counted for scale. */
+static int g_counting = 0;
+static uint64_t g_count[8];
+static float g_scene_lo[3], g_scene_hi[3];
+static inline void count_add(int i) { __atomic_fetch_add(&g_count[i], 1ull, __ATOMIC_RELAXED); }
+void orc_debug_counting(const orc_scene *sc, int on)
+{
+    g_counting = 0;
+    memset(g_count, 0, sizeof g_count);
+    if (!on || !sc) return;
+    for (int a = 0; a < 3; a++) { g_scene_lo[a] = INFINITY; g_scene_hi[a] = -INFINITY; }
+    for (size_t i = 0; i < (size_t)sc->n_tri * 9; i++) {
+        const float v = sc->tri[i]; const int a = (int)(i % 3);
+        if (v < g_scene_lo[a]) g_scene_lo[a] = v;
+        if (v > g_scene_hi[a]) g_scene_hi[a] = v;
+    }
+    g_counting = 1;
+}
+void orc_debug_counters(uint64_t out[8]) { for (int i = 0; i < 8; i++) out[i] = __atomic_load_n(&g_count[i], __ATOMIC_RELAXED); }
+
+/* the three edge tests of processTriangle at fraction frac; *p_out = the interpolated point they were made at */
+static inline int tri_edges(v3 v0, v3 v1, v3 v2, v3 n, v3 from, v3 to, float frac, v3 *p_out)
+{
+    float edge_tol = vdot(n, n) * -0.0001f;
+    float s = 1.0f - frac;
+    v3 p = V(s * from.x + frac * to.x, s * from.y + frac * to.y, s * from.z + frac * to.z);
+    *p_out = p;
+    v3 v0p = vsub(v0, p), v1p = vsub(v1, p);
+    v3 cp0 = vcross(v0p, v1p);
+    if (vdot(cp0, n) >= edge_tol) {
+        v3 v2p = vsub(v2, p);
+        v3 cp1 = vcross(v1p, v2p);
+        if (vdot(cp1, n) >= edge_tol) {
+            v3 cp2 = vcross(v2p, v0p);
+            if (vdot(cp2, n) >= edge_tol) return 1;
+        }
+    }
+    return 0;
+}
+static void count_rule_reject(v3 v0, v3 v1, v3 v2, v3 n, v3 from, v3 to, float frac)
+{
+    v3 p;
+    if (!tri_edges(v0, v1, v2, n, from, to, frac, &p)) return;
+    count_add(1);
+    if (p.x >= g_scene_lo[0] && p.x <= g_scene_hi[0] && p.y >= g_scene_lo[1] && p.y <= g_scene_hi[1] &&
+        p.z >= g_scene_lo[2] && p.z <= g_scene_hi[2]) count_add(0);
+}
+
 static inline void tri_test(const float *t9, int32_t id, v3 from, v3 to, v3 inv, v3 rc, float pad_abs, hit_t *best)
 {
     v3 v0 = V(t9[0], t9[1], t9[2]), v1 = V(t9[3], t9[4], t9[5]), v2 = V(t9[6], t9[7], t9[8]);
@@ -424,22 +479,13 @@ static inline void tri_test(const float *t9, int32_t id, v3 from, v3 to, v3 inv,
     if (frac < best->frac || (frac == best->frac && id < best->tri)) {
         float lo[3], hi[3], tmin, tmax;
         tri_bounds(t9, pad_abs, lo, hi);
-        if (!slab(lo, hi, rc, inv, 1.0f, &tmin, &tmax)) return;
-        if (!(frac >= tmin && frac <= tmax)) return;
-        float edge_tol = vdot(n, n) * -0.0001f;
-        float s = 1.0f - frac;
-        v3 p = V(s * from.x + frac * to.x, s * from.y + frac * to.y, s * from.z + frac * to.z);
-        v3 v0p = vsub(v0, p), v1p = vsub(v1, p);
-        v3 cp0 = vcross(v0p, v1p);
-        if (vdot(cp0, n) >= edge_tol) {
-            v3 v2p = vsub(v2, p);
-            v3 cp1 = vcross(v1p, v2p);
-            if (vdot(cp1, n) >= edge_tol) {
-                v3 cp2 = vcross(v2p, v0p);
-                if (vdot(cp2, n) >= edge_tol) {
-                    best->frac = frac; best->tri = id; best->n = n; best->da = da;
-                }
-            }
+        if (!slab(lo, hi, rc, inv, 1.0f, &tmin, &tmax) || !(frac >= tmin && frac <= tmax)) {
+            if (g_counting) count_rule_reject(v0, v1, v2, n, from, to, frac);
+            return;
+        }
+        v3 p;
+        if (tri_edges(v0, v1, v2, n, from, to, frac, &p)) {
+            best->frac = frac; best->tri = id; best->n = n; best->da = da;
         }
     }
 }
@@ -615,7 +661,7 @@ static float power_cosine_variate(int v, double number)
 }
 
 /* ray.cpp:167-211 random_unit_vector; draws come from blocks 2,3,... (one block per attempt) */
-static v3 random_unit_vector(v3 v, float cos_theta, const rng_t *g)
+static v3 random_unit_vector(v3 v, float cos_theta, const rng_t *g, uint32_t *attempts_out)
 {
     int flag = 0;
     float px, py, p;
@@ -632,6 +678,8 @@ static v3 random_unit_vector(v3 v, float cos_theta, const rng_t *g)
         p = px * px + py * py;
         attempt++;
     } while (!(p <= 0.25f) && attempt < 8u);
+    if (attempts_out) *attempts_out = attempt;
+    if (g_counting && attempt > 1u) { for (uint32_t i = 1; i < attempt; i++) count_add(3); if (!(p <= 0.25f)) count_add(4); }
     float vx = v.x, vy = v.y, vz = v.z;
     if (fabsf(vx) > fabsf(vy)) { vx = vy; vy = v.x; flag = 1; }
     float b = 1 - vx * vx;
@@ -652,9 +700,9 @@ static inline float std_max(float a, float b) { return (a < b) ? b : a; }   /* s
 
 typedef struct { float reflected_intensity; ray_t returned; } hit_result;
 
-/* ray.cpp:11-97 */
+/* ray.cpp:11-97.  dbg (tests only, NULL on the trace path): the intermediate values, see orc_hit_debug */
 static hit_result hit_boundary(const ray_t *r, v3 hit_point, v3 surface_normal, const orc_mesh *cm,
-                               const orc_scene *sc, const orc_params *prm, const rng_t *g)
+                               const orc_scene *sc, const orc_params *prm, const rng_t *g, orc_hit_debug *dbg)
 {
     int32_t after_vasc, mat_after;
     if (r->outside != OUT_NONE) {
@@ -673,13 +721,15 @@ static hit_result hit_boundary(const ray_t *r, v3 hit_point, v3 surface_normal, 
     double u_pc, u_x;
     rng_block(g, 1u, &u_pc, &u_x);
     float random_angle = power_cosine_variate((int)ma[M_SHINE], u_pc);
-    v3 random_normal = random_unit_vector(surface_normal, random_angle, g);
+    uint32_t ruv_attempts = 0;
+    v3 random_normal = random_unit_vector(surface_normal, random_angle, g, &ruv_attempts);
 
     float incidence = vdot(r->dir, vneg(random_normal));
     if (incidence < 0) incidence = vdot(r->dir, random_normal);
     const float refr_ratio = mr[M_IMP] / ma[M_IMP];
     float refraction_angle = 1 - refr_ratio * refr_ratio * (1 - incidence * incidence);
     const int tir = refraction_angle < 0;
+    if (g_counting && tir) count_add(5);
     refraction_angle = sqrtf(refraction_angle);
 
     /* snells_law ray.cpp:115-124: r*l + (r*c - c2)*n */
@@ -726,6 +776,18 @@ static hit_result hit_boundary(const ray_t *r, v3 hit_point, v3 surface_normal, 
         res.returned.outside = after_vasc;
         res.returned.intensity = intensity_refr > prm->intensity_epsilon ? intensity_refr : 0.0f;
     }
+    if (dbg) {
+        dbg->random_angle = random_angle;
+        dbg->random_normal[0] = random_normal.x; dbg->random_normal[1] = random_normal.y; dbg->random_normal[2] = random_normal.z;
+        dbg->incidence = incidence; dbg->refr_ratio = refr_ratio; dbg->refraction_angle = refraction_angle;
+        dbg->refr_dir[0] = refr.x; dbg->refr_dir[1] = refr.y; dbg->refr_dir[2] = refr.z;
+        dbg->refl_dir[0] = refl.x; dbg->refl_dir[1] = refl.y; dbg->refl_dir[2] = refl.z;
+        dbg->intensity_refl = intensity_refl; dbg->intensity_refr = intensity_refr;
+        dbg->refraction_factor = refraction_factor; dbg->reflection_factor = reflection_factor;
+        dbg->u_pc = u_pc; dbg->u_x = u_x;
+        dbg->tir = tir; dbg->chose_reflection = prob > x; dbg->mat_after = mat_after; dbg->after_vasc = after_vasc;
+        dbg->ruv_attempts = ruv_attempts;
+    }
     return res;
 }
 
@@ -763,7 +825,7 @@ static inline uint32_t steps_from(double q)
 #define FIX_SCALE 1099511627776.0   /* 2^40: |echo| < 1024 keeps every term below 2^50 */
 static inline void fix_add(int64_t *acc, uint8_t *flag, float echo)
 {
-    if (!(fabsf(echo) < 1024.0f)) { if (flag) *flag = 1; return; }
+    if (!(fabsf(echo) < 1024.0f)) { if (flag) *flag = 1; if (g_counting) count_add(echo != echo ? 6 : 2); return; }
     *acc += (int64_t)rint((double)echo * FIX_SCALE);
 }
 
@@ -871,7 +933,7 @@ static void trace_path(const orc_scene *sc, const orc_params *prm, const orc_con
             double mm = distance_in_mm(sc, r.from, inside);
             r.dist_mm = r.dist_mm + mm;
             r.intensity = r.intensity * orc_expf(-mr[M_ATT] * ((float)mm * 0.01f) * r.frequency);
-            hit_result hr = hit_boundary(&r, hp, V(nrm[0], nrm[1], nrm[2]), organ, sc, prm, &g);
+            hit_result hr = hit_boundary(&r, hp, V(nrm[0], nrm[1], nrm[2]), organ, sc, prm, &g, NULL);
             sg.from[0] = r.from.x; sg.from[1] = r.from.y; sg.from[2] = r.from.z;
             sg.to[0] = inside.x; sg.to[1] = inside.y; sg.to[2] = inside.z;
             sg.dir[0] = r.dir.x; sg.dir[1] = r.dir.y; sg.dir[2] = r.dir.z;
@@ -892,6 +954,96 @@ static void trace_path(const orc_scene *sc, const orc_params *prm, const orc_con
         if (k && (k->rf_ref || k->rf_fix)) accumulate_segment(sc, prm, c, tex, &sg, k, st);
     }
     if (seg_count) *seg_count = nseg;
+}
+
+/* ===================================================================================== */
+/*  Test entry points into the static physics above (tests/test_oracle_physics.py and the  */
+/*  independent reading tests/ref_reading.py).  They call the SAME static functions the     */
+/*  trace path calls; nothing here is a second implementation.                              */
+/* ===================================================================================== */
+static ray_t ray_from_state(const orc_ray_state *q)
+{
+    ray_t r;
+    r.from = V(q->from[0], q->from[1], q->from[2]); r.dir = V(q->dir[0], q->dir[1], q->dir[2]);
+    r.media = q->media; r.outside = q->outside; r.intensity = q->intensity; r.frequency = q->frequency;
+    r.dist_mm = q->dist_mm; r.alive = 1;
+    return r;
+}
+static void state_from_ray(const ray_t *r, orc_ray_state *q)
+{
+    q->from[0] = r->from.x; q->from[1] = r->from.y; q->from[2] = r->from.z;
+    q->dir[0] = r->dir.x; q->dir[1] = r->dir.y; q->dir[2] = r->dir.z;
+    q->media = r->media; q->outside = r->outside; q->intensity = r->intensity; q->frequency = r->frequency; q->dist_mm = r->dist_mm;
+}
+static rng_t rng_from(const uint32_t c[5]) { rng_t g; g.key[0] = c[0]; g.key[1] = c[1]; g.element = c[2]; g.sample = c[3]; g.bounce = c[4]; return g; }
+
+float orc_debug_power_cosine(int v, double number) { return power_cosine_variate(v, number); }
+
+uint32_t orc_debug_random_unit_vector(const float v[3], float cos_theta, const uint32_t rng[5], float w[3])
+{
+    const rng_t g = rng_from(rng);
+    uint32_t attempts = 0;
+    v3 r = random_unit_vector(V(v[0], v[1], v[2]), cos_theta, &g, &attempts);
+    w[0] = r.x; w[1] = r.y; w[2] = r.z;
+    return attempts;
+}
+
+void orc_debug_hit_boundary(const orc_scene *sc, const orc_params *prm, const orc_ray_state *rs, const float hit_point[3],
+                            const float normal[3], uint32_t mesh, const uint32_t rng[5], orc_hit_debug *out)
+{
+    const ray_t r = ray_from_state(rs);
+    const rng_t g = rng_from(rng);
+    hit_result hr = hit_boundary(&r, V(hit_point[0], hit_point[1], hit_point[2]), V(normal[0], normal[1], normal[2]),
+                                 &sc->mesh[mesh], sc, prm, &g, out);
+    out->reflected_intensity = hr.reflected_intensity;
+    state_from_ray(&hr.returned, &out->returned);
+}
+
+/* max_ray_length ray.cpp:110-113 + enlarge scene.cpp:292-298 + the 0.1 start offset scene.cpp:115, as trace_path applies them */
+float orc_debug_ray_segment(const orc_scene *sc, const orc_params *prm, const orc_ray_state *rs, float from_off[3], float to[3])
+{
+    const float *mr = sc->mat + (size_t)rs->media * 8;
+    float L = 10.f * orc_logf(prm->intensity_epsilon / rs->intensity) / -mr[M_ATT] * rs->frequency;
+    float Ls = L / 100.0f;
+    for (int a = 0; a < 3; a++) {
+        to[a] = rs->from[a] + Ls * (sc->spacing[a] * rs->dir[a]);
+        from_off[a] = rs->from[a] + prm->ray_start_offset * rs->dir[a];
+    }
+    return L;
+}
+
+/* travel ray.cpp:99-103 over distance_in_mm(from, to_point) scene.cpp:281-290; returns the millimetres */
+double orc_debug_travel(const orc_scene *sc, orc_ray_state *rs, const float to_point[3])
+{
+    const float *mr = sc->mat + (size_t)rs->media * 8;
+    double mm = distance_in_mm(sc, V(rs->from[0], rs->from[1], rs->from[2]), V(to_point[0], to_point[1], to_point[2]));
+    rs->dist_mm = rs->dist_mm + mm;
+    rs->intensity = rs->intensity * orc_expf(-mr[M_ATT] * ((float)mm * 0.01f) * rs->frequency);
+    return mm;
+}
+
+/* the thickness draw of scene.cpp:132-139 as the contract makes it (Box-Muller on block 0) */
+float orc_debug_thickness(float sigma, const uint32_t rng[5])
+{
+    const rng_t g = rng_from(rng);
+    if (sigma == 0.0f) return 0.0f;
+    double n1, n2, sn, cs;
+    rng_block(&g, 0u, &n1, &n2);
+    orc_sincos_d(n2 * 2 * PI_D, &sn, &cs);
+    double z = sqrt(-2.0 * orc_log_d(1.0 - n1)) * cs;
+    return (float)fabs(z * (double)sigma + 0.0);
+}
+
+/* main.cpp:106-144 for ONE segment into a single RF line rf[R] (float, reference order); returns the RF steps taken */
+uint64_t orc_debug_accumulate_segment(const orc_scene *sc, const orc_params *prm, const float *tex, const orc_segment *sg, float *rf)
+{
+    orc_consts c;
+    orc_constants(prm->frequency, prm->sos, prm->depth_cm, &c);
+    rf_sink k; memset(&k, 0, sizeof k);
+    k.rf_ref = rf; k.ref_cols = 1; k.ref_col = 0;
+    orc_stats st; memset(&st, 0, sizeof st);
+    accumulate_segment(sc, prm, &c, tex, sg, &k, &st);
+    return st.rf_steps;
 }
 
 #define ORC_PRIV_ROWS 2048      /* rows of a sample block's private bins (on the task's stack); more rows: one task per scan-line */

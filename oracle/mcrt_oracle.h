@@ -152,6 +152,41 @@ void orc_trace_frame(const orc_scene *sc, const orc_params *p,
                      int32_t *hits, orc_segment *segs, uint32_t *seg_count,
                      float *rf_ref, int64_t *rf_fix, uint8_t *rf_flags, orc_stats *st);
 
+
+/* ---- test entry points into the physics (ray.cpp) -- tests/test_oracle_physics.py, tests/ref_reading.py.  They run the same
+ * static functions the trace path runs.  rng = { key0 (seed), key1 (frame), element, sample, bounce }: the draws are the contract's
+ * (block 0 thickness, block 1 {power-cosine u, choice x}, block 2+attempt {disc a, disc r}), see DESIGN.md 3. */
+typedef struct {
+    float from[3], dir[3];
+    int32_t media;              /* material index (ray.h:17 holds the material by value)                                   */
+    int32_t outside;            /* media_outside: -1 = nullptr, -2 = aliases the ray's own media (quirk 2), >= 0 = index   */
+    float intensity, frequency;
+    double dist_mm;
+} orc_ray_state;                /* 48 bytes */
+typedef struct {
+    float reflected_intensity;  /* hit_result.reflected_intensity (ray.cpp:82,96)                                           */
+    uint32_t _pad0;
+    orc_ray_state returned;     /* hit_result.returned (ray.cpp:91-94)                                                      */
+    float random_angle, random_normal[3], incidence, refr_ratio, refraction_angle, refr_dir[3], refl_dir[3];
+    float intensity_refl, intensity_refr, refraction_factor, reflection_factor;
+    double u_pc, u_x;           /* the two uniforms of block 1                                                              */
+    int32_t tir, chose_reflection, mat_after, after_vasc;
+    uint32_t ruv_attempts, _pad1;
+} orc_hit_debug;
+float    orc_debug_power_cosine(int v, double number);
+uint32_t orc_debug_random_unit_vector(const float v[3], float cos_theta, const uint32_t rng[5], float w[3]);
+void     orc_debug_hit_boundary(const orc_scene *sc, const orc_params *prm, const orc_ray_state *r, const float hit_point[3],
+                                const float normal[3], uint32_t mesh, const uint32_t rng[5], orc_hit_debug *out);
+float    orc_debug_ray_segment(const orc_scene *sc, const orc_params *prm, const orc_ray_state *r, float from_off[3], float to[3]);
+double   orc_debug_travel(const orc_scene *sc, orc_ray_state *r, const float to_point[3]);
+float    orc_debug_thickness(float sigma, const uint32_t rng[5]);
+uint64_t orc_debug_accumulate_segment(const orc_scene *sc, const orc_params *prm, const float *tex, const orc_segment *sg, float *rf /*[R]*/);
+/* measured zeros: counters of the contract's additions (see mcrt_oracle.c "MEASURED ZEROS"); counting(sc, 1) zeroes and starts,
+ * counting(NULL, 0) stops.  out = { pad-rule rejects inside the scene bounds, pad-rule rejects anywhere, echo-guard trips,
+ * random_unit_vector retries, ... give-ups, total internal reflections, NaN echoes, 0 } */
+void orc_debug_counting(const orc_scene *sc, int on);
+void orc_debug_counters(uint64_t out[8]);
+
 /* contract finalisation: float = flag ? NaN : (float)((double)acc * 2^-40); out [R][E] row-major */
 void orc_finalize_rf(const int64_t *rf_fix, const uint8_t *rf_flags, uint32_t n_elem, uint32_t n_rows, float *out_rows_by_cols);
 

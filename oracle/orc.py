@@ -44,6 +44,25 @@ class Stats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class RayState(C.Structure):
+    """orc_ray_state: outside = -1 (nullptr), -2 (aliases the ray's own media, quirk 2) or a material index"""
+    _fields_ = [("origin", C.c_float * 3), ("dir", C.c_float * 3), ("media", C.c_int32), ("outside", C.c_int32),
+                ("intensity", C.c_float), ("frequency", C.c_float), ("dist_mm", C.c_double)]
+
+
+class HitDebug(C.Structure):
+    _fields_ = [("reflected_intensity", C.c_float), ("_pad0", C.c_uint32), ("returned", RayState),
+                ("random_angle", C.c_float), ("random_normal", C.c_float * 3), ("incidence", C.c_float), ("refr_ratio", C.c_float),
+                ("refraction_angle", C.c_float), ("refr_dir", C.c_float * 3), ("refl_dir", C.c_float * 3),
+                ("intensity_refl", C.c_float), ("intensity_refr", C.c_float), ("refraction_factor", C.c_float), ("reflection_factor", C.c_float),
+                ("u_pc", C.c_double), ("u_x", C.c_double),
+                ("tir", C.c_int32), ("chose_reflection", C.c_int32), ("mat_after", C.c_int32), ("after_vasc", C.c_int32),
+                ("ruv_attempts", C.c_uint32), ("_pad1", C.c_uint32)]
+
+
+OUT_NONE, OUT_SELF = -1, -2
+COUNTER_NAMES = ("pad_rule_rejects_in_bounds", "pad_rule_rejects_anywhere", "echo_guard_trips", "ruv_retries", "ruv_giveups", "tir_hits", "nan_echoes")
+
 SEGMENT_DTYPE = np.dtype([("from", "<f4", 3), ("to", "<f4", 3), ("dir", "<f4", 3),
                           ("reflected_intensity", "<f4"), ("initial_intensity", "<f4"), ("attenuation", "<f4"),
                           ("distance_traveled", "<f8"), ("media", "<i4"), ("tri", "<i4")])
@@ -76,6 +95,20 @@ def lib():
         L.orc_trace_frame.argtypes = [C.POINTER(Scene), C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_debug_power_cosine.restype = C.c_float; L.orc_debug_power_cosine.argtypes = [C.c_int, C.c_double]
+        L.orc_debug_random_unit_vector.restype = C.c_uint32
+        L.orc_debug_random_unit_vector.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_debug_hit_boundary.restype = None
+        L.orc_debug_hit_boundary.argtypes = [C.POINTER(Scene), C.POINTER(Params), C.POINTER(RayState), C.c_void_p, C.c_void_p, C.c_uint32,
+                                             C.c_void_p, C.POINTER(HitDebug)]
+        L.orc_debug_ray_segment.restype = C.c_float
+        L.orc_debug_ray_segment.argtypes = [C.POINTER(Scene), C.POINTER(Params), C.POINTER(RayState), C.c_void_p, C.c_void_p]
+        L.orc_debug_travel.restype = C.c_double; L.orc_debug_travel.argtypes = [C.POINTER(Scene), C.POINTER(RayState), C.c_void_p]
+        L.orc_debug_thickness.restype = C.c_float; L.orc_debug_thickness.argtypes = [C.c_float, C.c_void_p]
+        L.orc_debug_accumulate_segment.restype = C.c_uint64
+        L.orc_debug_accumulate_segment.argtypes = [C.POINTER(Scene), C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_debug_counting.restype = None; L.orc_debug_counting.argtypes = [C.c_void_p, C.c_int]
+        L.orc_debug_counters.restype = None; L.orc_debug_counters.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -92,6 +125,44 @@ def philox(ctr, key):
     c = np.asarray(ctr, dtype=np.uint32); k = np.asarray(key, dtype=np.uint32); o = np.zeros(4, np.uint32)
     lib().orc_philox4x32_10(_p(c), _p(k), _p(o))
     return o
+
+
+def u53(hi, lo):
+    return lib().orc_u53(C.c_uint32(int(hi)), C.c_uint32(int(lo)))
+
+
+def rng_block(rng, block):
+    """the contract's two uniforms of `block` for rng = (seed, frame, element, sample, bounce)  """
+    o = philox([rng[2], rng[3], rng[4], block], [rng[0], rng[1]])
+    return u53(o[0], o[1]), u53(o[2], o[3])
+
+
+def ray_state(origin, direction, media, outside=OUT_NONE, intensity=1.0, frequency=4.5, dist_mm=0.0):
+    r = RayState()
+    r.origin = (C.c_float * 3)(*[float(x) for x in origin]); r.dir = (C.c_float * 3)(*[float(x) for x in direction])
+    r.media = int(media); r.outside = int(outside); r.intensity = float(intensity); r.frequency = float(frequency); r.dist_mm = float(dist_mm)
+    return r
+
+
+def power_cosine(v, number):
+    return lib().orc_debug_power_cosine(int(v), float(number))
+
+
+def random_unit_vector(v, cos_theta, rng):
+    vv = np.asarray(v, np.float32); g = np.asarray(rng, np.uint32); w = np.zeros(3, np.float32)
+    n = lib().orc_debug_random_unit_vector(_p(vv), C.c_float(cos_theta), _p(g), _p(w))
+    return w, int(n)
+
+
+def thickness(sigma, rng):
+    g = np.asarray(rng, np.uint32)
+    return lib().orc_debug_thickness(C.c_float(sigma), _p(g))
+
+
+def counters():
+    o = np.zeros(8, np.uint64)
+    lib().orc_debug_counters(_p(o))
+    return {n: int(o[i]) for i, n in enumerate(COUNTER_NAMES)}
 
 
 def math_vec(name, x, y=None):
@@ -188,6 +259,33 @@ class OracleScene:
             self.c.bvh_tri = self.bvh_tri.ctypes.data
         self.c.n_nodes4 = self.bvh4_nodes.nbytes // 128
         self.c.nodes4 = self.bvh4_nodes.ctypes.data
+
+    # ---- test entry points into the physics (ray.cpp) ----
+    def hit_boundary(self, params, ray, hit_point, normal, mesh, rng):
+        hp = np.asarray(hit_point, np.float32); n = np.asarray(normal, np.float32); g = np.asarray(rng, np.uint32)
+        out = HitDebug()
+        lib().orc_debug_hit_boundary(C.byref(self.c), C.byref(params), C.byref(ray), _p(hp), _p(n), C.c_uint32(mesh), _p(g), C.byref(out))
+        return out
+
+    def ray_segment(self, params, ray):
+        f = np.zeros(3, np.float32); t = np.zeros(3, np.float32)
+        L = lib().orc_debug_ray_segment(C.byref(self.c), C.byref(params), C.byref(ray), _p(f), _p(t))
+        return L, f, t
+
+    def travel(self, ray, to_point):
+        t = np.asarray(to_point, np.float32)
+        return lib().orc_debug_travel(C.byref(self.c), C.byref(ray), _p(t))
+
+    def accumulate_segment(self, params, tex, seg):
+        """seg: one SEGMENT_DTYPE record -> (rf[R] float32 in reference order, RF steps)"""
+        sg = np.ascontiguousarray(np.asarray(seg, SEGMENT_DTYPE).reshape(1))
+        rf = np.zeros(params.n_rows, np.float32)
+        tex = np.ascontiguousarray(tex, np.float32)
+        n = lib().orc_debug_accumulate_segment(C.byref(self.c), C.byref(params), _p(tex), _p(sg), _p(rf))
+        return rf, int(n)
+
+    def counting(self, on=True):
+        lib().orc_debug_counting(C.cast(C.byref(self.c), C.c_void_p) if on else None, 1 if on else 0)
 
     def closest_hit(self, frm, to, use_bvh=False):
         f = np.asarray(frm, np.float32); t = np.asarray(to, np.float32)
