@@ -517,7 +517,7 @@ def live_pmc(args):
             # (the walk's ACCESSES are counted on its four-wavefront form: the five-wavefront form, which large launches take, adds the spill
             #  traffic of its refill code -- coalesced 4-byte scratch accesses that the counter counts per lane but the pipe serves a wavefront
             #  at a time, so the floor price per counted access does not apply to them; "tcp_all" counts that form as it runs)
-            env_pass = dict(env, MCRT_WIDE_FROM="4294967295") if name == "tcp" else env
+            env_pass = dict(env, MCRT_TUNING="1", MCRT_WIDE_FROM="4294967295") if name == "tcp" else env
             r = subprocess.run([exe, "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env_pass,
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
             rows, kname = _pmc_rows(d)

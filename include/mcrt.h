@@ -29,9 +29,10 @@
 extern "C" {
 #endif
 
-#define MCRT_VERSION 105   /* round 3: + mcrt_trace_frames_poses, mcrt_envelope_frames, mcrt_scan_convert_frames; the slab rule of the closest-hit contract is one fma per plane;
+#define MCRT_VERSION 106   /* round 3: + mcrt_trace_frames_poses, mcrt_envelope_frames, mcrt_scan_convert_frames; the slab rule of the closest-hit contract is one fma per plane;
                               104: + the test hooks mcrt_debug_set_error, mcrt_debug_fast_paths; RF images are NaN while the device error word is set;
-                              105 (round 4): + mcrt_group_* (several GPUs behind one call), mcrt_scan_maps; the scan-conversion maps follow the reference's float promotions */
+                              105 (round 4): + mcrt_group_* (several GPUs behind one call), mcrt_scan_maps; the scan-conversion maps follow the reference's float promotions;
+                              106 (round 5): environment knobs are only read under MCRT_TUNING=1; the HIP-graph replay of passes (MCRT_GRAPH) is gone */
 
 typedef enum {
     MCRT_OK = 0,
@@ -304,7 +305,7 @@ int mcrt_debug_stamps(mcrt_ctx *ctx, uint64_t out[200], int reset);
 /* which of the RF accumulation's fast paths the context's LAST traced frame ran with (they are switched on by checks made on the
  * device, and a check that fails silently costs a third of the frame): out[0] the reciprocal-multiply voxel quotient (verified
  * exhaustively against IEEE division for params.tex_res), out[1] the branch-free voxel cell, out[2] the entries of the padded
- * { threshold, bin } image of k_march's fast variant (0: generic variant), out[3] the passes this context has replayed as HIP graphs so far */
+ * { threshold, bin } image of k_march's fast variant (0: generic variant), out[3] reserved (0) */
 int mcrt_debug_fast_paths(mcrt_ctx *ctx, uint32_t out[4]);
 /* TEST HOOK, refused (MCRT_ERR_INVALID) unless the context was created with MCRT_TEST_HOOKS set in the environment: ORs `bits` into the
  * context's device error word on its stream, as an abandoned launch would (bit 0: traversal stack ran out, bit 1: kernel watchdog

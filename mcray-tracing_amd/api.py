@@ -156,12 +156,6 @@ class Context:
         check(self.L.mcrt_debug_fast_paths(self.h, out))
         return bool(out[0]), bool(out[1]), int(out[2])
 
-    def debug_graph_launches(self):
-        """passes this context has replayed as HIP graphs (MCRT_GRAPH=1)"""
-        out = (C.c_uint32 * 4)()
-        check(self.L.mcrt_debug_fast_paths(self.h, out))
-        return int(out[3])
-
     def debug_set_error(self, bits):
         """test hook: mark the context as an abandoned launch would (mcrt_debug_set_error)"""
         check(self.L.mcrt_debug_set_error(self.h, int(bits)))

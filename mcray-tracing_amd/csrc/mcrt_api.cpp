@@ -64,31 +64,32 @@ struct Work {
     float4 *d_mrec = nullptr; size_t paths = 0; uint32_t depth = 0;
 };
 
-// tuning knobs from the environment, read ONCE at mcrt_create (never on the frame path)
+// tuning knobs from the environment, read ONCE at mcrt_create (never on the frame path) -- and only in a process started with
+// MCRT_TUNING=1 (mcrt::tuning_env): linked into someone else's program the library has its defaults and nothing else.
 struct Knobs {
     uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, trace_blocks_wide = 0, wide_from = 0 /* 0: the kernels' own default */, wide_max_tree_mb = 128, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 0;   // march_blocks 0: launch_march picks
-    bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false, graph = false;
+    bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false;
     uint32_t march_cus = 0;                    // CUs the accumulation's side stream is confined to (0 = no mask); the mask's bit order is the driver's
     bool main_mask = false;                    // with march_cus: the walk / shade chain runs on its own stream confined to the OTHER CUs
     bool test_hooks = false;                   // MCRT_TEST_HOOKS: mcrt_debug_set_error may poison the context (tests only)
 };
 static Knobs read_knobs()
 {
+    using mcrt::tuning_env;
     Knobs k;
-    if (const char *e = getenv("MCRT_KSPLIT_LIMIT")) { long v = atol(e); if (v >= 0 && v <= MCRT_KSPLIT_MAX) k.ksplit_limit = (uint32_t)v; }   // 0 = off
-    if (const char *e = getenv("MCRT_TRACE_BLOCKS")) { int v = atoi(e); if (v >= 1) k.trace_blocks = (uint32_t)v; }
-    if (const char *e = getenv("MCRT_TRACE_BLOCKS_WIDE")) { int v = atoi(e); if (v >= 1) k.trace_blocks_wide = (uint32_t)v; }
-    if (const char *e = getenv("MCRT_WIDE_MAX_TREE_MB")) { long long v = atoll(e); if (v >= 0 && v <= 0xffffffffll) k.wide_max_tree_mb = (uint32_t)v; }
-    if (const char *e = getenv("MCRT_WIDE_FROM")) { long long v = atoll(e); if (v >= 1 && v <= 0xffffffffll) k.wide_from = (uint32_t)v; }   // rays in a launch from which the walk takes its five-wavefront form (1: always; 4294967295: never)
-    if (const char *e = getenv("MCRT_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 16) k.groups = (uint32_t)v; }
-    if (const char *e = getenv("MCRT_MARCH_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= MCRT_SIDE_STREAMS) k.march_streams = (uint32_t)v; }
-    if (const char *e = getenv("MCRT_MARCH_BLOCKS")) { int v = atoi(e); if (v >= 1) k.march_blocks = (uint32_t)v; }
-    k.no_overlap = getenv("MCRT_NO_OVERLAP") != nullptr; k.no_priority = getenv("MCRT_NO_PRIORITY") != nullptr;
-    k.no_fast_div = getenv("MCRT_NO_FAST_DIV") != nullptr; k.no_lean = getenv("MCRT_NO_LEAN") != nullptr;
-    k.graph = getenv("MCRT_GRAPH") != nullptr;   // passes replayed as HIP graphs (measured slower on ROCm 7.2: see trace_frames_graph)
-    if (const char *e = getenv("MCRT_MARCH_CUS")) { int v = atoi(e); if (v >= 0 && v <= 248) k.march_cus = (uint32_t)v; }
-    k.main_mask = getenv("MCRT_MAIN_MASK") != nullptr;
-    k.test_hooks = getenv("MCRT_TEST_HOOKS") != nullptr;
+    if (const char *e = tuning_env("MCRT_KSPLIT_LIMIT")) { long v = atol(e); if (v >= 0 && v <= MCRT_KSPLIT_MAX) k.ksplit_limit = (uint32_t)v; }   // 0 = off
+    if (const char *e = tuning_env("MCRT_TRACE_BLOCKS")) { int v = atoi(e); if (v >= 1) k.trace_blocks = (uint32_t)v; }
+    if (const char *e = tuning_env("MCRT_TRACE_BLOCKS_WIDE")) { int v = atoi(e); if (v >= 1) k.trace_blocks_wide = (uint32_t)v; }
+    if (const char *e = tuning_env("MCRT_WIDE_MAX_TREE_MB")) { long long v = atoll(e); if (v >= 0 && v <= 0xffffffffll) k.wide_max_tree_mb = (uint32_t)v; }
+    if (const char *e = tuning_env("MCRT_WIDE_FROM")) { long long v = atoll(e); if (v >= 1 && v <= 0xffffffffll) k.wide_from = (uint32_t)v; }   // rays in a launch from which the walk takes its five-wavefront form (1: always; 4294967295: never)
+    if (const char *e = tuning_env("MCRT_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 16) k.groups = (uint32_t)v; }
+    if (const char *e = tuning_env("MCRT_MARCH_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= MCRT_SIDE_STREAMS) k.march_streams = (uint32_t)v; }
+    if (const char *e = tuning_env("MCRT_MARCH_BLOCKS")) { int v = atoi(e); if (v >= 1) k.march_blocks = (uint32_t)v; }
+    k.no_overlap = tuning_env("MCRT_NO_OVERLAP") != nullptr; k.no_priority = tuning_env("MCRT_NO_PRIORITY") != nullptr;
+    k.no_fast_div = tuning_env("MCRT_NO_FAST_DIV") != nullptr; k.no_lean = tuning_env("MCRT_NO_LEAN") != nullptr;
+    if (const char *e = tuning_env("MCRT_MARCH_CUS")) { int v = atoi(e); if (v >= 0 && v <= 248) k.march_cus = (uint32_t)v; }
+    k.main_mask = tuning_env("MCRT_MAIN_MASK") != nullptr;
+    k.test_hooks = tuning_env("MCRT_TEST_HOOKS") != nullptr;
     return k;
 }
 
@@ -107,7 +108,6 @@ struct mcrt_ctx {
     float4 *d_nodes = nullptr, *d_tris = nullptr, *d_mats = nullptr;
     mcrt_bvh4_node *walked_nodes = nullptr; bool walked_stale = true;   // host copy of the tree as the lane walk sees it (mcrt_get_bvh4)
     uint4 *d_nodes_walk = nullptr; uint32_t nodes_walk_cap = 0;   // the walk's child-transposed half-float nodes
-    uint32_t *d_top_list = nullptr; uint4 *d_top_table = nullptr;  // the walk's top-of-tree table: its nodes [slots] + their count [1]; the table [4][slots] (k_pick_top)
     uint4 *d_meshes = nullptr;
     uint32_t *d_tri_slot = nullptr;
     uint32_t n_mesh = 0, n_mat = 0, start_mat = 0, n_cu = 256;
@@ -131,12 +131,6 @@ struct mcrt_ctx {
     // row thresholds (exact replacement of the per-echo double division) and the verified fast division by tex_res
     double *d_row_thr = nullptr; uint32_t thr_rows = 0; double thr_dt = 0.0;
     float verified_res = 0.0f; bool fast_div = false, fast_div_all = false;
-    // HIP graphs of whole passes (mcrt_trace_frames): the ~35 launches of a pass replayed as one graph launch.  An entry is keyed by the
-    // kernel arguments of the pass (every pointer and parameter the kernels see, frame number excepted), its output buffer and stream;
-    // the frame number reaches the kernels through the entry's device word (d_frame_words[1 + slot]; word 0 stays 0 for direct launches).
-    struct GraphEntry { mcrt::FrameArgs key; float *rf = nullptr; hipStream_t stream = nullptr; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t used = 0; bool live = false; };
-    GraphEntry graphs[MCRT_GRAPH_SLOTS]; uint64_t graph_tick = 0; bool graph_off = false; uint32_t graph_launches = 0;
-    uint32_t *d_frame_words = nullptr;
     float last_lean_bound = 0.0f; uint32_t last_march_rows = 0;   // what the last frame's kernels were given (mcrt_debug_fast_paths)
     // per-material table of k_march (depends on the materials, the axial step and the frequency)
     float4 *d_mtab = nullptr; uint32_t mtab_n = 0; float mtab_key[2] = { 0.0f, 0.0f }; bool mtab_valid = false;
@@ -231,8 +225,7 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     c->c = derive_consts(c->p);
     c->stream = c->own_stream;
     if (hipMalloc(&c->d_stats, 256 * sizeof(unsigned long long)) != hipSuccess || hipMemsetAsync(c->d_stats, 0, 256 * sizeof(unsigned long long), c->stream) != hipSuccess ||
-        hipMalloc(&c->d_error, 4) != hipSuccess || hipMemsetAsync(c->d_error, 0, 4, c->stream) != hipSuccess ||
-        hipMalloc(&c->d_frame_words, 4 * (1 + MCRT_GRAPH_SLOTS)) != hipSuccess || hipMemsetAsync(c->d_frame_words, 0, 4 * (1 + MCRT_GRAPH_SLOTS), c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        hipMalloc(&c->d_error, 4) != hipSuccess || hipMemsetAsync(c->d_error, 0, 4, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
         hipStreamDestroy(c->own_stream); delete c; return set_error(MCRT_ERR_HIP, "hipMalloc failed");
     }
     { int rc = prepare_tables(c); if (rc) { mcrt_destroy(c); return rc; } }
@@ -316,7 +309,7 @@ static int side_stream(mcrt_ctx *c, Work &w, uint32_t i, hipStream_t *out)
 // allocation HERE; mcrt_refit_triangles itself still frees its staging copy of the vertices, which synchronises the device).
 // Nothing here waits: the rebuild is ordered on the stream it was issued on, and an event recorded behind it orders a trace that
 // is issued on ANOTHER stream after mcrt_set_stream (enqueue_frame waits for it).
-static int refresh_soa(mcrt_ctx *c, bool new_tree)
+static int refresh_soa(mcrt_ctx *c)
 {
     c->walked_stale = true;
     if (c->bvh4.n_nodes == 0) { hipFree(c->d_nodes_walk); c->d_nodes_walk = nullptr; c->nodes_walk_cap = 0; return MCRT_OK; }
@@ -326,14 +319,7 @@ static int refresh_soa(mcrt_ctx *c, bool new_tree)
         HIP_TRY(hipMalloc(&c->d_nodes_walk, 64 * (size_t)c->bvh4.n_nodes));
         c->nodes_walk_cap = c->bvh4.n_nodes;
     }
-    const uint32_t slots = mcrt::lane_top_slots();
-    if (slots && !c->d_top_list) {
-        HIP_TRY(hipMalloc(&c->d_top_list, 4 * ((size_t)slots + 1)));
-        HIP_TRY(hipMalloc(&c->d_top_table, 80 * (size_t)slots));
-        HIP_TRY(hipMemsetAsync(c->d_top_table, 0, 80 * (size_t)slots, c->stream));
-        new_tree = true;
-    }
-    HIP_TRY(mcrt::launch_nodes_walk(c->d_nodes, c->bvh4.n_nodes, c->d_nodes_walk, c->d_top_list, c->d_top_table, new_tree, c->stream));
+    HIP_TRY(mcrt::launch_nodes_walk(c->d_nodes, c->bvh4.n_nodes, c->d_nodes_walk, c->stream));
     if (!c->ev_scene) HIP_TRY(hipEventCreateWithFlags(&c->ev_scene, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c->ev_scene, c->stream));
     c->scene_stream = c->stream; c->scene_pending = true;
@@ -359,15 +345,13 @@ extern "C" int mcrt_destroy(mcrt_ctx *c)
     free_scene(c);
     free_work(c);
     free(c->walked_nodes); c->walked_nodes = nullptr;
-    hipFree(c->d_pose[0]); hipFree(c->d_pose[1]); hipFree(c->d_top_list); hipFree(c->d_top_table);
+    hipFree(c->d_pose[0]); hipFree(c->d_pose[1]);
     if (c->h_pose[0]) hipHostFree(c->h_pose[0]);
     if (c->h_pose[1]) hipHostFree(c->h_pose[1]);
     if (c->ev_pose) hipEventDestroy(c->ev_pose);
     if (c->ev_scene) hipEventDestroy(c->ev_scene);
     hipFree(c->d_tex); hipFree(c->d_pos); hipFree(c->d_dir); hipFree(c->d_acc); hipFree(c->d_flags); hipFree(c->d_tmp);
     hipFree(c->d_map_col); hipFree(c->d_map_row); hipFree(c->d_stats); hipFree(c->d_row_thr); hipFree(c->d_error); hipFree(c->d_mtab);
-    for (auto &g : c->graphs) { if (g.exec) hipGraphExecDestroy(g.exec); if (g.graph) hipGraphDestroy(g.graph); }
-    hipFree(c->d_frame_words);
     for (auto &e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (c->ev_start) hipEventDestroy(c->ev_start);
     hipStreamDestroy(c->own_stream);
@@ -529,7 +513,7 @@ extern "C" int mcrt_update_triangles(mcrt_ctx *c, const float *tri, uint32_t n_t
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_scene = false;                           // a failed rebuild leaves no scene
     int rc = index_triangles(c, tri, n_tri); if (rc) return rc;
-    rc = refresh_soa(c, true); if (rc) return rc;
+    rc = refresh_soa(c); if (rc) return rc;
     c->have_scene = true;
     return MCRT_OK;
 }
@@ -548,7 +532,7 @@ extern "C" int mcrt_refit_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tr
     float pad = 0.0f, lo[3], hi[3];
     if (!rc) rc = mcrt::bvh_refit(d_tri, n_tri, c->d_nodes, c->bvh4.n_nodes, c->d_tris, c->stream, &pad, lo, hi);
     hipFree(d_tri);
-    if (!rc) rc = refresh_soa(c, false);                    // (same topology: the top-of-tree table keeps its nodes, with their new boxes)
+    if (!rc) rc = refresh_soa(c);
     if (rc) { c->have_scene = false; return rc; }           // a failed refit leaves no scene
     c->bvh.pad_abs = pad;
     for (int i = 0; i < 3; i++) { c->scene_lo[i] = lo[i]; c->scene_hi[i] = hi[i]; }
@@ -577,7 +561,7 @@ extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *
     if (n_tri) {
         c->tri_mesh.assign(tri_mesh, tri_mesh + n_tri);
         int rc = index_triangles(c, tri, n_tri); if (rc) return rc;
-        rc = refresh_soa(c, true); if (rc) return rc;
+        rc = refresh_soa(c); if (rc) return rc;
     }
     HIP_TRY(hipMalloc(&c->d_mats, 32 * (size_t)n_mat));
     HIP_TRY(hipMemcpy(c->d_mats, mats, 32 * (size_t)n_mat, hipMemcpyHostToDevice));
@@ -609,7 +593,7 @@ extern "C" int mcrt_get_bvh4(mcrt_ctx *c, mcrt_bvh4 *out)
             const size_t bytes = sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes;
             float4 *d_tmp = nullptr;
             HIP_TRY(hipMalloc(&d_tmp, bytes));
-            hipError_t e = mcrt::launch_nodes_walk_decode(c->d_nodes_walk, c->bvh4.n_nodes, d_tmp, c->d_top_list, c->stream);
+            hipError_t e = mcrt::launch_nodes_walk_decode(c->d_nodes_walk, c->bvh4.n_nodes, d_tmp, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             free(c->walked_nodes);
             c->walked_nodes = (mcrt_bvh4_node *)malloc(bytes);
@@ -755,7 +739,7 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne_frame, uint32_t n_frame
 static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, uint32_t acc_e0, uint32_t acc_ne)
 {
     memset(&a, 0, sizeof a);
-    a.nodes_walk = c->d_nodes_walk; a.top_nodes = c->d_top_table; a.stack_ovf = w.d_stack_ovf; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
+    a.nodes_walk = c->d_nodes_walk; a.stack_ovf = w.d_stack_ovf; a.tris = c->d_tris; a.meshes = c->d_meshes; a.mats = c->d_mats; a.tex = c->d_tex;
     a.el_pos = c->pose_pos ? c->pose_pos : c->d_pos; a.el_dir = c->pose_pos ? c->pose_dir : c->d_dir; a.pose_stride = c->pose_pos ? c->p.n_elements : 0u;
     a.row_thr = c->d_row_thr;
     a.acc = c->d_acc; a.flags = c->d_flags;                 // the frame block [n_frames][acc_ne][R]; this group owns columns e0-acc_e0 ...
@@ -777,7 +761,7 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     if ((uint64_t)c->bvh4.n_nodes * 64ull > (uint64_t)c->knobs.wide_max_tree_mb * 1048576ull) a.trace_blocks_wide = 0;
     if (c->knobs.main_mask) a.trace_blocks_wide = 0;                                                   // (CU-masked streams: the four-wavefront form only)
     a.march_blocks = c->knobs.march_blocks;
-    a.frame = frame; a.frame_dev = c->d_frame_words; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n; a.tex_mask = (c->tex_n & (c->tex_n - 1u)) == 0u ? c->tex_n - 1u : 0u;
+    a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n; a.tex_mask = (c->tex_n & (c->tex_n - 1u)) == 0u ? c->tex_n - 1u : 0u;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
     a.freq = c->p.frequency; a.eps = c->p.intensity_epsilon; a.I0 = c->p.initial_intensity; a.offs = c->p.ray_start_offset;
     a.sx = c->spacing[0]; a.sy = c->spacing[1]; a.sz = c->spacing[2]; a.tex_res = c->p.tex_res; a.axial_res_f = c->c.axial_res_f; a.pad_abs = c->bvh.pad_abs; a.tex_rcp = 1.0f / c->p.tex_res; a.fast_div = c->fast_div ? 1u : 0u;
@@ -914,70 +898,6 @@ static uint32_t frame_groups(const mcrt_ctx *c)
     return c->stats_on ? 1u : c->knobs.groups;
 }
 
-// A pass as ONE graph launch.  The ~35 launches of a pass (k_init, per bounce the walk, the shade and -- on the side stream -- the
-// accumulation, k_finalize) are dependent kernels a few microseconds apart; for small passes (one frame at a time: 10 walks of
-// ~130 us) the boundaries between them are a tenth of the frame.  The first pass of a shape is enqueued directly (it also creates
-// the streams and events the capture needs), the second is captured from the very same code (stream capture follows the side
-// stream through its events) and instantiated, every later one is a 4-byte device word with the frame number + hipGraphLaunch.
-// The key of an entry is the kernels' whole argument block: whatever changes a pointer or a parameter (a new scene, a refit that
-// reallocates, other parameters, another output buffer or stream) simply misses, and the least recently used entry is replaced.
-// Not used when kernels are counted or timed individually (stats, mcrt_enable_timing), with scan-line groups or CU masks.
-// MEASURED (MI355X, ROCm 7.2, 128 x 1024 rays, 1 M triangles) and therefore OFF unless MCRT_GRAPH is set: one frame at a time 2.30 ms per
-// frame as a graph against 1.51 ms with direct launches, a 128-frame pass with per-frame poses 0.411 against 0.369 -- the runtime
-// replays the graph's two branches (chain and accumulation) through its own streams with more synchronisation than the hand-placed
-// events of the direct path.  Kept as a knob, parity-tested (test_passes_replayed_as_hip_graphs).
-static int trace_frames_graph(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, float *rf_dev, uint32_t lines, bool *done)
-{
-    *done = false;
-    if (!c->knobs.graph || c->graph_off || c->stats_on || c->timing_on || frame_groups(c) != 1u || c->knobs.march_cus) return MCRT_OK;
-    std::vector<mcrt::FrameArgs> args; std::vector<Work *> ws;
-    uint32_t groups = 1;
-    int rc = prepare_frame(c, 0u, n_frames, e0, e1, groups, 0, args, ws); if (rc) return rc;
-    mcrt::FrameArgs key = args[0]; key.frame_dev = nullptr;
-    int slot = -1, lru = 0;
-    for (int i = 0; i < MCRT_GRAPH_SLOTS; i++) {
-        const mcrt_ctx::GraphEntry &g = c->graphs[i];
-        if (g.live && g.rf == rf_dev && g.stream == c->stream && memcmp(&g.key, &key, sizeof key) == 0) { slot = i; break; }
-        if (!c->graphs[i].live) lru = i; else if (c->graphs[lru].live && g.used < c->graphs[lru].used) lru = i;
-    }
-    if (slot < 0) {          // first pass of this shape: remember it, run it directly
-        mcrt_ctx::GraphEntry &g = c->graphs[lru];
-        if (g.exec || g.graph) HIP_TRY(hipDeviceSynchronize());   // (a replaced graph may still be running; its stream was the caller's and may be gone: wait for the device, not for a stored handle)
-        if (g.exec) hipGraphExecDestroy(g.exec);
-        if (g.graph) hipGraphDestroy(g.graph);
-        g.exec = nullptr; g.graph = nullptr; g.key = key; g.rf = rf_dev; g.stream = c->stream; g.used = ++c->graph_tick; g.live = true;
-        return MCRT_OK;
-    }
-    mcrt_ctx::GraphEntry &g = c->graphs[slot];
-    g.used = ++c->graph_tick;
-    uint32_t *word = c->d_frame_words + 1 + slot;
-    if (!g.exec) {            // second pass: capture what the direct path enqueues
-        args[0].frame_dev = word;
-        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
-        if (ok) {
-            const int rq = enqueue_frame(c, args, ws, true);
-            const hipError_t ef = rq ? hipSuccess : mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, lines, c->p.n_rows, c->d_error, c->stream);
-            const hipError_t ee = hipStreamEndCapture(c->stream, &graph);            // (always: the stream must leave capture mode)
-            ok = rq == 0 && ef == hipSuccess && ee == hipSuccess && graph != nullptr;
-            if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-        }
-        if (!ok) {             // this runtime will not capture the pass: direct launches from now on
-            (void)hipGetLastError();
-            if (exec) hipGraphExecDestroy(exec);
-            if (graph) hipGraphDestroy(graph);
-            c->graph_off = true; g.live = false;
-            return MCRT_OK;
-        }
-        g.graph = graph; g.exec = exec;
-    }
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)word, (int)frame, 1, c->stream));
-    HIP_TRY(hipGraphLaunch(g.exec, c->stream));
-    c->graph_launches++;
-    *done = true;
-    return MCRT_OK;
-}
-
 extern "C" int mcrt_trace_frames(mcrt_ctx *c, uint32_t frame, uint32_t n_frames, uint32_t e0, uint32_t e1, float *rf_dev)
 {
     CTX_TRY(c);
@@ -988,12 +908,8 @@ extern "C" int mcrt_trace_frames(mcrt_ctx *c, uint32_t frame, uint32_t n_frames,
         return set_error(MCRT_ERR_LIMIT, "%u frames x %u scan-lines x %u samples: more than 2^27 paths in one pass", n_frames, e1 - e0, c->p.n_samples);
     const uint32_t lines = (e1 - e0) * n_frames;
     rc = ensure_acc(c, lines); if (rc) return rc;
-    bool done = false;
-    rc = trace_frames_graph(c, frame, n_frames, e0, e1, rf_dev, lines, &done); if (rc) return rc;
-    if (!done) {
-        rc = run_frame(c, frame, n_frames, e0, e1, true, frame_groups(c), 0); if (rc) return rc;
-        HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, lines, c->p.n_rows, c->d_error, c->stream));
-    }
+    rc = run_frame(c, frame, n_frames, e0, e1, true, frame_groups(c), 0); if (rc) return rc;
+    HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, lines, c->p.n_rows, c->d_error, c->stream));
     c->acc_clean_ne = lines; c->acc_clean_rows = c->p.n_rows;
     return MCRT_OK;
 }
@@ -1265,7 +1181,7 @@ extern "C" int mcrt_debug_fast_paths(mcrt_ctx *c, uint32_t out[4])
 {
     CTX_TRY(c);
     if (!out) return set_error(MCRT_ERR_INVALID, "null out pointer");
-    out[0] = c->fast_div ? 1u : 0u; out[1] = c->last_lean_bound > 0.0f ? 1u : 0u; out[2] = c->last_march_rows; out[3] = c->graph_launches;
+    out[0] = c->fast_div ? 1u : 0u; out[1] = c->last_lean_bound > 0.0f ? 1u : 0u; out[2] = c->last_march_rows; out[3] = 0u;
     return MCRT_OK;
 }
 

@@ -12,6 +12,13 @@
 #include <cstring>
 #include <vector>
 
+// tuning knobs (mcrt_internal.h): only a process started with MCRT_TUNING=1 has any
+const char *mcrt::tuning_env(const char *name)
+{
+    const char *e = getenv("MCRT_TUNING");       // (looked at when a knob is asked for -- mcrt_create, a BVH build --, never on the frame path)
+    return (e && e[0] == '1') ? getenv(name) : nullptr;
+}
+
 namespace {
 
 struct Prim {
@@ -124,8 +131,8 @@ extern "C" int mcrt_build_bvh(const float *tri, const uint32_t *tri_mesh, uint32
     if (!tri || !out || n_tri == 0) return mcrt::set_error(MCRT_ERR_INVALID, "mcrt_build_bvh: no triangles");
     if (n_tri >= (1u << 28)) return mcrt::set_error(MCRT_ERR_LIMIT, "mcrt_build_bvh: more than 2^28 triangles");
     Builder b;
-    if (const char *e = getenv("MCRT_SAH_LEAF_MAX")) { int v = atoi(e); if (v >= 1 && v <= 8) b.kLeafMax = v; }
-    if (const char *e = getenv("MCRT_SAH_COST_TRI")) { float v = (float)atof(e); if (v > 0.0f) b.kCostTri = v; }
+    if (const char *e = mcrt::tuning_env("MCRT_SAH_LEAF_MAX")) { int v = atoi(e); if (v >= 1 && v <= 8) b.kLeafMax = v; }
+    if (const char *e = mcrt::tuning_env("MCRT_SAH_COST_TRI")) { float v = (float)atof(e); if (v > 0.0f) b.kCostTri = v; }
     b.prims.resize(n_tri);
     // Padding (DESIGN.md "Closest hit"): Bullet's triangle test accepts points up to 1e-4 of the triangle's
     // height outside an edge, and the slab arithmetic rounds; each triangle's bounds are widened accordingly.

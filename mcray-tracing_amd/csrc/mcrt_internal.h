@@ -24,5 +24,8 @@
 
 namespace mcrt {
 int set_error(int code, const char *fmt, ...);
+// A TUNING knob from the environment: nullptr unless the process runs with MCRT_TUNING=1 (mcrt_host.cpp).  The library is meant to be
+// linked into someone else's program: left alone it reads ONE environment variable, once; the knobs themselves are
+// for tools/ and tests/, which set MCRT_TUNING=1 beside the knob they turn.
+const char *tuning_env(const char *name);
 }
-#define MCRT_GRAPH_SLOTS 8            // passes of different shapes / output buffers whose HIP graphs a context keeps (least recently used replaced)

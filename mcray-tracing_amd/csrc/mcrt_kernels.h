@@ -10,7 +10,6 @@ namespace mcrt {
 struct FrameArgs {
     // scene (HBM-resident, read-only)
     const uint4 *nodes_walk;   // [n_nodes][4]  the walk's 64-byte nodes: child-transposed half-float boxes (rounded outwards) + refs
-    const uint4 *top_nodes;    // [4][MCRT_LANE_TOP] the walk's top-of-tree table, piece-major (k_pick_top / k_top_table); every workgroup copies it to LDS
     int *stack_ovf;            // [max_stack - MCRT_LANE_STACK][trace_blocks * 256] traversal-stack entries beyond the LDS part (this work set's own)
     const float4 *tris;        // [T][MCRT_TRI_PIECES]  48-B triangle records, leaf order: v0|id, v1|mesh, v2|edge tolerance (64-B form: n|dist first)
     const uint4 *meshes;       // [n_mesh]      mat_inside, mat_outside, vascular, -
@@ -19,7 +18,6 @@ struct FrameArgs {
     const float *el_pos;       // [E][3], or [F][E][3] when the frames of a pass have their own probe poses (pose_stride = E)
     const float *el_dir;       // same shape
     const double *row_thr;     // [R+1] row thresholds (see row_of)
-    const uint32_t *frame_dev; // a device word ADDED to `frame`: 0 for direct launches; the frame number itself when the pass is replayed as a HIP graph (frame = 0 then)
     // per-frame work buffers; np = ne * S paths
     float4 *st0, *st1, *st2;   // [2][np] path state in queue order, two halves by bounce parity: from, ray length factor | dir, media | distance_traveled(f64), outside, intensity
                                //         (the walk reads st0 + st1 and rebuilds the ray from them: ray_of)
@@ -51,9 +49,8 @@ struct ConvTaps { float ax[16]; float lat[32]; uint32_t n_ax, n_lat; };
 
 hipError_t launch_init(const FrameArgs &a, hipStream_t st);
 hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
-hipError_t launch_nodes_walk(const float4 *nodes, uint32_t n_nodes, uint4 *out, uint32_t *top_list, uint4 *top_table, bool pick, hipStream_t st);
-hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 *out, const uint32_t *top_list, hipStream_t st);
-uint32_t lane_top_slots();
+hipError_t launch_nodes_walk(const float4 *nodes, uint32_t n_nodes, uint4 *out, hipStream_t st);
+hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 *out, hipStream_t st);
 uint32_t lane_stack_entries();
 uint32_t lane_wide_from();
 hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);

@@ -405,27 +405,9 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 // Traversal stacks: MCRT_LANE_STACK entries per lane in LDS ([entry][thread], conflict-free); deeper entries (only reachable on
 // degenerate paths of deep trees) go to a global overflow array.
 // =============================================================================================================
-#ifndef MCRT_LANE_TOP
-#define MCRT_LANE_TOP 0              // nodes of the TOP-OF-TREE TABLE each workgroup of the walk keeps in LDS (see k_pick_top).  OFF: built and measured in round 4
-#endif                               // (64 / 128 / 192 / 256 nodes, with 28 / 24 / 20 / 16 stack entries: every GPU parity test green, 14-19 % of the node visits served
-                                     // from LDS -- and the walk 3.31-3.33 ms per launch against 3.20-3.21, the frame 0.348-0.351 against 0.342-0.345 ms: the vector
-                                     // memory pipe's saving does not shorten a step that ends with its last lane; the flat-load form the same; profiles/round4/exp_top_of_tree.txt)
-#ifndef MCRT_LANE_QUAD
-#define MCRT_LANE_QUAD 0             // 1: nodes are fetched a QUAD of lanes at a time, whole 64-byte lines straight into LDS (lane_node_fetch_quad).  OFF: parity green,
-                                     // 2.4x / 1.2x on a bare dependent fetch chain (tools/quad_line.hip), the walk 3.35-3.38 ms per launch against 3.20-3.21
-                                     // (profiles/round4/exp_quad_fetch.txt: the instructions it adds weigh more than the pipe time it saves)
-#endif
-#define MCRT_QUAD_PITCH 1040         // bytes between the LDS images of a wavefront's four quad loads (1 KiB + 16: the four lanes of a quad read their nodes from different banks)
 #ifndef MCRT_LANE_STACK
-#define MCRT_LANE_STACK (MCRT_LANE_QUAD ? 20 : MCRT_LANE_TOP ? 24 : 32)     // (the headline workload's deepest walk stacks 16 entries, 14 at the 99.9th percentile: profiles/round4/bvh_width.json)
+#define MCRT_LANE_STACK 32           // (the headline workload's deepest walk stacks 16 entries, 14 at the 99.9th percentile: profiles/round4/bvh_width.json)
 #endif
-#ifndef MCRT_LANE_TOP_FLAT
-#define MCRT_LANE_TOP_FLAT 0         // 1: the table node-major with an 80-byte pitch and ONE flat load per piece for both kinds of lanes (the address picks LDS or memory)
-#endif
-#define MCRT_TOP_PITCH (MCRT_LANE_TOP_FLAT ? 5 : 1)                       // 16-byte units from slot to slot ...
-#define MCRT_TOP_PIECE (MCRT_LANE_TOP_FLAT ? 1 : MCRT_LANE_TOP)           // ... and from piece to piece
-#define MCRT_TOP_UNITS (MCRT_LANE_TOP_FLAT ? 5 * MCRT_LANE_TOP : 4 * MCRT_LANE_TOP)
-#define MCRT_TOP_FLAG 0x40000000     // a child reference with this bit names slot (ref & 0xffff) of the table instead of a node (node numbers stay below 2^25)
 // Persistent kernels carry a WATCHDOG: every 4096 iterations of its outer loop a wavefront compares the 100 MHz wall clock
 // with its start, and a kernel that is still running after MCRT_WATCHDOG_SECONDS sets bit 1 of the device error word and leaves
 // -- a logic error then surfaces as MCRT_ERR_LIMIT from the next synchronising call instead of a hung GPU.
@@ -504,14 +486,7 @@ MCRT_DEV uint32_t half_towards(float x, bool up)
 MCRT_DEV float half_bits_to_float(uint32_t b) { return __half2float(__ushort_as_half((unsigned short)b)); }
 
 // the walk's 64-byte nodes from the builders' 128-byte ones
-// slot of node `ref` in the sorted list of table nodes, or -1
-MCRT_DEV int top_slot(const uint32_t *top_list, uint32_t n_top, uint32_t ref)
-{
-    uint32_t lo = 0, hi = n_top;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (top_list[mid] < ref) lo = mid + 1; else hi = mid; }
-    return (lo < n_top && top_list[lo] == ref) ? (int)lo : -1;
-}
-__global__ void k_nodes_walk(const float4 *in, uint32_t n_nodes, uint4 *out, const uint32_t *top_list, const uint32_t *n_top_p)
+__global__ void k_nodes_walk(const float4 *in, uint32_t n_nodes, uint4 *out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
@@ -521,7 +496,6 @@ __global__ void k_nodes_walk(const float4 *in, uint32_t n_nodes, uint4 *out, con
         const float4 A = in[8 * (size_t)i + 2 * c], B = in[8 * (size_t)i + 2 * c + 1];
         ref[c] = __float_as_int(B.z);
         const bool empty = ref[c] == MCRT_BVH4_EMPTY;
-        if (ref[c] >= 0 && top_list) { const int slot = top_slot(top_list, *n_top_p, (uint32_t)ref[c]); if (slot >= 0) ref[c] = MCRT_TOP_FLAG | slot; }
         const float l[3] = { A.x, A.y, A.z }, h[3] = { A.w, B.x, B.y };
 #pragma unroll
         for (int k = 0; k < 3; k++) { lo[k][c] = empty ? 0x7c00u : half_towards(l[k], false); hi[k][c] = empty ? 0x7c00u : half_towards(h[k], true); }
@@ -535,66 +509,7 @@ __global__ void k_nodes_walk(const float4 *in, uint32_t n_nodes, uint4 *out, con
 #undef MCRT_PACK4
 }
 // ... and back: the tree as the walk sees it, in the builders' layout (for mcrt_get_bvh4)
-// THE TOP-OF-TREE TABLE.  The walk is bound by the compute units' vector memory pipe (1.3 cycles per lane and 16-byte piece, four pieces
-// per node: profiles/round4/tcp_access_cost.json), and nine of ten pieces it fetches are nodes -- but LDS is a different pipe.  The N nodes
-// a ray is most likely to visit are therefore kept in LDS by every workgroup of the walk (child-transposed like the nodes, piece-major so
-// that lanes on different slots spread over the banks), and a child reference that names one of them carries MCRT_TOP_FLAG | slot: which
-// copy of a node a lane reads changes nothing about the walk (same boxes, same order, same counts).
-// k_pick_top chooses them without looking at rays: from the root, always the pending inner node with the LARGEST BOX next (the chance
-// that a random line meets a convex box is proportional to its area).  One workgroup, n_top rounds of an argmax over the frontier in LDS;
-// the list comes out sorted by node number (slot 0 = the root).
-__global__ void __launch_bounds__(256) k_pick_top(const float4 *nodes, uint32_t n_nodes, uint32_t want, uint32_t *top_list, uint32_t *n_top_p)
-{
-    constexpr int CAP = 3 * 1024 + 4;                 // the frontier grows by at most three entries per round
-    __shared__ float f_area[CAP]; __shared__ uint32_t f_node[CAP];
-    __shared__ float r_area[256]; __shared__ int r_idx[256];
-    __shared__ uint32_t picked[1024]; __shared__ int n_front, n_pick;
-    const int tid = threadIdx.x;
-    if (want > 1024u) want = 1024u;
-    if (tid == 0) { n_front = 0; n_pick = 0; if (n_nodes) { f_area[0] = INFINITY; f_node[0] = 0u; n_front = 1; } }
-    __syncthreads();
-    while (n_pick < (int)want && n_front > 0) {
-        float best = -1.0f; int bi = -1;
-        for (int i = tid; i < n_front; i += 256) if (f_area[i] > best) { best = f_area[i]; bi = i; }      // (strict: the earliest entry wins a tie)
-        r_area[tid] = best; r_idx[tid] = bi;
-        __syncthreads();
-        for (int w = 128; w >= 1; w >>= 1) {
-            if (tid < w) { const float o = r_area[tid + w]; const int oi = r_idx[tid + w];
-                           if (oi >= 0 && (r_idx[tid] < 0 || o > r_area[tid] || (o == r_area[tid] && oi < r_idx[tid]))) { r_area[tid] = o; r_idx[tid] = oi; } }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            const int at = r_idx[0];
-            const uint32_t me = f_node[at];
-            f_area[at] = f_area[n_front - 1]; f_node[at] = f_node[n_front - 1]; n_front--;
-            picked[n_pick++] = me;
-            for (int c = 0; c < 4; c++) {
-                const float4 A = nodes[8 * (size_t)me + 2 * c], B = nodes[8 * (size_t)me + 2 * c + 1];
-                const int ref = __float_as_int(B.z);
-                if (ref < 0) continue;                 // a leaf or an unused slot
-                const float dx = A.w - A.x, dy = B.x - A.y, dz = B.y - A.z;
-                f_area[n_front] = dx * dy + dy * dz + dz * dx; f_node[n_front] = (uint32_t)ref; n_front++;
-            }
-        }
-        __syncthreads();
-    }
-    const int np = n_pick;
-    for (int i = tid; i < np; i += 256) {             // rank sort by node number (distinct)
-        const uint32_t v = picked[i]; int rank = 0;
-        for (int j = 0; j < np; j++) rank += picked[j] < v;
-        top_list[rank] = v;
-    }
-    if (tid == 0) *n_top_p = (uint32_t)np;
-}
-// the table itself: pieces of the walk's nodes, piece-major ([4][MCRT_LANE_TOP])
-__global__ void k_top_table(const uint4 *walk, const uint32_t *top_list, const uint32_t *n_top_p, uint4 *table, uint32_t slots)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 4u * slots) return;
-    const uint32_t piece = i / slots, slot = i - piece * slots;
-    table[slot * MCRT_TOP_PITCH + piece * MCRT_TOP_PIECE] = slot < *n_top_p ? walk[4 * (size_t)top_list[slot] + piece] : make_uint4(0x7c007c00u, 0x7c007c00u, 0x7c007c00u, 0x7c007c00u);
-}
-__global__ void k_nodes_walk_decode(const uint4 *in, uint32_t n_nodes, float4 *out, const uint32_t *top_list)
+__global__ void k_nodes_walk_decode(const uint4 *in, uint32_t n_nodes, float4 *out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
@@ -604,7 +519,6 @@ __global__ void k_nodes_walk_decode(const uint4 *in, uint32_t n_nodes, float4 *o
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         float v[6];
-        if ((int)ref[c] >= 0 && (ref[c] & MCRT_TOP_FLAG)) ref[c] = top_list[ref[c] & 0xffffu];     // a table slot: back to the node it stands for
 #pragma unroll
         for (int k = 0; k < 6; k++) v[k] = half_bits_to_float((w[2 * k + (c >> 1)] >> ((c & 1) * 16)) & 0xffffu);
         const bool empty = (int)ref[c] == MCRT_BVH4_EMPTY;
@@ -630,7 +544,7 @@ MCRT_DEV Planes4 planes4(uint32_t w01, uint32_t w23, float c, float inv)
 // ---- the lane-per-ray walk's two steps ---------------------------------------------------------------------------------
 // A lane's traversal stack: entries [sb, sp), entry e of thread t at lds[e * 256 + t] while e < MCRT_LANE_STACK, beyond that in the
 // global overflow array (only reachable on degenerate paths of deep trees).
-template <int STACK> struct LaneStackT { int *lds; int *ovf; size_t ovf_stride; int tid; const uint4 *top; static constexpr int depth = STACK; };     // depth: entries in LDS; top: the top-of-tree table in LDS
+template <int STACK> struct LaneStackT { int *lds; int *ovf; size_t ovf_stride; int tid; static constexpr int depth = STACK; };     // depth: entries in LDS
 constexpr int CUR_IDLE = (int)0x80000000;      // walk state: cur >= 0 inner node, cur < 0 ~(leaf descriptor), CUR_IDLE = no walk in progress
 template <class LS> MCRT_DEV void lane_pop(const LS &S, int &cur, int &sp, int sb)
 {
@@ -660,60 +574,9 @@ MCRT_DEV bool slab_near_far(float nx, float ny, float nz, float fx, float fy, fl
 template <class LS> MCRT_DEV void lane_node_compute(const LS &S, const LaneRay &r, float t_lo, float tcap, const uint4 Q0, const uint4 Q1, const uint4 Q2, const uint4 RF, int &cur, int &sp, int sb);
 template <class LS> MCRT_DEV void lane_node_step(const FrameArgs &a, const LS &S, const LaneRay &r, float t_lo, float tcap, int &cur, int &sp, int sb)
 {
-    uint4 Q0, Q1, Q2, RF;
-    if (MCRT_LANE_TOP && MCRT_LANE_TOP_FLAT) {                  // one generic address per lane: flat loads go to LDS or to memory lane by lane
-        const uint4 *N = (cur & MCRT_TOP_FLAG) ? S.top + 5 * (cur & 0xffff) : (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
-        Q0 = N[0]; Q1 = N[1]; Q2 = N[2]; RF = N[3];
-    } else if (MCRT_LANE_TOP && (cur & MCRT_TOP_FLAG)) {        // one of the table's nodes: four LDS reads instead of four trips through the vector memory pipe
-        const uint4 *T = S.top + (cur & 0xffff);
-        Q0 = T[0]; Q1 = T[MCRT_LANE_TOP]; Q2 = T[2 * MCRT_LANE_TOP]; RF = T[3 * MCRT_LANE_TOP];
-        asm volatile("" : "+v"(Q0.x), "+v"(Q1.x), "+v"(Q2.x), "+v"(RF.x));      // (keeps the two sides apart: merged, they become flat loads)
-    } else {
-        const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
-        Q0 = N[0]; Q1 = N[1]; Q2 = N[2]; RF = N[3];            // (as eight 8-byte pieces instead: 0.492 vs 0.427 ms per frame, round 3)
-    }
-#if defined(MCRT_SENS_LOAD)
-    // SENSITIVITY build (make variant DEFS=-DMCRT_SENS_LOAD=n): n more loads per node step and lane (4 bytes of the node's own line through a pointer the
-    // compiler cannot see through, so they are neither merged nor dropped; ordinary cached loads), folded into a word that cannot change the walk --
-    // what does one more lane access cost the launch?
-    { uint32_t off = (uint32_t)(cur & ~MCRT_TOP_FLAG) << 6; asm volatile("" : "+v"(off)); uint32_t sink = 0;
-      const uint32_t *E = (const uint32_t *)((const char *)a.nodes_walk + off);
-      for (int e = 0; e < MCRT_SENS_LOAD; e++) sink |= E[4 * (e & 3) + 1];
-      asm volatile("" : "+v"(sink)); RF.x |= sink & 0u; }
-#endif
-#if defined(MCRT_SENS_VALU)
-    // ... and n more VALU instructions per node step (a dependent chain of integer adds on a dead value)
-    { uint32_t d = Q0.x;
-      for (int e = 0; e < MCRT_SENS_VALU; e++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(d) : "v"(Q1.x));
-      asm volatile("" :: "v"(d)); }
-#endif
+    const uint4 *N = (const uint4 *)((const char *)a.nodes_walk + ((uint32_t)cur << 6));
+    const uint4 Q0 = N[0], Q1 = N[1], Q2 = N[2], RF = N[3];            // (as eight 8-byte pieces instead: 0.492 vs 0.427 ms per frame, round 3)
     lane_node_compute(S, r, t_lo, tcap, Q0, Q1, Q2, RF, cur, sp, sb);
-}
-
-// THE QUAD FETCH (MCRT_LANE_QUAD).  The vector memory pipe works through a 16-byte-per-lane load a quad of lanes at a time, and a lane that
-// reads the four pieces of ITS OWN node makes every quad of each of the four loads touch four different lines.  Here load k (k = 0..3) is
-// issued for the node of the quad's k-th lane BY ALL FOUR lanes of the quad, lane j reading piece j: a quad reads one whole line per load, and
-// the load is an LDS-DMA (global_load_lds_dwordx4: destination = image k + lane x 16), so the line lands in LDS as the contiguous node of
-// lane 4q+k, which then reads it with four ds_read_b128.  tools/quad_line.hip, dependent fetches, 16 wavefronts per CU: 490 against 1178 ns
-// per step from L1-resident nodes, 988 against 1199 ns from L2 (either half alone -- quad lines into registers, or own pieces through LDS
-// -- gains nothing).  Runs for ALL lanes of the wavefront (a lane not on an inner node stands in with the root's line for its slot).
-MCRT_DEV void lane_node_fetch_quad(const FrameArgs &a, int cur, uint32_t stage_wave /*LDS address of the wavefront's images, wave-uniform*/, uint32_t piece_off /*(lane & 3) * 16*/)
-{
-    // byte offset of piece j of the node of the quad's k-th lane: max(cur of lane k, 0) << 6 | j * 16 -- the quad broadcast and the clamp in one
-    // DPP instruction each
-    int m0, m1, m2, m3; const int zero = 0;
-    asm("v_max_i32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "=v"(m0) : "v"(cur), "v"(zero));
-    asm("v_max_i32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "=v"(m1) : "v"(cur), "v"(zero));
-    asm("v_max_i32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "=v"(m2) : "v"(cur), "v"(zero));
-    asm("v_max_i32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "=v"(m3) : "v"(cur), "v"(zero));
-    const uint32_t o0 = ((uint32_t)m0 << 6) | piece_off, o1 = ((uint32_t)m1 << 6) | piece_off, o2 = ((uint32_t)m2 << 6) | piece_off, o3 = ((uint32_t)m3 << 6) | piece_off;
-    // (M0 = LDS address of the image; one wait state between writing M0 and the LDS-DMA that reads it)
-    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %5\n\t"
-                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
-                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 :: "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(stage_wave), "s"(a.nodes_walk), "n"(MCRT_QUAD_PITCH) : "memory", "m0", "scc");
 }
 
 template <class LS> MCRT_DEV void lane_node_compute(const LS &S, const LaneRay &r, float t_lo, float tcap, const uint4 Q0, const uint4 Q1, const uint4 Q2, const uint4 RF, int &cur, int &sp, int sb)
@@ -836,14 +699,7 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
     extern __shared__ int stack_dyn[];
     __shared__ int stack_fix[DYN ? 1 : STACK * 256];
     int *const stack = DYN ? stack_dyn : stack_fix;
-    __shared__ uint4 top[MCRT_LANE_TOP ? MCRT_TOP_UNITS : 1];      // the top-of-tree table (k_pick_top), piece-major
-    __shared__ __attribute__((aligned(16))) char quad_stage[MCRT_LANE_QUAD ? 4 * 4 * MCRT_QUAD_PITCH : 16];      // [wavefront][load][lane x 16]: the quad fetch's landing area
-    static_assert(!(MCRT_LANE_QUAD && MCRT_LANE_TOP), "the quad fetch and the top-of-tree table are alternatives");
     const int tid = threadIdx.x, lane = tid & 63;
-    if (MCRT_LANE_TOP && a.n_nodes != 0u) {
-        for (int k = tid; k < MCRT_TOP_UNITS; k += 256) top[k] = a.top_nodes[k];
-        __syncthreads();
-    }
     // Bounce 0 is special: every sample path of a scan-line starts as a copy of the same first_ray (scene.cpp:83-101), so only
     // ONE ray per (frame, scan-line) is walked -- the first sample's -- and k_shade hands its hit to all S samples.
     const uint32_t n_rays = (b == 0u) ? a.ne : a.counts[b];
@@ -860,10 +716,7 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
 #define MCRT_KEYP(p) (&keys[p])
     unsigned long long st_nodes = 0, st_tris = 0, st_q = 0;
     // (overflow entries of this lane: [entry - MCRT_LANE_STACK][grid thread])
-    const LaneStackT<STACK> S = { stack, a.stack_ovf + ((size_t)blockIdx.x * 256 + tid), (size_t)gridDim.x * 256, tid, top };
-    const uint32_t quad_wave = (uint32_t)(size_t)(__attribute__((address_space(3))) char *)quad_stage + (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6) * (4u * MCRT_QUAD_PITCH);   // LDS address of this wavefront's four images
-    const uint4 *quad_node = (const uint4 *)(quad_stage + (tid >> 6) * (4 * MCRT_QUAD_PITCH) + (lane & 3) * MCRT_QUAD_PITCH + (lane >> 2) * 64);      // where this lane's node lands
-    const uint32_t quad_piece = (uint32_t)(lane & 3) * 16u;
+    const LaneStackT<STACK> S = { stack, a.stack_ovf + ((size_t)blockIdx.x * 256 + tid), (size_t)gridDim.x * 256, tid };
 
     // WORK DISTRIBUTION, XCD-aware.  Workgroups are dealt round-robin to the 8 XCDs (workgroup w runs on XCD w % 8), each with
     // its own L2.  The queue is cut into 8 contiguous sub-queues, one per XCD, each with its own cursor: an XCD sweeps ITS part
@@ -977,7 +830,7 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
                         } else if (piece > 0u) t_hi = 0.0f;
                     }
                     best.frac = t_hi; best.tri = -1;
-                    sp = 0; sb = 0; shared = false; helper = false; cur = (a.n_nodes != 0u && t_lo < t_hi) ? (MCRT_LANE_TOP ? MCRT_TOP_FLAG : 0) : CUR_IDLE; fresh = false;   // (the root is slot 0 of the table)
+                    sp = 0; sb = 0; shared = false; helper = false; cur = (a.n_nodes != 0u && t_lo < t_hi) ? 0 : CUR_IDLE; fresh = false;
                     if (STATS && piece == 0u) st_q++;
                 } else exhausted = true;
             }
@@ -1052,14 +905,7 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
                 sc_dist++;
             }
 #endif
-            if (MCRT_LANE_QUAD) {
-                lane_node_fetch_quad(a, cur, quad_wave, quad_piece);
-                if (cur >= 0) {
-                    if (STATS) st_nodes++;
-                    const uint4 Q0 = quad_node[0], Q1 = quad_node[1], Q2 = quad_node[2], RF = quad_node[3];
-                    lane_node_compute(S, lr, t_lo, tcap, Q0, Q1, Q2, RF, cur, sp, sb);
-                }
-            } else if (cur >= 0) {
+            if (cur >= 0) {
                 if (STATS) st_nodes++;
                 lane_node_step(a, S, lr, t_lo, tcap, cur, sp, sb);
             }
@@ -1188,7 +1034,7 @@ MCRT_DEV bool shade_path(const FrameArgs &a, const ShadeTables &tb, uint32_t b, 
         }
         const uint32_t line = pid / a.S, fr = line / a.ne_frame;      // (two divisions; the remainders by multiply-subtract)
         const uint32_t e_abs = a.e_begin + (line - fr * a.ne_frame);
-        Rng g; g.k0 = a.seed; g.k1 = a.frame + *a.frame_dev + fr; g.element = e_abs; g.sample = pid - line * a.S; g.bounce = b;
+        Rng g; g.k0 = a.seed; g.k1 = a.frame + fr; g.element = e_abs; g.sample = pid - line * a.S; g.bounce = b;
         const float4 m0 = tb.mat(2 * media);   // imp, att, mu0, mu1  (second half: sigma, spec, shine, thick)
         const float att = m0.y;
 
@@ -1869,20 +1715,14 @@ hipError_t launch_init(const FrameArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-uint32_t lane_top_slots() { return MCRT_LANE_TOP; }
-// top (MCRT_LANE_TOP > 0): {list of the table's nodes [MCRT_LANE_TOP], their count [1]} and the table [4][MCRT_LANE_TOP]; pick = choose the nodes again
-// (a new tree), otherwise the list is kept (a refit: same topology, new boxes)
-hipError_t launch_nodes_walk(const float4 *nodes, uint32_t n_nodes, uint4 *out, uint32_t *top_list, uint4 *top_table, bool pick, hipStream_t st)
+hipError_t launch_nodes_walk(const float4 *nodes, uint32_t n_nodes, uint4 *out, hipStream_t st)
 {
-    uint32_t *n_top = top_list ? top_list + MCRT_LANE_TOP : nullptr;
-    if (top_list && pick) hipLaunchKernelGGL(k_pick_top, dim3(1), dim3(256), 0, st, nodes, n_nodes, (uint32_t)MCRT_LANE_TOP, top_list, n_top);
-    hipLaunchKernelGGL(k_nodes_walk, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, nodes, n_nodes, out, (const uint32_t *)top_list, (const uint32_t *)n_top);
-    if (top_list) hipLaunchKernelGGL(k_top_table, dim3((4u * MCRT_LANE_TOP + 255u) / 256u), dim3(256), 0, st, (const uint4 *)out, (const uint32_t *)top_list, (const uint32_t *)n_top, top_table, (uint32_t)MCRT_LANE_TOP);
+    hipLaunchKernelGGL(k_nodes_walk, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, nodes, n_nodes, out);
     return hipGetLastError();
 }
-hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 *out, const uint32_t *top_list, hipStream_t st)
+hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_nodes_walk_decode, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, walk, n_nodes, out, top_list);
+    hipLaunchKernelGGL(k_nodes_walk_decode, dim3((n_nodes + 255u) / 256u), dim3(256), 0, st, walk, n_nodes, out);
     return hipGetLastError();
 }
 

@@ -374,7 +374,7 @@ int lbvh_build(const float *tri_dev, const uint32_t *mesh_dev, uint32_t n_tri, h
     if (n_tri >= (1u << 28)) return set_error(MCRT_ERR_LIMIT, "more than 2^28 triangles");
     const int n = (int)n_tri;
     int leaf_max = MCRT_LBVH_LEAF;                    // a subtree of at most this many triangles becomes one leaf
-    if (const char *e = getenv("MCRT_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 4) leaf_max = v; }   // tuning knob
+    if (const char *e = mcrt::tuning_env("MCRT_LBVH_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 4) leaf_max = v; }   // tuning knob
     const dim3 blk(256), grid_t((n_tri + 255u) / 256u);
     Temp tmp;
     Scal *s = nullptr; float4 *plo, *phi, *pc, *ilo, *ihi; uint64_t *k0, *k1; uint32_t *v0, *v1, *arrivals, *depth, *is4, *id4; int2 *child, *range; int *par_i, *par_l; uint8_t *k4;

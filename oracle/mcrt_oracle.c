@@ -1424,3 +1424,36 @@ void orc_wide_count(const struct orc_wide *w, const orc_scene *sc, const orc_par
         out[4 * q] = nn; out[4 * q + 1] = nl; out[4 * q + 2] = nt; out[4 * q + 3] = ms;
     }
 }
+
+/* ANALYSIS (tools/seed_count.py): what would a closest-hit bound known BEFORE the walk save?  The queries of traced segments
+ * walked over the product's BVH4 (walk_bvh4, the GPU's order) three ways, nodes and triangles counted per query:
+ *   mode 0  as today (best = 1.0, no triangle);
+ *   mode 1  PERFECT seed: best = the query's own answer (the lower bound of what any seed can give);
+ *   mode 2  LEADER seed: best = triangle seed_tri[q] (the answer of the bundle's representative ray) tested against THIS ray with the
+ *           contract's tri_test -- exact by construction (a real hit is an upper bound, the id rule still decides ties); -1 = no seed.
+ * out[q] = { nodes, triangles }, tri[q] = the triangle found (must equal the segment's own in every mode). */
+void orc_seed_count(const orc_scene *sc, const orc_params *prm, const orc_segment *segs, uint64_t n, int mode, const int32_t *seed_tri,
+                    uint32_t *out /*[n][2]*/, int32_t *tri /*[n]*/, int n_threads)
+{
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t q = 0; q < (int64_t)n; q++) {
+        const orc_segment *sg = &segs[q];
+        const v3 from0 = V(sg->from[0], sg->from[1], sg->from[2]), dir = V(sg->dir[0], sg->dir[1], sg->dir[2]);
+        const float L = 10.f * orc_logf(prm->intensity_epsilon / sg->initial_intensity) / -sg->attenuation * prm->frequency;
+        const float Ls = L / 100.0f;
+        const v3 to = V(from0.x + Ls * (sc->spacing[0] * dir.x), from0.y + Ls * (sc->spacing[1] * dir.y), from0.z + Ls * (sc->spacing[2] * dir.z));
+        const v3 from = V(from0.x + prm->ray_start_offset * dir.x, from0.y + prm->ray_start_offset * dir.y, from0.z + prm->ray_start_offset * dir.z);
+        hit_t best; best.frac = 1.0f; best.tri = -1; best.n = V(0, 0, 0); best.da = 0;
+        v3 d = vsub(to, from);
+        v3 inv = V(rcp_dir(d.x), rcp_dir(d.y), rcp_dir(d.z));
+        const v3 rc = ray_c(from, inv);
+        int32_t s = -1;
+        if (mode == 1) s = sg->tri; else if (mode == 2 && seed_tri) s = seed_tri[q];
+        if (s >= 0) tri_test(sc->tri + (size_t)s * 9, s, from, to, inv, rc, sc->pad_abs, &best);
+        orc_stats st; memset(&st, 0, sizeof st);
+        walk_bvh4(sc, from, to, &best, &st);
+        out[2 * q] = (uint32_t)st.nodes_visited; out[2 * q + 1] = (uint32_t)st.tris_tested + (s >= 0 ? 1u : 0u);
+        tri[q] = best.tri;
+    }
+}

@@ -215,6 +215,11 @@ void orc_wide_visits(struct orc_wide *w, uint32_t *visits /*[nodes] or NULL*/);
 void orc_wide_count(const struct orc_wide *w, const orc_scene *sc, const orc_params *prm, const orc_segment *segs, uint64_t n,
                     uint32_t *out, int32_t *tri, int n_threads);
 
+/* ANALYSIS (tools/seed_count.py): the queries of traced segments walked over the BVH4 with no seed (mode 0), the query's own answer as
+ * the initial closest hit (mode 1) or triangle seed_tri[q] tested against the query's ray first (mode 2); out[q] = { nodes, triangles } */
+void orc_seed_count(const orc_scene *sc, const orc_params *prm, const orc_segment *segs, uint64_t n, int mode, const int32_t *seed_tri,
+                    uint32_t *out, int32_t *tri, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

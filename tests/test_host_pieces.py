@@ -151,3 +151,19 @@ def test_single_triangle_known_answers(orc):
     assert osc.closest_hit((-0.00004, 0.5, 1), (-0.00004, 0.5, -1))[0] == 0                                   # inside Bullet's 1e-4 edge tolerance
     assert osc.closest_hit((-0.001, 0.5, 1), (-0.001, 0.5, -1))[0] == -1
     assert osc.closest_hit((0.25, 0.25, 0.0), (0.25, 0.25, -1))[0] == -1                                       # dist_a*dist_b >= 0: starts on the plane
+
+
+def test_tuning_knobs_are_gated(mcrt, monkeypatch):
+    """the library's environment knobs are read only under MCRT_TUNING=1 (csrc/mcrt_host.cpp tuning_env): here the SAH builder's leaf size"""
+    rng = np.random.default_rng(4)
+    V, F = mcrt.synth.random_triangles(3000, seed=4)
+    tri = V[F].reshape(-1, 9); tm = np.zeros(len(tri), np.uint32)
+    monkeypatch.delenv("MCRT_TUNING", raising=False)
+    monkeypatch.delenv("MCRT_SAH_LEAF_MAX", raising=False); monkeypatch.delenv("MCRT_SAH_COST_TRI", raising=False)
+    base = mcrt.host_build_bvh(tri, tm)[0]
+    monkeypatch.setenv("MCRT_SAH_LEAF_MAX", "8"); monkeypatch.setenv("MCRT_SAH_COST_TRI", "0.001")
+    ignored = mcrt.host_build_bvh(tri, tm)[0]
+    assert ignored.tobytes() == base.tobytes()                  # no MCRT_TUNING: the knobs are not even looked at
+    monkeypatch.setenv("MCRT_TUNING", "1")
+    tuned = mcrt.host_build_bvh(tri, tm)[0]
+    assert len(tuned) < len(base) // 2                          # eight cheap triangles per leaf: far fewer nodes

@@ -4,6 +4,7 @@ try:
     d=json.loads([x for x in open('gpurun_out/cs_$name.log') if x.startswith('{')][-1]); print('%-14s %.3e rays/s %8.3f ms/frame' % ('$name', d['value'], d['ms_per_step']))
 except Exception as e: print('$name FAILED', e)
 "; }
+export MCRT_TUNING=1
 for mb in auto 4096 8192; do
   if [ $mb != auto ]; then export MCRT_MARCH_BLOCKS=$mb; else unset MCRT_MARCH_BLOCKS; fi
   run C3_$mb --workload liver --scanlines 128 --rays 4096 --steps 32 --warmup 16 --frames-in-flight 16

@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC passes for one kernel (PMC_KERNEL, default k_trace_lane<false>): separate rocprofv3 runs per counter group, as the pool requires
+export MCRT_TUNING=1      # (MCRT_WIDE_FROM below is a tuning knob)
 out=gpurun_out/pmc_$1; rm -rf $out; mkdir -p $out; export TMPDIR=/tmp      # (a fresh directory: rocprofv3 names its files by process id, an older run's would be summarised too)
 B="python3 bench.py --steps 128 --warmup 128 --no-cpu-baseline --no-latency-leg --no-pmc ${BENCH_ARGS}"
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 128 --warmup 128 --no-cpu-baseline --no-latency-leg --no-pmc ${BENCH_ARGS} > $out/stats.log 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # everything profiles/<round>/ is packaged from (tools/package_profiles.py): the bench line (with its live PMC passes, CPU baseline
 # and parity check), the driver's own command, kernel statistics overlapped and standalone, PMC passes, timelines, the BASELINE configs
-tag=${1:-round}; export TMPDIR=/tmp
+tag=${1:-round}; export TMPDIR=/tmp; export MCRT_TUNING=1      # (MCRT_NO_OVERLAP below is a tuning knob)
 O=gpurun_out/profile_$tag; mkdir -p $O
 ( time timeout 600 python bench.py ) > $O/bench.json 2> $O/bench.err
 ( time timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err

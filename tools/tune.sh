@@ -8,7 +8,7 @@ fi
 for spec in "$@"; do
   name=${spec%%:*}; vars=""
   if [[ "$spec" == *:* ]]; then vars=$(echo "${spec#*:}" | tr ',' ' '); fi
-  envs=""
+  envs="MCRT_TUNING=1"      # (the knobs are only read under MCRT_TUNING=1)
   for v in $vars; do
     if [[ "$v" == LIB=* ]]; then envs="$envs MCRT_LIB=$PWD/mcray-tracing_amd/build/libmcrt_hip_${v#LIB=}.so"; else envs="$envs $v"; fi
   done
