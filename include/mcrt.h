@@ -234,12 +234,17 @@ mcrt_ctx *mcrt_group_root(mcrt_group *grp);                        /* context on
 mcrt_ctx *mcrt_group_member(mcrt_group *grp, uint32_t rank);       /* the rank's tracing context (statistics, timing, mcrt_cast_rays on one shard) */
 /* the contiguous scan-line shard of `rank` when n_elements are cut over n_ranks (no group needed) */
 int mcrt_group_shard(uint32_t rank, uint32_t n_ranks, uint32_t n_elements, uint32_t *e_begin, uint32_t *e_end);
-/* the replicated set-up calls: the single-context call of the same name on every rank (concurrently), params also on the root */
+/* the replicated set-up calls: the single-context call of the same name on every rank (concurrently), params also on the root (the ranks
+ * first: a set of parameters a context refuses leaves the whole group on the old ones).  Scene data is HOST memory in every group call: a
+ * device pointer belongs to one GPU and is refused.  With the host SAH builder (the default) the tree is built ONCE, on the calling
+ * thread, and every rank uploads a copy (round 4 built it once per rank); the device LBVH builder runs per rank on its own GPU. */
 int mcrt_group_set_params(mcrt_group *grp, const mcrt_params *p);
 int mcrt_group_set_bvh_builder(mcrt_group *grp, int builder);
-int mcrt_group_upload_scene(mcrt_group *grp, const float *tri_xyz, const uint32_t *tri_mesh, uint32_t n_tri, const mcrt_mesh *meshes, uint32_t n_mesh,
+int mcrt_group_upload_scene(mcrt_group *grp, const float *tri_xyz_host, const uint32_t *tri_mesh, uint32_t n_tri, const mcrt_mesh *meshes, uint32_t n_mesh,
                             const float *materials, uint32_t n_mat, uint32_t start_mat, const float spacing[3]);
-int mcrt_group_update_triangles(mcrt_group *grp, const float *tri_xyz_host, uint32_t n_tri);      /* host pointers only: a device pointer belongs to one GPU */
+int mcrt_group_update_triangles(mcrt_group *grp, const float *tri_xyz_host, uint32_t n_tri);
+/* seconds the last mcrt_group_upload_scene / _update_triangles spent in the host builder (once) and in the ranks' concurrent uploads */
+int mcrt_group_last_scene_seconds(mcrt_group *grp, double *build_s, double *upload_s);
 int mcrt_group_refit_triangles(mcrt_group *grp, const float *tri_xyz_host, uint32_t n_tri);
 int mcrt_group_upload_texture(mcrt_group *grp, const float *voxels, uint32_t n);                  /* NULL: the reference's texture, generated once */
 int mcrt_group_set_transducer(mcrt_group *grp, const float *pos, const float *dir, uint32_t n_elements);   /* all E elements */

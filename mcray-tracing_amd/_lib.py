@@ -64,7 +64,7 @@ SYMBOLS = ["mcrt_last_error", "mcrt_version", "mcrt_device_count", "mcrt_create"
            "mcrt_transducer_elements", "mcrt_debug_math", "mcrt_debug_philox", "mcrt_debug_stamps", "mcrt_debug_set_error", "mcrt_debug_fast_paths", "mcrt_scan_maps",
            "mcrt_group_create", "mcrt_group_destroy", "mcrt_group_size", "mcrt_group_root", "mcrt_group_member", "mcrt_group_shard", "mcrt_group_set_params",
            "mcrt_group_set_bvh_builder", "mcrt_group_upload_scene", "mcrt_group_update_triangles", "mcrt_group_refit_triangles", "mcrt_group_upload_texture",
-           "mcrt_group_set_transducer", "mcrt_group_trace_frames", "mcrt_group_trace_frames_poses", "mcrt_group_synchronize", "mcrt_group_last_pass_ms"]
+           "mcrt_group_set_transducer", "mcrt_group_trace_frames", "mcrt_group_trace_frames_poses", "mcrt_group_synchronize", "mcrt_group_last_pass_ms", "mcrt_group_last_scene_seconds"]
 
 
 def build_library(force=False):
@@ -116,6 +116,7 @@ def load_library():
         "mcrt_group_upload_scene": [vp, vp, vp, u32, vp, u32, vp, u32, u32, vp], "mcrt_group_update_triangles": [vp, vp, u32], "mcrt_group_refit_triangles": [vp, vp, u32],
         "mcrt_group_upload_texture": [vp, vp, u32], "mcrt_group_set_transducer": [vp, vp, vp, u32], "mcrt_group_trace_frames": [vp, u32, u32, vp],
         "mcrt_group_trace_frames_poses": [vp, u32, u32, vp, vp, vp], "mcrt_group_synchronize": [vp], "mcrt_group_last_pass_ms": [vp, vp, vp],
+        "mcrt_group_last_scene_seconds": [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     }
     for name, args in sig.items():
         f = getattr(L, name)

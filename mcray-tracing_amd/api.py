@@ -366,9 +366,12 @@ class Group:
             if not hasattr(self.params, k):
                 raise AttributeError(k)
             setattr(self.params, k, v)
-        check(self.L.mcrt_group_set_params(self.h, C.byref(self.params)))
-        for c in [self.root] + self.members:
-            check(self.L.mcrt_get_params(c.h, C.byref(c.params)))
+        try:
+            check(self.L.mcrt_group_set_params(self.h, C.byref(self.params)))
+        finally:       # (refused parameters leave every context on the old ones: read back what the group really holds)
+            for c in [self.root] + self.members:
+                check(self.L.mcrt_get_params(c.h, C.byref(c.params)))
+            check(self.L.mcrt_get_params(self.root.h, C.byref(self.params)))
 
     def set_bvh_builder(self, builder):
         kind = {"sah": 0, "lbvh": 1}[builder] if isinstance(builder, str) else int(builder)
@@ -408,6 +411,12 @@ class Group:
 
     def synchronize(self):
         check(self.L.mcrt_group_synchronize(self.h))
+
+    def last_scene_seconds(self):
+        """(host SAH build -- once, on the calling thread --, the ranks' concurrent uploads) of the last upload_scene / update_triangles"""
+        b, u = C.c_double(), C.c_double()
+        check(self.L.mcrt_group_last_scene_seconds(self.h, C.byref(b), C.byref(u)))
+        return b.value, u.value
 
     def last_pass_ms(self):
         t = np.zeros(self.size, np.float32); c = np.zeros(self.size, np.float32)

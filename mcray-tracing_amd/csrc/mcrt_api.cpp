@@ -392,8 +392,22 @@ extern "C" int mcrt_get_params(mcrt_ctx *c, mcrt_params *out)
     return MCRT_OK;
 }
 
-// builds the BVH over tri[n_tri][9] (host or device pointer) with the context's builder and installs it on the device
-static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
+// a deep copy of a host-built tree (the context frees its trees with mcrt_free_bvh / mcrt_free_bvh4: malloc'ed arrays)
+static int copy_tree(const mcrt::HostTree &src, mcrt_bvh *bvh, mcrt_bvh4 *bvh4)
+{
+    *bvh = *src.bvh; *bvh4 = *src.bvh4;
+    bvh->nodes = nullptr; bvh->tri = nullptr; bvh4->nodes = nullptr;
+    const size_t nb = sizeof(mcrt_bvh_node) * (size_t)src.bvh->n_nodes, tb = 48 * (size_t)src.bvh->n_tri, n4 = sizeof(mcrt_bvh4_node) * (size_t)src.bvh4->n_nodes;
+    bvh->nodes = (mcrt_bvh_node *)malloc(nb ? nb : 1); bvh->tri = (float *)malloc(tb ? tb : 1); bvh4->nodes = (mcrt_bvh4_node *)malloc(n4 ? n4 : 1);
+    if (!bvh->nodes || !bvh->tri || !bvh4->nodes) { mcrt_free_bvh(bvh); mcrt_free_bvh4(bvh4); return set_error(MCRT_ERR_NOMEM, "out of host memory"); }
+    memcpy(bvh->nodes, src.bvh->nodes, nb); memcpy(bvh->tri, src.bvh->tri, tb); memcpy(bvh4->nodes, src.bvh4->nodes, n4);
+    return MCRT_OK;
+}
+
+// builds the BVH over tri[n_tri][9] (host or device pointer) with the context's builder and installs it on the device.
+// pre: a tree the HOST builder has already made of exactly these triangles (mcrt_group builds once for all its ranks); ignored by the
+// device builder, which needs no host work
+static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri, const mcrt::HostTree *pre = nullptr)
 {
     // k_trace addresses nodes (64 B as walked) and triangle records (64 B) with 32-bit byte offsets
     if (n_tri >= (1u << 25)) return set_error(MCRT_ERR_LIMIT, "%u triangles: the walk addresses at most 2^25 (32-bit byte offsets into 64-byte nodes and records)", n_tri);
@@ -430,7 +444,7 @@ static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
         return MCRT_OK;
     }
     std::vector<float> host_copy;
-    {   // the host builder reads host memory
+    if (!pre) {   // the host builder reads host memory
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, tri) == hipSuccess && at.type == hipMemoryTypeDevice) {
             host_copy.resize((size_t)n_tri * 9);
@@ -438,10 +452,17 @@ static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
             tri = host_copy.data();
         } else (void)hipGetLastError();
     }
-    int rc = mcrt_build_bvh(tri, c->tri_mesh.data(), n_tri, &c->bvh);
-    if (rc) return rc;
-    rc = mcrt_build_bvh4(&c->bvh, &c->bvh4);
-    if (rc) return rc;
+    int rc;
+    if (pre) {
+        if (pre->bvh->n_tri != n_tri) return set_error(MCRT_ERR_INVALID, "prebuilt tree has %u triangles, the scene %u", pre->bvh->n_tri, n_tri);
+        rc = copy_tree(*pre, &c->bvh, &c->bvh4);
+        if (rc) return rc;
+    } else {
+        rc = mcrt_build_bvh(tri, c->tri_mesh.data(), n_tri, &c->bvh);
+        if (rc) return rc;
+        rc = mcrt_build_bvh4(&c->bvh, &c->bvh4);
+        if (rc) return rc;
+    }
     for (int i = 0; i < 3; i++) { c->scene_lo[i] = INFINITY; c->scene_hi[i] = -INFINITY; }
     for (int k = 0; k < 4; k++) {
         const mcrt_bvh4_child &ch = c->bvh4.nodes[0].c[k];
@@ -504,7 +525,7 @@ extern "C" int mcrt_set_bvh_builder(mcrt_ctx *c, int builder)
     return MCRT_OK;
 }
 
-extern "C" int mcrt_update_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
+static int update_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri, const mcrt::HostTree *pre)
 {
     CTX_TRY(c);
     if (!c->have_scene) return set_error(MCRT_ERR_INVALID, "no scene uploaded");
@@ -512,11 +533,12 @@ extern "C" int mcrt_update_triangles(mcrt_ctx *c, const float *tri, uint32_t n_t
     if (n_tri != c->bvh.n_tri || n_tri == 0) return set_error(MCRT_ERR_INVALID, "the scene has %u triangles, the update has %u", c->bvh.n_tri, n_tri);
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_scene = false;                           // a failed rebuild leaves no scene
-    int rc = index_triangles(c, tri, n_tri); if (rc) return rc;
+    int rc = index_triangles(c, tri, n_tri, pre); if (rc) return rc;
     rc = refresh_soa(c); if (rc) return rc;
     c->have_scene = true;
     return MCRT_OK;
 }
+extern "C" int mcrt_update_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri) { return update_triangles(c, tri, n_tri, nullptr); }
 
 extern "C" int mcrt_refit_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri)
 {
@@ -544,9 +566,9 @@ extern "C" int mcrt_refit_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tr
     return MCRT_OK;
 }
 
-extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *tri_mesh, uint32_t n_tri,
-                                 const mcrt_mesh *meshes, uint32_t n_mesh, const float *mats, uint32_t n_mat,
-                                 uint32_t start_mat, const float spacing[3])
+static int upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *tri_mesh, uint32_t n_tri,
+                        const mcrt_mesh *meshes, uint32_t n_mesh, const float *mats, uint32_t n_mat,
+                        uint32_t start_mat, const float spacing[3], const mcrt::HostTree *pre)
 {
     CTX_TRY(c);
     if (!meshes || !mats || n_mesh == 0 || n_mat == 0 || !spacing) return set_error(MCRT_ERR_INVALID, "mcrt_upload_scene: missing tables");
@@ -560,7 +582,7 @@ extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *
     free_scene(c);
     if (n_tri) {
         c->tri_mesh.assign(tri_mesh, tri_mesh + n_tri);
-        int rc = index_triangles(c, tri, n_tri); if (rc) return rc;
+        int rc = index_triangles(c, tri, n_tri, pre); if (rc) return rc;
         rc = refresh_soa(c); if (rc) return rc;
     }
     HIP_TRY(hipMalloc(&c->d_mats, 32 * (size_t)n_mat));
@@ -571,6 +593,22 @@ extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *
     for (int i = 0; i < 3; i++) c->spacing[i] = spacing[i];
     c->have_scene = true; c->mtab_valid = false;
     return prepare_tables(c);
+}
+extern "C" int mcrt_upload_scene(mcrt_ctx *c, const float *tri, const uint32_t *tri_mesh, uint32_t n_tri,
+                                 const mcrt_mesh *meshes, uint32_t n_mesh, const float *mats, uint32_t n_mat,
+                                 uint32_t start_mat, const float spacing[3])
+{
+    return upload_scene(c, tri, tri_mesh, n_tri, meshes, n_mesh, mats, n_mat, start_mat, spacing, nullptr);
+}
+// for mcrt_group.cpp: the same calls with a tree the host builder has already made (see index_triangles)
+namespace mcrt {
+int ctx_bvh_builder(const mcrt_ctx *c) { return c ? c->builder : MCRT_BVH_HOST_SAH; }
+int upload_scene_with_tree(mcrt_ctx *c, const float *tri, const uint32_t *tri_mesh, uint32_t n_tri, const mcrt_mesh *meshes, uint32_t n_mesh,
+                           const float *mats, uint32_t n_mat, uint32_t start_mat, const float spacing[3], const HostTree *pre)
+{
+    return upload_scene(c, tri, tri_mesh, n_tri, meshes, n_mesh, mats, n_mat, start_mat, spacing, pre);
+}
+int update_triangles_with_tree(mcrt_ctx *c, const float *tri, uint32_t n_tri, const HostTree *pre) { return update_triangles(c, tri, n_tri, pre); }
 }
 
 extern "C" int mcrt_get_bvh(mcrt_ctx *c, mcrt_bvh *out)

@@ -18,6 +18,7 @@
 #include "mcrt_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -43,6 +44,7 @@ struct Member {
     bool used[2] = { false, false };                 // the events of slot i have been recorded at least once
     float *blk[2] = { nullptr, nullptr }; size_t blk_cap[2] = { 0, 0 };
     int last_slot = -1;
+    uint64_t copied_pass = 0;                        // the pass (1-based) whose peer copy this rank enqueued last
 };
 }  // namespace
 
@@ -54,6 +56,9 @@ struct mcrt_group {
     float *stage[2] = { nullptr, nullptr }; size_t stage_cap[2] = { 0, 0 };
     hipEvent_t ev_reordered[2] = {}, ev_root_now[2] = {}; bool reordered_used[2] = { false, false };
     uint64_t pass = 0;
+    int builder = MCRT_BVH_HOST_SAH;                 // what mcrt_group_set_bvh_builder last set on every rank
+    std::vector<uint32_t> tri_mesh;                  // per-triangle mesh index of the uploaded scene (the host builder of mcrt_group_update_triangles needs it)
+    double last_build_s = 0.0, last_upload_s = 0.0;  // host SAH build (once, calling thread) and the ranks' uploads (concurrent) of the last scene call
     // the ranks' host threads
     std::vector<std::thread> threads;
     std::mutex mu; std::condition_variable cv_job, cv_done;
@@ -195,28 +200,31 @@ extern "C" mcrt_ctx *mcrt_group_member(mcrt_group *g, uint32_t rank) { return (g
 
 #define GRP_TRY(g) do { if (!(g)) return set_error(MCRT_ERR_INVALID, "null group"); } while (0)
 
+// The ranks take the new parameters first and the root last: a set of parameters some context refuses leaves the group on the old ones
+// (the ranks that had accepted are put back), never half on each.
 extern "C" int mcrt_group_set_params(mcrt_group *g, const mcrt_params *p)
 {
     GRP_TRY(g);
     if (!p) return set_error(MCRT_ERR_INVALID, "null params");
-    int rc = mcrt_set_params(g->root, p); if (rc) return rc;
-    const mcrt_params pp = *p;
-    rc = run_all(g, [g, pp](uint32_t r) { return mcrt_set_params(g->mem[r].ctx, &pp); });
-    if (!rc) g->p = pp;
-    return rc;
+    const mcrt_params pp = *p, old = g->p;
+    int rc = run_all(g, [g, pp](uint32_t r) { return mcrt_set_params(g->mem[r].ctx, &pp); });
+    if (!rc) rc = mcrt_set_params(g->root, &pp);
+    if (rc) {
+        const std::string keep = mcrt_last_error();
+        (void)run_all(g, [g, old](uint32_t r) { return mcrt_set_params(g->mem[r].ctx, &old); });
+        (void)mcrt_set_params(g->root, &old);
+        return set_error(rc, "%s", keep.c_str());
+    }
+    g->p = pp;
+    return MCRT_OK;
 }
 
 extern "C" int mcrt_group_set_bvh_builder(mcrt_group *g, int builder)
 {
     GRP_TRY(g);
-    return run_all(g, [g, builder](uint32_t r) { return mcrt_set_bvh_builder(g->mem[r].ctx, builder); });
-}
-
-extern "C" int mcrt_group_upload_scene(mcrt_group *g, const float *tri, const uint32_t *tri_mesh, uint32_t n_tri, const mcrt_mesh *meshes, uint32_t n_mesh,
-                                       const float *mats, uint32_t n_mat, uint32_t start_mat, const float spacing[3])
-{
-    GRP_TRY(g);
-    return run_all(g, [=](uint32_t r) { return mcrt_upload_scene(g->mem[r].ctx, tri, tri_mesh, n_tri, meshes, n_mesh, mats, n_mat, start_mat, spacing); });
+    const int rc = run_all(g, [g, builder](uint32_t r) { return mcrt_set_bvh_builder(g->mem[r].ctx, builder); });
+    if (!rc) g->builder = builder;
+    return rc;
 }
 
 static int host_pointer_only(const void *p, const char *who)
@@ -228,12 +236,69 @@ static int host_pointer_only(const void *p, const char *who)
     return MCRT_OK;
 }
 
+// THE HOST BUILDER RUNS ONCE.  The SAH build (mcrt_build_bvh + mcrt_build_bvh4: 0.7 s for 1 M triangles, itself multi-threaded) is host work that
+// does not depend on the GPU: the calling thread builds the tree, every rank's thread copies it and uploads (rounds 4 ran the single-context
+// call on every rank: N identical builds racing for the host's cores).  The device builder (MCRT_BVH_DEVICE_LBVH) needs no host work and runs
+// per rank, on its own GPU.
+namespace {
+struct BuiltOnce {
+    mcrt_bvh bvh{}; mcrt_bvh4 bvh4{}; mcrt::HostTree tree{ nullptr, nullptr }; bool have = false;
+    ~BuiltOnce() { if (have) { mcrt_free_bvh(&bvh); mcrt_free_bvh4(&bvh4); } }
+    int build(const float *tri, const uint32_t *tri_mesh, uint32_t n_tri)
+    {
+        int rc = mcrt_build_bvh(tri, tri_mesh, n_tri, &bvh);
+        if (!rc) { have = true; rc = mcrt_build_bvh4(&bvh, &bvh4); }
+        if (!rc) { tree.bvh = &bvh; tree.bvh4 = &bvh4; }
+        return rc;
+    }
+};
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+extern "C" int mcrt_group_upload_scene(mcrt_group *g, const float *tri, const uint32_t *tri_mesh, uint32_t n_tri, const mcrt_mesh *meshes, uint32_t n_mesh,
+                                       const float *mats, uint32_t n_mat, uint32_t start_mat, const float spacing[3])
+{
+    GRP_TRY(g);
+    if (n_tri && (!tri || !tri_mesh)) return set_error(MCRT_ERR_INVALID, "mcrt_group_upload_scene: missing triangles");
+    if (tri) { int rc = host_pointer_only(tri, "mcrt_group_upload_scene"); if (rc) return rc; }
+    BuiltOnce once;
+    const double t0 = now_s();
+    if (n_tri && g->builder == MCRT_BVH_HOST_SAH) {
+        for (uint32_t i = 0; i < n_tri; i++)          // (mcrt_upload_scene's own check, needed before the builder reads the table)
+            if (tri_mesh[i] >= n_mesh) return set_error(MCRT_ERR_INVALID, "triangle %u references mesh %u out of range", i, tri_mesh[i]);
+        int rc = once.build(tri, tri_mesh, n_tri); if (rc) return rc;
+    }
+    const double t1 = now_s();
+    const mcrt::HostTree *pre = once.tree.bvh ? &once.tree : nullptr;
+    const int rc = run_all(g, [=](uint32_t r) { return mcrt::upload_scene_with_tree(g->mem[r].ctx, tri, tri_mesh, n_tri, meshes, n_mesh, mats, n_mat, start_mat, spacing, pre); });
+    g->last_build_s = t1 - t0; g->last_upload_s = now_s() - t1;
+    if (!rc) { if (n_tri) g->tri_mesh.assign(tri_mesh, tri_mesh + n_tri); else g->tri_mesh.clear(); }
+    return rc;
+}
+
 extern "C" int mcrt_group_update_triangles(mcrt_group *g, const float *tri, uint32_t n_tri)
 {
     GRP_TRY(g);
     if (!tri) return set_error(MCRT_ERR_INVALID, "null triangles");
     { int rc = host_pointer_only(tri, "mcrt_group_update_triangles"); if (rc) return rc; }
-    return run_all(g, [=](uint32_t r) { return mcrt_update_triangles(g->mem[r].ctx, tri, n_tri); });
+    BuiltOnce once;
+    const double t0 = now_s();
+    if (g->builder == MCRT_BVH_HOST_SAH && n_tri != 0 && n_tri == g->tri_mesh.size()) {      // (a wrong count is the ranks' error to report)
+        int rc = once.build(tri, g->tri_mesh.data(), n_tri); if (rc) return rc;
+    }
+    const double t1 = now_s();
+    const mcrt::HostTree *pre = once.tree.bvh ? &once.tree : nullptr;
+    const int rc = run_all(g, [=](uint32_t r) { return mcrt::update_triangles_with_tree(g->mem[r].ctx, tri, n_tri, pre); });
+    g->last_build_s = t1 - t0; g->last_upload_s = now_s() - t1;
+    return rc;
+}
+
+extern "C" int mcrt_group_last_scene_seconds(mcrt_group *g, double *build_s, double *upload_s)
+{
+    GRP_TRY(g);
+    if (build_s) *build_s = g->last_build_s;
+    if (upload_s) *upload_s = g->last_upload_s;
+    return MCRT_OK;
 }
 
 extern "C" int mcrt_group_refit_triangles(mcrt_group *g, const float *tri, uint32_t n_tri)
@@ -284,6 +349,7 @@ static int group_trace(mcrt_group *g, uint32_t frame, uint32_t F, const float *p
     if (E < G) return set_error(MCRT_ERR_INVALID, "%u scan-lines cannot be cut over %u ranks", E, G);
     const int i = (int)(g->pass & 1u);
     g->pass++;
+    const uint64_t this_pass = g->pass;                 // (>= 1: a Member's copied_pass starts at 0)
     std::vector<uint32_t> off(G + 1);
     for (uint32_t r = 0; r < G; r++) { uint32_t b, e; mcrt_group_shard(r, G, E, &b, &e); off[r] = b; off[r + 1] = e; }
     // one frame (or one rank): the blocks are contiguous pieces of the frame and land in place; otherwise they are staged on the root
@@ -315,12 +381,16 @@ static int group_trace(mcrt_group *g, uint32_t frame, uint32_t F, const float *p
         if (m.device == g->root_device) G_HIP(hipMemcpyAsync(dst, m.blk[i], bytes, hipMemcpyDeviceToDevice, m.copy));
         else G_HIP(hipMemcpyPeerAsync(dst, g->root_device, m.blk[i], m.device, bytes, m.copy));
         G_HIP(hipEventRecord(m.ev_copied[i], m.copy));
-        m.used[i] = true; m.last_slot = i;
+        m.used[i] = true; m.last_slot = i; m.copied_pass = this_pass;
         return MCRT_OK;
     });
-    if (rc) return rc;
+    // Also when a rank failed: the ranks that succeeded have peer copies into rf_dev / the staging buffer in flight on their own copy streams.
+    // The root's stream is ordered behind every copy that WAS enqueued in this pass, so a caller that handles the error by reusing or freeing
+    // rf_dev behind the root's stream (mcrt_synchronize(mcrt_group_root(g)), or more work on that stream) does not race with them.
     G_HIP(hipSetDevice(g->root_device));
-    for (uint32_t r = 0; r < G; r++) G_HIP(hipStreamWaitEvent(root_stream, g->mem[r].ev_copied[i], 0));
+    for (uint32_t r = 0; r < G; r++)
+        if (g->mem[r].copied_pass == this_pass) G_HIP(hipStreamWaitEvent(root_stream, g->mem[r].ev_copied[i], 0));
+    if (rc) return rc;
     if (staged) {
         G_HIP(mcrt::launch_blocks_to_frames(stage, rf_dev, F, E, R, G, off.data(), root_stream));
         G_HIP(hipEventRecord(g->ev_reordered[i], root_stream));

@@ -29,3 +29,14 @@ int set_error(int code, const char *fmt, ...);
 // for tools/ and tests/, which set MCRT_TUNING=1 beside the knob they turn.
 const char *tuning_env(const char *name);
 }
+#ifdef MCRT_H
+// mcrt_api.cpp <-> mcrt_group.cpp: a scene (or a triangle update) installed with a tree the HOST builder has already made of exactly
+// these triangles -- a group builds once on the calling thread and every rank copies and uploads (the device builder ignores it)
+namespace mcrt {
+struct HostTree { const mcrt_bvh *bvh; const mcrt_bvh4 *bvh4; };
+int ctx_bvh_builder(const mcrt_ctx *c);
+int upload_scene_with_tree(mcrt_ctx *c, const float *tri, const uint32_t *tri_mesh, uint32_t n_tri, const mcrt_mesh *meshes, uint32_t n_mesh,
+                           const float *mats, uint32_t n_mat, uint32_t start_mat, const float spacing[3], const HostTree *pre);
+int update_triangles_with_tree(mcrt_ctx *c, const float *tri, uint32_t n_tri, const HostTree *pre);
+}
+#endif

@@ -4,7 +4,40 @@ rank g traces the contiguous block [g*E/G, (g+1)*E/G) with the scene replicated,
 pass needs 12 columns of halo (rfimage.h:113-118), so convolution runs on the gathered image."""
 import torch
 
-_GATHER_TO_ROOT_OK = True      # cleared when the backend refuses dist.gather (every rank then falls back to the all-gather, in the same call)
+_GATHER_TO_ROOT = {}           # backend name -> does it gather to a root?  Decided ONCE per backend, by ALL ranks together (_gather_to_root_ok)
+
+
+def _unsupported(ex):
+    """is this the backend saying "I have no such collective" (raised on every rank before anything is sent) -- as opposed to a failure of
+    this rank, which must not be papered over: the peers would sit in a different collective"""
+    if isinstance(ex, NotImplementedError):
+        return True
+    msg = str(ex).lower()
+    return isinstance(ex, RuntimeError) and any(k in msg for k in ("not support", "unsupported", "not implemented", "does not implement"))
+
+
+def _gather_to_root_ok(dist, group, like):
+    """Can the group's backend gather to a root?  Probed with a 1-element gather the first time a backend is used, and the answer is the
+    MINIMUM over the ranks (an all-reduce), so every rank takes the same branch from then on -- a rank-local surprise can no longer send
+    one rank into an all-gather while its peers wait in a gather.  Anything but "unsupported" is re-raised."""
+    be = dist.get_backend(group)
+    if be not in _GATHER_TO_ROOT:
+        me, world = dist.get_rank(group), dist.get_world_size(group)
+        ok = 1
+        probe = torch.zeros(1, dtype=torch.float32, device=like.device)
+        try:
+            dist.gather(probe, [torch.zeros_like(probe) for _ in range(world)] if me == 0 else None,
+                        dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        except Exception as ex:
+            if not _unsupported(ex):
+                raise
+            ok = 0
+            import sys
+            sys.stderr.write("mcray_tracing_amd.dist: %s has no gather (%s): all_gather_into_tensor instead\n" % (be, str(ex).splitlines()[0]))
+        flag = torch.tensor([ok], dtype=torch.int32, device=like.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        _GATHER_TO_ROOT[be] = bool(int(flag.item()))
+    return _GATHER_TO_ROOT[be]
 
 
 def shard_range(rank, world, n_elements):
@@ -36,22 +69,14 @@ def gather_rf(rf_local, n_elements, n_rows, dist=None, group=None, root=None):
     else:                                                           # ragged shards: pad to the largest block
         mine = torch.zeros((F, ne_max, n_rows), dtype=loc.dtype, device=loc.device)
         mine[:, : loc.shape[1]] = loc
-    global _GATHER_TO_ROOT_OK
     stacked = None
-    if root is not None and _GATHER_TO_ROOT_OK:
+    if root is not None and _gather_to_root_ok(dist, group, mine):
         me = dist.get_rank(group)
         flat = torch.empty((world, F, ne_max, n_rows), dtype=loc.dtype, device=loc.device) if me == root else None
-        try:
-            dist.gather(mine, list(flat.unbind(0)) if me == root else None, dst=dist.get_global_rank(group, root) if group is not None else root, group=group)
-        except (RuntimeError, NotImplementedError, ValueError) as ex:
-            # a backend without gather raises on EVERY rank before anything is sent: all of them take the all-gather below, now and from here on
-            _GATHER_TO_ROOT_OK = False
-            import sys
-            sys.stderr.write("mcray_tracing_amd.dist: dist.gather refused (%s): falling back to all_gather_into_tensor\n" % str(ex).splitlines()[0])
-        else:
-            if me != root:
-                return None
-            stacked = flat
+        dist.gather(mine, list(flat.unbind(0)) if me == root else None, dst=dist.get_global_rank(group, root) if group is not None else root, group=group)
+        if me != root:           # (an error here is this rank's own and propagates: no silent change of collective)
+            return None
+        stacked = flat
     if stacked is None:
         flat = torch.empty((world * F, ne_max, n_rows), dtype=loc.dtype, device=loc.device)      # rank blocks concatenated along dim 0
         dist.all_gather_into_tensor(flat, mine, group=group)

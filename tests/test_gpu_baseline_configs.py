@@ -5,9 +5,8 @@ Every configuration is traced on the GPU at FULL size and compared with the CPU 
   C3        liver-like scene (225 280 triangles), 128 x 4096
   C4        1 M random triangles, 256 x 8192
   C5        liver-like scene, 512 x 16384, + PSF convolution
-(C1 and C2, the sphere configurations, are in test_gpu_parity.py.)  The oracle checks every scan-line where that takes it
-well under a minute on the box's host cores, else a seeded subset of scan-line blocks (its e_begin/e_end range) -- the
-GPU always traces the whole frame.  Bars: hit indices bit-exact; fixed-point RF image bit-exact; reference-order float
+(C1 and C2, the sphere configurations, are in test_gpu_parity.py.)  The oracle checks EVERY scan-line of every configuration (since
+round 5 also C5's: ~40 s of the box's 16 cores), in blocks of scan-lines (its e_begin/e_end range); the GPU traces the whole frame at once.  Bars: hit indices bit-exact; fixed-point RF image bit-exact; reference-order float
 image within 1e-4 both relative to the peak and element-wise (|d| <= 1e-4 |ref| + 1e-6 peak; see assert_rf for how the
 reference's own float accumulation noise is kept out of the comparison at thousands of samples per scan-line); BVH node / triangle
 visit counts equal to the oracle's walk of the same tree (they are the roofline's algorithmic bytes)."""
@@ -62,7 +61,7 @@ def _setup(mcrt, orc, cfg, sd, E, S, tex, **kw):
 def _blocks(E, width, n, seed):
     """n disjoint scan-line blocks of `width`, seeded; always includes the first and the last block of the frame"""
     starts = list(range(0, E - width + 1, width))
-    if n is None or os.environ.get("MCRT_FULL_ORACLE"):          # the oracle on EVERY scan-line (C4 always: ~16 s of 16 cores; C5 with MCRT_FULL_ORACLE=1: ~75 s)
+    if n is None or os.environ.get("MCRT_FULL_ORACLE"):          # the oracle on EVERY scan-line (C4: ~16 s of 16 cores; C5: ~40 s)
         return [(s0, s0 + width) for s0 in starts]
     rng = np.random.default_rng(seed)
     pick = {0, len(starts) - 1}
@@ -187,9 +186,9 @@ def test_c4_1m_triangles_256x8192(mcrt, orc, tex256):
 
 def test_c5_liver_512x16384_psf(mcrt, orc, tex256):
     """BASELINE config 5: liver-like scene, 512 scan-lines x 16384 rays (8.4 M paths) + PSF convolution -- GPU traces and
-    convolves the full frame; the oracle checks eight seeded blocks of 32 scan-lines (half the frame, 4.2 M paths; MCRT_FULL_ORACLE=1: all
-    sixteen, run by hand once per round on the final binary), and the convolution of the block
-    interiors (the lateral pass reads 12 columns to the right, rfimage.h:113-118)"""
+    convolves the full frame; the oracle checks EVERY scan-line (round 5: the whole frame by default, in sixteen blocks of 32 scan-lines,
+    each traced once by the oracle: hits, fixed-point and reference-order RF, and the convolution of the block's interior -- the lateral pass
+    reads 12 columns to the right, rfimage.h:113-118)"""
     cfg, meshes = mcrt.synth.liver_scene(5)
     sd = mcrt.scene_io.build_scene(cfg, meshes)
     E, S, frame = 512, 16384, 7
@@ -198,17 +197,18 @@ def test_c5_liver_512x16384_psf(mcrt, orc, tex256):
     hits, _, _ = sim.ctx.trace_frame_debug(frame, sim.rf_dev)
     rf = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
     p = orc.default_params(n_elements=E, n_samples=S)
-    blocks = _blocks(E, 32, 8, seed=5)
-    _check_blocks(orc, osc, tr, tex256, hits, rf, p, frame, blocks, threads)
-    del hits
-    # PSF convolution of the whole frame on the GPU == the oracle's convolution of the GPU's (verified) raw image
+    # PSF convolution of the whole frame on the GPU == the oracle's convolution of the GPU's raw image (verified block by block below)
     sim.convolve()
     rfc = sim.ctx.export_rf(sim.rf_dev, E, sim.R)
     oc = orc.convolve(rf, sim.psf.axial_kernel, sim.psf.lateral_kernel)
     assert np.array_equal(rfc.view(np.uint32), oc.view(np.uint32))
-    # ... and, independently of the GPU's raw image, inside every oracle-checked block
+    blocks = _blocks(E, 32, None, seed=5)
+    assert blocks[0][0] == 0 and blocks[-1][1] == E and len(blocks) == 16
     for b0, b1 in blocks:
-        o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, e_begin=b0, e_end=b1, use_bvh=2, n_threads=threads, want_hits=False, want_ref=False)
+        o = osc.trace_frame(p, tr.pos, tr.dir, tex256, frame_id=frame, e_begin=b0, e_end=b1, use_bvh=2, n_threads=threads, want_ref64=True)
+        assert np.array_equal(hits[b0:b1], o["hits"]), "hit indices differ in scan-lines [%d,%d)" % (b0, b1)
+        assert_rf(rf, o, (b0, b1))
+        # ... and, independently of the GPU's raw image, the convolved frame inside the block
         ob = orc.convolve(o["rf"], sim.psf.axial_kernel, sim.psf.lateral_kernel)          # [R][32]: columns 6..18 of the block are complete
         lo, hi = 6, (b1 - b0) - 13
         assert np.array_equal(rfc[:, b0 + lo:b0 + hi].view(np.uint32), ob[:, lo:hi].view(np.uint32))

@@ -752,6 +752,11 @@ def test_two_ranks_gather_equals_single_process():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["scan_lines_total"] == 32
     g = out["gather_check"]
     assert g["equal"] and g["ranks"] == 2 and g["nonzero"] > 1000, g
+    # WHICH backend carried the green run is part of the record (pytest -q prints the warnings summary): "nccl" = RCCL saw two ranks
+    import warnings
+    assert g["backend"] in ("nccl", "gloo") and g["backend"] == tried[-1][0]
+    warnings.warn("two-rank gather on this box ran over backend=%s%s" % (g["backend"], " (RCCL)" if g["backend"] == "nccl" else
+                  " (host-staged; RCCL refused two ranks on one device: %s)" % (tried[0][2].strip().splitlines()[-1][:160] if tried[0][2].strip() else "timed out")))
     # strong scaling: a fixed 24-scan-line frame over the two ranks
     r, out = _run_bench([a for a in small if a not in ("--scanlines", "16")] + ["--scanlines-total", "24", "--backend", g["backend"]], nproc=2, timeout=300)
     assert r is not None and r.returncode == 0 and out is not None, "" if r is None else (r.stderr or "")[-800:]
