@@ -307,6 +307,9 @@ int mcrt_debug_philox(mcrt_ctx *ctx, const uint32_t ctr[4], const uint32_t key[2
  * latest wave end, summed wave lifetimes; the first two stored complemented), out[60..119] per-bounce wavefront counts, start
  * times, longest lifetime and node-step iterations, out[120..129] cycle sums of k_march's sections (tools/stamps.py decodes them); all zero otherwise */
 int mcrt_debug_stamps(mcrt_ctx *ctx, uint64_t out[200], int reset);
+/* the same diagnostic builds: per bounce b < 10, out[256 b + ...]: [0..63] wavefronts of the walk by the time they END, [64..127] by the time they
+ * find the ray queue dry (20 us bins on the wavefront's own clock), [128..191] by the node-step iterations (bins of 8) since their last successful claim, [192..255] by the time since their last successful claim; all zero otherwise */
+int mcrt_debug_tail_histograms(mcrt_ctx *ctx, uint64_t out[2560], int reset);
 /* which of the RF accumulation's fast paths the context's LAST traced frame ran with (they are switched on by checks made on the
  * device, and a check that fails silently costs a third of the frame): out[0] the reciprocal-multiply voxel quotient (verified
  * exhaustively against IEEE division for params.tex_res), out[1] the branch-free voxel cell, out[2] the entries of the padded

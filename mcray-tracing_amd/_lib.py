@@ -61,7 +61,7 @@ SYMBOLS = ["mcrt_last_error", "mcrt_version", "mcrt_device_count", "mcrt_create"
            "mcrt_envelope", "mcrt_scan_convert", "mcrt_export_rf", "mcrt_alloc", "mcrt_free", "mcrt_memcpy_d2h",
            "mcrt_memcpy_h2d", "mcrt_enable_stats", "mcrt_get_stats", "mcrt_enable_timing", "mcrt_get_kernel_time",
            "mcrt_build_bvh", "mcrt_free_bvh", "mcrt_get_bvh", "mcrt_build_bvh4", "mcrt_free_bvh4", "mcrt_get_bvh4", "mcrt_row_thresholds", "mcrt_generate_texture", "mcrt_psf_kernels",
-           "mcrt_transducer_elements", "mcrt_debug_math", "mcrt_debug_philox", "mcrt_debug_stamps", "mcrt_debug_set_error", "mcrt_debug_fast_paths", "mcrt_scan_maps",
+           "mcrt_transducer_elements", "mcrt_debug_math", "mcrt_debug_philox", "mcrt_debug_stamps", "mcrt_debug_tail_histograms", "mcrt_debug_set_error", "mcrt_debug_fast_paths", "mcrt_scan_maps",
            "mcrt_group_create", "mcrt_group_destroy", "mcrt_group_size", "mcrt_group_root", "mcrt_group_member", "mcrt_group_shard", "mcrt_group_set_params",
            "mcrt_group_set_bvh_builder", "mcrt_group_upload_scene", "mcrt_group_update_triangles", "mcrt_group_refit_triangles", "mcrt_group_upload_texture",
            "mcrt_group_set_transducer", "mcrt_group_trace_frames", "mcrt_group_trace_frames_poses", "mcrt_group_synchronize", "mcrt_group_last_pass_ms", "mcrt_group_last_scene_seconds"]
@@ -109,7 +109,7 @@ def load_library():
         "mcrt_row_thresholds": [C.c_double, u32, vp],
         "mcrt_generate_texture": [vp, u32], "mcrt_psf_kernels": [C.c_float, C.c_float, C.c_float, u32, vp, u32, vp, u32],
         "mcrt_transducer_elements": [u32, C.c_double, C.c_double, vp, vp, vp, vp],
-        "mcrt_debug_math": [vp, i32, vp, vp, vp, u32], "mcrt_debug_philox": [vp, vp, vp, vp], "mcrt_debug_stamps": [vp, vp, i32], "mcrt_debug_set_error": [vp, u32], "mcrt_debug_fast_paths": [vp, vp],
+        "mcrt_debug_math": [vp, i32, vp, vp, vp, u32], "mcrt_debug_philox": [vp, vp, vp, vp], "mcrt_debug_stamps": [vp, vp, i32], "mcrt_debug_tail_histograms": [vp, vp, i32], "mcrt_debug_set_error": [vp, u32], "mcrt_debug_fast_paths": [vp, vp],
         "mcrt_scan_maps": [u32, u32, C.c_double, C.c_double, u32, u32, u32, u32, vp, vp],
         "mcrt_group_create": [vp, u32, C.POINTER(vp)], "mcrt_group_destroy": [vp], "mcrt_group_size": [vp], "mcrt_group_root": [vp], "mcrt_group_member": [vp, u32],
         "mcrt_group_shard": [u32, u32, u32, C.POINTER(u32), C.POINTER(u32)], "mcrt_group_set_params": [vp, C.POINTER(Params)], "mcrt_group_set_bvh_builder": [vp, i32],

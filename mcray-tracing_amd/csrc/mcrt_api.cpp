@@ -224,7 +224,7 @@ extern "C" int mcrt_create(int device, mcrt_ctx **out)
     mcrt_default_params(&c->p);
     c->c = derive_consts(c->p);
     c->stream = c->own_stream;
-    if (hipMalloc(&c->d_stats, 256 * sizeof(unsigned long long)) != hipSuccess || hipMemsetAsync(c->d_stats, 0, 256 * sizeof(unsigned long long), c->stream) != hipSuccess ||
+    if (hipMalloc(&c->d_stats, MCRT_STATS_WORDS * sizeof(unsigned long long)) != hipSuccess || hipMemsetAsync(c->d_stats, 0, MCRT_STATS_WORDS * sizeof(unsigned long long), c->stream) != hipSuccess ||
         hipMalloc(&c->d_error, 4) != hipSuccess || hipMemsetAsync(c->d_error, 0, 4, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
         hipStreamDestroy(c->own_stream); delete c; return set_error(MCRT_ERR_HIP, "hipMalloc failed");
     }
@@ -1212,6 +1212,16 @@ extern "C" int mcrt_debug_stamps(mcrt_ctx *c, uint64_t out[200], int reset)
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, c->d_stats + 8, 200 * 8, hipMemcpyDeviceToHost));
     if (reset) { HIP_TRY(hipMemsetAsync(c->d_stats + 8, 0, 200 * 8, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+    return MCRT_OK;
+}
+
+extern "C" int mcrt_debug_tail_histograms(mcrt_ctx *c, uint64_t out[2560], int reset)
+{
+    CTX_TRY(c);
+    if (!out) return set_error(MCRT_ERR_INVALID, "null out pointer");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->d_stats + 256, 2560 * 8, hipMemcpyDeviceToHost));
+    if (reset) { HIP_TRY(hipMemsetAsync(c->d_stats + 256, 0, 2560 * 8, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); }
     return MCRT_OK;
 }
 

@@ -17,6 +17,7 @@
 #define MCRT_XCD_MIN_ITEMS 262144     // bounces with fewer work items use a single queue
 #define MCRT_MAX_ROWS 2048
 #define MCRT_MAX_BOUNCES 16
+#define MCRT_STATS_WORDS (256 + 2560)  // the context's counter block: 8 statistics, 248 stamps (mcrt_debug_stamps), 10 x 256 tail histograms (mcrt_debug_tail_histograms)
 
 #ifndef MCRT_TRI_PIECES
 #define MCRT_TRI_PIECES 3             // 16-byte pieces of the walk's triangle record: 3 = v0|id, v1|mesh, v2|edge tolerance (48 B, the plane rebuilt from the vertices);

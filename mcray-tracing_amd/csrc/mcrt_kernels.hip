@@ -758,7 +758,13 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
 #endif
 #if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
     // timeline only (a handful of atomics per wavefront: usable on the production schedule)
-    const unsigned long long wc_start = wall_clock64(); unsigned long long wc_empty = 0, wc_steps = 0;
+    const unsigned long long wc_start = wall_clock64(); unsigned long long wc_empty = 0, wc_steps = 0, wc_lastclaim = 0, wc_claimsteps = 0, wc_drysteps = 0; uint32_t wc_inflight = 0;
+    // histograms of the launch's tail, per bounce b < 10 at a.stamps[248 + 256 b + ...] (mcrt_debug_tail_histograms; 20 us bins on the wavefront's own clock):
+    // [0..63] wavefront ends, [64..127] wavefront finds the queue dry, [128..191] node-step iterations (bins of 8) between the wavefront's last successful claim and that moment, [192..255] time from the wavefront's last successful claim to that moment
+    unsigned long long *const hist = a.stamps + 248 + 256 * (b < 10u ? b : 9u);
+    __shared__ unsigned long long wg_end[4]; __shared__ unsigned int wg_done;      // when this workgroup's wavefronts ended (the last one bins how long it outlived the others)
+    if (tid == 0) wg_done = 0u;
+    __syncthreads();
     if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 0], ~wc_start);
 #endif
     MCRT_WATCHDOG_DECL()
@@ -789,12 +795,18 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
                     base = __shfl(base, 0, 64);
                     const uint32_t hi = MCRT_SUB_LO(cur_x + 1u);
                     const unsigned long long start = (unsigned long long)MCRT_SUB_LO(cur_x) + MCRT_SUB_STATIC(cur_x) + base;
-                    if (start < hi) { pool_next = (uint32_t)start; pool_end = min((uint32_t)start + fetch, hi); }
+                    if (start < hi) {
+#if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
+                        wc_lastclaim = wall_clock64(); wc_claimsteps = wc_steps;
+#endif
+                        pool_next = (uint32_t)start; pool_end = min((uint32_t)start + fetch, hi);
+                    }
                     else if (++visited >= X) queue_empty = true;      // (the launch enters its TAIL: it only finishes the rays in flight from here on.  Round 4 let the
                                                                       //  accumulation's stream wait for this moment -- a device word + hipStreamWaitValue32 --: slower)
                     else cur_x = (cur_x + 1u) & (X - 1u);
 #if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
-                    if (queue_empty) { wc_empty = wall_clock64(); if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 1], ~wc_empty); }
+                    if (queue_empty) { wc_empty = wall_clock64(); if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 1], ~wc_empty);
+                                       wc_inflight = (uint32_t)__popcll(MCRT_WALKING(cur)); wc_drysteps = wc_steps - wc_claimsteps; }
 #endif
                 }
                 if (need && i == 0xffffffffu) {
@@ -956,6 +968,17 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
         atomicAdd(&a.stamps[60 + 2 * b], wc_empty ? wc_end - wc_empty : 0ull); atomicAdd(&a.stamps[61 + 2 * b], 1ull);   // time after the queue ran dry; wavefronts
         atomicAdd(&a.stamps[80 + b], wc_start); atomicMax(&a.stamps[90 + b], wc_end - wc_start);                          // start times (sum); longest life
         atomicAdd(&a.stamps[100 + b], wc_steps); atomicMax(&a.stamps[110 + b], wc_steps);                                  // node-step iterations: sum, most
+        atomicAdd(&hist[min(63ull, (wc_end - wc_start) / 2000ull)], 1ull);
+        wg_end[tid >> 6] = wc_end;
+        __threadfence_block();
+        if (atomicAdd(&wg_done, 1u) == 3u) {          // the workgroup's last wavefront: how long after the SECOND-last did it end?
+            unsigned long long second = 0;
+            for (int k = 0; k < 4; k++) if (k != (tid >> 6) && wg_end[k] > second) second = wg_end[k];
+            atomicAdd(&a.stamps[160 + min(15ull, (wc_end - second) / 2000ull)], 1ull);      // 20 us bins, all bounces together: stamps[160..175]
+            if (b == 1u && (wc_end - wc_start) / 2000ull >= 47ull) atomicAdd(&a.stamps[140 + min(15ull, (wc_end - second) / 2000ull)], 1ull);   // ... and of bounce 1's workgroups that end after 940 us: stamps[140..155]
+        }
+        if (wc_empty) { atomicAdd(&hist[64 + min(63ull, (wc_empty - wc_start) / 2000ull)], 1ull); atomicAdd(&hist[128 + min(63ull, wc_drysteps / 8ull)], 1ull);
+                        atomicAdd(&hist[192 + min(63ull, (wc_empty - (wc_lastclaim ? wc_lastclaim : wc_start)) / 2000ull)], 1ull); }
     }
 #endif
 #undef LSTAMP

@@ -735,6 +735,13 @@ def _run_bench(extra, nproc=1, timeout=600):
     return r, (json.loads(lines[-1]) if lines else None)
 
 
+def _why(stderr_tail):
+    """the most telling line of a failed child's stderr"""
+    lines = [l.strip() for l in (stderr_tail or "").splitlines() if l.strip() and set(l.strip()) - set("=-")]
+    hits = [l for l in lines if "rror" in l or "NCCL" in l or "nccl" in l]
+    return (hits[-1] if hits else (lines[-1] if lines else "timed out"))[:200]
+
+
 def test_two_ranks_gather_equals_single_process():
     """bench.py's N > 1 path (scan-line shards, ONE all-gather per pass on the post stream, PSF on the gathered frames,
     double-buffered against the next pass's trace) with two ranks in fresh child processes on this box's one GPU: the gathered
@@ -756,7 +763,7 @@ def test_two_ranks_gather_equals_single_process():
     import warnings
     assert g["backend"] in ("nccl", "gloo") and g["backend"] == tried[-1][0]
     warnings.warn("two-rank gather on this box ran over backend=%s%s" % (g["backend"], " (RCCL)" if g["backend"] == "nccl" else
-                  " (host-staged; RCCL refused two ranks on one device: %s)" % (tried[0][2].strip().splitlines()[-1][:160] if tried[0][2].strip() else "timed out")))
+                  " (host-staged; RCCL did not carry two ranks on one device: %s)" % _why(tried[0][2])))
     # strong scaling: a fixed 24-scan-line frame over the two ranks
     r, out = _run_bench([a for a in small if a not in ("--scanlines", "16")] + ["--scanlines-total", "24", "--backend", g["backend"]], nproc=2, timeout=300)
     assert r is not None and r.returncode == 0 and out is not None, "" if r is None else (r.stderr or "")[-800:]

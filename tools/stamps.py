@@ -15,13 +15,16 @@ sim = m.Simulator(sd, tr, n_samples=rays)
 ctx = sim.ctx
 rf = torch.empty((F, 128, sim.R), dtype=torch.float32, device="cuda")
 out = (C.c_uint64 * 200)()
+hist = (C.c_uint64 * 2560)()
 for f in range(3):
     ctx.trace_frames(f * F, F, rf, 0, 128)
 ctx.synchronize()
 ctx.L.mcrt_debug_stamps(ctx.h, out, 1)
+ctx.L.mcrt_debug_tail_histograms(ctx.h, hist, 1)
 ctx.trace_frames(100, F, rf, 0, 128)          # ONE pass: the timeline slots hold min/max over what ran since the reset
 ctx.synchronize()
 ctx.L.mcrt_debug_stamps(ctx.h, out, 1)
+ctx.L.mcrt_debug_tail_histograms(ctx.h, hist, 1)
 v = [int(x) for x in out]
 if v[8]:      # (a -DMCRT_STAMP_LITE build carries only the timeline)
     names = ["refill cyc", "phase1 cyc", "phase2 cyc", "phase1 iters", "phase2 iters", "outer iters", "active lanes p1 (sum)", "active lanes p2 (sum)", "waves"]
@@ -50,6 +53,25 @@ for b in range(10):
     print("%4d   %10.1f   %10.1f (%.0f%%)   %8d   %10.1f   %10.1f" % (b, dur, em, 100 * em / dur if dur else 0, waves, life / 100.0 / max(waves, 1), (v[60 + 2 * b] / 100.0 / max(waves, 1)) if lane else float("nan")), end="")
     if lane and waves: print("   | %8.1f %10.1f | %8.1f %8d" % ((v[80 + b] / waves - start) / 100.0, v[90 + b] / 100.0, v[100 + b] / waves, v[110 + b]))
     else: print()
+H = np.array([int(x) for x in hist], np.int64).reshape(10, 256)
+if H.sum():
+    print("\ntail of each walk launch (wavefronts by 20 us bins on their own clock): when they END / when they FIND THE QUEUE DRY; lanes still walking at that moment")
+    for b in range(10):
+        end, dry, infl, since = H[b, :64], H[b, 64:128], H[b, 128:192], H[b, 192:256]
+        if not end.sum(): continue
+        def pct(h, q):
+            c = np.cumsum(h); return 20.0 * (int(np.searchsorted(c, q * c[-1])) + 1) if c[-1] else float("nan")
+        print("bounce %d: end p10 / p50 / p90 / p99 / last = %4.0f / %4.0f / %4.0f / %4.0f / %4.0f us   dry p10 / p50 / p90 / p99 / last = %4.0f / %4.0f / %4.0f / %4.0f / %4.0f us   node-step iterations last claim -> dry p50 / p90 / p99 / last = %3.0f / %3.0f / %3.0f / %3.0f   last claim -> dry p50 / p90 / p99 / last = %4.0f / %4.0f / %4.0f / %4.0f us"
+              % (b, pct(end, .1), pct(end, .5), pct(end, .9), pct(end, .99), 20.0 * (np.nonzero(end)[0].max() + 1),
+                 pct(dry, .1), pct(dry, .5), pct(dry, .9), pct(dry, .99), 20.0 * (np.nonzero(dry)[0].max() + 1) if dry.sum() else float("nan"),
+                 pct(infl, .5) * 0.4, pct(infl, .9) * 0.4, pct(infl, .99) * 0.4, 8.0 * (np.nonzero(infl)[0].max() + 1) if infl.sum() else float("nan"), pct(since, .5), pct(since, .9), pct(since, .99), 20.0 * (np.nonzero(since)[0].max() + 1) if since.sum() else float("nan")))
+    if os.environ.get("STAMPS_DUMP"):
+        for b in (1, 5, 9):
+            print("bounce %d end  :" % b, " ".join(str(int(x)) for x in H[b, :64]))
+            print("bounce %d dry  :" % b, " ".join(str(int(x)) for x in H[b, 64:128]))
+if sum(v[160:176]):
+    print("\nthe LAST wavefront of a workgroup outlives the second-last by (20 us bins, all bounces):", " ".join(str(x) for x in v[160:176]))
+    print("... of bounce 1's workgroups that end after 940 us:", " ".join(str(x) for x in v[140:156]))
 if lane: sys.exit(0)
 h = v[60:77]
 tot_h = sum(h) or 1
