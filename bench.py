@@ -23,10 +23,11 @@ frame (mcrt_trace_frames_poses: the moving probe of transducer.h:82-118).  `per_
 rank's trace / gather / post-processing time per step (HIP events on the streams they run on).
 
 The JSON line carries
-  roofline      dominant kernel (k_trace) against the roof that binds it -- VALU issue, calibrated by
-                tools/valu_roof.hip (profiles/round2/valu_roof.json) -- plus the measured HBM share
-                (`hbm_measured_frac`: fabric bytes from rocprofv3 PMC passes of this same command, taken
-                live in child processes at the same pass size) and the cache-served algorithmic rate;
+  roofline      the dominant kernel (the BVH walk) against the guide's architectural VALU issue rate (`frac`), its
+                lane-level share, the measured HBM share (`hbm.measured_frac`: fabric bytes from rocprofv3 PMC
+                passes of this same command, taken live in child processes at the same pass size; `traffic`),
+                the cache-served algorithmic rate, the vector-memory-pipe roof, the self-calibrated roof of
+                earlier rounds (`calibrated`), and the same figures for k_march and k_shade (`kernels`);
   cpu_baseline  the oracle (a port of the reference algorithm) on this box's host cores;
   parity_check  frame 0 of the timed workload against the oracle, bit for bit.
 """
@@ -48,8 +49,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMD = 1024           # 256 CUs x 4 SIMD-32
+PMC_ROUND = "round5" if os.path.exists(os.path.join(ROOT, "profiles", "round5", "pmc_bench.json")) else "round4"      # the committed single-GPU passes N > 1 runs fall back to
 MIN_SPLIT_PASS = 48     # N > 1: a timed region is cut into two passes (gather + post of the first hidden behind the second) only if each has this many frames
 TRACE_KERNELS = ("k_trace_lane<false", "k_trace_lane_wide")   # the walk of the timed build: its four- and five-wavefront forms (large launches take the second), pooled
+KERNEL_FAMILIES = {"walk": TRACE_KERNELS, "march": ("k_march<false",), "shade": ("k_shade<false",)}
+ARCH_IPC = 0.5          # MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles on the SIMD-32 -> 0.5 instructions per cycle and SIMD
 
 
 def build_workload(m, name):
@@ -354,16 +358,56 @@ def main():
                        "warmup_steps_run": W_run, "step": "clear, trace, accumulate, [all-gather], PSF, envelope, scan conversion to %dx%d" % (pipe.OUT_ROWS, pipe.OUT_COLS)},
             "ranks_seen": world, "per_rank": per_rank,
         }
-        roof = {"frac_vs_architectural": None, "kernel": "k_trace_lane<false> / k_trace_lane_wide (the walk: launches of >= 4 Mi rays take the five-wavefront form)", "kernel_ms": k_ms, "launches": k_n, "launches_per_frame": launches_per_frame,
-                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps_cache_served": alg_gbs, "node_bytes": node_bytes,
-                "trace_bytes_per_frame": trace_bytes_frame, "other_stage_bytes_per_frame": other_bytes_frame,
-                "per_frame": {k: v / K for k, v in st.items()}}
+        per_frame = {k: v / K for k, v in st.items()}
         pmc = None
         if world == 1 and not args.no_pmc:
             pmc = live_pmc(args)
         if pmc is None:
-            pmc = committed_pmc(args, pass_sizes, roof["per_frame"]["queries"] / launches_per_frame)
-        roof.update(roofline_from(pmc, k_ms, alg_gbs))
+            pmc = committed_pmc(args, pass_sizes, per_frame["queries"] / launches_per_frame)
+        roof = roofline_from(pmc, k_ms, alg_gbs, alg_bytes)
+        roof.update({"kernel": "k_trace_lane<false> / k_trace_lane_wide (the walk: launches of >= 4 Mi rays take the five-wavefront form)", "kernel_ms": k_ms, "launches": k_n,
+                     "launches_per_frame": launches_per_frame, "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps_cache_served": alg_gbs, "node_bytes": node_bytes,
+                     "trace_bytes_per_frame": trace_bytes_frame, "other_stage_bytes_per_frame": other_bytes_frame, "per_frame": per_frame})
+        if world == 1 and not args.no_latency_leg:
+            # ---- the bounce's OTHER kernels: one more region with k_shade's and k_march's launches bracketed too (untimed: the timed
+            # region carries the walk's events only), and the same region on a context whose kernels do not overlap (each alone on the GPU)
+            ctx.enable_timing(2); ctx.kernel_times(reset=True)
+            pipe.run_steps(4000, K); pipe.sync()
+            t_over = ctx.kernel_times(reset=True)
+            ctx.enable_timing(False)
+            t_alone = None
+            try:
+                os.environ["MCRT_TUNING"] = "1"; os.environ["MCRT_NO_OVERLAP"] = "1"
+                ctx2 = m.Context(local_rank)
+            finally:
+                os.environ.pop("MCRT_NO_OVERLAP", None); os.environ.pop("MCRT_TUNING", None)
+            try:
+                ctx2.set_params(n_elements=E, n_samples=S, n_rows=R, frequency=tr.frequency, tex_n=args.tex_n)
+                ctx2.set_bvh_builder(args.bvh); ctx2.upload_scene(sd); ctx2.upload_texture(None, args.tex_n); ctx2.set_transducer(tr.pos, tr.dir)
+                ctx2.set_stream(pipe.s_trace.cuda_stream)
+                f = 5000
+                for rep in range(2):
+                    if rep == 1: ctx2.enable_timing(2); ctx2.kernel_times(reset=True)
+                    for nf in pass_sizes:
+                        ctx2.trace_frames(f, nf, pipe.buf[0], e0, e1); f += nf
+                    ctx2.synchronize()
+                t_alone = ctx2.kernel_times(reset=True)
+            finally:
+                ctx2.close(); ctx.set_stream(pipe.s_trace.cuda_stream)
+            clock = valu_calibration()["clock_ghz"]
+            other = (pmc or {}).get("other_kernels", {})
+            lpf = launches_per_frame                      # launches per frame of every per-bounce kernel
+            roof["kernels"] = {
+                "k_trace_lane": {"what": "the walk (this block's top level): duration beside k_march / alone", "ms_per_launch_overlapped": t_over["walk"][0], "ms_per_launch_alone": t_alone["walk"][0],
+                                 "dilation_beside_the_rest": t_over["walk"][0] / t_alone["walk"][0] if t_alone["walk"][0] else None},
+                "k_march": kernel_block("k_march", "RF accumulation (main.cpp:106-144): per RF step one 8-byte texture gather + the sequential advance of point, time, intensity that reproduces the reference's float recurrence bit for bit (both lanes of a pair repeat it: half of its ~63 lane-instructions per step)",
+                                        t_over["march"][0], t_alone["march"][0], other.get("march"),
+                                        (per_frame["rf_steps"] * 8.0 + per_frame["segments"] * 48.0) / lpf, clock,
+                                        note="algorithmic bytes = RF steps x 8 B (texture gather) + segments x 48 B (march record); runs on a low-priority side stream beside the NEXT bounce's walk"),
+                "k_shade": kernel_block("k_shade", "interface physics + queue compaction (scene.cpp:122-165, ray.cpp:11-97), one lane per ray",
+                                        t_over["shade"][0], t_alone["shade"][0], other.get("shade"), per_frame["queries"] * 212.0 / lpf, clock,
+                                        note="algorithmic bytes = 212 B per ray (state in and out 96, march record 48, winning triangle 3 x 16, keys / queue / counts 20)"),
+            }
         out["roofline"] = roof
         if world == 1 and F > 1 and not args.no_latency_leg:
             # the same workload strictly one frame at a time (each launch carries one frame's rays), for the record
@@ -434,67 +478,108 @@ def tcp_access_cost():
         return 1.32, "default (no calibration file)"
 
 
-def roofline_from(pmc, k_ms, alg_gbs):
-    """k_trace against the roofs that bind it.  The BVH is served from L1 / L2 / Infinity Cache (fabric traffic is a few per cent of the
-    HBM peak at 1 M triangles), so the binding roofs are on the CU: VALU issue -- achieved = wave-level VALU instructions per second
-    (SQ_INSTS_VALU of the launch / its duration), peak = 1024 SIMDs x calibrated instructions per cycle x calibrated clock -- and the vector
-    memory pipe (second_roof: the time the launch's counted cache accesses need at the cheapest measured cost per access, over its duration)."""
+def roofline_from(pmc, k_ms, alg_gbs, alg_bytes):
+    """The walk against its roofs, GUIDE-ANCHORED numbers first.
+    The path has no dense contraction (no MFMA) and its tree is served from L1 / L2 / Infinity Cache (fabric traffic is a few per cent of the HBM
+    peak at 1 M triangles), so neither of the contract's two roofs binds; the roof that does is on the CU:
+      frac      = wave-level VALU instructions per second (SQ_INSTS_VALU of the launch / its HIP-event duration) over the ARCHITECTURAL issue rate,
+                  1024 SIMDs x 0.5 instructions per cycle (MI355X_MICROARCH.md: 2 cycles per wave64 instruction) x the clock the calibration run held;
+                  frac_lane_level = frac x the share of lanes active in those instructions
+      hbm       = the contract's HBM view, kept beside it: algorithmic bytes per launch over the launch's duration (a cache-served rate: it may exceed
+                  the HBM peak) and the MEASURED fabric bytes per launch (`traffic`; separate --pmc passes, gfx950 correction) over the same duration
+      second_roof = the CU's vector memory pipe (time the launch's counted cache accesses need at the cheapest measured cost per access)
+      calibrated  = rounds 2-4's self-calibrated roof (the issue rate of a register-only replica of the kernel's own node step): secondary"""
     cal = valu_calibration()
-    peak = N_SIMD * cal["ipc_per_simd"] * cal["clock_ghz"]            # G wave-instructions / s
-    r = {"frac_vs_architectural": None, "bound": "valu", "unit": "Ginstr/s", "peak": peak, "peak_source": cal,
-         "peak_is": "the issue rate of a register-only replica of this kernel's CURRENT node step (tools/valu_roof.hip, round 4), NOT the architectural rate: see frac_vs_architectural",
-         "kernel_ms_is": "HIP-event time of the walk's launches on the stream they run on, with k_march running beside them on its side stream (contention included)",
-         "hbm_peak_GBps": HBM_PEAK_GBS, "algorithmic_over_hbm_peak": alg_gbs / HBM_PEAK_GBS}
+    clock = cal["clock_ghz"]
+    peak = N_SIMD * ARCH_IPC * clock                                   # G wave-instructions / s, architectural
+    r = {"bound": "valu", "unit": "Ginstr/s", "peak": peak,
+         "peak_is": "architectural VALU issue rate: 1024 SIMDs x 0.5 wave64 instructions per cycle (MI355X_MICROARCH.md) x %.3f GHz (the clock held during tools/valu_roof.hip)" % clock,
+         "bound_note": "neither HBM nor MFMA binds this kernel (cache-resident tree, no dense contraction); the contract's HBM figures are under `hbm`, `traffic` is the measured fabric bytes per launch",
+         "kernel_ms_is": "HIP-event time of the walk's launches on the stream they run on, with k_march running beside them on its side stream (contention included)"}
+    hbm = {"peak_GBps": HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps_cache_served": alg_gbs, "algorithmic_over_hbm_peak": alg_gbs / HBM_PEAK_GBS}
     if pmc and pmc.get("valu_instructions_per_launch") and k_ms > 0:
         ach = pmc["valu_instructions_per_launch"] / (k_ms * 1e-3) / 1e9
-        r.update({"achieved": ach, "frac": ach / peak, "frac_of_calibrated_mix": ach / peak,
-                  "frac_vs_best_class": ach / (N_SIMD * cal.get("best_class_ipc_per_simd", 0.43) * cal["clock_ghz"]),        # plain integer adds: the best class measured
-                  "frac_vs_architectural": ach / (N_SIMD * 0.5 * cal["clock_ghz"]),                                       # MI355X_MICROARCH.md: 2 cycles per wave64 instruction
-                  "derived": bool(pmc.get("derived"))})
+        cal_peak = N_SIMD * cal["ipc_per_simd"] * clock
+        r.update({"achieved": ach, "frac": ach / peak, "frac_vs_architectural": ach / peak, "derived": bool(pmc.get("derived"))})
         if pmc.get("lane_utilisation") is not None:
             r["valu_lane_utilisation"] = pmc["lane_utilisation"]
+            r["frac_lane_level"] = ach / peak * pmc["lane_utilisation"]
+        r["calibrated"] = {"what": "rounds 2-4's roof: the issue rate of a register-only replica of this kernel's CURRENT node step (tools/valu_roof.hip) -- 'this code minus its memory stalls', not a hardware peak",
+                           "peak": cal_peak, "frac": ach / cal_peak, "frac_vs_best_class": ach / (N_SIMD * cal.get("best_class_ipc_per_simd", 0.43) * clock), "peak_source": cal}
     else:
-        r.update({"achieved": None, "frac": None})
+        r.update({"achieved": None, "frac": None, "frac_vs_architectural": None})
     if pmc and pmc.get("tcp_lane_accesses_per_launch") and k_ms > 0:
-        # the OTHER roof of the walk (DESIGN.md 5.2): the CU's vector memory pipe.  Cost model (round 4, fetch_roof_same under --pmc): every
-        # access the counter counts costs at least `cost` cycles of its CU's pipe, whatever the sharing pattern; the launch cannot be shorter
-        # than its accesses x cost / (256 CUs x clock).  frac = that time / the launch's duration: it cannot exceed 1 (up to the clock).
+        # the OTHER roof of the walk (DESIGN.md 5.1): the CU's vector memory pipe.  Cost model (round 4, fetch_roof_same under --pmc): every access the
+        # counter counts costs at least `cost` cycles of its CU's pipe, whatever the sharing pattern; the launch cannot be shorter than its accesses
+        # x cost / (256 CUs x clock).  The accesses are counted on the walk's FOUR-wavefront form (what the walk needs); where the timed launches ran
+        # in the five-wavefront form (>= 4 Mi rays: its refill code spills, coalesced scratch accesses the counter counts per lane) the as-run count
+        # is reported beside it and the pair (needed accesses, as-run duration) is labelled as mixed (ADVICE r4).
         cost, src = tcp_access_cost()
-        t_ms = pmc["tcp_lane_accesses_per_launch"] * cost / 256.0 / (cal["clock_ghz"] * 1e6)
+        need, as_run = pmc["tcp_lane_accesses_per_launch"], pmc.get("tcp_lane_accesses_per_launch_as_run")
+        t_ms = need * cost / 256.0 / (clock * 1e6)
+        same_form = as_run is None or abs(as_run - need) <= 0.02 * need
         r["second_roof"] = {"what": "vector memory pipe (TCP) of the CUs: time the launch's counted cache accesses need at the cheapest measured cost per access",
-                            "accesses_per_launch": pmc["tcp_lane_accesses_per_launch"], "cycles_per_access_floor": cost, "clock_ghz": cal["clock_ghz"],
-                            "pipe_ms": t_ms, "kernel_ms": k_ms, "frac": t_ms / k_ms, "source": "TCP_TOTAL_CACHE_ACCESSES of the walk's launches; cost: " + src}
+                            "accesses_per_launch": need, "accesses_per_launch_as_run": as_run, "cycles_per_access_floor": cost, "clock_ghz": clock,
+                            "pipe_ms": t_ms, "kernel_ms": k_ms, "frac": t_ms / k_ms,
+                            "consistent_pair": bool(same_form),
+                            "pair_note": ("accesses and duration are of the same (four-wavefront) form" if same_form else
+                                          "MIXED: accesses counted on the four-wavefront form, duration of the five-wavefront form the timed launches took; as-run accesses x cost / duration = %.3f is an upper bound (spill accesses are served a wavefront at a time)" % (as_run * cost / 256.0 / (clock * 1e6) / k_ms)),
+                            "source": "TCP_TOTAL_CACHE_ACCESSES of the walk's launches; cost: " + src}
         if r.get("frac") is not None:
-            r["binding_roof"] = "vector memory pipe (second_roof)" if t_ms / k_ms > r["frac"] else "valu issue (frac)"
+            calf = r["calibrated"]["frac"]
+            r["binding_roof"] = "vector memory pipe (second_roof)" if t_ms / k_ms > calf else "valu issue (calibrated mix)"
             # sensitivity builds (profiles/round4/exp_sensitivity.txt): one more load per node step costs the walk 3 %, ten more instructions 2 % -- the
             # nearer roof is not a wall on its own, the walk sits at the knee of the two
-            r["binding_roof_note"] = "both roofs are within a few per cent of the launch; measured marginal costs in profiles/round4/exp_sensitivity.txt"
+            r["binding_roof_note"] = "compared on the self-calibrated scale (pipe time share vs calibrated VALU share); both within a few per cent of the launch; marginal costs in profiles/round4/exp_sensitivity.txt"
     if pmc and pmc.get("traffic_bytes_per_launch") is not None and k_ms > 0:
         r["traffic"] = pmc["traffic_bytes_per_launch"]
-        r["hbm_measured_GBps"] = pmc["traffic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9
-        r["hbm_measured_frac"] = r["hbm_measured_GBps"] / HBM_PEAK_GBS
+        hbm["measured_GBps"] = pmc["traffic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9
+        hbm["measured_frac"] = hbm["measured_GBps"] / HBM_PEAK_GBS
+        hbm["traffic_over_algorithmic"] = pmc["traffic_bytes_per_launch"] / alg_bytes if alg_bytes else None
         if pmc.get("fetch_size_kib") is not None:
             # profiles/round4/fetch_size_calibration.json: the walk's scattered 64-byte node reads are ONE fabric request each, counted as 64 bytes;
             # the guide's doubling (right for coalesced 128-byte requests) is an upper bound for them.  Both readings are reported.
             one = (pmc["fetch_size_kib"] + pmc["write_size_kib"]) * 1024.0
-            r["traffic_one_unit_per_request"] = one
-            r["hbm_measured_frac_one_unit_per_request"] = one / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            hbm["traffic_one_unit_per_request"] = one
+            hbm["measured_frac_one_unit_per_request"] = one / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        r["hbm_measured_frac"] = hbm["measured_frac"]
     else:
         r["traffic"] = None; r["hbm_measured_frac"] = None
+    r["hbm"] = hbm
     r["pmc"] = pmc
     return r
 
 
-def _pmc_rows(d):
-    """counter values of the walk's launches (both of its kernels), per counter"""
+def kernel_block(name, what, t_ms, t_alone_ms, pmc_k, alg_bytes, clock, note=None):
+    """one of the bounce's other kernels in the walk's terms: duration per launch beside the rest of the pipeline and alone (dilation), its VALU
+    issue share of the architectural rate over its own duration, lane-level share, algorithmic and measured bytes"""
+    peak = N_SIMD * ARCH_IPC * clock
+    o = {"what": what, "ms_per_launch_overlapped": t_ms, "ms_per_launch_alone": t_alone_ms,
+         "dilation_beside_the_rest": (t_ms / t_alone_ms) if t_ms and t_alone_ms else None,
+         "algorithmic_bytes_per_launch": alg_bytes}
+    if note: o["note"] = note
+    for label, t in (("overlapped", t_ms), ("alone", t_alone_ms)):
+        if pmc_k and t:
+            ach = pmc_k["valu_instructions_per_launch"] / (t * 1e-3) / 1e9
+            o["valu_frac_vs_architectural_" + label] = ach / peak
+            if alg_bytes: o["algorithmic_GBps_" + label] = alg_bytes / (t * 1e-3) / 1e9
+            if pmc_k.get("traffic_bytes_per_launch") is not None: o["hbm_measured_frac_" + label] = pmc_k["traffic_bytes_per_launch"] / (t * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if pmc_k:
+        o.update({"valu_instructions_per_launch": pmc_k["valu_instructions_per_launch"], "valu_lane_utilisation": pmc_k.get("lane_utilisation"),
+                  "tcp_lane_accesses_per_launch": pmc_k.get("tcp_lane_accesses_per_launch"), "traffic": pmc_k.get("traffic_bytes_per_launch")})
+    return o
+
+
+def _pmc_rows(d, family="walk"):
+    """counter values of one kernel family's launches (the walk: both of its kernels), per counter"""
     per = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if any(k in row["Kernel_Name"] for k in TRACE_KERNELS):
+            if any(k in row["Kernel_Name"] for k in KERNEL_FAMILIES[family]):
                 per.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     if not per:
         return {}, None
-    return per, "k_trace_lane<false> + k_trace_lane_wide"
+    return per, " + ".join(k + ">" if k.endswith("false") else k for k in KERNEL_FAMILIES[family])
 
 
 def live_pmc(args):
@@ -508,6 +593,7 @@ def live_pmc(args):
              "--workload", args.workload, "--scanlines", str(args.scanlines), "--scanlines-total", str(args.scanlines_total), "--rays", str(args.rays),
              "--rows", str(args.rows), "--tex-n", str(args.tex_n), "--frames-in-flight", str(args.frames_in_flight), "--bvh", args.bvh]
     got = {}
+    other = {}
     tmp = tempfile.mkdtemp(prefix="mcrt_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
@@ -527,6 +613,11 @@ def live_pmc(args):
             got["kernel"] = kname
             for c, v in rows.items():
                 got[c + "@all" if name == "tcp_all" else c] = (sum(v) / len(v), len(v))
+            if name != "tcp":                                   # the other two kernels of a bounce, from the same passes (as run)
+                for fam in ("march", "shade"):
+                    rows_f, _ = _pmc_rows(d, fam)
+                    for c, v in rows_f.items():
+                        other.setdefault(fam, {})[c] = (sum(v) / len(v), len(v))
     except Exception:
         return None
     finally:
@@ -541,7 +632,13 @@ def live_pmc(args):
                 "tcp_lane_accesses_counted_on": "the walk's four-wavefront form (MCRT_WIDE_FROM off for this pass): the accesses the walk needs",
                 "tcp_lane_accesses_per_launch_as_run": got.get("TCP_TOTAL_CACHE_ACCESSES_sum@all", (None, 0))[0],      # (with the five-wavefront form's coalesced spill traffic)
                 "fetch_size_kib": got["FETCH_SIZE"][0], "write_size_kib": got["WRITE_SIZE"][0],
-                "traffic_bytes_per_launch": (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0}
+                "traffic_bytes_per_launch": (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0,
+                "other_kernels": {fam: {"launches_profiled": o["SQ_INSTS_VALU"][1], "valu_instructions_per_launch": o["SQ_INSTS_VALU"][0],
+                                        "busy_cu_cycles_per_launch": o["SQ_BUSY_CU_CYCLES"][0] / 256.0,
+                                        "lane_utilisation": o["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * o["SQ_ACTIVE_INST_VALU"][0]) if o["SQ_ACTIVE_INST_VALU"][0] else None,
+                                        "tcp_lane_accesses_per_launch": o["TCP_TOTAL_CACHE_ACCESSES_sum"][0],
+                                        "traffic_bytes_per_launch": (2.0 * o["FETCH_SIZE"][0] + o["WRITE_SIZE"][0]) * 1024.0}
+                                  for fam, o in other.items() if "SQ_INSTS_VALU" in o and "FETCH_SIZE" in o and "WRITE_SIZE" in o and "TCP_TOTAL_CACHE_ACCESSES_sum" in o}}
     except KeyError:
         return None
 
@@ -552,17 +649,17 @@ def committed_pmc(args, pass_sizes, queries_per_launch):
     match; otherwise the walk's VALU instructions are DERIVED as the committed instructions per closest-hit query x the queries this
     run counted per launch (labelled `derived`), and the fabric bytes are left out."""
     try:
-        with open(os.path.join(ROOT, "profiles", "round4", "pmc_bench.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_ROUND, "pmc_bench.json")) as f:
             d = json.load(f)
         key = d.get("config_key")
         if key[:1] != [args.workload] or key[4] != args.rows:            # (the instructions per query are the scene's, to a few per cent whatever the ray count)
             return None
         p = dict(d["pmc"])
         if key == [args.workload, args.scanlines, args.scanlines_total, args.rays, args.rows, args.gpus, pass_sizes]:
-            p["source"] = "file: profiles/round4/pmc_bench.json (%s)" % d.get("taken_at", "?")
+            p["source"] = "file: profiles/%s/pmc_bench.json (%s)" % (PMC_ROUND, d.get("taken_at", "?"))
             return p
         per_query = d["valu_instructions_per_query"]
-        return {"source": "derived: profiles/round4/pmc_bench.json instructions per closest-hit query (%.1f, N = 1) x the %.0f queries per launch counted in this run" % (per_query, queries_per_launch),
+        return {"source": "derived: profiles/" + PMC_ROUND + "/pmc_bench.json instructions per closest-hit query (%.1f, N = 1) x the %.0f queries per launch counted in this run" % (per_query, queries_per_launch),
                 "derived": True, "kernel": p.get("kernel"), "valu_instructions_per_launch": per_query * queries_per_launch,
                 "lane_utilisation": p.get("lane_utilisation"), "traffic_bytes_per_launch": None}
     except Exception:

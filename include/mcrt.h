@@ -271,8 +271,10 @@ int mcrt_enable_stats(mcrt_ctx *ctx, int enable);
 int mcrt_get_stats(mcrt_ctx *ctx, mcrt_stats *out, int reset);
 /* average device time of the trace kernel over the launches since the last reset (HIP events on the
  * context's stream), in milliseconds; n = launches measured */
-int mcrt_enable_timing(mcrt_ctx *ctx, int enable);
+int mcrt_enable_timing(mcrt_ctx *ctx, int enable);      /* 1: the walk's launches; 2: also k_shade's and k_march's (each on the stream it runs on) */
 int mcrt_get_kernel_time(mcrt_ctx *ctx, double *avg_ms, uint32_t *n, int reset);
+/* the same per kernel: [0] the walk, [1] k_shade, [2] k_march (the last two only under mcrt_enable_timing(ctx, 2)) */
+int mcrt_get_kernel_times(mcrt_ctx *ctx, double avg_ms[3], uint32_t n[3], int reset);
 
 /* ---- host-side pieces of the path (no GPU needed) ---- */
 int mcrt_build_bvh(const float *tri_xyz, const uint32_t *tri_mesh, uint32_t n_tri, mcrt_bvh *out);

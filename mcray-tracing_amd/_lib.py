@@ -59,7 +59,7 @@ SYMBOLS = ["mcrt_last_error", "mcrt_version", "mcrt_device_count", "mcrt_create"
            "mcrt_synchronize", "mcrt_default_params", "mcrt_set_params", "mcrt_get_params", "mcrt_import_rf", "mcrt_set_bvh_builder", "mcrt_upload_scene", "mcrt_update_triangles", "mcrt_refit_triangles", "mcrt_upload_texture",
            "mcrt_set_transducer", "mcrt_trace_frame", "mcrt_trace_frames", "mcrt_trace_frames_poses", "mcrt_envelope_frames", "mcrt_scan_convert_frames", "mcrt_trace_frame_debug", "mcrt_cast_rays", "mcrt_convolve", "mcrt_convolve_frames",
            "mcrt_envelope", "mcrt_scan_convert", "mcrt_export_rf", "mcrt_alloc", "mcrt_free", "mcrt_memcpy_d2h",
-           "mcrt_memcpy_h2d", "mcrt_enable_stats", "mcrt_get_stats", "mcrt_enable_timing", "mcrt_get_kernel_time",
+           "mcrt_memcpy_h2d", "mcrt_enable_stats", "mcrt_get_stats", "mcrt_enable_timing", "mcrt_get_kernel_time", "mcrt_get_kernel_times",
            "mcrt_build_bvh", "mcrt_free_bvh", "mcrt_get_bvh", "mcrt_build_bvh4", "mcrt_free_bvh4", "mcrt_get_bvh4", "mcrt_row_thresholds", "mcrt_generate_texture", "mcrt_psf_kernels",
            "mcrt_transducer_elements", "mcrt_debug_math", "mcrt_debug_philox", "mcrt_debug_stamps", "mcrt_debug_tail_histograms", "mcrt_debug_set_error", "mcrt_debug_fast_paths", "mcrt_scan_maps",
            "mcrt_group_create", "mcrt_group_destroy", "mcrt_group_size", "mcrt_group_root", "mcrt_group_member", "mcrt_group_shard", "mcrt_group_set_params",
@@ -103,7 +103,7 @@ def load_library():
         "mcrt_export_rf": [vp, vp, u32, u32, vp], "mcrt_alloc": [vp, C.c_size_t, C.POINTER(vp)], "mcrt_free": [vp, vp],
         "mcrt_memcpy_d2h": [vp, vp, vp, C.c_size_t], "mcrt_memcpy_h2d": [vp, vp, vp, C.c_size_t],
         "mcrt_enable_stats": [vp, i32], "mcrt_get_stats": [vp, C.POINTER(Stats), i32],
-        "mcrt_enable_timing": [vp, i32], "mcrt_get_kernel_time": [vp, C.POINTER(C.c_double), C.POINTER(u32), i32],
+        "mcrt_enable_timing": [vp, i32], "mcrt_get_kernel_time": [vp, C.POINTER(C.c_double), C.POINTER(u32), i32], "mcrt_get_kernel_times": [vp, vp, vp, i32],
         "mcrt_build_bvh": [vp, vp, u32, C.POINTER(Bvh)], "mcrt_free_bvh": [C.POINTER(Bvh)], "mcrt_get_bvh": [vp, C.POINTER(Bvh)],
         "mcrt_build_bvh4": [C.POINTER(Bvh), C.POINTER(Bvh4)], "mcrt_free_bvh4": [C.POINTER(Bvh4)], "mcrt_get_bvh4": [vp, C.POINTER(Bvh4)],
         "mcrt_row_thresholds": [C.c_double, u32, vp],

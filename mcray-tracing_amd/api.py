@@ -305,6 +305,12 @@ class Context:
     def enable_timing(self, on=True):
         check(self.L.mcrt_enable_timing(self.h, int(on)))
 
+    def kernel_times(self, reset=True):
+        """{"walk" | "shade" | "march": (average ms per launch, launches)} since the last reset (shade / march only under enable_timing(2))"""
+        ms = (C.c_double * 3)(); n = (C.c_uint32 * 3)()
+        check(self.L.mcrt_get_kernel_times(self.h, ms, n, int(reset)))
+        return {k: (ms[i], n[i]) for i, k in enumerate(("walk", "shade", "march"))}
+
     def kernel_time(self, reset=True):
         ms = C.c_double(); n = C.c_uint32()
         check(self.L.mcrt_get_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))

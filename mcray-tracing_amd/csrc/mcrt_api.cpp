@@ -138,7 +138,8 @@ struct mcrt_ctx {
     float *d_map_col = nullptr, *d_map_row = nullptr; uint32_t map_key[6] = { 0, 0, 0, 0, 0, 0 }; double map_keyd[2] = { 0, 0 };
     // instrumentation
     unsigned long long *d_stats = nullptr; bool stats_on = false;
-    bool timing_on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0;
+    bool timing_on = false; int timing_level = 0;       // 1: the walk's launches are bracketed by HIP events; 2: k_shade's and k_march's too
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; std::vector<unsigned char> ev_kind; size_t ev_used = 0;
 };
 
 
@@ -828,7 +829,7 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
 
 static uint32_t side_streams(const mcrt_ctx *c) { return c->knobs.march_streams; }
 
-static int timing_events(mcrt_ctx *c, hipEvent_t *e0, hipEvent_t *e1);
+static int timing_events(mcrt_ctx *c, int kind, hipEvent_t *e0, hipEvent_t *e1);
 
 // one bounce of one group: k_trace_lane + k_shade on the group's stream, k_march of the finished segments on its side stream.
 // With timing enabled every k_trace launch (the dominant kernel) is bracketed by HIP events on the stream it is launched on.
@@ -838,34 +839,44 @@ static int timing_events(mcrt_ctx *c, hipEvent_t *e0, hipEvent_t *e1);
 static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArgs &a, uint32_t b, bool accumulate, bool overlap)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    { int rc = timing_events(c, &e0, &e1); if (rc) return rc; }
+    { int rc = timing_events(c, 0, &e0, &e1); if (rc) return rc; }
     if (e0) HIP_TRY(hipEventRecord(e0, st));
     HIP_TRY(mcrt::launch_trace(a, b, c->stats_on, st));
-    if (c->timing_on) HIP_TRY(hipEventRecord(e1, st));
+    if (e1) HIP_TRY(hipEventRecord(e1, st));
+    { int rc = timing_events(c, 1, &e0, &e1); if (rc) return rc; }
+    if (e0) HIP_TRY(hipEventRecord(e0, st));
     HIP_TRY(mcrt::launch_shade(a, b, c->stats_on, st));
+    if (e1) HIP_TRY(hipEventRecord(e1, st));
     if (accumulate && overlap) {   // the segments of bounce b are final: accumulate them beside the next bounce's walk
         HIP_TRY(hipEventRecord(w.ev_bounce[b], st));
         hipStream_t side;
         { int rc = side_stream(c, w, b % side_streams(c), &side); if (rc) return rc; }
         HIP_TRY(hipStreamWaitEvent(side, w.ev_bounce[b], 0));
+        { int rc = timing_events(c, 2, &e0, &e1); if (rc) return rc; }
+        if (e0) HIP_TRY(hipEventRecord(e0, side));
         HIP_TRY(mcrt::launch_march(a, b, c->stats_on, side));
+        if (e1) HIP_TRY(hipEventRecord(e1, side));
     } else if (accumulate) {
+        { int rc = timing_events(c, 2, &e0, &e1); if (rc) return rc; }
+        if (e0) HIP_TRY(hipEventRecord(e0, st));
         HIP_TRY(mcrt::launch_march(a, b, c->stats_on, st));
+        if (e1) HIP_TRY(hipEventRecord(e1, st));
     }
     return MCRT_OK;
 }
 
-static int timing_events(mcrt_ctx *c, hipEvent_t *e0, hipEvent_t *e1)
+// a pair of events for a launch of kind 0 (the walk), 1 (k_shade) or 2 (k_march) -- or none when that kind is not being timed
+static int timing_events(mcrt_ctx *c, int kind, hipEvent_t *e0, hipEvent_t *e1)
 {
     *e0 = *e1 = nullptr;
-    if (!c->timing_on) return MCRT_OK;
+    if (!c->timing_on || (kind != 0 && c->timing_level < 2)) return MCRT_OK;
     if (c->ev_used == c->ev.size()) {
         if (c->ev.size() >= 65536) return set_error(MCRT_ERR_LIMIT, "timing buffer full: call mcrt_get_kernel_time(reset=1)");
         hipEvent_t x, y;
         HIP_TRY(hipEventCreate(&x)); HIP_TRY(hipEventCreate(&y));
-        c->ev.emplace_back(x, y);
+        c->ev.emplace_back(x, y); c->ev_kind.push_back(0);
     }
-    *e0 = c->ev[c->ev_used].first; *e1 = c->ev[c->ev_used].second; c->ev_used++;
+    *e0 = c->ev[c->ev_used].first; *e1 = c->ev[c->ev_used].second; c->ev_kind[c->ev_used] = (unsigned char)kind; c->ev_used++;
     return MCRT_OK;
 }
 
@@ -1245,16 +1256,27 @@ extern "C" int mcrt_debug_set_error(mcrt_ctx *c, uint32_t bits)
     return MCRT_OK;
 }
 
-extern "C" int mcrt_enable_timing(mcrt_ctx *c, int on) { CTX_TRY(c); c->timing_on = on != 0; return MCRT_OK; }
-extern "C" int mcrt_get_kernel_time(mcrt_ctx *c, double *avg_ms, uint32_t *n, int reset)
+extern "C" int mcrt_enable_timing(mcrt_ctx *c, int on) { CTX_TRY(c); c->timing_on = on != 0; c->timing_level = on; return MCRT_OK; }
+extern "C" int mcrt_get_kernel_times(mcrt_ctx *c, double avg_ms[3], uint32_t n[3], int reset)
 {
     CTX_TRY(c);
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    double sum = 0;
-    for (size_t i = 0; i < c->ev_used; i++) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[i].first, c->ev[i].second)); sum += ms; }
-    if (avg_ms) *avg_ms = c->ev_used ? sum / (double)c->ev_used : 0.0;
-    if (n) *n = (uint32_t)c->ev_used;
+    HIP_TRY(hipDeviceSynchronize());                 // (k_march's events live on the side streams)
+    double sum[3] = { 0, 0, 0 }; uint32_t cnt[3] = { 0, 0, 0 };
+    for (size_t i = 0; i < c->ev_used; i++) {
+        float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[i].first, c->ev[i].second));
+        const int k = c->ev_kind[i] < 3 ? c->ev_kind[i] : 0;
+        sum[k] += ms; cnt[k]++;
+    }
+    for (int k = 0; k < 3; k++) { if (avg_ms) avg_ms[k] = cnt[k] ? sum[k] / (double)cnt[k] : 0.0; if (n) n[k] = cnt[k]; }
     if (reset) c->ev_used = 0;
+    return MCRT_OK;
+}
+extern "C" int mcrt_get_kernel_time(mcrt_ctx *c, double *avg_ms, uint32_t *n, int reset)
+{
+    double a[3]; uint32_t k[3];
+    const int rc = mcrt_get_kernel_times(c, a, k, reset); if (rc) return rc;
+    if (avg_ms) *avg_ms = a[0];
+    if (n) *n = k[0];
     return MCRT_OK;
 }
 

@@ -19,7 +19,7 @@ name=sys.argv[1]
 try:
     l=[x for x in open('gpurun_out/tune/%s.log'%name) if x.startswith('{')][-1]; d=json.loads(l)
     r=d['roofline']
-    print("%-16s value %.3e rays/s  ms/step %.3f  k_trace avg %.4f ms x%d = %.3f ms/frame  algorithmic %.0f GB/s" % (name, d['value'], d['ms_per_step'], r['kernel_ms'], int(round(r.get('launches_per_frame',1))), r['kernel_ms']*r.get('launches_per_frame',1), r['algorithmic_GBps_cache_served']))
+    print("%-16s value %.3e rays/s  ms/step %.3f  k_trace avg %.4f ms x%d = %.3f ms/frame  algorithmic %.0f GB/s" % (name, d['value'], d['ms_per_step'], r['kernel_ms'], int(round(r.get('launches_per_frame',1))), r['kernel_ms']*r.get('launches_per_frame',1), r["algorithmic_GBps_cache_served"]))
 except Exception as e:
     print(name, 'FAILED', e)
 PY
