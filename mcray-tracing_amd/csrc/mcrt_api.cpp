@@ -835,7 +835,7 @@ static int timing_events(mcrt_ctx *c, int kind, hipEvent_t *e0, hipEvent_t *e1);
 // With timing enabled every k_trace launch (the dominant kernel) is bracketed by HIP events on the stream it is launched on.
 // (Round 4 tried holding k_march of bounce b back until the walk of bounce b+1 had claimed its last ray -- a device word raised by the walk, waited
 //  for with hipStreamWaitValue32, which the command processor releases ~1 us after the store --: 0.360 against 0.343 ms per frame at 128 frames in
-//  flight, 0.414 against 0.405 on the driver's pass, and a hang under `rocprofv3 --pmc`.  Removed; DESIGN.md 5.6, profiles/round4/exp_round4_kernels.txt.)
+//  flight, 0.414 against 0.405 on the driver's pass, and a hang under `rocprofv3 --pmc`.  Removed; DESIGN.md A.6, profiles/round4/exp_round4_kernels.txt.)
 static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArgs &a, uint32_t b, bool accumulate, bool overlap)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -91,7 +91,7 @@ struct Best { float frac; int tri; };
 //   v0 | id, v1 | mesh     the vertices (edge tests; the triangle's own padded bounds are rebuilt from them: tri_padded_bounds)
 //   v2 | -1e-4 |n|^2       ... and processTriangle's edge tolerance
 // Rounds 1-3 stored plane AND padded bounds (96 bytes, six 16-byte pieces per triangle tested).  The walk is bound by the cache accesses
-// it makes (DESIGN.md 5.6): what a few register instructions rebuild -- with the contract's own expressions, so bit for bit -- is not
+// it makes (DESIGN.md A.6): what a few register instructions rebuild -- with the contract's own expressions, so bit for bit -- is not
 // fetched.
 constexpr int TRI_V0 = MCRT_TRI_PIECES - 3;          // index of the v0 piece in a record
 __global__ void k_expand_tris(const float4 *in, uint32_t n_tri, float pad_abs, float4 *out)
@@ -322,7 +322,7 @@ MCRT_DEV void rf_add(RowBin *rb, uint32_t *lflags, int row, float echo)
 // the queue every bounce (ping-pong halves by bounce parity): every launch reads and writes them densely and coalesced.
 // (Round 3 measured the alternative the sample loop of scene.cpp:102-110 suggests -- queues SORTED into bundles of the sample
 // paths of a scan-line with the same reflect / refract history, path state in place by path id: 58 vs 56 % of the walk's lanes
-// active, the pass 8 % slower; DESIGN.md 5.4, profiles/round3/exp_*.)
+// active, the pass 8 % slower; DESIGN.md A.4, profiles/round3/exp_*.)
 // =============================================================================================================
 
 struct Ray { f3 f2, to; };
@@ -802,7 +802,7 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
                         pool_next = (uint32_t)start; pool_end = min((uint32_t)start + fetch, hi);
                     }
                     else if (++visited >= X) queue_empty = true;      // (the launch enters its TAIL: it only finishes the rays in flight from here on.  Round 4 let the
-                                                                      //  accumulation's stream wait for this moment -- a device word + hipStreamWaitValue32 --: slower, DESIGN.md 5.6)
+                                                                      //  accumulation's stream wait for this moment -- a device word + hipStreamWaitValue32 --: slower, DESIGN.md A.6)
                     else cur_x = (cur_x + 1u) & (X - 1u);
 #if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
                     if (queue_empty) { wc_empty = wall_clock64(); if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 1], ~wc_empty);
@@ -857,7 +857,7 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
         // atomicMin is exactly the contract's (smaller fraction, then smaller triangle id) rule -- the answer is the single walk's.
         // A launch then ends after its wavefronts' remaining WORK, not after their longest walk.  (Not in the counting build, whose
         // visit counts are those of one walk per ray.)
-        // Measured and not kept (DESIGN.md 5.4): the same hand-over BETWEEN wavefronts through tickets and entries in global memory
+        // Measured and not kept (DESIGN.md A.4): the same hand-over BETWEEN wavefronts through tickets and entries in global memory
         // (the heaviest wavefront's walks are chains with little to give away: its 230-odd node steps stayed, the pushes' round
         // trips were added); one ray per four lanes at the start of a small launch; rays dealt out across the wavefronts.
         if (!STATS && queue_empty) {
@@ -1188,7 +1188,7 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
     if (blockIdx.x * blockDim.x >= n) return;
     const int lane = threadIdx.x & 63;
     // the scene's material and mesh tables in LDS when they fit (they nearly always do: the reference's scenes have 9 materials and <= 11 meshes):
-    // a ray looks up five material rows and one mesh row -- a quarter of this kernel's cache accesses, and the frame is bound by their sum (DESIGN.md 5.6)
+    // a ray looks up five material rows and one mesh row -- a quarter of this kernel's cache accesses, and the frame is bound by their sum (DESIGN.md A.6)
     __shared__ float4 mats_l[2 * MCRT_SHADE_TABLE];
     __shared__ uint4 meshes_l[MCRT_SHADE_TABLE];
     const bool tables_in_lds = a.n_mat <= (uint32_t)MCRT_SHADE_TABLE && a.n_mesh <= (uint32_t)MCRT_SHADE_TABLE;
@@ -1302,7 +1302,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
     unsigned char *sort_list = (unsigned char *)(lflags + ((nf + 3u) & ~3u) + 4 * 64) + wv * MCRT_MARCH_TILE;   // ... its tile's slots, longest first ...
     unsigned char *sort_cls = (unsigned char *)(lflags + ((nf + 3u) & ~3u) + 4 * 64) + 4 * MCRT_MARCH_TILE + wv * MCRT_MARCH_TILE;   // ... and their classes (worked out once)
     // the per-material table (a few 16-byte rows) in LDS: the tile sort and every segment load look it up -- as reads of the vector memory pipe
-    // they were a tenth of this kernel's cache accesses, and the frame is bound by the sum of its kernels' accesses (DESIGN.md 5.6)
+    // they were a tenth of this kernel's cache accesses, and the frame is bound by the sum of its kernels' accesses (DESIGN.md A.6)
     float4 *mtab_l = (float4 *)((unsigned char *)(lflags + ((nf + 3u) & ~3u) + 4 * 64) + 8 * MCRT_MARCH_TILE);
     const bool mtab_in_lds = MCRT_MARCH_LDS_TABLES && a.n_mat <= (uint32_t)MCRT_MARCH_MTAB;
     for (uint32_t r = tid; r < nrt; r += nthr) { rb[r].thr = r <= R ? a.row_thr[r] : -__builtin_inf(); rb[r].bin = 0; }

@@ -110,7 +110,7 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 | `valu_roof.json` | `tools/valu_roof.hip --quick`, round 4: the VALU issue ceiling per instruction class, now with a register-only replica of the node step the walk runs TODAY (`BVH4 LANE node-step mix`: 12 `v_cndmask`, 24 `v_fma_mix_f32`, min / max / min3 / max3, keys, ranking, branch-free pushes: 91 instructions) beside round 2's mix |
 | `fetch_roof_same.json`, `tcp_access_cost.json` | `tools/fetch_roof_same.hip` alone and under `rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum SQ_INSTS_VMEM_RD`: what the counter counts (one access per lane, a uniform adjacent quad once) and what a counted access costs a CU's vector memory pipe in every sharing pattern -- the cheapest, %.3f cycles, is the floor `bench.py`'s `second_roof` uses |
 | `fetch_size_calibration.json` | `tools/fetch_calib.hip` under `--pmc FETCH_SIZE` / `TCC_EA0_RDREQ` / `TCC_MISS`: FETCH_SIZE against KNOWN byte counts in the walk's access shapes (a coalesced stream reads 1/2, as the guide says; a scattered 64-byte node is one request counted at 64 bytes: 1.00) |
-| `bvh_width.json` | `tools/bvh_width.py` (CPU): the headline frame's 816 k closest-hit queries walked over the product's BVH2 collapsed to 2 / 4 / 8 / 16-wide nodes, float and 8-bit boxes -- visits, chains, 16-byte pieces (DESIGN.md 5.6: rules 8-wide nodes out) |
+| `bvh_width.json` | `tools/bvh_width.py` (CPU): the headline frame's 816 k closest-hit queries walked over the product's BVH2 collapsed to 2 / 4 / 8 / 16-wide nodes, float and 8-bit boxes -- visits, chains, 16-byte pieces (DESIGN.md A.6: rules 8-wide nodes out) |
 | `exp_refill_threshold.txt` | the walk's refill threshold at 4 / 8 / 16 idle lanes, timed and with the stamp build: more lanes step per iteration, every iteration costs proportionally more (the walk is bound by the vector memory pipe, not by idle lanes) |
 | `exp_pass_split.txt` | what cutting a timed region into smaller passes costs (decides `bench.py`'s N > 1 rule) |
 | `exp_round4_kernels.txt` | round 4's kernel changes one by one (triangle records, LDS tables, the held-back accumulation, the register trap) |
@@ -154,7 +154,7 @@ in `pmc_k_trace_lane.json`).
 %s
 
 The walk alone lasts %.0f us and the cache accesses it needs cost %.0f us of the CUs' vector memory pipes at the cheapest measured price: it runs
-AT that roof and at the VALU's at once (DESIGN.md 5.6: `exp_sensitivity.txt`), at %.0f %% of the calibrated VALU ceiling with %.0f %% of its lanes active.  The BVH is served on-die: L1 hit rate
+AT that roof and at the VALU's at once (DESIGN.md A.6: `exp_sensitivity.txt`), at %.0f %% of the calibrated VALU ceiling with %.0f %% of its lanes active.  The BVH is served on-die: L1 hit rate
 %.0f %%, L2 %.0f %% of the rest, fabric traffic %.0f MB per launch -- `hbm_measured_frac` = %.3f of the 8 TB/s HBM figure (the algorithmic
 bytes, %.1f GB per launch, flow at %.1f TB/s from the caches).
 
