@@ -69,6 +69,7 @@ struct Work {
 struct Knobs {
     uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, trace_blocks_wide = 0, wide_from = 0 /* 0: the kernels' own default */, wide_max_tree_mb = 128, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 0;   // march_blocks 0: launch_march picks
     bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false;
+    uint32_t packet_mask = MCRT_PACKET_MASK_DEFAULT, packet_from = MCRT_PACKET_FROM;   // bit b: bounce b is walked by k_trace_packet (one wavefront per packet of 64 queue neighbours), in passes of at least packet_from paths
     uint32_t march_cus = 0;                    // CUs the accumulation's side stream is confined to (0 = no mask); the mask's bit order is the driver's
     bool main_mask = false;                    // with march_cus: the walk / shade chain runs on its own stream confined to the OTHER CUs
     bool test_hooks = false;                   // MCRT_TEST_HOOKS: mcrt_debug_set_error may poison the context (tests only)
@@ -83,6 +84,8 @@ static Knobs read_knobs()
     if (const char *e = tuning_env("MCRT_WIDE_MAX_TREE_MB")) { long long v = atoll(e); if (v >= 0 && v <= 0xffffffffll) k.wide_max_tree_mb = (uint32_t)v; }
     if (const char *e = tuning_env("MCRT_WIDE_FROM")) { long long v = atoll(e); if (v >= 1 && v <= 0xffffffffll) k.wide_from = (uint32_t)v; }   // rays in a launch from which the walk takes its five-wavefront form (1: always; 4294967295: never)
     if (const char *e = tuning_env("MCRT_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 16) k.groups = (uint32_t)v; }
+    if (const char *e = tuning_env("MCRT_PACKET_BOUNCES")) { long v = strtol(e, nullptr, 0); if (v >= 0) k.packet_mask = (uint32_t)v; }
+    if (const char *e = tuning_env("MCRT_PACKET_FROM")) { long long v = atoll(e); if (v >= 0 && v <= 0xffffffffll) k.packet_from = (uint32_t)v; }
     if (const char *e = tuning_env("MCRT_MARCH_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= MCRT_SIDE_STREAMS) k.march_streams = (uint32_t)v; }
     if (const char *e = tuning_env("MCRT_MARCH_BLOCKS")) { int v = atoi(e); if (v >= 1) k.march_blocks = (uint32_t)v; }
     k.no_overlap = tuning_env("MCRT_NO_OVERLAP") != nullptr; k.no_priority = tuning_env("MCRT_NO_PRIORITY") != nullptr;
@@ -800,6 +803,7 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     if ((uint64_t)c->bvh4.n_nodes * 64ull > (uint64_t)c->knobs.wide_max_tree_mb * 1048576ull) a.trace_blocks_wide = 0;
     if (c->knobs.main_mask) a.trace_blocks_wide = 0;                                                   // (CU-masked streams: the four-wavefront form only)
     a.march_blocks = c->knobs.march_blocks;
+    a.packet_mask = (c->stats_on || (uint64_t)a.ne * a.S < c->knobs.packet_from) ? 0u : c->knobs.packet_mask;   // bounces walked a wavefront per ray packet (k_trace_packet); the counting build walks ray by ray
     a.frame = frame; a.seed = c->p.seed; a.start_mat = c->start_mat; a.tex_n = c->tex_n; a.tex_mask = (c->tex_n & (c->tex_n - 1u)) == 0u ? c->tex_n - 1u : 0u;
     a.sanitize = c->p.sanitize_tir; a.tex_finite = c->tex_finite ? 1u : 0u;
     a.freq = c->p.frequency; a.eps = c->p.intensity_epsilon; a.I0 = c->p.initial_intensity; a.offs = c->p.ray_start_offset;

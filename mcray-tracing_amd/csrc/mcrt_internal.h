@@ -15,6 +15,9 @@
 #define MCRT_XCDS 8                   // XCDs of the MI355X = sub-queues of a bounce's ray queue (see k_trace)
 #define MCRT_CURSOR_STRIDE 64         // uint32 between two queue cursors: 256 B, so they sit in different L2 lines / channels
 #define MCRT_XCD_MIN_ITEMS 262144     // bounces with fewer work items use a single queue
+#define MCRT_PACKET_MASK_DEFAULT 2u   // bounces (bit b) walked a wavefront per ray packet (k_trace_packet): bounce 1 -- every pass size from two frames up and every BASELINE
+                                      // configuration gains 0.3-6 % (profiles/round5/exp_packet.txt); bounce 2 is a wash, later bounces lose (packet_count_*.json)
+#define MCRT_PACKET_FROM 262144u      // ... in passes of at least this many paths (one 128 x 1024 frame at a time keeps the lane walk: its launches are cut into pieces, 1.624 vs 1.634 ms)
 #define MCRT_MAX_ROWS 2048
 #define MCRT_MAX_BOUNCES 16
 #define MCRT_STATS_WORDS (256 + 2560)  // the context's counter block: 8 statistics, 248 stamps (mcrt_debug_stamps), 10 x 256 tail histograms (mcrt_debug_tail_histograms)

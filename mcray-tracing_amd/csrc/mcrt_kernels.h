@@ -37,7 +37,7 @@ struct FrameArgs {
     uint32_t *error_flag;      // device word, bit 0: traversal stack overflow
     unsigned long long *stamps; // [80] diagnostic build (-DMCRT_STAMP) only
     // sizes / parameters
-    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, pose_stride, acc_stride, acc_off, trace_blocks, trace_blocks_wide, wide_from, march_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift, march_rows, n_mat, n_mesh;   // march_rows: entries of k_march's padded LDS image when its fast variant applies, else 0
+    uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, pose_stride, acc_stride, acc_off, trace_blocks, trace_blocks_wide, wide_from, packet_mask, march_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift, march_rows, n_mat, n_mesh;   // march_rows: entries of k_march's padded LDS image when its fast variant applies, else 0
     float scene_lo[3], scene_hi[3];   // bounds of the whole BVH
     float freq, eps, I0, offs, sx, sy, sz, tex_res, axial_res_f, pad_abs, tex_rcp, lean_bound;
     double axial_res_mm, time_step, row_dt, max_travel, sos_d, inv_row_dt;

@@ -541,6 +541,17 @@ MCRT_DEV Planes4 planes4(uint32_t w01, uint32_t w23, float c, float inv)
     return r;
 }
 
+// the same with the node's packed word in a SCALAR register (k_trace_packet: the node is wave-uniform)
+MCRT_DEV Planes4 planes4_s(uint32_t w01, uint32_t w23, float c, float inv)
+{
+    Planes4 r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r.a0) : "s"(w01), "v"(inv), "v"(c));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.a1) : "s"(w01), "v"(inv), "v"(c));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r.b0) : "s"(w23), "v"(inv), "v"(c));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.b1) : "s"(w23), "v"(inv), "v"(c));
+    return r;
+}
+
 // ---- the lane-per-ray walk's two steps ---------------------------------------------------------------------------------
 // A lane's traversal stack: entries [sb, sp), entry e of thread t at lds[e * 256 + t] while e < MCRT_LANE_STACK, beyond that in the
 // global overflow array (only reachable on degenerate paths of deep trees).
@@ -1023,6 +1034,169 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6),
     trace_lane_body<false, MCRT_LANE_WIDE_STACK, true>(a, b);
 }
 
+// =============================================================================================================
+// k_trace_packet -- north_star's literal traversal: ONE WAVEFRONT PER RAY PACKET.  The 64 lanes of a wavefront hold 64 consecutive rays
+// of the queue (neighbours: the sample paths of one scan-line with one reflect / refract history) and walk the BVH4 TOGETHER: one
+// traversal stack for the wavefront (64 entries in ONE vector register, entry e in lane e), the current node wave-uniform and fetched
+// through the SCALAR cache (one s_load_dwordx16 per node and wavefront instead of 64 lanes x four 16-byte pieces through the vector memory
+// pipe -- the pipe that binds the lane walk), every lane tests the four child boxes against ITS ray with ITS closest fraction (the lane
+// walk's arithmetic), a child is entered when ANY lane passes it, nearest first by the first passing lane's t_near; a leaf's triangles are
+// fetched the same way and tested by every lane.  Legal under the contract: the closest hit (smaller fraction, then smaller triangle id, of
+// the triangles whose padded bounds the ray passes) does not depend on the visiting order, boxes only cull, and a lane that does not pass a
+// box passes nothing inside it -- so every lane gets exactly the lane walk's answer, bit for bit (the parity tests do not know which kernel ran).
+// What it costs is counted in profiles/round5/packet_count_*.json: the packet visits the UNION of its rays' nodes -- 1.1 x the longest ray's at
+// bounce 1, 1.7 x at bounce 2, 7 x at bounce 9 (a wavefront's 64 neighbours then belong to several histories) -- so launch_trace takes it only
+// for the bounces named in FrameArgs::packet_mask.
+// =============================================================================================================
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+MCRT_DEV u32x16 sload16(const void *p) { u32x16 r; asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory"); return r; }
+MCRT_DEV u32x8 sload8(const void *p) { u32x8 r; asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory"); return r; }
+// entry `l` (wave-uniform) of the wavefront's stack register becomes the wave-uniform value `v`: a vector compare and select (v_writelane_b32 wants the lane
+// number in M0 and its moves on the scalar ALU, the pipe this kernel is short of)
+MCRT_DEV int writelane(int v, int l, int old) { return (int)(threadIdx.x & 63u) == l ? v : old; }
+MCRT_DEV u32x4 sload4(const void *p) { u32x4 r; asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory"); return r; }
+
+// the packet's walk.  SGN: 0..7 = every ray of the packet runs the same way along every axis, bit 0 / 1 / 2 = towards -x / -y / -z (a bundle's rays differ by a
+// fraction of a degree: the common case) -- which plane of a slab is the near one is then a COMPILE-TIME pick and the 24 plane distances read the node's words
+// straight from scalar registers; 8 = mixed directions, picked per lane.  (The scalar ALU is this kernel's scarce pipe -- one per CU, and every step of every
+// wavefront needs its ballots, keys and stack moves there: 12 selects per step are worth eight copies of the loop.)
+template <int SGN>
+MCRT_DEV void packet_walk(const FrameArgs &a, const LaneRay &lr, const f3 f2, const f3 to, const f3 inv, const f3 rc, Best &best)
+{
+    constexpr bool UNI = SGN < 8, NX = (SGN & 1) != 0, NY = (SGN & 2) != 0, NZ = (SGN & 4) != 0;
+    int stk = 0;                                                          // the wavefront's traversal stack: entry e in lane e
+    int sp = 0, cur = 0;                                                  // wave-uniform
+    const unsigned long long wd_start = wall_clock64(); uint32_t wd_iter = 0;
+    for (;;) {
+        if ((++wd_iter & 4095u) == 0u && wall_clock64() - wd_start > (unsigned long long)MCRT_WATCHDOG_SECONDS * 100000000ull) { if ((threadIdx.x & 63) == 0) atomicOr(a.error_flag, 2u); break; }
+        if (cur >= 0) {
+            // the node: through the scalar cache, one load per wavefront
+            // (words: lo.x[4] lo.y[4] | lo.z[4] hi.x[4] | hi.y[4] hi.z[4] | ref[4]; two halves per word)
+            const u32x16 N = sload16((const char *)a.nodes_walk + ((size_t)(uint32_t)cur << 6));
+            const uint32_t lox0 = N[0], lox1 = N[1], loy0 = N[2], loy1 = N[3], loz0 = N[4], loz1 = N[5], hix0 = N[6], hix1 = N[7], hiy0 = N[8], hiy1 = N[9], hiz0 = N[10], hiz1 = N[11];
+            const float tcap = fminf(1.0f, best.frac);
+            float tn0, tn1, tn2, tn3;
+            bool h0, h1, h2, h3;
+            if (UNI) {
+                const Planes4 XN = planes4_s(NX ? hix0 : lox0, NX ? hix1 : lox1, lr.cx, lr.ix), XF = planes4_s(NX ? lox0 : hix0, NX ? lox1 : hix1, lr.cx, lr.ix);
+                const Planes4 YN = planes4_s(NY ? hiy0 : loy0, NY ? hiy1 : loy1, lr.cy, lr.iy), YF = planes4_s(NY ? loy0 : hiy0, NY ? loy1 : hiy1, lr.cy, lr.iy);
+                const Planes4 ZN = planes4_s(NZ ? hiz0 : loz0, NZ ? hiz1 : loz1, lr.cz, lr.iz), ZF = planes4_s(NZ ? loz0 : hiz0, NZ ? loz1 : hiz1, lr.cz, lr.iz);
+                h0 = slab_near_far(XN.a0, YN.a0, ZN.a0, XF.a0, YF.a0, ZF.a0, 0.0f, tcap, tn0);
+                h1 = slab_near_far(XN.a1, YN.a1, ZN.a1, XF.a1, YF.a1, ZF.a1, 0.0f, tcap, tn1);
+                h2 = slab_near_far(XN.b0, YN.b0, ZN.b0, XF.b0, YF.b0, ZF.b0, 0.0f, tcap, tn2);
+                h3 = slab_near_far(XN.b1, YN.b1, ZN.b1, XF.b1, YF.b1, ZF.b1, 0.0f, tcap, tn3);
+            } else {
+                const Planes4 XN = planes4(lr.nx ? hix0 : lox0, lr.nx ? hix1 : lox1, lr.cx, lr.ix), XF = planes4(lr.nx ? lox0 : hix0, lr.nx ? lox1 : hix1, lr.cx, lr.ix);
+                const Planes4 YN = planes4(lr.ny ? hiy0 : loy0, lr.ny ? hiy1 : loy1, lr.cy, lr.iy), YF = planes4(lr.ny ? loy0 : hiy0, lr.ny ? loy1 : hiy1, lr.cy, lr.iy);
+                const Planes4 ZN = planes4(lr.nz ? hiz0 : loz0, lr.nz ? hiz1 : loz1, lr.cz, lr.iz), ZF = planes4(lr.nz ? loz0 : hiz0, lr.nz ? loz1 : hiz1, lr.cz, lr.iz);
+                h0 = slab_near_far(XN.a0, YN.a0, ZN.a0, XF.a0, YF.a0, ZF.a0, 0.0f, tcap, tn0);
+                h1 = slab_near_far(XN.a1, YN.a1, ZN.a1, XF.a1, YF.a1, ZF.a1, 0.0f, tcap, tn1);
+                h2 = slab_near_far(XN.b0, YN.b0, ZN.b0, XF.b0, YF.b0, ZF.b0, 0.0f, tcap, tn2);
+                h3 = slab_near_far(XN.b1, YN.b1, ZN.b1, XF.b1, YF.b1, ZF.b1, 0.0f, tcap, tn3);
+            }
+            // WHICH children: any lane's.  In WHICH ORDER: nearest first by the t_near of the FIRST lane that passes each (one v_readlane per entered child; bits
+            // order like the value, t_near >= 0; the slot in the two low bits makes the keys distinct).  Sorted pushes cost scalar work but save visits: with the
+            // lane walk's rule instead (nearest first, the others in slot order: one v_readlane, no sort) the packet ran 1 % slower (profiles/round5/exp_packet.txt).
+            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+            const int r0 = (int)N[12], r1 = (int)N[13], r2 = (int)N[14], r3 = (int)N[15];
+            const uint32_t nh = (m0 ? 1u : 0u) + (m1 ? 1u : 0u) + (m2 ? 1u : 0u) + (m3 ? 1u : 0u);
+            if (nh == 1u) { cur = m0 ? r0 : m1 ? r1 : m2 ? r2 : r3; continue; }          // one child entered: no order to work out, nothing to stack
+            if (nh >= 2u) {
+                uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
+                if (m0) k0 = ((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn0), __ffsll((long long)m0) - 1) & ~3u) | 0u;
+                if (m1) k1 = ((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn1), __ffsll((long long)m1) - 1) & ~3u) | 1u;
+                if (m2) k2 = ((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn2), __ffsll((long long)m2) - 1) & ~3u) | 2u;
+                if (m3) k3 = ((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn3), __ffsll((long long)m3) - 1) & ~3u) | 3u;
+                // a sorting network on the four (key, reference) pairs: five compare-and-swaps
+                int a0 = r0, a1 = r1, a2 = r2, a3 = r3;
+#define MCRT_PK_CAS(ka, ra, kb, rb) { const bool sw_ = kb < ka; const uint32_t kl_ = sw_ ? kb : ka, kh_ = sw_ ? ka : kb; const int rl_ = sw_ ? rb : ra, rh_ = sw_ ? ra : rb; ka = kl_; kb = kh_; ra = rl_; rb = rh_; }
+                MCRT_PK_CAS(k0, a0, k1, a1) MCRT_PK_CAS(k2, a2, k3, a3) MCRT_PK_CAS(k0, a0, k2, a2) MCRT_PK_CAS(k1, a1, k3, a3) MCRT_PK_CAS(k1, a1, k2, a2)
+#undef MCRT_PK_CAS
+                if (k3 != 0xffffffffu) { stk = writelane(a3, sp, stk); sp++; }     // farthest first: the nearest pops first
+                if (k2 != 0xffffffffu) { stk = writelane(a2, sp, stk); sp++; }
+                stk = writelane(a1, sp, stk); sp++;
+                cur = a0;
+                continue;
+            }
+        } else {
+            const uint32_t v = (uint32_t)~cur;
+            const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; k++) {
+                const char *T = (const char *)a.tris + (size_t)(first + k) * (16u * MCRT_TRI_PIECES) + 16u * TRI_V0;
+                const u32x8 A = sload8(T); const u32x4 C2 = sload4(T + 32);
+                const f3 v0 = mk(__uint_as_float(A[0]), __uint_as_float(A[1]), __uint_as_float(A[2])), v1 = mk(__uint_as_float(A[4]), __uint_as_float(A[5]), __uint_as_float(A[6]));
+                const f3 v2 = mk(__uint_as_float(C2[0]), __uint_as_float(C2[1]), __uint_as_float(C2[2]));
+                const int id = (int)A[3];
+                const float edge_tol = __uint_as_float(C2[3]);
+                const float4 P = tri_plane(v0, v1, v2);
+                const f3 nrm = xyz(P);
+                const float da = dot(nrm, f2) - P.w;
+                const float db = dot(nrm, to) - P.w;
+                bool ok = da * db < 0.0f;
+                if (!__any(ok)) continue;
+                const float proj = da - db;
+                const float frac = da / proj;
+                ok = ok && (frac < best.frac || (frac == best.frac && id < best.tri)) && frac >= 0.0f;
+                if (!__any(ok)) continue;
+                float tmin, tmax;
+                f3 plo, phi;
+                tri_padded_bounds(v0, v1, v2, a.pad_abs, plo, phi);
+                ok = ok && slab_c(plo, phi, rc, inv, 0.0f, 1.0f, tmin, tmax) && frac >= tmin && frac <= tmax;
+                if (!__any(ok)) continue;
+                const float s = 1.0f - frac;
+                const f3 p = mk(s * f2.x + frac * to.x, s * f2.y + frac * to.y, s * f2.z + frac * to.z);
+                const f3 p0 = v0 - p, p1 = v1 - p, p2 = v2 - p;
+                ok = ok && dot(cross(p0, p1), nrm) >= edge_tol && dot(cross(p1, p2), nrm) >= edge_tol && dot(cross(p2, p0), nrm) >= edge_tol;
+                if (ok) { best.frac = frac; best.tri = id; }
+            }
+        }
+        if (sp == 0) break;
+        sp = __builtin_amdgcn_readfirstlane(sp - 1);
+        cur = __builtin_amdgcn_readlane(stk, sp);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_trace_packet(FrameArgs a, uint32_t b)
+{
+    const uint32_t n_rays = a.counts[b];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t base = blockIdx.x * 64u;
+    if (base >= n_rays || a.n_nodes == 0u) return;
+    const uint32_t i = base + lane;
+    const bool live = i < n_rays;
+    const uint32_t ray_id = live ? i : n_rays - 1u;
+    const size_t st_half = (size_t)(b & 1u) * a.ne * a.S;
+    const float4 s0 = a.st0[st_half + ray_id], s1 = a.st1[st_half + ray_id];
+    const Ray ry = ray_of(mk(s0.x, s0.y, s0.z), mk(s1.x, s1.y, s1.z), s0.w, a);
+    const f3 f2 = ry.f2, to = ry.to;
+    const f3 d = to - f2;
+    const f3 inv = mk(rcp_dir(d.x), rcp_dir(d.y), rcp_dir(d.z));
+    const f3 rc = ray_c(f2, inv);
+    const LaneRay lr = { rc.x, rc.y, rc.z, inv.x, inv.y, inv.z, inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f };
+    Best best; best.frac = live ? 1.0f : -1.0f; best.tri = -1;            // (a lane beyond the queue passes no box: its closest fraction is negative)
+    // do all the packet's rays run the same way along every axis?  (lane 0 is live: base < n_rays)
+    const int sgn = (lr.nx ? 1 : 0) | (lr.ny ? 2 : 0) | (lr.nz ? 4 : 0);
+    const int sgn0 = __builtin_amdgcn_readfirstlane(sgn);
+    const int which = __all(!live || sgn == sgn0) ? sgn0 : 8;               // wave-uniform
+    switch (which) {
+    case 0: packet_walk<0>(a, lr, f2, to, inv, rc, best); break;
+    case 1: packet_walk<1>(a, lr, f2, to, inv, rc, best); break;
+    case 2: packet_walk<2>(a, lr, f2, to, inv, rc, best); break;
+    case 3: packet_walk<3>(a, lr, f2, to, inv, rc, best); break;
+    case 4: packet_walk<4>(a, lr, f2, to, inv, rc, best); break;
+    case 5: packet_walk<5>(a, lr, f2, to, inv, rc, best); break;
+    case 6: packet_walk<6>(a, lr, f2, to, inv, rc, best); break;
+    case 7: packet_walk<7>(a, lr, f2, to, inv, rc, best); break;
+    default: packet_walk<8>(a, lr, f2, to, inv, rc, best); break;
+    }
+    if (live && best.tri >= 0) {
+        unsigned long long *keys = (b & 1u) ? a.key1 : a.key0;
+        keys[i] = ((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri;
+    }
+}
+
 // ---- interface interaction (scene.cpp:122-165, ray.cpp:11-97) of ONE path at bounce b, given its ray and the closest-hit
 // word of the walk: thickness draw, travel, hit_boundary, the segment's records, the continuing ray's state.  Returns whether
 // the path goes on.
@@ -1224,14 +1398,14 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
     const f3 from = ps.from, dir = ps.dir; const float intensity = ps.intensity; const int media = ps.media, outside = ps.outside; const double dist_mm = ps.dist_mm;
 
     // survivors -> next bounce's queue (ballot + prefix; ONE atomic per workgroup: tens of thousands of returning atomics on the
-    // single counter would serialise in L2 and bound the kernel).  Inside a wavefront's block the reflected rays
+    // single counter would serialise in L2 and bound the kernel).  Inside a workgroup's block the reflected rays
     // come first, then the refracted ones, each in queue order: the samples of a scan-line that took the same decisions stay
     // adjacent, so the rays of a k_trace_lane wavefront mostly belong to a few tight bundles (same nodes, similar walk length).
-    __shared__ uint32_t wave_live[4], block_base;
+    __shared__ uint32_t wave_live[4], wave_refl[4], block_base;
     const unsigned long long live = __ballot(alive);
     const unsigned long long live_refl = __ballot(alive && reflected);
     const int wv = threadIdx.x >> 6;
-    if (lane == 0) wave_live[wv] = (uint32_t)__popcll(live);
+    if (lane == 0) { wave_live[wv] = (uint32_t)__popcll(live); wave_refl[wv] = (uint32_t)__popcll(live_refl); }
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t total = wave_live[0] + wave_live[1] + wave_live[2] + wave_live[3];
@@ -1239,12 +1413,15 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
     }
     __syncthreads();
     if (live) {
-        uint32_t base = block_base;
-        for (int w = 0; w < wv; w++) base += wave_live[w];
+        // (round 5: reflected-first over the WORKGROUP's 256 rays, not per wavefront -- three of the next bounce's four 64-ray blocks are then of one history,
+        //  which is what a ray packet wants, k_trace_packet)
+        const uint32_t refl_all = wave_refl[0] + wave_refl[1] + wave_refl[2] + wave_refl[3];
+        uint32_t refl_before = 0, refr_before = 0;
+        for (int w = 0; w < wv; w++) { refl_before += wave_refl[w]; refr_before += wave_live[w] - wave_refl[w]; }
         if (alive) {
             const unsigned long long below = (1ull << lane) - 1ull;
-            const uint32_t pos = base + (reflected ? (uint32_t)__popcll(live_refl & below)
-                                                   : (uint32_t)__popcll(live_refl) + (uint32_t)__popcll(live & ~live_refl & below));
+            const uint32_t pos = block_base + (reflected ? refl_before + (uint32_t)__popcll(live_refl & below)
+                                                         : refl_all + refr_before + (uint32_t)__popcll(live & ~live_refl & below));
             q_out[pos] = pid;
             ((b & 1u) ? a.key0 : a.key1)[pos] = MCRT_KEY_MISS;            // the next bounce's closest-hit word of this ray
             const size_t so = (size_t)((b + 1u) & 1u) * a.ne * a.S + pos;
@@ -1760,9 +1937,13 @@ hipError_t launch_trace(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
     if (np < a.ksplit_limit) np = a.ksplit_limit;          // small bounces are cut into up to ksplit_limit pieces
     const uint32_t blocks = (np + 255u) / 256u;
     const dim3 grid(blocks < a.trace_blocks ? blocks : a.trace_blocks), blk(256);
-    if (!stats && a.trace_blocks_wide != 0u && np >= a.wide_from) {          // a large launch: five wavefronts per SIMD (k_trace_lane_wide)
+    if (!stats && a.trace_blocks_wide != 0u && np >= a.wide_from && !(b >= 1u && b < 32u && ((a.packet_mask >> b) & 1u))) {          // a large launch: five wavefronts per SIMD (k_trace_lane_wide)
         const dim3 gridw(blocks < a.trace_blocks_wide ? blocks : a.trace_blocks_wide);
         hipLaunchKernelGGL(k_trace_lane_wide, gridw, blk, (size_t)MCRT_LANE_WIDE_STACK * 256 * sizeof(int), st, a, b);
+        return hipGetLastError();
+    }
+    if (!stats && b >= 1u && b < 32u && ((a.packet_mask >> b) & 1u)) {       // a bounce walked a wavefront per ray packet (k_trace_packet)
+        hipLaunchKernelGGL(k_trace_packet, dim3((a.ne * a.S + 63u) / 64u), dim3(64), 0, st, a, b);
         return hipGetLastError();
     }
     if (stats) hipLaunchKernelGGL((k_trace_lane<true>), grid, blk, 0, st, a, b);

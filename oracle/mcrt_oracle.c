@@ -1457,3 +1457,83 @@ void orc_seed_count(const orc_scene *sc, const orc_params *prm, const orc_segmen
         tri[q] = best.tri;
     }
 }
+
+/* ANALYSIS (tools/packet_count.py): north_star's literal design -- "one wavefront per ray packet" -- counted before it is built.  W consecutive
+ * queries (queue order: the sample paths of a scan-line with one history are neighbours) walk the BVH4 TOGETHER: one shared stack, a node is
+ * visited when ANY ray of the packet passes the box of that child with its OWN current closest fraction, every ray tests every triangle of a
+ * visited leaf.  Legal under the contract (the closest hit does not depend on the visiting order; boxes only cull).  Children are visited
+ * nearest first by the smallest t_near among the rays that hit them (order 0) or by the FIRST hitting ray's t_near (order 1: what a wavefront
+ * can do with one readfirstlane).  out[p] = { nodes the packet visits, leaves, triangles (each tested by all W lanes), sum over its rays of the nodes
+ * a ray walking alone visits, the largest of those, live rays }; tri[q] must equal the segments' own triangles. */
+void orc_packet_count(const orc_scene *sc, const orc_params *prm, const orc_segment *segs, uint64_t n, uint32_t W, int order,
+                      uint32_t *out /*[packets][6]*/, int32_t *tri /*[n]*/, int n_threads)
+{
+    const orc_bvh4_child *nodes = (const orc_bvh4_child *)sc->nodes4;
+    const int64_t n_pack = (int64_t)((n + W - 1) / W);
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t p = 0; p < n_pack; p++) {
+        v3 from[64], to[64], inv[64], rc[64]; hit_t best[64]; uint32_t alone[64];
+        const uint32_t m = (uint32_t)((uint64_t)(p + 1) * W <= n ? W : n - (uint64_t)p * W);
+        for (uint32_t r = 0; r < m; r++) {
+            const orc_segment *sg = &segs[(uint64_t)p * W + r];
+            const v3 f0 = V(sg->from[0], sg->from[1], sg->from[2]), dir = V(sg->dir[0], sg->dir[1], sg->dir[2]);
+            const float L = 10.f * orc_logf(prm->intensity_epsilon / sg->initial_intensity) / -sg->attenuation * prm->frequency;
+            const float Ls = L / 100.0f;
+            to[r] = V(f0.x + Ls * (sc->spacing[0] * dir.x), f0.y + Ls * (sc->spacing[1] * dir.y), f0.z + Ls * (sc->spacing[2] * dir.z));
+            from[r] = V(f0.x + prm->ray_start_offset * dir.x, f0.y + prm->ray_start_offset * dir.y, f0.z + prm->ray_start_offset * dir.z);
+            const v3 d = vsub(to[r], from[r]);
+            inv[r] = V(rcp_dir(d.x), rcp_dir(d.y), rcp_dir(d.z)); rc[r] = ray_c(from[r], inv[r]);
+            best[r].frac = 1.0f; best[r].tri = -1; best[r].n = V(0, 0, 0); best[r].da = 0;
+            hit_t b1 = best[r]; orc_stats st; memset(&st, 0, sizeof st);
+            walk_bvh4(sc, from[r], to[r], &b1, &st); alone[r] = (uint32_t)st.nodes_visited;
+        }
+        int32_t stack[256]; int sp = 0; int32_t cur = 0;
+        uint32_t nn = 0, nl = 0, nt = 0;
+        for (;;) {
+            if (cur >= 0) {
+                const orc_bvh4_child *N = nodes + 4 * (size_t)cur;
+                nn++;
+                float key[4]; int hitc[4]; int nh = 0;
+                for (int k = 0; k < 4; k++) {
+                    hitc[k] = 0; key[k] = INFINITY;
+                    if (N[k].ref == ORC_BVH4_EMPTY) continue;
+                    const float hi[3] = { N[k].hix, N[k].hiy, N[k].hiz };
+                    for (uint32_t r = 0; r < m; r++) {
+                        float tn;
+                        if (slab_node(N[k].lo, hi, rc[r], inv[r], fminf(1.0f, best[r].frac), &tn)) {
+                            if (!hitc[k] || (order == 0 && tn < key[k])) key[k] = tn;
+                            hitc[k] = 1;
+                            if (order == 1) break;            /* the first hitting ray decides the order */
+                        }
+                    }
+                    if (order == 1 && hitc[k]) { /* the remaining rays are not consulted for the ORDER; whether the child is visited is already decided */ }
+                    nh += hitc[k];
+                }
+                if (nh > 0) {
+                    int ord[4], c = 0;
+                    for (int k = 0; k < 4; k++) if (hitc[k]) ord[c++] = k;
+                    for (int i = 1; i < c; i++) { int x = ord[i], j = i - 1; while (j >= 0 && key[ord[j]] > key[x]) { ord[j + 1] = ord[j]; j--; } ord[j + 1] = x; }
+                    for (int i = c - 1; i >= 1; i--) if (sp < 256) stack[sp++] = N[ord[i]].ref;        /* farthest first: the nearest pops first */
+                    cur = N[ord[0]].ref;
+                    continue;
+                }
+            } else {
+                const uint32_t v = (uint32_t)~cur, first = v >> 3, cnt = (v & 7u) + 1u;
+                nl++;
+                for (uint32_t i = 0; i < cnt; i++) {
+                    const float *t = sc->bvh_tri + (size_t)(first + i) * 12;
+                    float t9[9] = { t[0], t[1], t[2], t[4], t[5], t[6], t[8], t[9], t[10] };
+                    for (uint32_t r = 0; r < m; r++) tri_test(t9, (int32_t)f2u(t[3]), from[r], to[r], inv[r], rc[r], sc->pad_abs, &best[r]);
+                    nt++;
+                }
+            }
+            if (sp == 0) break;
+            cur = stack[--sp];
+        }
+        uint32_t sum = 0, mx = 0;
+        for (uint32_t r = 0; r < m; r++) { sum += alone[r]; if (alone[r] > mx) mx = alone[r]; tri[(uint64_t)p * W + r] = best[r].tri; }
+        uint32_t *o = out + 6 * p;
+        o[0] = nn; o[1] = nl; o[2] = nt; o[3] = sum; o[4] = mx; o[5] = m;
+    }
+}

@@ -220,6 +220,11 @@ void orc_wide_count(const struct orc_wide *w, const orc_scene *sc, const orc_par
 void orc_seed_count(const orc_scene *sc, const orc_params *prm, const orc_segment *segs, uint64_t n, int mode, const int32_t *seed_tri,
                     uint32_t *out, int32_t *tri, int n_threads);
 
+/* ANALYSIS (tools/packet_count.py): W consecutive queries walking the BVH4 as ONE packet (shared stack; a node is visited when any ray passes it);
+ * out[p] = { nodes, leaves, triangles, sum and max of the rays' solo node visits, live rays }; tri[q] the triangle each ray finds */
+void orc_packet_count(const orc_scene *sc, const orc_params *prm, const orc_segment *segs, uint64_t n, uint32_t W, int order,
+                      uint32_t *out, int32_t *tri, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -628,12 +628,16 @@ def test_randomised_configurations(mcrt, orc, case, monkeypatch, tex256):
     textures of several sizes, TIR sanitising on and off, frequency, seed, frames in flight -- hits and RF bit for bit"""
     rng = np.random.default_rng(1000 + case)
     # every fourth case without cutting the rays of small bounces into pieces, one with two scan-line groups on two streams (the library reads its knobs at mcrt_create)
-    for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS"):
+    for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_PACKET_BOUNCES", "MCRT_PACKET_FROM"):
         monkeypatch.delenv(k, raising=False)
     if case % 4 == 3:
         monkeypatch.setenv("MCRT_KSPLIT_LIMIT", "0")
     if case == 6:
         monkeypatch.setenv("MCRT_GROUPS", "2")
+    if case % 2 == 1:
+        # every other case walks some of its bounces a WAVEFRONT PER RAY PACKET (k_trace_packet: by default only bounce 1 of passes of >= 262144 paths):
+        # a drawn set of bounces at ANY pass size -- partial packets (rays not a multiple of 64), packets of mixed directions, depth-16 paths
+        monkeypatch.setenv("MCRT_PACKET_BOUNCES", hex(int(rng.integers(1, 1 << 16)) | 2)); monkeypatch.setenv("MCRT_PACKET_FROM", "0")
     if case % 3 == 0:
         cfg, meshes = mcrt.synth.random_scene(int(rng.integers(2000, 30000)), 8, seed=int(rng.integers(1, 1000)))
     elif case % 3 == 1:
@@ -738,7 +742,7 @@ def _run_bench(extra, nproc=1, timeout=600):
 def _why(stderr_tail):
     """the most telling line of a failed child's stderr"""
     lines = [l.strip() for l in (stderr_tail or "").splitlines() if l.strip() and set(l.strip()) - set("=-")]
-    hits = [l for l in lines if "rror" in l or "NCCL" in l or "nccl" in l]
+    hits = [l for l in lines if ("NCCL" in l or "nccl" in l or "Duplicate GPU" in l or "invalid usage" in l) and "traceback" not in l.lower()] or [l for l in lines if "rror" in l and "traceback" not in l.lower()]
     return (hits[-1] if hits else (lines[-1] if lines else "timed out"))[:200]
 
 
@@ -752,10 +756,10 @@ def test_two_ranks_gather_equals_single_process():
     tried = []
     for backend, limit in (("nccl", 90), ("gloo", 300)):          # (two RCCL ranks on ONE device may be refused, or never finish their rendezvous)
         r, out = _run_bench(small + ["--backend", backend], nproc=2, timeout=limit)
-        tried.append((backend, None if r is None else r.returncode, "" if r is None else (r.stderr or "")[-400:]))
+        tried.append((backend, None if r is None else r.returncode, "" if r is None else (r.stderr or "")[-6000:]))
         if r is not None and r.returncode == 0 and out is not None:
             break
-    assert r is not None and out is not None and r.returncode == 0, tried
+    assert r is not None and out is not None and r.returncode == 0, [(t[0], t[1], t[2][-400:]) for t in tried]
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["scan_lines_total"] == 32
     g = out["gather_check"]
     assert g["equal"] and g["ranks"] == 2 and g["nonzero"] > 1000, g
@@ -827,18 +831,19 @@ def test_host_shim_surface(mcrt, orc, tex256, tmp_path):
 
 def test_schedules_do_not_change_anything(mcrt, orc, tex256, monkeypatch):
     """how a pass is scheduled is free (counter-keyed RNG, integer RF bins): the default, scan-line groups on their own streams, rays
-    of small bounces cut into pieces or not, the accumulation (and the walk) confined to their own CUs, everything on one stream, the walk
-    in its five-wavefronts-per-SIMD form (k_trace_lane_wide, which large launches take by themselves) -- all give bit-identical hits,
+    of small bounces cut into pieces or not, every bounce walked a wavefront per ray packet (k_trace_packet) or none, the accumulation (and the walk)
+    confined to their own CUs, everything on one stream, the walk in its five-wavefronts-per-SIMD form (k_trace_lane_wide, which large launches take by themselves) -- all give bit-identical hits,
     segments, RF images and visit counts, equal to the oracle's."""
     cfg, meshes = mcrt.synth.random_scene(60000, 8, seed=5)
     sd = mcrt.scene_io.build_scene(cfg, meshes)
     E, S, frame = 24, 160, 11
     got = {}
-    variants = (("default", {}), ("two_groups", {"MCRT_GROUPS": "2"}), ("three_groups_no_split", {"MCRT_GROUPS": "3", "MCRT_KSPLIT_LIMIT": "0"}),
+    variants = (("default", {}), ("packets_every_bounce", {"MCRT_PACKET_BOUNCES": "0xfffe", "MCRT_PACKET_FROM": "0"}), ("no_packets", {"MCRT_PACKET_BOUNCES": "0"}),
+                ("two_groups", {"MCRT_GROUPS": "2"}), ("three_groups_no_split", {"MCRT_GROUPS": "3", "MCRT_KSPLIT_LIMIT": "0"}),
                 ("masked", {"MCRT_MARCH_CUS": "64", "MCRT_MAIN_MASK": "1"}), ("march_masked", {"MCRT_MARCH_CUS": "96"}), ("no_overlap", {"MCRT_NO_OVERLAP": "1"}),
                 ("wide_walk", {"MCRT_WIDE_FROM": "1"}), ("wide_walk_two_groups_no_split", {"MCRT_WIDE_FROM": "1", "MCRT_GROUPS": "2", "MCRT_KSPLIT_LIMIT": "0"}))
     for name, env in variants:
-        for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP", "MCRT_WIDE_FROM"):
+        for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP", "MCRT_WIDE_FROM", "MCRT_PACKET_BOUNCES", "MCRT_PACKET_FROM"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)                               # (the library reads its knobs once, at mcrt_create)
@@ -856,7 +861,7 @@ def test_schedules_do_not_change_anything(mcrt, orc, tex256, monkeypatch):
         nodes4 = sim.ctx.get_bvh4()[0]
         sim.close()
         got[name] = (hits, segs.tobytes(), cnt, rf, st, batch[1].T.copy(), nodes4)
-    for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP", "MCRT_WIDE_FROM"):
+    for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP", "MCRT_WIDE_FROM", "MCRT_PACKET_BOUNCES", "MCRT_PACKET_FROM"):
         monkeypatch.delenv(k, raising=False)
     a = got["default"]
     for name in [v[0] for v in variants[1:]]:
@@ -897,10 +902,13 @@ def test_deep_tree_overflow_stacks_of_two_groups(mcrt, orc, tex256, monkeypatch)
     sd.tri = np.ascontiguousarray(tri); sd.tri_mesh = (np.arange(n) % len(sd.meshes)).astype(np.uint32)
     E, S = 16, 96
     out = {}
-    for groups in ("1", "2", "2w"):
+    for groups in ("1", "2", "2w", "1p"):
         monkeypatch.setenv("MCRT_GROUPS", groups[0])
         if groups == "2w":
             monkeypatch.setenv("MCRT_WIDE_FROM", "1")
+        if groups == "1p":          # every bounce a wavefront per ray packet: the packet's ONE 64-entry stack register against a 51-entry worst case
+            monkeypatch.delenv("MCRT_WIDE_FROM", raising=False)
+            monkeypatch.setenv("MCRT_PACKET_BOUNCES", "0xfffe"); monkeypatch.setenv("MCRT_PACKET_FROM", "0")
         tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256)
         _, max_stack = sim.ctx.get_bvh4()
         dev = sim.ctx.alloc(2 * E * sim.R * 4)
@@ -911,9 +919,11 @@ def test_deep_tree_overflow_stacks_of_two_groups(mcrt, orc, tex256, monkeypatch)
             hits, _, _ = sim.ctx.trace_frame_debug(5, sim.rf_dev)
             nodes4 = sim.ctx.get_bvh4()[0]; _, btri, _ = sim.ctx.get_bvh()
         sim.close()
-    monkeypatch.delenv("MCRT_GROUPS", raising=False); monkeypatch.delenv("MCRT_WIDE_FROM", raising=False)
+    for k in ("MCRT_GROUPS", "MCRT_WIDE_FROM", "MCRT_PACKET_BOUNCES", "MCRT_PACKET_FROM"):
+        monkeypatch.delenv(k, raising=False)
     assert np.array_equal(out["1"].view(np.uint32), out["2"].view(np.uint32))
     assert np.array_equal(out["1"].view(np.uint32), out["2w"].view(np.uint32))
+    assert np.array_equal(out["1"].view(np.uint32), out["1p"].view(np.uint32))
     osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing)
     osc.set_bvh4(nodes4, btri)
     o = osc.trace_frame(orc.default_params(n_elements=E, n_samples=S), tr.pos, tr.dir, tex256, frame_id=5, use_bvh=2, n_threads=16, want_ref=False)
