@@ -51,7 +51,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMD = 1024           # 256 CUs x 4 SIMD-32
 PMC_ROUND = "round5" if os.path.exists(os.path.join(ROOT, "profiles", "round5", "pmc_bench.json")) else "round4"      # the committed single-GPU passes N > 1 runs fall back to
 MIN_SPLIT_PASS = 48     # N > 1: a timed region is cut into two passes (gather + post of the first hidden behind the second) only if each has this many frames
-TRACE_KERNELS = ("k_trace_lane<false", "k_trace_lane_wide")   # the walk of the timed build: its four- and five-wavefront forms (large launches take the second), pooled
+TRACE_KERNELS = ("k_trace_lane<false", "k_trace_lane_wide", "k_trace_packet")   # the walk of the timed build, pooled: the lane walk's four- and five-wavefront forms (large launches take the second) and bounce 1's ray packets
 KERNEL_FAMILIES = {"walk": TRACE_KERNELS, "march": ("k_march<false",), "shade": ("k_shade<false",)}
 ARCH_IPC = 0.5          # MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles on the SIMD-32 -> 0.5 instructions per cycle and SIMD
 
@@ -365,7 +365,7 @@ def main():
         if pmc is None:
             pmc = committed_pmc(args, pass_sizes, per_frame["queries"] / launches_per_frame)
         roof = roofline_from(pmc, k_ms, alg_gbs, alg_bytes)
-        roof.update({"kernel": "k_trace_lane<false> / k_trace_lane_wide (the walk: launches of >= 4 Mi rays take the five-wavefront form)", "kernel_ms": k_ms, "launches": k_n,
+        roof.update({"kernel": "the walk, one launch per bounce, pooled: k_trace_lane<false> / k_trace_lane_wide (a lane per ray; launches of >= 4 Mi rays take the five-wavefront form) and k_trace_packet (bounce 1 of passes of >= 262144 paths: a wavefront per ray packet)", "kernel_ms": k_ms, "launches": k_n,
                      "launches_per_frame": launches_per_frame, "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps_cache_served": alg_gbs, "node_bytes": node_bytes,
                      "trace_bytes_per_frame": trace_bytes_frame, "other_stage_bytes_per_frame": other_bytes_frame, "per_frame": per_frame})
         if world == 1 and not args.no_latency_leg:

@@ -1114,6 +1114,7 @@ MCRT_DEV void packet_walk(const FrameArgs &a, const LaneRay &lr, const f3 f2, co
 #define MCRT_PK_CAS(ka, ra, kb, rb) { const bool sw_ = kb < ka; const uint32_t kl_ = sw_ ? kb : ka, kh_ = sw_ ? ka : kb; const int rl_ = sw_ ? rb : ra, rh_ = sw_ ? ra : rb; ka = kl_; kb = kh_; ra = rl_; rb = rh_; }
                 MCRT_PK_CAS(k0, a0, k1, a1) MCRT_PK_CAS(k2, a2, k3, a3) MCRT_PK_CAS(k0, a0, k2, a2) MCRT_PK_CAS(k1, a1, k3, a3) MCRT_PK_CAS(k1, a1, k2, a2)
 #undef MCRT_PK_CAS
+                if (sp > 60) { if ((threadIdx.x & 63) == 0) atomicOr(a.error_flag, 1u); break; }      // (cannot happen: trees that need more than MCRT_STACK = 64 entries are refused at upload; never silently)
                 if (k3 != 0xffffffffu) { stk = writelane(a3, sp, stk); sp++; }     // farthest first: the nearest pops first
                 if (k2 != 0xffffffffu) { stk = writelane(a2, sp, stk); sp++; }
                 stk = writelane(a1, sp, stk); sp++;

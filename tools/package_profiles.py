@@ -39,7 +39,7 @@ shutil.copy(os.path.join(src, "configs.txt"), os.path.join(dst, "baseline_config
 
 # ---- PMC passes per kernel
 pmc = {}
-for kernel, name in (("k_trace_lane<false|k_trace_lane_wide", "pmc_k_trace_lane.json"), ("k_march<false", "pmc_k_march.json"), ("k_shade<false", "pmc_k_shade.json")):
+for kernel, name in (("k_trace_lane<false|k_trace_lane_wide|k_trace_packet", "pmc_k_trace_lane.json"), ("k_march<false", "pmc_k_march.json"), ("k_shade<false", "pmc_k_shade.json")):
     env = dict(os.environ, PMC_KERNEL=kernel)
     subprocess.check_output([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), os.path.join(out, "pmc_" + tag)], env=env)
     d = json.load(open(os.path.join(out, "pmc_" + tag, "summary.json")))
@@ -74,7 +74,7 @@ ks = {}
 for row in csv.DictReader(open(os.path.join(dst, "kernel_stats.csv"))):
     ks[row["Name"].split("(")[0].replace("void mcrt::", "")] = row
 # the walk has two forms (k_trace_lane<false>: four wavefronts per SIMD; k_trace_lane_wide: five, taken by launches of >= 4 Mi rays): one row, launch-weighted
-walk_rows = [v for k, v in ks.items() if k.replace("mcrt::", "").startswith("k_trace_lane<false>") or k.replace("mcrt::", "").startswith("k_trace_lane_wide")]
+walk_rows = [v for k, v in ks.items() if k.replace("mcrt::", "").startswith(("k_trace_lane<false>", "k_trace_lane_wide", "k_trace_packet"))]
 walk_calls = sum(int(v["Calls"]) for v in walk_rows)
 ks["k_trace_lane<false>"] = {"AverageNs": sum(int(v["Calls"]) * float(v["AverageNs"]) for v in walk_rows) / max(walk_calls, 1), "Calls": walk_calls}
 alone = {}; walk_alone = [0.0, 0]
@@ -82,7 +82,7 @@ for line in open(os.path.join(dst, "kernels_standalone.txt")):
     for k in ("k_march<false", "k_shade<false>"):
         if k in line and " avg " in line:
             alone[k] = float(line.split(" avg ")[1].split()[0])
-    if ("k_trace_lane<false>" in line or "k_trace_lane_wide" in line) and " avg " in line and " calls " in line:
+    if ("k_trace_lane<false>" in line or "k_trace_lane_wide" in line or "k_trace_packet" in line) and " avg " in line and " calls " in line:
         n = int(line.split(" calls ")[1].split()[0]); walk_alone[0] += n * float(line.split(" avg ")[1].split()[0]); walk_alone[1] += n
 alone["k_trace_lane<false>"] = walk_alone[0] / max(walk_alone[1], 1)
 r = bench["roofline"]; t = pmc["pmc_k_trace_lane.json"]; m = pmc["pmc_k_march.json"]; s = pmc["pmc_k_shade.json"]

@@ -18,6 +18,8 @@ workload = sys.argv[1] if len(sys.argv) > 1 else "random1m"
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 order = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 pure = len(sys.argv) > 4 and sys.argv[4] == "pure"       # packets cut from PURE bundles (the queue sorted by reflect / refract history: what a sorting compaction would give)
+blk3 = len(sys.argv) > 4 and sys.argv[4] == "blk3"       # k_shade's 256-ray blocks sorted by the class of the last three reflect / refract decisions (a counting sort inside the workgroup)
+dec = None
 E, W = 128, 64
 cfg, meshes = {"random1m": lambda: m.synth.random_scene(1_000_000, 8, 12345), "liver": lambda: m.synth.liver_scene(5), "sphere": lambda: m.synth.sphere_scene(5)}[workload]()
 sd = m.scene_io.build_scene(cfg, meshes)
@@ -46,7 +48,11 @@ for b in range(1, p.max_depth):
     blk = (e_idx * S + s_idx) // 64
     side = (np.einsum("esk,esk->es", segs["dir"][:, :, b].astype(np.float64), tri_n[np.maximum(hits[:, :, b - 1].astype(np.int64), 0)]) > 0).astype(np.uint64)
     key = (key * np.uint64(0x9E3779B97F4A7C15) + (hits[:, :, b - 1].astype(np.int64).astype(np.uint64) * np.uint64(2) + side + np.uint64(1))) & np.uint64(0xFFFFFFFFFFFFFFFF)
-    order_idx = np.lexsort((s_idx, key[e_idx, s_idx], e_idx)) if pure else np.lexsort((s_idx, ~refl, blk))
+    d_now = np.zeros((E, S), np.uint64); d_now[e_idx, s_idx] = refl.astype(np.uint64)
+    dec = d_now if dec is None else (((dec << np.uint64(1)) | d_now) & np.uint64(7))
+    if pure: order_idx = np.lexsort((s_idx, key[e_idx, s_idx], e_idx))
+    elif blk3: order_idx = np.lexsort((s_idx, dec[e_idx, s_idx], (e_idx * S + s_idx) // 256))
+    else: order_idx = np.lexsort((s_idx, ~refl, (e_idx * S + s_idx) // 256))          # (round 5: reflected-first over the workgroup's 256 rays)
     q = np.ascontiguousarray(segs[e_idx, s_idx, b][order_idx]); own = hits[e_idx, s_idx, b][order_idx]
     n = len(q); n_pack = (n + W - 1) // W
     out = np.zeros((n_pack, 6), np.uint32); tri = np.zeros(n, np.int32)
@@ -61,7 +67,7 @@ for b in range(1, p.max_depth):
          "packet_nodes_p50_p90_p99": [float(np.percentile(out[:, 0], x)) for x in (50, 90, 99)]}
     rows.append(r); sys.stderr.write(json.dumps(r) + "\n")
 tot_pack = sum(r["packet_nodes_mean"] * r["packets"] for r in rows); tot_solo = sum(r["solo_nodes_per_ray"] * r["rays"] for r in rows)
-print(json.dumps({"queue": "sorted into pure bundles (scan-line, history)" if pure else "as k_shade's compaction leaves it", "workload": workload, "scan_lines": E, "rays": S, "packet": W, "order": "first hitting ray" if order else "smallest t_near of the packet", "seconds": round(time.time() - t0, 1),
+print(json.dumps({"queue": "sorted into pure bundles (scan-line, history)" if pure else "256-ray blocks sorted by the last three decisions" if blk3 else "as k_shade's compaction leaves it (reflected first inside a 256-ray block)", "workload": workload, "scan_lines": E, "rays": S, "packet": W, "order": "first hitting ray" if order else "smallest t_near of the packet", "seconds": round(time.time() - t0, 1),
                   "per_bounce": rows,
                   "bounces_ge1": {"packet_node_visits_per_ray": tot_pack / sum(r["rays"] for r in rows), "solo_node_visits_per_ray": tot_solo / sum(r["rays"] for r in rows),
                                   "wave_level_node_steps_packet_over_lane_walk_at_full_lanes": tot_pack * 64 / tot_solo}}, indent=1))

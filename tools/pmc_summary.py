@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 output dirs (kernel stats + PMC passes) of tools/pmc.sh into one JSON + text table."""
 import csv, glob, json, os, sys, collections
-KERNELS = os.environ.get("PMC_KERNEL", "k_trace_lane<false>|k_trace_lane_wide").split("|")   # substrings of the kernel(s) the counters are reported for, pooled (the walk has two forms)
+KERNELS = os.environ.get("PMC_KERNEL", "k_trace_lane<false>|k_trace_lane_wide|k_trace_packet").split("|")   # substrings of the kernel(s) the counters are reported for, pooled (the walk has two forms)
 out = sys.argv[1]
 res = {"kernel_stats": [], "pmc": {}}
 
