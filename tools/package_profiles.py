@@ -95,87 +95,72 @@ def pipe_ms(d):          # the time a launch's counted cache accesses need at th
 
 def krow(name, key, d, over):
     return "| `%s` | %.0f us | %.0f us | %.0f M | %.3f (%.0f %%) | %.0f %% | %.0f %% | %.0f M = %.2f ms of the pipe | %.0f MB |" % (
-        name, alone.get(key, 0), over, d["valu_instructions"] / 1e6, d["valu_ipc_per_simd"], 100 * d["valu_ipc_per_simd"] / mix["simd_ipc"], 100 * d["valu_lane_utilisation"],
+        name, alone.get(key, 0), over, d["valu_instructions"] / 1e6, d["valu_ipc_per_simd"], 100 * d["valu_ipc_per_simd"] / 0.5, 100 * d["valu_lane_utilisation"],
         100 * d["wave_time_waiting_on_memory"], d["tcp_lane_accesses_per_cycle_per_cu"] * d["kernel_busy_cycles_per_cu"] * 256 / 1e6, pipe_ms(d), d["fabric_bytes_per_launch"] / 1e6)
 
 
+rk = r.get("kernels") or {}
+def kb(name, key):
+    k = rk.get(name) or {}
+    return "%s beside the rest / alone %.3f / %.3f ms per launch (dilation %.2f), VALU share of the architectural rate alone %.2f" % (
+        name, k.get("ms_per_launch_overlapped") or 0, k.get("ms_per_launch_alone") or 0, k.get("dilation_beside_the_rest") or 0, k.get("valu_frac_vs_architectural_alone") or 0) if k else name + ": -"
+dk = drv["roofline"].get("kernels") or {}
 txt = """# profiles/@RND@ -- MI355X (gfx950), ROCm 7.2
 
 Workload of every file unless it says otherwise: `bench.py` defaults = synthetic 1 M random triangles, 128 scan-lines x 1024 sample
 paths per frame, 465 RF rows, max depth 10, one GPU, @FIF@ frames in flight per pass.  Produced by `tools/profile_round.sh` on a gpurun
-box and packaged by `tools/package_profiles.py`, which also wrote this file from the files beside it.
+box and packaged by `tools/package_profiles.py`, which also wrote this file from the files beside it.  The roof and counter calibrations
+(`valu_roof.json`, `tcp_access_cost.json`, `fetch_size_calibration.json`) are round 4's: `profiles/round4/`.
 
 | file | what |
 |---|---|
-| `valu_roof.json` | `tools/valu_roof.hip --quick`, round 4: the VALU issue ceiling per instruction class, now with a register-only replica of the node step the walk runs TODAY (`BVH4 LANE node-step mix`: 12 `v_cndmask`, 24 `v_fma_mix_f32`, min / max / min3 / max3, keys, ranking, branch-free pushes: 91 instructions) beside round 2's mix |
-| `fetch_roof_same.json`, `tcp_access_cost.json` | `tools/fetch_roof_same.hip` alone and under `rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum SQ_INSTS_VMEM_RD`: what the counter counts (one access per lane, a uniform adjacent quad once) and what a counted access costs a CU's vector memory pipe in every sharing pattern -- the cheapest, %.3f cycles, is the floor `bench.py`'s `second_roof` uses |
-| `fetch_size_calibration.json` | `tools/fetch_calib.hip` under `--pmc FETCH_SIZE` / `TCC_EA0_RDREQ` / `TCC_MISS`: FETCH_SIZE against KNOWN byte counts in the walk's access shapes (a coalesced stream reads 1/2, as the guide says; a scattered 64-byte node is one request counted at 64 bytes: 1.00) |
-| `bvh_width.json` | `tools/bvh_width.py` (CPU): the headline frame's 816 k closest-hit queries walked over the product's BVH2 collapsed to 2 / 4 / 8 / 16-wide nodes, float and 8-bit boxes -- visits, chains, 16-byte pieces (DESIGN.md A.6: rules 8-wide nodes out) |
-| `exp_refill_threshold.txt` | the walk's refill threshold at 4 / 8 / 16 idle lanes, timed and with the stamp build: more lanes step per iteration, every iteration costs proportionally more (the walk is bound by the vector memory pipe, not by idle lanes) |
-| `exp_pass_split.txt` | what cutting a timed region into smaller passes costs (decides `bench.py`'s N > 1 rule) |
-| `exp_round4_kernels.txt` | round 4's kernel changes one by one (triangle records, LDS tables, the held-back accumulation, the register trap) |
-| `exp_pass20.txt` | the driver's 20-frame pass on its own: launch timeline, the walk's tails, the schedule knobs (already at the optimum) |
-| `top_of_tree.json`, `exp_top_of_tree.txt` | a top-of-tree table in LDS for the walk: what a static table can serve (`tools/top_of_tree.py`, CPU) and what it did on the GPU (parity green, 3 %% slower: off) |
-| `quad_line.json`, `exp_quad_fetch.txt` | the node fetch a quad of lanes at a time through LDS-DMA: 2.4 x on a bare dependent fetch chain (`tools/quad_line.hip`), 4-5 %% slower in the walk (parity green: off) |
-| `exp_wide_walk.txt` | the walk's five-wavefront form (`k_trace_lane_wide`): register budgets, pass sizes, the 16 M scene, constants re-swept, where it spills |
-| `exp_sensitivity.txt` | what one more load, and ten more instructions, per node step cost the walk: 3 %% and 2 %% -- neither pipe is the wall alone |
-| `bench_random16m_sah.json` | the 16 M scene with the host's SAH builder instead of the device LBVH: 9 %% faster frames for a 70 x longer build |
-| `bench_random16m.json` | `python bench.py --workload random16m`: the STREAMING regime (16 M triangles, 2 GB of BVH past the Infinity Cache), with live PMC, CPU baseline and parity check |
-| `group_bench.json` | `tools/group_bench.py 0,0`: whole B-mode frames through `mcrt_group_*` (two ranks sharing the GPU) against one context |
-| `bench_unprofiled.json` | `python bench.py`: the JSON line (live PMC passes in child processes, CPU baseline, inline parity check) |
+| `bench_unprofiled.json` | `python bench.py`: the JSON line (live PMC passes in child processes, CPU baseline, inline parity check, the per-kernel block `roofline.kernels`) |
 | `bench_driver_cmd.json` | `python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command: one 20-frame pass per timed region) |
-| `pmc_bench.json` | the PMC block of `bench_unprofiled.json`, the labelled fall-back `bench.py` reads when it cannot profile itself |
+| `pmc_bench.json` | the PMC block of `bench_unprofiled.json`, the labelled fall-back `bench.py` reads when it cannot profile itself (N > 1) |
 | `kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps @FIF@ --warmup @FIF@ --no-cpu-baseline --no-latency-leg --no-pmc` (kernels overlap as in production) |
-| `kernels_standalone.txt` | the same with `MCRT_NO_OVERLAP=1`: every kernel alone on the GPU |
-| `pmc_k_trace_lane.json`, `pmc_k_march.json`, `pmc_k_shade.json` | separate `--pmc` passes (tools/pmc.sh), per-launch averages + derived figures |
+| `kernels_standalone.txt` | the same with `MCRT_TUNING=1 MCRT_NO_OVERLAP=1`: every kernel alone on the GPU |
+| `pmc_k_trace_lane.json`, `pmc_k_march.json`, `pmc_k_shade.json` | separate `--pmc` passes (tools/pmc.sh), per-launch averages + derived figures; the walk = `k_trace_lane<false>`, `k_trace_lane_wide` and bounce 1's `k_trace_packet`, pooled |
 | `frame_timeline.txt`, `frame_timeline_one_frame.txt` | start / duration of every launch of one pass: @FIF@ frames in flight, and one frame at a time |
 | `baseline_configs.txt` | the five BASELINE.json configurations on one GPU (tools/configs.sh) |
+| `bench_random16m.json` | `python bench.py --workload random16m`: the STREAMING regime (16 M triangles, 2 GB of BVH past the Infinity Cache) |
+| `group_bench.json` | `tools/group_bench.py 0,0`: whole B-mode frames through `mcrt_group_*` (two ranks sharing the GPU) against one context |
+| `seed_count_random1m.json`, `seed_count_liver.json` | `tools/seed_count.py` (CPU): node visits with no seed / the query's own answer / the bundle leader's answer as the initial closest-hit bound (VERDICT r4 #3: -11 %%, not built) |
+| `packet_count_random1m.json`, `packet_count_random1m_pure.json` | `tools/packet_count.py` (CPU): nodes a 64-ray packet visits against its rays' solo walks, per bounce, for the queue as it is and sorted into pure bundles |
+| `exp_packet.txt` | `k_trace_packet` (one wavefront per ray packet): every version measured, PMC of the kept one, which pass sizes and BASELINE configurations take it |
+| `exp_tail.txt`, `stamps_pass20_tail_histograms.txt`, `stamps_pass20_ilv4.txt` | the tail of the driver's 20-frame pass: per-wavefront histograms (`mcrt_debug_tail_histograms`), its cause, four ways out built and measured |
 
-## The two roofs (calibrated, not assumed)
+## What the kernels do (per launch = one bounce of a @FIF@-frame pass)
 
-**VALU issue.**  The register-only part of the node step the walk runs today issues at **%.3f instructions per cycle and SIMD at 4 wavefronts per
-SIMD, clock %.2f GHz** (round 2's step, the one `bench.py` priced against until round 3: %.3f at 5 wavefronts): 1024 SIMDs x %.3f x %.2f GHz =
-**%.0f G wave-instructions per second** is the ceiling of `roofline.frac`; the guide's two cycles per wave64 instruction (0.5) is
-`frac_vs_architectural`, which leads the block.
-
-**Vector memory pipe.**  Every SCATTERED access `TCP_TOTAL_CACHE_ACCESSES` counts costs a CU at least %.3f cycles, whatever lanes share (a uniform
-adjacent quad counts once and costs 1.6; scattered lanes count one each at 1.35).  A launch cannot be shorter than its scattered accesses x %.3f /
-(256 CUs x clock): `second_roof.frac` = that time over the launch's duration.  The walk's accesses are counted on its four-wavefront form
-(`k_trace_lane<false>`, `MCRT_WIDE_FROM` off for that pass): the five-wavefront form that large launches take (`k_trace_lane_wide`) adds the spill traffic of
-its refill code -- coalesced 4-byte scratch accesses, which the counter counts per lane but the pipe serves a wavefront at a time (`tcp_lane_accesses_as_run`
-in `pmc_k_trace_lane.json`).
-
-## What the kernels do with them (per launch = one bounce of a @FIF@-frame pass)
-
-| kernel | alone | overlapped | VALU instr. | IPC / SIMD (of %.3f) | lanes active | waiting on memory | cache accesses | fabric bytes |
+| kernel | alone | overlapped | VALU instr. | IPC / SIMD (of the 0.5 architectural; %.3f = the calibrated node-step mix) | lanes active | waiting on memory | cache accesses | fabric bytes |
 |---|---|---|---|---|---|---|---|---|
 %s
 %s
 %s
 
-The walk alone lasts %.0f us and the cache accesses it needs cost %.0f us of the CUs' vector memory pipes at the cheapest measured price: it runs
-AT that roof and at the VALU's at once (DESIGN.md A.6: `exp_sensitivity.txt`), at %.0f %% of the calibrated VALU ceiling with %.0f %% of its lanes active.  The BVH is served on-die: L1 hit rate
-%.0f %%, L2 %.0f %% of the rest, fabric traffic %.0f MB per launch -- `hbm_measured_frac` = %.3f of the 8 TB/s HBM figure (the algorithmic
+(`alone` from `kernels_standalone.txt`, `overlapped` from `kernel_stats.csv`; the walk row pools the lane walk's launches and bounce 1's packet launch.)  The BVH is served on-die: L1 hit rate
+%.0f %%, L2 %.0f %% of the rest, fabric traffic %.0f MB per launch -- `roofline.hbm.measured_frac` = %.3f of the 8 TB/s HBM figure (the algorithmic
 bytes, %.1f GB per launch, flow at %.1f TB/s from the caches).
 
 `bench_unprofiled.json` (a step is a WHOLE B-mode frame: trace, accumulate, PSF, envelope, scan conversion): **%.1f M rays/s, %.3f ms per frame (%.0f frames/s)**, timed region repeated %d times (min / median / max
-%.3f / %.3f / %.3f ms per frame); one frame at a time %.2f ms per frame; roofline `frac` = %.2f of the VALU ceiling, `frac_vs_architectural` %.2f,
-`second_roof.frac` %.2f (wall time of the launches with `k_march` running beside them);
+%.3f / %.3f / %.3f ms per frame); one frame at a time %.2f ms per frame; `roofline.frac` = %.2f of the architectural VALU issue rate (%.2f at lane level), `calibrated.frac` %.2f,
+`second_roof.frac` %.2f; %s; %s.
 `parity_check.rf_bit_exact` = %s on %d scan-lines.  CPU baseline (the oracle, %d usable cores of %d hardware threads, %.1f kept busy):
-%.2f M rays/s, one thread %.1f k rays/s.  `bench_driver_cmd.json` (one 20-frame pass): %.1f M rays/s, %.3f ms per frame; the same pass with a
-different probe pose in every frame (`sweep`): %.3f ms per frame.
+%.2f M rays/s, one thread %.1f k rays/s.
+
+`bench_driver_cmd.json` (one 20-frame pass): **%.1f M rays/s, %.3f ms per frame**; the same pass with a different probe pose in every frame (`sweep`): %.3f ms per frame; %s; %s.
 """ % (
-    cost, mix["simd_ipc"], mix["clock_ghz"], old_mix["simd_ipc"], mix["simd_ipc"], mix["clock_ghz"], 1024 * mix["simd_ipc"] * mix["clock_ghz"], cost, cost,
     mix["simd_ipc"],
-    krow("k_trace_lane", "k_trace_lane<false>", t, float(ks["k_trace_lane<false>"]["AverageNs"]) / 1e3),
+    krow("walk (k_trace_lane / _wide / _packet)", "k_trace_lane<false>", t, float(ks["k_trace_lane<false>"]["AverageNs"]) / 1e3),
     krow("k_march", "k_march<false", m, float(next(v for k, v in ks.items() if k.startswith("k_march<false, 2"))["AverageNs"]) / 1e3),
     krow("k_shade", "k_shade<false>", s, float(ks["k_shade<false>"]["AverageNs"]) / 1e3),
-    alone.get("k_trace_lane<false>", 0), 1e3 * pipe_ms(t), 100 * t["valu_ipc_per_simd"] / mix["simd_ipc"], 100 * t["valu_lane_utilisation"],
     100 * t["l1_hit_rate"], 100 * t["l2_hit_rate"], t["fabric_bytes_per_launch"] / 1e6, r.get("hbm_measured_frac") or 0.0, r["algorithmic_bytes_per_launch"] / 1e9, r["algorithmic_GBps_cache_served"] / 1e3,
     bench["value"] / 1e6, bench["ms_per_step"], bench["frames_per_sec"], bench["config"]["timed_region_repeats"], *bench["config"]["repeat_ms_per_step_min_median_max"],
-    bench["one_frame_at_a_time"]["ms_per_step"], r.get("frac") or 0.0, r.get("frac_vs_architectural") or 0.0, (r.get("second_roof") or {}).get("frac") or 0.0,
+    bench["one_frame_at_a_time"]["ms_per_step"], r.get("frac") or 0.0, r.get("frac_lane_level") or 0.0, (r.get("calibrated") or {}).get("frac") or 0.0, (r.get("second_roof") or {}).get("frac") or 0.0,
+    kb("k_march", "k_march"), kb("k_shade", "k_shade"),
     bench["parity_check"]["rf_bit_exact"], bench["parity_check"]["scan_lines"], cb["cores"], cb["host"]["cpu_count"], cb["cores_kept_busy"], cb["value"] / 1e6, cb["single_thread"]["value"] / 1e3,
-    drv["value"] / 1e6, drv["ms_per_step"], drv["sweep"]["ms_per_step"])
+    drv["value"] / 1e6, drv["ms_per_step"], drv["sweep"]["ms_per_step"],
+    ("k_march " + kb("", "")[2:]) if False else ("k_march beside the walk / alone %.3f / %.3f ms per launch" % ((dk.get("k_march") or {}).get("ms_per_launch_overlapped") or 0, (dk.get("k_march") or {}).get("ms_per_launch_alone") or 0)),
+    "the walk %.3f / %.3f ms per launch" % ((dk.get("k_trace_lane") or {}).get("ms_per_launch_overlapped") or 0, (dk.get("k_trace_lane") or {}).get("ms_per_launch_alone") or 0))
 txt = txt.replace("@FIF@", str(FIF)).replace("@RND@", rnd)
 open(os.path.join(dst, "README.md"), "w").write(txt)
 for extra in ("bench_random16m.json", "group_bench.json"):
