@@ -27,7 +27,7 @@ def test_passes_are_the_fewest_and_even():
 
 def test_roofline_block_and_the_derived_fallback():
     b = _bench()
-    with open(os.path.join(ROOT, "profiles", "round4", "pmc_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", b.PMC_ROUND, "pmc_bench.json")) as f:
         committed = json.load(f)
     args = argparse.Namespace(workload="random1m", scanlines=128, scanlines_total=0, rays=1024, rows=465, gpus=1)
     same = b.committed_pmc(args, committed["config_key"][6], 1.0)
