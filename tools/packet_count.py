@@ -18,6 +18,8 @@ workload = sys.argv[1] if len(sys.argv) > 1 else "random1m"
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 order = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 pure = len(sys.argv) > 4 and sys.argv[4] == "pure"       # packets cut from PURE bundles (the queue sorted by reflect / refract history: what a sorting compaction would give)
+wgkey = len(sys.argv) > 4 and sys.argv[4] == "wgkey"     # 256-ray blocks grouped by (triangle hit last, decision): largest group first (what a workgroup-local grouping in k_shade would give)
+stray = len(sys.argv) > 4 and sys.argv[4] == "stray"     # 256-ray blocks ordered: rays that hit their wavefront's dominant triangle (reflected, then refracted), then the strays
 blk3 = len(sys.argv) > 4 and sys.argv[4] == "blk3"       # k_shade's 256-ray blocks sorted by the class of the last three reflect / refract decisions (a counting sort inside the workgroup)
 dec = None
 E, W = 128, 64
@@ -51,6 +53,18 @@ for b in range(1, p.max_depth):
     d_now = np.zeros((E, S), np.uint64); d_now[e_idx, s_idx] = refl.astype(np.uint64)
     dec = d_now if dec is None else (((dec << np.uint64(1)) | d_now) & np.uint64(7))
     if pure: order_idx = np.lexsort((s_idx, key[e_idx, s_idx], e_idx))
+    elif wgkey:
+        pos = e_idx * S + s_idx; b256 = pos // 256
+        k2 = prev.astype(np.int64) * 2 + refl.astype(np.int64)
+        # group size within the block (largest first), then key, then sample
+        comb = b256.astype(np.int64) * (1 << 40) + k2
+        uq, inv, cnts = np.unique(comb, return_inverse=True, return_counts=True)
+        order_idx = np.lexsort((s_idx, k2, -cnts[inv], b256))
+    elif stray:
+        pos = e_idx * S + s_idx; w64 = pos // 64
+        first = np.concatenate([[True], w64[1:] != w64[:-1]])
+        dom = prev[np.maximum.accumulate(np.where(first, np.arange(len(pos)), 0))]          # the triangle the wavefront's first live ray hit
+        order_idx = np.lexsort((s_idx, ~refl, prev != dom, pos // 256))
     elif blk3: order_idx = np.lexsort((s_idx, dec[e_idx, s_idx], (e_idx * S + s_idx) // 256))
     else: order_idx = np.lexsort((s_idx, ~refl, (e_idx * S + s_idx) // 256))          # (round 5: reflected-first over the workgroup's 256 rays)
     q = np.ascontiguousarray(segs[e_idx, s_idx, b][order_idx]); own = hits[e_idx, s_idx, b][order_idx]
@@ -59,12 +73,20 @@ for b in range(1, p.max_depth):
     L.orc_packet_count(C.byref(osc.c), C.byref(p), q.ctypes.data, n, W, order, out.ctypes.data, tri.ctypes.data, os.cpu_count())
     assert np.array_equal(tri, own), "the packet walk found another triangle on bounce %d" % b
     full = out[:, 5] == W
+    # packets whose rays all hit the SAME triangle last and took the same decision (what k_shade can see): their share and their cost
+    k2s = (prev.astype(np.int64) * 2 + refl.astype(np.int64))[order_idx]
+    padn = n_pack * W - n
+    k2p = np.concatenate([k2s, np.full(padn, k2s[-1])]).reshape(n_pack, W)
+    is_pure = (k2p.min(1) == k2p.max(1))
     r = {"bounce": b, "rays": int(n), "packets": int(n_pack),
          "packet_nodes_mean": float(out[:, 0].mean()), "packet_leaves_mean": float(out[:, 1].mean()), "packet_triangles_mean": float(out[:, 2].mean()),
          "solo_nodes_per_ray": float(out[:, 3].sum() / out[:, 5].sum()), "solo_nodes_max_in_packet_mean": float(out[:, 4].mean()),
          "packet_nodes_over_solo_mean_ray": float(out[:, 0].mean() / (out[:, 3].sum() / out[:, 5].sum())),
          "packet_nodes_over_longest_ray": float((out[:, 0] / np.maximum(out[:, 4], 1)).mean()),
-         "packet_nodes_p50_p90_p99": [float(np.percentile(out[:, 0], x)) for x in (50, 90, 99)]}
+         "packet_nodes_p50_p90_p99": [float(np.percentile(out[:, 0], x)) for x in (50, 90, 99)],
+         "one_key_packets_share": float(is_pure.mean()), "one_key_packet_nodes_mean": float(out[is_pure, 0].mean()) if is_pure.any() else None,
+         "one_key_packet_solo_nodes_per_ray": float(out[is_pure, 3].sum() / max(out[is_pure, 5].sum(), 1)) if is_pure.any() else None,
+         "other_packets_solo_nodes_per_ray": float(out[~is_pure, 3].sum() / max(out[~is_pure, 5].sum(), 1)) if (~is_pure).any() else None}
     rows.append(r); sys.stderr.write(json.dumps(r) + "\n")
 tot_pack = sum(r["packet_nodes_mean"] * r["packets"] for r in rows); tot_solo = sum(r["solo_nodes_per_ray"] * r["rays"] for r in rows)
 print(json.dumps({"queue": "sorted into pure bundles (scan-line, history)" if pure else "256-ray blocks sorted by the last three decisions" if blk3 else "as k_shade's compaction leaves it (reflected first inside a 256-ray block)", "workload": workload, "scan_lines": E, "rays": S, "packet": W, "order": "first hitting ray" if order else "smallest t_near of the packet", "seconds": round(time.time() - t0, 1),
