@@ -784,6 +784,49 @@ def test_two_ranks_gather_equals_single_process():
     assert out["roofline"]["frac"] is not None and out["roofline"]["derived"] is True and 0.0 < out["roofline"]["frac"] < 1.0
 
 
+def test_rccl_carries_the_collectives_of_the_pass():
+    """What a one-GPU box can show of the RCCL leg: a process group over the `nccl` backend (= RCCL on ROCm) with its one rank on this
+    GPU runs every collective bench.py's N > 1 path issues -- the gather-to-root probe, the gather of a pass's [F][E/N][R] block on a side
+    stream, the all-gather form, the MAX all-reduce of the timed region, the object all-gather of the per-rank records, the barrier --
+    and hands the block back unchanged.  (Two ranks on one device are RCCL's to refuse: test_two_ranks_gather_equals_single_process.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from mcray_tracing_amd import dist as md
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+g = torch.Generator(device="cuda").manual_seed(5)
+blk = torch.rand((3, 16, 465), device="cuda", generator=g)
+assert md._gather_to_root_ok(dist, None, blk) is True                       # RCCL gathers to a root: no all-gather stand-in
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    out = [torch.empty_like(blk)]
+    dist.gather(blk, out, dst=0)
+    flat = torch.empty_like(blk)
+    dist.all_gather_into_tensor(flat, blk)
+s.synchronize()
+assert torch.equal(out[0], blk) and torch.equal(flat, blk)
+t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t.item()) == 1.25
+rec = [None]
+dist.all_gather_object(rec, {"rank": 0, "trace_ms": 0.5})
+assert rec[0]["trace_ms"] == 0.5
+assert md.gather_rf(blk, 16, 465, dist, root=0) is blk                      # one rank: the block IS the frame
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok")
+""" % root
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29950 + os.getpid() % 40),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", child], env=env, cwd=root, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout[-400:], _why(r.stderr[-6000:]))
+
+
 def test_bench_line_contract_and_inline_parity():
     """a small single-GPU bench run: the JSON contract keys, the inline parity check against the oracle, a VALU roofline with
     frac <= 1"""
