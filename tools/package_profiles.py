@@ -128,6 +128,8 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 | `packet_count_random1m.json`, `packet_count_random1m_pure.json` | `tools/packet_count.py` (CPU): nodes a 64-ray packet visits against its rays' solo walks, per bounce, for the queue as it is and sorted into pure bundles |
 | `exp_packet.txt` | `k_trace_packet` (one wavefront per ray packet): every version measured, PMC of the kept one, which pass sizes and BASELINE configurations take it |
 | `exp_tail.txt`, `stamps_pass20_tail_histograms.txt`, `stamps_pass20_ilv4.txt` | the tail of the driver's 20-frame pass: per-wavefront histograms (`mcrt_debug_tail_histograms`), its cause, four ways out built and measured |
+| `exp_line_order.txt` | heavy scan-lines first: counted (`tools/tail_predict.py`), modelled (`tools/tail_sim.py`), measured with the archived hook — no gain |
+| `exp_walk_share.txt`, `frame_timeline_no_overlap.txt` | the wide walk at 3 / 4 / 5 / 6 wavefronts per SIMD against the pass; every launch of a 128-frame pass one after the other: the pass is bound by the sum of its kernels' work |
 
 ## What the kernels do (per launch = one bounce of a @FIF@-frame pass)
 
