@@ -129,7 +129,7 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 | `exp_packet.txt` | `k_trace_packet` (one wavefront per ray packet): every version measured, PMC of the kept one, which pass sizes and BASELINE configurations take it |
 | `exp_tail.txt`, `stamps_pass20_tail_histograms.txt`, `stamps_pass20_ilv4.txt` | the tail of the driver's 20-frame pass: per-wavefront histograms (`mcrt_debug_tail_histograms`), its cause, four ways out built and measured |
 | `exp_line_order.txt` | heavy scan-lines first: counted (`tools/tail_predict.py`), modelled (`tools/tail_sim.py`), measured with the archived hook — no gain |
-| `exp_walk_share.txt`, `frame_timeline_no_overlap.txt` | the wide walk at 3 / 4 / 5 / 6 wavefronts per SIMD against the pass; every launch of a 128-frame pass one after the other: the pass is bound by the sum of its kernels' work |
+| `exp_walk_share.txt`, `frame_timeline_no_overlap.txt`, `frame_timeline_pass20.txt` | the wide walk at 3 / 4 / 5 / 6 wavefronts per SIMD against the pass; every launch of a 128-frame pass one after the other: the pass is bound by the sum of its kernels' work; the driver's 20-frame pass launch by launch (`k_march`'s stream is busy for 7.0 of its 7.6 ms) |
 
 ## What the kernels do (per launch = one bounce of a @FIF@-frame pass)
 
