@@ -1,5 +1,6 @@
 """The oracle under AddressSanitizer + UBSan (CPU build only; GPU sanitizers are not available on the pool): a small frame
-through every code path -- brute force, BVH2 and BVH4 walks, thickness draw, vessels, convolution, envelope, scan conversion."""
+through every code path -- brute force, BVH2 and BVH4 walks, thickness draw, vessels, convolution, envelope, scan conversion, the
+test entry points into the physics, the counting build and the analysis walks of tools/."""
 import os
 import subprocess
 import sys
@@ -30,6 +31,30 @@ def test_oracle_runs_clean_under_asan_ubsan(mcrt):
         ax, lat = orc.psf()
         img = orc.envelope(orc.convolve(np.nan_to_num(outs[0]["rf"]), ax, lat))
         sc = orc.scan_convert(img)
+        # the test entry points into the physics, the counting walk and the analysis walks (tools/seed_count.py, tools/packet_count.py) as well
+        osc.counting(True)
+        oc = osc.trace_frame(p, tr.pos, tr.dir, tex, use_bvh=2, want_segs=True); osc.counting(False)
+        assert np.array_equal(oc["hits"], outs[0]["hits"]) and orc.counters()["echo_guard_trips"] == 0
+        rng = (int(p.seed), 0, 1, 2, 3)
+        w, tries = orc.random_unit_vector([0.0, 0.6, 0.8], 0.999, rng); assert tries >= 1 and np.isfinite(w).all()
+        assert 0.0 < orc.power_cosine(1000000, 0.5) <= 1.0 and orc.thickness(0.3, rng) >= 0.0
+        ray = orc.ray_state([0.0, 0.0, 0.0], [0.0, 0.6, 0.8], media=int(sd.start_mat), intensity=0.25)
+        hd = osc.hit_boundary(p, ray, [0.1, 0.2, 0.3], [0.0, -0.6, -0.8], 0, rng); assert hd.ruv_attempts >= 1
+        L, f, t = osc.ray_segment(p, ray); assert L > 0 and osc.travel(ray, [0.0, 0.6, 0.8]) > 0
+        segs = np.ascontiguousarray(oc["segs"][:, :, 0].reshape(-1))
+        rfseg, steps = osc.accumulate_segment(p, tex, segs[0]); assert rfseg.shape == (p.n_rows,)
+        L_ = orc.lib(); n = len(segs)
+        out = np.zeros((n, 2), np.uint32); tri = np.zeros(n, np.int32)
+        L_.orc_seed_count.restype = None
+        L_.orc_seed_count.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        for mode in (0, 1):
+            L_.orc_seed_count(ctypes.byref(osc.c), ctypes.byref(p), segs.ctypes.data, n, mode, None, out.ctypes.data, tri.ctypes.data, 2)
+            assert np.array_equal(tri, oc["hits"][:, :, 0].reshape(-1))
+        pk = np.zeros(((n + 15) // 16, 6), np.uint32)
+        L_.orc_packet_count.restype = None
+        L_.orc_packet_count.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L_.orc_packet_count(ctypes.byref(osc.c), ctypes.byref(p), segs.ctypes.data, n, 16, 1, pk.ctypes.data, tri.ctypes.data, 2)
+        assert np.array_equal(tri, oc["hits"][:, :, 0].reshape(-1)) and pk[:, 0].sum() > 0
         print("OK", int((outs[0]["hits"] >= 0).sum()), float(np.abs(sc).sum()) >= 0)
     """) % (ROOT, os.path.join(ROOT, "oracle", "libmcrt_oracle_asan.so"))
     env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
