@@ -376,11 +376,14 @@ def main():
             t_over = ctx.kernel_times(reset=True)
             ctx.enable_timing(False)
             t_alone = None
+            prev_env = {k_: os.environ.get(k_) for k_ in ("MCRT_TUNING", "MCRT_NO_OVERLAP")}      # (a caller's own MCRT_TUNING=1 + knobs must survive this leg)
             try:
                 os.environ["MCRT_TUNING"] = "1"; os.environ["MCRT_NO_OVERLAP"] = "1"
                 ctx2 = m.Context(local_rank)
             finally:
-                os.environ.pop("MCRT_NO_OVERLAP", None); os.environ.pop("MCRT_TUNING", None)
+                for k_, v_ in prev_env.items():
+                    if v_ is None: os.environ.pop(k_, None)
+                    else: os.environ[k_] = v_
             try:
                 ctx2.set_params(n_elements=E, n_samples=S, n_rows=R, frequency=tr.frequency, tex_n=args.tex_n)
                 ctx2.set_bvh_builder(args.bvh); ctx2.upload_scene(sd); ctx2.upload_texture(None, args.tex_n); ctx2.set_transducer(tr.pos, tr.dir)

@@ -83,9 +83,11 @@ typedef struct {
     float *tri;              /* [n_tri][12] leaf order: v0.xyz,bits(tri id) | v1.xyz,bits(mesh id) | v2.xyz,0 */
 } mcrt_bvh;
 
-/* 128-byte BVH4 node read by the GPU walk: four 32-byte child records, so the four lanes that own a ray fetch one
- * record each and the quad reads one contiguous 128-B line.  ref: >= 0 inner node; < 0 leaf (as in mcrt_bvh_node,
- * at most 4 triangles); MCRT_BVH4_EMPTY = unused slot.  Built by collapsing the SAH BVH2. */
+/* 128-byte BVH4 node, the BUILDERS' form: four 32-byte child records with float boxes -- what mcrt_build_bvh4 and the device builder
+ * emit, what a refit updates and what this ABI exports.  The GPU walk reads a 64-byte copy made from it after every build / refit
+ * (child-transposed half-float boxes rounded outwards, csrc/mcrt_kernels.hip k_nodes_walk); mcrt_get_bvh4 hands out that copy decoded
+ * back into this form, i.e. the tree exactly as walked.  ref: >= 0 inner node; < 0 leaf (as in mcrt_bvh_node, at most 4 triangles);
+ * MCRT_BVH4_EMPTY = unused slot.  Built by collapsing the SAH BVH2. */
 #define MCRT_BVH4_EMPTY ((int32_t)0x80000000)
 typedef struct { float lo[3]; float hi_x; float hi_y, hi_z; int32_t ref; uint32_t pad; } mcrt_bvh4_child;
 typedef struct { mcrt_bvh4_child c[4]; } mcrt_bvh4_node;

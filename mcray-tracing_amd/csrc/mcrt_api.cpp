@@ -16,16 +16,6 @@
 #include <vector>
 #include <algorithm>
 
-namespace mcrt {
-static thread_local std::string g_err;
-int set_error(int code, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    g_err = buf;
-    return code;
-}
-}  // namespace mcrt
 using mcrt::set_error;
 
 // (an allocation the device cannot satisfy is MCRT_ERR_NOMEM, every other HIP failure MCRT_ERR_HIP)
@@ -183,7 +173,6 @@ static int prepare_tables(mcrt_ctx *c)
     return MCRT_OK;
 }
 
-extern "C" const char *mcrt_last_error(void) { return mcrt::g_err.c_str(); }
 extern "C" int mcrt_version(void) { return MCRT_VERSION; }
 extern "C" int mcrt_device_count(void)
 {
@@ -433,7 +422,7 @@ static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri, const 
         c->d_nodes = r.d_nodes; c->d_tri_slot = r.d_tri_slot;
         {   // the walk's 64-byte records from the builder's 48-byte leaf-order array
             hipError_t e = hipMalloc(&c->d_tris, 16 * MCRT_TRI_PIECES * (size_t)n_tri);
-            if (e == hipSuccess) e = mcrt::launch_expand_tris(r.d_tris, n_tri, r.pad_abs, c->d_tris, c->stream);
+            if (e == hipSuccess) e = mcrt::launch_expand_tris(r.d_tris, n_tri, c->d_tris, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             hipFree(r.d_tris);
             if (e != hipSuccess) return set_error(MCRT_ERR_HIP, "triangle records: %s", hipGetErrorString(e));
@@ -484,7 +473,7 @@ static int index_triangles(mcrt_ctx *c, const float *tri, uint32_t n_tri, const 
         HIP_TRY(hipMalloc(&d_in, 48 * (size_t)n_tri));
         hipError_t e = hipMalloc(&c->d_tris, 16 * MCRT_TRI_PIECES * (size_t)n_tri);
         if (e == hipSuccess) e = hipMemcpy(d_in, c->bvh.tri, 48 * (size_t)n_tri, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = mcrt::launch_expand_tris(d_in, n_tri, c->bvh.pad_abs, c->d_tris, c->stream);
+        if (e == hipSuccess) e = mcrt::launch_expand_tris(d_in, n_tri, c->d_tris, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         hipFree(d_in);
         if (e != hipSuccess) return set_error(MCRT_ERR_HIP, "triangle records: %s", hipGetErrorString(e));
@@ -507,11 +496,11 @@ static int download_bvh(mcrt_ctx *c)
     c->bvh4.nodes = (mcrt_bvh4_node *)malloc(sizeof(mcrt_bvh4_node) * (size_t)c->bvh4.n_nodes);
     if (!c->bvh.tri || !c->bvh4.nodes) return set_error(MCRT_ERR_NOMEM, "out of memory");
     {   // back from the walk's records to the ABI's 48-byte layout (v0|id, v1|mesh, v2|0)
-        const size_t W = 4 * MCRT_TRI_PIECES, V = 4 * (MCRT_TRI_PIECES - 3);      // floats per record, first float of v0
+        const size_t W = 4 * MCRT_TRI_PIECES;      // floats per record
         std::vector<float> rec((size_t)c->bvh.n_tri * W);
         HIP_TRY(hipMemcpy(rec.data(), c->d_tris, 4 * W * (size_t)c->bvh.n_tri, hipMemcpyDeviceToHost));
         for (size_t t = 0; t < c->bvh.n_tri; t++) {
-            const float *r = &rec[t * W + V]; float *o = &c->bvh.tri[t * 12];
+            const float *r = &rec[t * W]; float *o = &c->bvh.tri[t * 12];
             memcpy(o, r, 32);                                          // v0 | id, v1 | mesh
             o[8] = r[8]; o[9] = r[9]; o[10] = r[10]; o[11] = 0.0f;      // v2 | 0 (the record keeps the edge tolerance there)
         }
@@ -1103,37 +1092,6 @@ extern "C" int mcrt_envelope(mcrt_ctx *c, float *rf_dev, uint32_t E, uint32_t R)
     return mcrt_envelope_frames(c, rf_dev, 1, E, R);
 }
 
-// rfimage.h:183-215 create_mapping, evaluated once per geometry on the host (as the reference does in its constructor).
-// Operand types as C++ gives them to the reference's statements (pinned by tests/golden/ref_probe.json "scan_maps_*": the same
-// statements evaluated with the reference's own unit types, compiled from its units.h):
-//   :186 ratio: `max_travel_time * speed_of_sound * 0.001f` is an unsigned product times a float = FLOAT (150.0f for 100 us x 1500);
-//        `+ radius` stays float; `- radius * cos(angle_f / 2.0)` is double; `/ rows` double; rounded once to float
-//   :189 shift_y: millimeter_t (double) * cosf(angle_f / 2.0f)
-//   :201-205 fi, fj, r: float throughout            :208 angle: atan2f, widened
-//   :211 map_x (row coordinate): float throughout, the divisor the same float depth as in :186
-//   :212 map_y (column coordinate): radian_t arithmetic in double, * (float)rf_width, rounded once
-// (Rounds 1-3 held the depth as a double -- 150.0000071 -- and divided in double: ratio 0.385048121 instead of 0.385048091.)
-extern "C" int mcrt_scan_maps(uint32_t E, uint32_t R, double radius_mm, double total_angle, uint32_t max_travel_us, uint32_t speed_of_sound,
-                              uint32_t orows, uint32_t ocols, float *map_row, float *map_col)
-{
-    if (!map_row || !map_col || E == 0 || R == 0 || orows == 0 || ocols == 0 || !(total_angle > 0.0)) return set_error(MCRT_ERR_INVALID, "mcrt_scan_maps: bad arguments");
-    const float radius_f = (float)radius_mm, ta_f = (float)total_angle;
-    const float depth_mm_f = (float)(uint32_t)(max_travel_us * speed_of_sound) * 0.001f;
-    const float ratio = (float)(((double)(depth_mm_f + radius_f) - (double)radius_f * std::cos((double)ta_f / 2.0)) / (double)(int)orows);
-    const double shift_y = radius_mm * (double)std::cos(ta_f / 2.0f);
-    const float half_width = (float)(int)ocols / 2.0f;
-    for (uint32_t j = 0; j < ocols; j++)
-        for (uint32_t i = 0; i < orows; i++) {
-            const float fi = (float)(int)i + (float)shift_y / ratio;
-            const float fj = (float)(int)j - half_width;
-            const float r = std::sqrt(fi * fi + fj * fj);
-            const double angle = (double)std::atan2(fj, fi);
-            map_row[(size_t)i * ocols + j] = (r * ratio - radius_f) / depth_mm_f * (float)R;
-            map_col[(size_t)i * ocols + j] = (float)(((angle - (-total_angle / 2)) / total_angle) * (double)(float)E);
-        }
-    return MCRT_OK;
-}
-
 extern "C" int mcrt_scan_convert_frames(mcrt_ctx *c, const float *rf_dev, uint32_t n_frames, uint32_t E, uint32_t R, double radius_mm, double total_angle,
                                         float *out_dev, uint32_t orows, uint32_t ocols)
 {
@@ -1264,7 +1222,11 @@ extern "C" int mcrt_enable_timing(mcrt_ctx *c, int on) { CTX_TRY(c); c->timing_o
 extern "C" int mcrt_get_kernel_times(mcrt_ctx *c, double avg_ms[3], uint32_t n[3], int reset)
 {
     CTX_TRY(c);
-    HIP_TRY(hipDeviceSynchronize());                 // (k_march's events live on the side streams)
+    // level 1: every event was recorded on the context's stream -- wait for that stream only (a caller polling the walk's time must not stall on other
+    // contexts of the device: a group's other ranks on the root GPU, a host application's own streams); level 2: k_march's events live on the side streams,
+    // so each recorded pair is waited for by itself
+    if (c->timing_level < 2) HIP_TRY(hipStreamSynchronize(c->stream));
+    else for (size_t i = 0; i < c->ev_used; i++) HIP_TRY(hipEventSynchronize(c->ev[i].second));
     double sum[3] = { 0, 0, 0 }; uint32_t cnt[3] = { 0, 0, 0 };
     for (size_t i = 0; i < c->ev_used; i++) {
         float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev[i].first, c->ev[i].second));

@@ -2,15 +2,32 @@
 //   * BVH2 builder (binned SAH) replacing btBvhTriangleMeshShape construction + the DBVT
 //     broadphase (scene.cpp:255,309): ONE flattened tree over the triangles of all meshes.
 //   * the reference's static tables: tissue texture (volume.h:19-35), PSF taps (psf.h:34-58),
-//     transducer element geometry (transducer.h:24-62).
+//     transducer element geometry (transducer.h:24-62), scan-conversion maps (rfimage.h:183-215).
+//   * the library's error string (mcrt_last_error).
+// Plain C++ with no HIP in it: tests/test_host_sanitize.py compiles this file by itself under ASan + UBSan.
 #include "../../include/mcrt.h"
 #include "mcrt_internal.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdarg>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
+
+namespace mcrt {
+static thread_local std::string g_err;
+int set_error(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+}  // namespace mcrt
+extern "C" const char *mcrt_last_error(void) { return mcrt::g_err.c_str(); }
 
 // tuning knobs (mcrt_internal.h): only a process started with MCRT_TUNING=1 has any
 const char *mcrt::tuning_env(const char *name)
@@ -359,5 +376,36 @@ extern "C" int mcrt_transducer_elements(uint32_t n, double radius_cm, double sep
         dir[3 * t] = d.x; dir[3 * t + 1] = d.y; dir[3 * t + 2] = d.z;
         angle = angle + amplitude;
     }
+    return MCRT_OK;
+}
+
+// rfimage.h:183-215 create_mapping, evaluated once per geometry on the host (as the reference does in its constructor).
+// Operand types as C++ gives them to the reference's statements (pinned by tests/golden/ref_probe.json "scan_maps_*": the same
+// statements evaluated with the reference's own unit types, compiled from its units.h):
+//   :186 ratio: `max_travel_time * speed_of_sound * 0.001f` is an unsigned product times a float = FLOAT (150.0f for 100 us x 1500);
+//        `+ radius` stays float; `- radius * cos(angle_f / 2.0)` is double; `/ rows` double; rounded once to float
+//   :189 shift_y: millimeter_t (double) * cosf(angle_f / 2.0f)
+//   :201-205 fi, fj, r: float throughout            :208 angle: atan2f, widened
+//   :211 map_x (row coordinate): float throughout, the divisor the same float depth as in :186
+//   :212 map_y (column coordinate): radian_t arithmetic in double, * (float)rf_width, rounded once
+// (Rounds 1-3 held the depth as a double -- 150.0000071 -- and divided in double: ratio 0.385048121 instead of 0.385048091.)
+extern "C" int mcrt_scan_maps(uint32_t E, uint32_t R, double radius_mm, double total_angle, uint32_t max_travel_us, uint32_t speed_of_sound,
+                              uint32_t orows, uint32_t ocols, float *map_row, float *map_col)
+{
+    if (!map_row || !map_col || E == 0 || R == 0 || orows == 0 || ocols == 0 || !(total_angle > 0.0)) return mcrt::set_error(MCRT_ERR_INVALID, "mcrt_scan_maps: bad arguments");
+    const float radius_f = (float)radius_mm, ta_f = (float)total_angle;
+    const float depth_mm_f = (float)(uint32_t)(max_travel_us * speed_of_sound) * 0.001f;
+    const float ratio = (float)(((double)(depth_mm_f + radius_f) - (double)radius_f * std::cos((double)ta_f / 2.0)) / (double)(int)orows);
+    const double shift_y = radius_mm * (double)std::cos(ta_f / 2.0f);
+    const float half_width = (float)(int)ocols / 2.0f;
+    for (uint32_t j = 0; j < ocols; j++)
+        for (uint32_t i = 0; i < orows; i++) {
+            const float fi = (float)(int)i + (float)shift_y / ratio;
+            const float fj = (float)(int)j - half_width;
+            const float r = std::sqrt(fi * fi + fj * fj);
+            const double angle = (double)std::atan2(fj, fi);
+            map_row[(size_t)i * ocols + j] = (r * ratio - radius_f) / depth_mm_f * (float)R;
+            map_col[(size_t)i * ocols + j] = (float)(((angle - (-total_angle / 2)) / total_angle) * (double)(float)E);
+        }
     return MCRT_OK;
 }

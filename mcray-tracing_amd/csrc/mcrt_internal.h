@@ -22,9 +22,7 @@
 #define MCRT_MAX_BOUNCES 16
 #define MCRT_STATS_WORDS (256 + 2560)  // the context's counter block: 8 statistics, 248 stamps (mcrt_debug_stamps), 10 x 256 tail histograms (mcrt_debug_tail_histograms)
 
-#ifndef MCRT_TRI_PIECES
-#define MCRT_TRI_PIECES 3             // 16-byte pieces of the walk's triangle record: 3 = v0|id, v1|mesh, v2|edge tolerance (48 B, the plane rebuilt from the vertices);
-#endif                                // 4 = plane first (64 B).  Round 1-3's records also carried the padded bounds (96 B)
+#define MCRT_TRI_PIECES 3             // 16-byte pieces of the walk's triangle record: v0|id, v1|mesh, v2|edge tolerance (48 B; the plane is rebuilt from the vertices)
 
 namespace mcrt {
 int set_error(int code, const char *fmt, ...);

@@ -11,7 +11,7 @@ struct FrameArgs {
     // scene (HBM-resident, read-only)
     const uint4 *nodes_walk;   // [n_nodes][4]  the walk's 64-byte nodes: child-transposed half-float boxes (rounded outwards) + refs
     int *stack_ovf;            // [max_stack - MCRT_LANE_STACK][trace_blocks * 256] traversal-stack entries beyond the LDS part (this work set's own)
-    const float4 *tris;        // [T][MCRT_TRI_PIECES]  48-B triangle records, leaf order: v0|id, v1|mesh, v2|edge tolerance (64-B form: n|dist first)
+    const float4 *tris;        // [T][3]         48-B triangle records, leaf order: v0|id, v1|mesh, v2|edge tolerance
     const uint4 *meshes;       // [n_mesh]      mat_inside, mat_outside, vascular, -
     const float4 *mats;        // [n_mat][2]    imp, att, mu0, mu1 | sigma, spec, shine, thick
     const float2 *tex;         // [n^3]         texture_noise, scattering_probability
@@ -35,7 +35,7 @@ struct FrameArgs {
     uint32_t *flags;           // [ne][(R+31)/32] non-finite flags
     unsigned long long *stats; // [6]
     uint32_t *error_flag;      // device word, bit 0: traversal stack overflow
-    unsigned long long *stamps; // [80] diagnostic build (-DMCRT_STAMP) only
+    unsigned long long *stamps; // diagnostic builds only (tools/variants/round6_stamps.patch); unused by the product's kernels
     // sizes / parameters
     uint32_t n_nodes, S, B, R, e_begin, ne, ne_frame, pose_stride, acc_stride, acc_off, trace_blocks, trace_blocks_wide, wide_from, packet_mask, march_blocks, ksplit_limit, frame, seed, start_mat, tex_n, tex_mask, sanitize, tex_finite, fast_div, want_segs, tex_shift, march_rows, n_mat, n_mesh;   // march_rows: entries of k_march's padded LDS image when its fast variant applies, else 0
     float scene_lo[3], scene_hi[3];   // bounds of the whole BVH
@@ -63,7 +63,7 @@ hipError_t launch_blocks_to_frames(const float *blocks, float *frames, uint32_t 
 hipError_t launch_transpose(const float *in, float *out, uint32_t E, uint32_t R, hipStream_t st);
 hipError_t launch_math_probe(int op, const double *x, const double *y, double *out, uint32_t n, hipStream_t st);
 hipError_t launch_verify_div(float res, float rcp, unsigned long long *bad, hipStream_t st);
-hipError_t launch_expand_tris(const float4 *in48, uint32_t n_tri, float pad_abs, float4 *out64, hipStream_t st);
+hipError_t launch_expand_tris(const float4 *in48, uint32_t n_tri, float4 *out, hipStream_t st);   // (v0|id, v1|mesh, v2|-) -> the walk's records (v2.w = the edge tolerance)
 hipError_t launch_material_table(const float4 *mats, uint32_t n_mat, float axial_res_f, float freq, float4 *mtab, hipStream_t st);
 hipError_t launch_philox_probe(const uint32_t c[4], const uint32_t k[2], uint32_t *out, hipStream_t st);
 

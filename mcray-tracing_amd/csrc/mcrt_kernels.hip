@@ -85,32 +85,25 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // the walk only needs (fraction, triangle): k_shade looks the plane of the winner up again
 struct Best { float frac; int tri; };
 
-// The walk's triangle record, from the 48-byte (v0|id, v1|mesh, v2|-) leaf-order array -- MCRT_TRI_PIECES x 16 bytes:
-//   [n.xyz | dot(v0,n)]    plane of Bullet's processTriangle, n = (v1-v0) x (v2-v0): only in the 4-piece record; the 3-piece record
-//                          leaves it out and tri_plane() rebuilds it (20 register instructions per triangle tested)
-//   v0 | id, v1 | mesh     the vertices (edge tests; the triangle's own padded bounds are rebuilt from them: tri_padded_bounds)
+// The walk's triangle record, 48 bytes = three 16-byte pieces in leaf order:
+//   v0 | id, v1 | mesh     the vertices (edge tests; the plane and the triangle's own padded bounds are rebuilt from them: tri_plane, tri_padded_bounds)
 //   v2 | -1e-4 |n|^2       ... and processTriangle's edge tolerance
-// Rounds 1-3 stored plane AND padded bounds (96 bytes, six 16-byte pieces per triangle tested).  The walk is bound by the cache accesses
-// it makes: what a few register instructions rebuild -- with the contract's own expressions, so bit for bit -- is not
+// Rounds 1-3 stored plane AND padded bounds (96 bytes, six pieces per triangle tested), round 4 tried the plane as a fourth piece.  The walk is bound by
+// the cache accesses it makes: what a few register instructions rebuild -- with the contract's own expressions, so bit for bit -- is not
 // fetched.
-constexpr int TRI_V0 = MCRT_TRI_PIECES - 3;          // index of the v0 piece in a record
-__global__ void k_expand_tris(const float4 *in, uint32_t n_tri, float pad_abs, float4 *out)
+__global__ void k_expand_tris(const float4 *in, uint32_t n_tri, float4 *out)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tri) return;
     const float4 t0 = in[3 * (size_t)t], t1 = in[3 * (size_t)t + 1], t2 = in[3 * (size_t)t + 2];
     const f3 v0 = xyz(t0), v1 = xyz(t1), v2 = xyz(t2);
-    const f3 v10 = v1 - v0, v20 = v2 - v0;
-    const f3 n = cross(v10, v20);
-    const float dist = dot(v0, n);
+    const f3 n = cross(v1 - v0, v2 - v0);
     float4 *o = out + MCRT_TRI_PIECES * (size_t)t;
-    if (TRI_V0 == 1) o[0] = make_float4(n.x, n.y, n.z, dist);
-    o[TRI_V0] = make_float4(v0.x, v0.y, v0.z, t0.w);
-    o[TRI_V0 + 1] = make_float4(v1.x, v1.y, v1.z, t1.w);
-    o[TRI_V0 + 2] = make_float4(v2.x, v2.y, v2.z, dot(n, n) * -0.0001f);           // processTriangle's edge tolerance, -1e-4 |n|^2
-    (void)pad_abs;
+    o[0] = make_float4(v0.x, v0.y, v0.z, t0.w);
+    o[1] = make_float4(v1.x, v1.y, v1.z, t1.w);
+    o[2] = make_float4(v2.x, v2.y, v2.z, dot(n, n) * -0.0001f);           // processTriangle's edge tolerance, -1e-4 |n|^2
 }
-// the plane of a triangle, n = (v1 - v0) x (v2 - v0) and dot(v0, n): k_expand_tris' expressions (what the 4-piece record stores)
+// the plane of a triangle, n = (v1 - v0) x (v2 - v0) and dot(v0, n) (Bullet's processTriangle)
 MCRT_DEV float4 tri_plane(f3 v0, f3 v1, f3 v2)
 {
     const f3 n = cross(v1 - v0, v2 - v0);
@@ -271,7 +264,10 @@ MCRT_DEV uint32_t vox_cell_lean(f3 p, const FrameArgs &a)
 {
     return (((vox_lean1(p.x, a) << a.tex_shift) | vox_lean1(p.y, a)) << a.tex_shift) | vox_lean1(p.z, a);
 }
-// ... and when the texture is the reference's 256^3 (volume.h:19): the three low bytes packed by two v_perm_b32
+// ... and when the texture is the reference's 256^3 (volume.h:19): the three low bytes packed by two v_perm_b32.
+// (The device copy keeps the reference's cell order, (x * 256 + y) * 256 + z.  Round 6 counted and measured other orders -- x fastest, 128-byte
+//  lines as 4 x 2 x 2 bricks or 4 x 1 x 4 tiles -- and the quotients as packed fp32: all slower, the kernel is bound by the instructions it issues,
+//  not by its gathers.  DESIGN.md A.8, profiles/round6/exp_march_layout.txt, tools/variants/round6_march_layout.patch.)
 MCRT_DEV uint32_t vox_q(float x, const FrameArgs &a)
 {
     const float q0 = x * a.tex_rcp;
@@ -447,10 +443,6 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 #endif
 #ifndef MCRT_LANE_ADOPT_STEPS
 #define MCRT_LANE_ADOPT_STEPS 4      // while idle lanes wait for a subtree, the inner-node phase returns to the hand-over after this many steps
-#endif
-#ifndef MCRT_LEAF_PREFETCH
-#define MCRT_LEAF_PREFETCH 1         // pieces of a triangle record fetched ahead of the tests that need them: 0 = the plane only, 1 = all four
-                                     // (round 2, 96-byte records, none / three / all six: 5833 / 4597 / 4153 cycles per leaf phase; frame 0.512 / 0.506 / 0.505 ms)
 #endif
 #ifndef MCRT_LANE_FETCH
 #define MCRT_LANE_FETCH 128          // queue positions a wavefront claims per atomic in a LARGE launch (>= MCRT_LANE_FETCH_FROM items), 64 below: measured
@@ -645,22 +637,15 @@ template <class LS> MCRT_DEV uint32_t lane_leaf_test(const FrameArgs &a, const L
     const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
     for (uint32_t k = 0; k < cnt; k++) {
         const float4 *T = (const float4 *)((const char *)a.tris + (first + k) * (uint32_t)(16 * MCRT_TRI_PIECES));
-#if MCRT_LEAF_PREFETCH >= 1 || MCRT_TRI_PIECES == 3
         // the record's pieces are fetched TOGETHER, not stage by stage behind the early exits: a leaf phase then costs one
         // memory round trip (the pieces of a rejected triangle are wasted loads; staged: 0.349 against 0.343 ms per frame, round 4)
-        float4 V0 = T[TRI_V0], V1 = T[TRI_V0 + 1], V2 = T[TRI_V0 + 2];
+        float4 V0 = T[0], V1 = T[1], V2 = T[2];
         asm volatile("" : "+v"(V0.x), "+v"(V0.y), "+v"(V0.z), "+v"(V0.w), "+v"(V1.x), "+v"(V1.y), "+v"(V1.z), "+v"(V2.x), "+v"(V2.y), "+v"(V2.z), "+v"(V2.w));
-        const float4 P = MCRT_TRI_PIECES == 3 ? tri_plane(xyz(V0), xyz(V1), xyz(V2)) : T[0];
-#else
-        const float4 P = T[0];
-#endif
+        const float4 P = tri_plane(xyz(V0), xyz(V1), xyz(V2));
         const f3 nrm = xyz(P);
         const float da = dot(nrm, f2) - P.w;
         const float db = dot(nrm, to) - P.w;
         if (da * db >= 0.0f) continue;
-#if MCRT_LEAF_PREFETCH < 1 && MCRT_TRI_PIECES == 4
-        const float4 V0 = T[1], V1 = T[2], V2 = T[3];
-#endif
         const int id = __float_as_int(V0.w);
         const float proj = da - db;
         const float frac = da / proj;
@@ -760,24 +745,6 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
     uint32_t pool_next = 0, pool_end = 0; bool queue_empty = false;   // wave-uniform
     const uint32_t fetch = n >= (uint32_t)MCRT_LANE_FETCH_FROM ? (uint32_t)MCRT_LANE_FETCH : (uint32_t)MCRT_LANE_FETCH_SMALL;
     unsigned long long poll_old = 0; uint32_t poll_ray = 0; bool poll_pending = false;      // (see the end of the loop)
-#ifdef MCRT_STAMP
-    // diagnostic build: cycles and lane counts per phase, summed over wavefronts (tools/stamps.py)
-    unsigned long long sc_refill = 0, sc_p1 = 0, sc_p2 = 0, sc_n1 = 0, sc_n2 = 0, sc_outer = 0, sc_t0 = __builtin_readcyclecounter(), sc_act1 = 0, sc_act2 = 0, sc_park1 = 0, sc_idle1 = 0, sc_adopt = 0, sc_dist = 0, sc_rclaim = 0, sc_rload = 0, sc_rounds = 0, sc_rlanes = 0;
-#define LSTAMP(var) { const unsigned long long t_ = __builtin_readcyclecounter(); var += t_ - sc_t0; sc_t0 = t_; }
-#else
-#define LSTAMP(var)
-#endif
-#if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
-    // timeline only (a handful of atomics per wavefront: usable on the production schedule)
-    const unsigned long long wc_start = wall_clock64(); unsigned long long wc_empty = 0, wc_steps = 0, wc_lastclaim = 0, wc_claimsteps = 0, wc_drysteps = 0; uint32_t wc_inflight = 0;
-    // histograms of the launch's tail, per bounce b < 10 at a.stamps[248 + 256 b + ...] (mcrt_debug_tail_histograms; 20 us bins on the wavefront's own clock):
-    // [0..63] wavefront ends, [64..127] wavefront finds the queue dry, [128..191] node-step iterations (bins of 8) between the wavefront's last successful claim and that moment, [192..255] time from the wavefront's last successful claim to that moment
-    unsigned long long *const hist = a.stamps + 248 + 256 * (b < 10u ? b : 9u);
-    __shared__ unsigned long long wg_end[4]; __shared__ unsigned int wg_done;      // when this workgroup's wavefronts ended (the last one bins how long it outlived the others)
-    if (tid == 0) wg_done = 0u;
-    __syncthreads();
-    if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 0], ~wc_start);
-#endif
     MCRT_WATCHDOG_DECL()
     for (;;) {
         MCRT_WATCHDOG_CHECK()
@@ -807,18 +774,11 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
                     const uint32_t hi = MCRT_SUB_LO(cur_x + 1u);
                     const unsigned long long start = (unsigned long long)MCRT_SUB_LO(cur_x) + MCRT_SUB_STATIC(cur_x) + base;
                     if (start < hi) {
-#if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
-                        wc_lastclaim = wall_clock64(); wc_claimsteps = wc_steps;
-#endif
                         pool_next = (uint32_t)start; pool_end = min((uint32_t)start + fetch, hi);
                     }
                     else if (++visited >= X) queue_empty = true;      // (the launch enters its TAIL: it only finishes the rays in flight from here on.  Round 4 let the
                                                                       //  accumulation's stream wait for this moment -- a device word + hipStreamWaitValue32 --: slower)
                     else cur_x = (cur_x + 1u) & (X - 1u);
-#if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
-                    if (queue_empty) { wc_empty = wall_clock64(); if (lane == 0) atomicMax(&a.stamps[16 + 4 * b + 1], ~wc_empty);
-                                       wc_inflight = (uint32_t)__popcll(MCRT_WALKING(cur)); wc_drysteps = wc_steps - wc_claimsteps; }
-#endif
                 }
                 if (need && i == 0xffffffffu) {
                     const uint32_t mine = pool_next + (uint32_t)__popcll(dynm & ((1ull << lane) - 1ull));
@@ -828,10 +788,6 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
                 const uint32_t taken = (uint32_t)__popcll(dynm);
                 pool_next = (pool_next + taken < pool_end) ? pool_next + taken : pool_end;
             }
-            LSTAMP(sc_rclaim)
-#ifdef MCRT_STAMP
-            sc_rounds++; sc_rlanes += __popcll(__ballot(need && i != 0xffffffffu && i < n));
-#endif
             if (need && i != 0xffffffffu) {
                 if (i < n) {
                     uint32_t piece = 0u;                                 // the pieces of one ray land in different wavefronts
@@ -857,7 +813,6 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
                     if (STATS && piece == 0u) st_q++;
                 } else exhausted = true;
             }
-            LSTAMP(sc_rload)
         }
         if (MCRT_WALKING(cur) == 0ull) { if (!__any(!exhausted)) break; else continue; }
 
@@ -897,12 +852,8 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
                                                                          // a lane that is itself a helper passes its owner's fraction on)
                 }
                 if (give) { sb++; shared = true; }
-#ifdef MCRT_STAMP
-                sc_adopt += pairs;
-#endif
             }
         }
-        LSTAMP(sc_refill)
 
         // ---- phase 1: inner nodes, until enough lanes are parked on a leaf ----
         const float tcap = fminf(1.0f, best.frac);               // best only changes in phase 2
@@ -916,34 +867,17 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
             if (inner == 0ull) break;
             if (popc_mask(MCRT_ON_LEAF(cur)) >= (uint32_t)MCRT_LANE_LEAF_BATCH) break;     // (as 32-bit scalars: a 64-bit comparison is a vector instruction)
             if (thieves_wait && --steps_left < 0) break;
-#if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
-            wc_steps++;
-#endif
-#ifdef MCRT_STAMP
-            sc_n1++; sc_act1 += __popcll(inner); sc_park1 += __popcll(MCRT_ON_LEAF(cur)); sc_idle1 += 64 - __popcll(MCRT_WALKING(cur));
-            for (unsigned long long rem = inner; rem != 0ull;) {             // distinct nodes among the stepping lanes: 1 = the wavefront walks as one ray
-                const int l0 = __ffsll((long long)rem) - 1;
-                const int v0 = __shfl(cur, l0, 64);
-                rem &= ~__ballot(cur == v0);
-                sc_dist++;
-            }
-#endif
             if (cur >= 0) {
                 if (STATS) st_nodes++;
                 lane_node_step(a, S, lr, t_lo, tcap, cur, sp, sb);
             }
         }
-        LSTAMP(sc_p1)
-#ifdef MCRT_STAMP
-        { const unsigned long long lm = MCRT_ON_LEAF(cur); if (lm) { sc_n2++; sc_act2 += __popcll(lm); } sc_outer++; }
-#endif
         // ---- phase 2: the parked leaves; the triangle test of the contract (btTriangleRaycastCallback::processTriangle behind
         // the padded-bounds rule), one lane per ray, same expressions as the quad walk's shared test ----
         if ((uint32_t)cur > 0x80000000u) {
             const uint32_t cnt = lane_leaf_test(a, S, f2, to, inv, rc, t_lo, helper, best, cur, sp, sb);
             if (STATS) st_tris += cnt;
         }
-        LSTAMP(sc_p2)
 
         // ---- walkers of ONE ray (the pieces of a cut ray, an owner and the lanes that took over its subtrees) meet in the ray's
         // closest-hit word: each publishes its find there and takes the smallest word back as its own closest hit, so a subtree or
@@ -964,35 +898,6 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
             }
         }
     }
-#ifdef MCRT_STAMP
-    if (lane == 0) {
-        atomicAdd(&a.stamps[0], sc_refill); atomicAdd(&a.stamps[1], sc_p1); atomicAdd(&a.stamps[2], sc_p2); atomicAdd(&a.stamps[3], sc_n1);
-        atomicAdd(&a.stamps[4], sc_n2); atomicAdd(&a.stamps[5], sc_outer); atomicAdd(&a.stamps[6], sc_act1); atomicAdd(&a.stamps[7], sc_act2); atomicAdd(&a.stamps[8], 1ull);
-        atomicAdd(&a.stamps[56], sc_park1); atomicAdd(&a.stamps[57], sc_idle1); atomicAdd(&a.stamps[58], sc_adopt); atomicAdd(&a.stamps[59], sc_dist);
-        atomicAdd(&a.stamps[130], sc_rclaim); atomicAdd(&a.stamps[131], sc_rload); atomicAdd(&a.stamps[132], sc_rounds); atomicAdd(&a.stamps[133], sc_rlanes);
-    }
-#endif
-#if defined(MCRT_STAMP) || defined(MCRT_STAMP_LITE)
-    if (lane == 0 && b < 10u) {
-        const unsigned long long wc_end = wall_clock64();
-        atomicMax(&a.stamps[16 + 4 * b + 2], wc_end); atomicAdd(&a.stamps[16 + 4 * b + 3], wc_end - wc_start);
-        atomicAdd(&a.stamps[60 + 2 * b], wc_empty ? wc_end - wc_empty : 0ull); atomicAdd(&a.stamps[61 + 2 * b], 1ull);   // time after the queue ran dry; wavefronts
-        atomicAdd(&a.stamps[80 + b], wc_start); atomicMax(&a.stamps[90 + b], wc_end - wc_start);                          // start times (sum); longest life
-        atomicAdd(&a.stamps[100 + b], wc_steps); atomicMax(&a.stamps[110 + b], wc_steps);                                  // node-step iterations: sum, most
-        atomicAdd(&hist[min(63ull, (wc_end - wc_start) / 2000ull)], 1ull);
-        wg_end[tid >> 6] = wc_end;
-        __threadfence_block();
-        if (atomicAdd(&wg_done, 1u) == 3u) {          // the workgroup's last wavefront: how long after the SECOND-last did it end?
-            unsigned long long second = 0;
-            for (int k = 0; k < 4; k++) if (k != (tid >> 6) && wg_end[k] > second) second = wg_end[k];
-            atomicAdd(&a.stamps[160 + min(15ull, (wc_end - second) / 2000ull)], 1ull);      // 20 us bins, all bounces together: stamps[160..175]
-            if (b == 1u && (wc_end - wc_start) / 2000ull >= 47ull) atomicAdd(&a.stamps[140 + min(15ull, (wc_end - second) / 2000ull)], 1ull);   // ... and of bounce 1's workgroups that end after 940 us: stamps[140..155]
-        }
-        if (wc_empty) { atomicAdd(&hist[64 + min(63ull, (wc_empty - wc_start) / 2000ull)], 1ull); atomicAdd(&hist[128 + min(63ull, wc_drysteps / 8ull)], 1ull);
-                        atomicAdd(&hist[192 + min(63ull, (wc_empty - (wc_lastclaim ? wc_lastclaim : wc_start)) / 2000ull)], 1ull); }
-    }
-#endif
-#undef LSTAMP
 #undef MCRT_SUB_LO
 #undef MCRT_SUB_STATIC
 #undef MCRT_ON_INNER
@@ -1114,7 +1019,7 @@ MCRT_DEV void packet_walk(const FrameArgs &a, const LaneRay &lr, const f3 f2, co
 #define MCRT_PK_CAS(ka, ra, kb, rb) { const bool sw_ = kb < ka; const uint32_t kl_ = sw_ ? kb : ka, kh_ = sw_ ? ka : kb; const int rl_ = sw_ ? rb : ra, rh_ = sw_ ? ra : rb; ka = kl_; kb = kh_; ra = rl_; rb = rh_; }
                 MCRT_PK_CAS(k0, a0, k1, a1) MCRT_PK_CAS(k2, a2, k3, a3) MCRT_PK_CAS(k0, a0, k2, a2) MCRT_PK_CAS(k1, a1, k3, a3) MCRT_PK_CAS(k1, a1, k2, a2)
 #undef MCRT_PK_CAS
-                if (sp > 60) { if ((threadIdx.x & 63) == 0) atomicOr(a.error_flag, 1u); break; }      // (cannot happen: trees that need more than MCRT_STACK = 64 entries are refused at upload; never silently)
+                if (sp + nh - 1u > (uint32_t)MCRT_STACK) { if ((threadIdx.x & 63) == 0) atomicOr(a.error_flag, 1u); break; }      // nh - 1 entries go onto the 64-lane stack register; trees whose worst case needs more than MCRT_STACK are refused at upload, so this guards the register, never silently
                 if (k3 != 0xffffffffu) { stk = writelane(a3, sp, stk); sp++; }     // farthest first: the nearest pops first
                 if (k2 != 0xffffffffu) { stk = writelane(a2, sp, stk); sp++; }
                 stk = writelane(a1, sp, stk); sp++;
@@ -1125,7 +1030,7 @@ MCRT_DEV void packet_walk(const FrameArgs &a, const LaneRay &lr, const f3 f2, co
             const uint32_t v = (uint32_t)~cur;
             const uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
             for (uint32_t k = 0; k < cnt; k++) {
-                const char *T = (const char *)a.tris + (size_t)(first + k) * (16u * MCRT_TRI_PIECES) + 16u * TRI_V0;
+                const char *T = (const char *)a.tris + (size_t)(first + k) * (16u * MCRT_TRI_PIECES);
                 const u32x8 A = sload8(T); const u32x4 C2 = sload4(T + 32);
                 const f3 v0 = mk(__uint_as_float(A[0]), __uint_as_float(A[1]), __uint_as_float(A[2])), v1 = mk(__uint_as_float(A[4]), __uint_as_float(A[5]), __uint_as_float(A[6]));
                 const f3 v2 = mk(__uint_as_float(C2[0]), __uint_as_float(C2[1]), __uint_as_float(C2[2]));
@@ -1224,8 +1129,8 @@ MCRT_DEV bool shade_path(const FrameArgs &a, const ShadeTables &tb, uint32_t b, 
         if (best.tri >= 0) {
             // plane normal, mesh and the origin-side value of the winning triangle, as the walk's test evaluated them
             const float4 *T = a.tris + MCRT_TRI_PIECES * (size_t)a.tri_slot[best.tri];
-            const float4 t2 = T[TRI_V0 + 1];                            // (v1, mesh)
-            const float4 P = MCRT_TRI_PIECES == 3 ? tri_plane(xyz(T[0]), xyz(t2), xyz(T[2])) : T[0];
+            const float4 t2 = T[1];                                     // (v1, mesh)
+            const float4 P = tri_plane(xyz(T[0]), xyz(t2), xyz(T[2]));
             best.n = xyz(P);
             best.da = dot(best.n, f2) - P.w;
             best.mesh = __float_as_int(t2.w);
@@ -1540,19 +1445,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
         _Pragma("unroll") for (int u = 1; u < G; u++) if (j >= u) MCRT_ADVANCE() \
         busy = true; }
 #define MCRT_ADVANCE() { point = point + delta; t = t + a.time_step; inten *= k_att; }
-#ifdef MCRT_STAMP
-    unsigned long long mc_iter = 0, mc_step_it = 0, mc_step_quads = 0, mc_fin_it = 0, mc_refill = 0;
-    unsigned long long mt_hand = 0, mt_adv = 0, mt_vox = 0, mt_acc = 0, mt_t0 = __builtin_readcyclecounter(); const unsigned long long mt_begin = mt_t0;
-#define MSTAMP(var) { const unsigned long long t_ = __builtin_readcyclecounter(); var += t_ - mt_t0; mt_t0 = t_; }
-#else
-#define MSTAMP(var)
-#endif
     for (;;) {
-#ifdef MCRT_STAMP
-        mc_iter++;
-        { const unsigned long long sm = __ballot(busy && more && j == 0), fm = __ballot(busy && !more && j == 0);
-          if (sm) { mc_step_it++; mc_step_quads += __popcll(sm); } if (fm) mc_fin_it++; }
-#endif
         // ---- finished segments and idle quads.  The boundary echo of a finished segment (main.cpp:139) and the probing of new
         // slots are code the whole wavefront runs however few quads need it, so both wait until REFILL quads are
         // finished or idle (or nothing is left to step) ----
@@ -1611,9 +1504,6 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
                 }
                 const unsigned long long want = __ballot(!busy && j == 0);
                 if (popc_mask(want) < (uint32_t)REFILL) break;
-#ifdef MCRT_STAMP
-                mc_refill++;
-#endif
                 const uint32_t mine = list_pos + (uint32_t)__popcll(want & ((1ull << (lane & ~(G - 1))) - 1ull));
                 if (!busy && mine < list_n) {
                     seg_pid = pid0 + list_base + (uint32_t)sort_list[mine];
@@ -1625,7 +1515,6 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
                 list_pos = (list_pos + nw < list_n) ? list_pos + nw : list_n;
             }
         }
-        MSTAMP(mt_hand)
         if (!__any(busy)) { if (list_pos >= list_n && !tiles_left) break; else continue; }
 
         // ---- G*H steps of every running segment ----
@@ -1642,7 +1531,6 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
             }
             // the quad goes on while its base step (lane 0's) passes the loop test
             more = dpp_i<G == 4 ? QP_BCAST(0) : 0xA0>((sidx < steps && t < a.max_travel) ? 1 : 0) != 0;   // (0xA0: quad_perm [0,0,2,2])
-            MSTAMP(mt_adv)
             float2 vox[H];
             if (reach < a.lean_bound) {
 #pragma unroll
@@ -1651,7 +1539,6 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
 #pragma unroll
                 for (int h = 0; h < H; h++) vox[h] = myv[h] ? a.tex[vox_cell(myp[h], a)] : make_float2(0.0f, 0.0f);
             }
-            MSTAMP(mt_vox)
             // the steps' rows while the gathers are in flight (LDS reads do not wait for them, and the times are dead afterwards:
             // 1407 -> 1382 us per 128-frame launch against looking each row up just before its add); a step's row is guessed from its
             // time, which misses only by a rounding -- the lane's previous row + its stride misses whenever the row advances by one more
@@ -1668,15 +1555,10 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
                 }
             }
         }
-        MSTAMP(mt_acc)
     }
 #undef MCRT_ADVANCE
 #undef MCRT_LOAD_SEGMENT
 #undef MCRT_MTAB
-#ifdef MCRT_STAMP
-    if (lane == 0) { atomicAdd(&a.stamps[120], mt_hand); atomicAdd(&a.stamps[121], mt_adv); atomicAdd(&a.stamps[122], mt_vox); atomicAdd(&a.stamps[123], mt_acc); atomicAdd(&a.stamps[124], __builtin_readcyclecounter() - mt_begin); }
-    if (lane == 0) { atomicAdd(&a.stamps[9], mc_iter); atomicAdd(&a.stamps[10], mc_step_it); atomicAdd(&a.stamps[11], mc_step_quads); atomicAdd(&a.stamps[12], mc_fin_it); atomicAdd(&a.stamps[13], mc_refill); atomicAdd(&a.stamps[14], 1ull); }
-#endif
     if (STATS) {
         long long x = wave_sum_i64((long long)st_steps);
         if (lane == 0 && x) atomicAdd(&a.stats[4], (unsigned long long)x);
@@ -2048,9 +1930,9 @@ hipError_t launch_verify_div(float res, float rcp, unsigned long long *bad, hipS
     return hipGetLastError();
 }
 
-hipError_t launch_expand_tris(const float4 *in48, uint32_t n_tri, float pad_abs, float4 *out64, hipStream_t st)
+hipError_t launch_expand_tris(const float4 *in48, uint32_t n_tri, float4 *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_expand_tris, dim3((n_tri + 255u) / 256u), dim3(256), 0, st, in48, n_tri, pad_abs, out64);
+    hipLaunchKernelGGL(k_expand_tris, dim3((n_tri + 255u) / 256u), dim3(256), 0, st, in48, n_tri, out);
     return hipGetLastError();
 }
 

@@ -279,22 +279,18 @@ __global__ void k_refit_records(const float *tri, const float4 *old_rec, uint32_
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_tri) return;
-    constexpr int V0 = MCRT_TRI_PIECES - 3;
-    const float4 id_rec = old_rec[MCRT_TRI_PIECES * (size_t)slot + V0], mesh_rec = old_rec[MCRT_TRI_PIECES * (size_t)slot + V0 + 1];
+    const float4 id_rec = old_rec[MCRT_TRI_PIECES * (size_t)slot], mesh_rec = old_rec[MCRT_TRI_PIECES * (size_t)slot + 1];
     const uint32_t id = __float_as_uint(id_rec.w);
     const float *v = tri + (size_t)id * 9;
     const float v0x = v[0], v0y = v[1], v0z = v[2], v1x = v[3], v1y = v[4], v1z = v[5], v2x = v[6], v2y = v[7], v2z = v[8];
     // the contract's expressions, exactly as k_expand_tris (mcrt_kernels.hip) evaluates them
     const float ax = v1x - v0x, ay = v1y - v0y, az = v1z - v0z, bx = v2x - v0x, by = v2y - v0y, bz = v2z - v0z;
     const float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
-    const float dist = v0x * nx + v0y * ny + v0z * nz;
     const float edge_tol = (nx * nx + ny * ny + nz * nz) * -0.0001f;
     float4 *o = rec + MCRT_TRI_PIECES * (size_t)slot;
-    if (V0 == 1) o[0] = make_float4(nx, ny, nz, dist);
-    o[V0] = make_float4(v0x, v0y, v0z, id_rec.w);
-    o[V0 + 1] = make_float4(v1x, v1y, v1z, mesh_rec.w);
-    o[V0 + 2] = make_float4(v2x, v2y, v2z, edge_tol);
-    (void)dist;
+    o[0] = make_float4(v0x, v0y, v0z, id_rec.w);
+    o[1] = make_float4(v1x, v1y, v1z, mesh_rec.w);
+    o[2] = make_float4(v2x, v2y, v2z, edge_tol);
     (void)s;
 }
 
@@ -322,7 +318,7 @@ __global__ void k_refit_nodes(float4 *nodes, uint32_t n4, const float4 *rec, con
         float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
         for (uint32_t t = 0; t < cnt; t++) {
             // the triangle's own padded bounds from its record's vertices -- bit for bit what k_prims / mcrt_build_bvh / the walk compute
-            const float4 *rp = rec + MCRT_TRI_PIECES * (size_t)(first + t) + (MCRT_TRI_PIECES - 3);
+            const float4 *rp = rec + MCRT_TRI_PIECES * (size_t)(first + t);
             const float4 a0 = rp[0], a1 = rp[1], a2 = rp[2];
             const float v[9] = { a0.x, a0.y, a0.z, a1.x, a1.y, a1.z, a2.x, a2.y, a2.z };
             float l[3], h[3], ext = 0.0f;

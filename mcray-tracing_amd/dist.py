@@ -4,7 +4,7 @@ rank g traces the contiguous block [g*E/G, (g+1)*E/G) with the scene replicated,
 pass needs 12 columns of halo (rfimage.h:113-118), so convolution runs on the gathered image."""
 import torch
 
-_GATHER_TO_ROOT = {}           # backend name -> does it gather to a root?  Decided ONCE per backend, by ALL ranks together (_gather_to_root_ok)
+_GATHER_TO_ROOT = {}           # (backend name, group) -> does it gather to a root?  Decided ONCE per backend and group, by ALL its ranks together (_gather_to_root_ok)
 
 
 def _unsupported(ex):
@@ -19,23 +19,27 @@ def _unsupported(ex):
 def _gather_to_root_ok(dist, group, like):
     """Can the group's backend gather to a root?  Probed with a 1-element gather the first time a backend is used, and the answer is the
     MINIMUM over the ranks (an all-reduce), so every rank takes the same branch from then on -- a rank-local surprise can no longer send
-    one rank into an all-gather while its peers wait in a gather.  Anything but "unsupported" is re-raised."""
-    be = dist.get_backend(group)
+    one rank into an all-gather while its peers wait in a gather.  Anything but "unsupported" is re-raised -- AFTER the all-reduce, which
+    every rank enters whatever its probe did (a rank that raised before it left its peers blocked there until the backend timed out)."""
+    be = (dist.get_backend(group), id(group) if group is not None else None)      # per (backend, group): another group may span other devices
     if be not in _GATHER_TO_ROOT:
         me, world = dist.get_rank(group), dist.get_world_size(group)
-        ok = 1
+        ok, failure = 1, None
         probe = torch.zeros(1, dtype=torch.float32, device=like.device)
         try:
             dist.gather(probe, [torch.zeros_like(probe) for _ in range(world)] if me == 0 else None,
                         dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        except Exception as ex:
-            if not _unsupported(ex):
-                raise
+        except Exception as ex:           # whatever went wrong, this rank still takes part in the all-reduce below: its peers are waiting there
             ok = 0
-            import sys
-            sys.stderr.write("mcray_tracing_amd.dist: %s has no gather (%s): all_gather_into_tensor instead\n" % (be, str(ex).splitlines()[0]))
+            if _unsupported(ex):
+                import sys
+                sys.stderr.write("mcray_tracing_amd.dist: %s has no gather (%s): all_gather_into_tensor instead\n" % (be[0], str(ex).splitlines()[0]))
+            else:
+                failure = ex
         flag = torch.tensor([ok], dtype=torch.int32, device=like.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if failure is not None:           # a failure of THIS rank is not "unsupported": it propagates, after the collective every rank entered
+            raise failure
         _GATHER_TO_ROOT[be] = bool(int(flag.item()))
     return _GATHER_TO_ROOT[be]
 

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -53,13 +54,34 @@ struct json {
     operator bool() const { if (kind != bool_k) throw std::domain_error("type must be boolean"); return b; }
     operator std::string() const { if (kind != str_k) throw std::domain_error("type must be string"); return str; }
 
-    static json parse(const std::string &s) { size_t i = 0; json j = value(s, i); ws(s, i); if (i != s.size()) fail("trailing characters", i); return j; }
+    static json parse(const std::string &s) { size_t i = 0; json j = value(s, i, 0); ws(s, i); if (i != s.size()) fail("trailing characters", i); return j; }
+
+    static constexpr int max_depth = 256;      // nesting the recursive descent accepts (a scene file nests 3 deep); deeper input is a parse error, not a stack overflow
 
 private:
     static void fail(const char *m, size_t i) { throw std::invalid_argument("parse error at " + std::to_string(i) + ": " + m); }
-    static void ws(const std::string &s, size_t &i) { while (i < s.size() && std::isspace((unsigned char)s[i])) i++; }
-    static json value(const std::string &s, size_t &i)
+    static void ws(const std::string &s, size_t &i) { while (i < s.size() && (s[i] == ' ' || s[i] == '\t' || s[i] == '\n' || s[i] == '\r')) i++; }
+    static unsigned hex4(const std::string &s, size_t &i)      // the four hex digits after \u; i is left on the last one
     {
+        if (i + 4 >= s.size()) fail("truncated \\u escape", i);
+        unsigned v = 0;
+        for (int k = 1; k <= 4; k++) {
+            const char h = s[i + (size_t)k];
+            v = v * 16u + (h >= '0' && h <= '9' ? (unsigned)(h - '0') : h >= 'a' && h <= 'f' ? (unsigned)(h - 'a' + 10) : h >= 'A' && h <= 'F' ? (unsigned)(h - 'A' + 10) : (fail("bad hex digit in \\u escape", i + (size_t)k), 0u));
+        }
+        i += 4;
+        return v;
+    }
+    static void utf8(std::string &o, unsigned cp)
+    {
+        if (cp < 0x80) o += (char)cp;
+        else if (cp < 0x800) { o += (char)(0xC0 | (cp >> 6)); o += (char)(0x80 | (cp & 0x3F)); }
+        else if (cp < 0x10000) { o += (char)(0xE0 | (cp >> 12)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+        else { o += (char)(0xF0 | (cp >> 18)); o += (char)(0x80 | ((cp >> 12) & 0x3F)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+    }
+    static json value(const std::string &s, size_t &i, int depth)
+    {
+        if (depth > max_depth) fail("nested too deeply", i);
         ws(s, i);
         if (i >= s.size()) fail("unexpected end", i);
         json j;
@@ -69,12 +91,12 @@ private:
             if (i < s.size() && s[i] == '}') { i++; return j; }
             for (;;) {
                 ws(s, i);
-                json k = value(s, i);
+                json k = value(s, i, depth + 1);
                 if (k.kind != str_k) fail("object key must be a string", i);
                 ws(s, i);
                 if (i >= s.size() || s[i] != ':') fail("expected ':'", i);
                 i++;
-                j.obj.emplace_back(k.str, value(s, i));
+                j.obj.emplace_back(k.str, value(s, i, depth + 1));
                 ws(s, i);
                 if (i < s.size() && s[i] == ',') { i++; continue; }
                 if (i < s.size() && s[i] == '}') { i++; return j; }
@@ -85,7 +107,7 @@ private:
             j.kind = arr_k; i++; ws(s, i);
             if (i < s.size() && s[i] == ']') { i++; return j; }
             for (;;) {
-                j.arr.push_back(value(s, i));
+                j.arr.push_back(value(s, i, depth + 1));
                 ws(s, i);
                 if (i < s.size() && s[i] == ',') { i++; continue; }
                 if (i < s.size() && s[i] == ']') { i++; return j; }
@@ -95,9 +117,28 @@ private:
         if (c == '"') {
             j.kind = str_k; i++;
             while (i < s.size() && s[i] != '"') {
-                if (s[i] == '\\' && i + 1 < s.size()) {
+                if ((unsigned char)s[i] < 0x20) fail("control character in string", i);
+                if (s[i] == '\\') {
+                    if (i + 1 >= s.size()) fail("unterminated string", i);
                     const char e = s[++i];
-                    j.str += e == 'n' ? '\n' : e == 't' ? '\t' : e;
+                    switch (e) {
+                    case '"': case '\\': case '/': j.str += e; break;
+                    case 'b': j.str += '\b'; break; case 'f': j.str += '\f'; break; case 'n': j.str += '\n'; break;
+                    case 'r': j.str += '\r'; break; case 't': j.str += '\t'; break;
+                    case 'u': {
+                        unsigned cp = hex4(s, i);
+                        if (cp >= 0xD800 && cp <= 0xDBFF) {                      // a surrogate pair: the low half must follow
+                            if (i + 2 >= s.size() || s[i + 1] != '\\' || s[i + 2] != 'u') fail("lone surrogate in \\u escape", i);
+                            i += 2;
+                            const unsigned lo = hex4(s, i);
+                            if (lo < 0xDC00 || lo > 0xDFFF) fail("bad low surrogate in \\u escape", i);
+                            cp = 0x10000u + ((cp - 0xD800u) << 10) + (lo - 0xDC00u);
+                        } else if (cp >= 0xDC00 && cp <= 0xDFFF) fail("lone surrogate in \\u escape", i);
+                        utf8(j.str, cp);
+                        break;
+                    }
+                    default: fail("bad escape", i);
+                    }
                 } else j.str += s[i];
                 i++;
             }
@@ -108,6 +149,11 @@ private:
         if (!s.compare(i, 4, "true")) { j.kind = bool_k; j.b = true; i += 4; return j; }
         if (!s.compare(i, 5, "false")) { j.kind = bool_k; j.b = false; i += 5; return j; }
         if (!s.compare(i, 4, "null")) { i += 4; return j; }
+        {   // a JSON number: -? digits ...  (strtod alone would take "nan", "inf", hex floats and a leading '+')
+            const size_t d = i + (c == '-' ? 1u : 0u);
+            if (d >= s.size() || !(s[d] >= '0' && s[d] <= '9')) fail("unexpected character", i);
+            if (s[d] == '0' && d + 1 < s.size() && ((s[d + 1] >= '0' && s[d + 1] <= '9') || s[d + 1] == 'x' || s[d + 1] == 'X')) fail("bad number", i);
+        }
         char *end = nullptr;
         j.num = std::strtod(s.c_str() + i, &end);
         if (end == s.c_str() + i) fail("unexpected character", i);
@@ -128,29 +174,45 @@ inline json load_json(const std::string &path)
 struct material { float impedance, attenuation, mu0, mu1, sigma, specularity, shininess, thickness; };
 struct mesh { std::string filename; bool is_rigid, is_vascular; std::array<float, 3> deltas; bool outside_normals; uint32_t material_inside, material_outside; };
 
-inline void load_obj_triangles(const std::string &path, std::vector<float> &tri9)
+// positions and faces the way the reference's loader reads them (tiny_obj_loader.cpp:97-187,504-717): a coordinate is (float)atof of its token
+// (so "nan" and "inf" are values, a missing coordinate is 0), a face corner is atoi of the token up to its first '/', index > 0 counts from one,
+// < 0 from the end, and 0 is the first vertex (fixIndex); polygons become fans.  The reference then indexes its arrays unchecked: a corner
+// outside the vertices read so far is an error here, never a wild read.
+inline void load_obj_triangles(std::istream &f, const std::string &name, std::vector<float> &tri9)
 {
-    std::ifstream f(path);
-    if (!f) throw std::runtime_error("cannot read mesh '" + path + "'");
     std::vector<std::array<float, 3>> v;
     std::string line;
     while (std::getline(f, line)) {
-        std::istringstream is(line);
-        std::string tag; is >> tag;
-        if (tag == "v") {   // decimal -> double -> float, like the reference's (float)atof (tiny_obj_loader.cpp parseFloat)
-            double d[3] = { 0, 0, 0 }; is >> d[0] >> d[1] >> d[2];
-            v.push_back({ (float)d[0], (float)d[1], (float)d[2] });
-        }
-        else if (tag == "f") {
-            std::vector<long> idx; std::string tok;
-            while (is >> tok) { long i = std::strtol(tok.c_str(), nullptr, 10); idx.push_back(i > 0 ? i - 1 : (long)v.size() + i); }
+        const char *t = line.c_str();
+        t += std::strspn(t, " \t");
+        if (t[0] == 'v' && (t[1] == ' ' || t[1] == '\t')) {
+            t += 2;
+            std::array<float, 3> p{};
+            for (int k = 0; k < 3; k++) { t += std::strspn(t, " \t"); p[(size_t)k] = (float)std::atof(t); t += std::strcspn(t, " \t\r"); }
+            v.push_back(p);
+        } else if (t[0] == 'f' && (t[1] == ' ' || t[1] == '\t')) {
+            t += 2;
+            std::vector<long> idx;
+            for (;;) {
+                t += std::strspn(t, " \t");
+                if (t[0] == '\0' || t[0] == '\r' || t[0] == '\n') break;
+                const long i = std::strtol(t, nullptr, 10);            // stops at '/': the position index of v, v/vt, v//vn, v/vt/vn
+                idx.push_back(i > 0 ? i - 1 : i == 0 ? 0 : (long)v.size() + i);
+                t += std::strcspn(t, " \t\r");
+            }
             for (size_t k = 1; k + 1 < idx.size(); k++)
                 for (long i : { idx[0], idx[k], idx[k + 1] }) {
-                    if (i < 0 || (size_t)i >= v.size()) throw std::runtime_error("face index out of range in '" + path + "'");
+                    if (i < 0 || (size_t)i >= v.size()) throw std::runtime_error("face index out of range in '" + name + "'");
                     tri9.insert(tri9.end(), v[(size_t)i].begin(), v[(size_t)i].end());
                 }
         }
     }
+}
+inline void load_obj_triangles(const std::string &path, std::vector<float> &tri9)
+{
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("cannot read mesh '" + path + "'");
+    load_obj_triangles(f, path, tri9);
 }
 
 // the subset of btVector3 the reference's host code uses (main.cpp:72,117,120,131; scene.cpp:342-346)
@@ -308,15 +370,88 @@ private:
 };
 
 // ---------------------------------------------------------------- scene (scene.h / scene.cpp)
-class scene {
+// what scene::parse_config (scene.cpp:185-247) reads of a scene file -- host data only, no GPU: every key but workingDirectory is mandatory
+// (nlohmann::json::at throws), and load() wraps any failure the way the reference's constructor does (scene.cpp:19-26)
+struct scene_config {
+    std::vector<std::string> material_names;
+    std::vector<material> materials;
+    std::vector<mesh> meshes;
+    std::string working_dir, starting_material;
+    std::array<float, 3> spacing{}, origin{};
+    float scaling = 1.f;
+
+    static scene_config load(const json &config)
+    {
+        scene_config c;
+        try { c.parse_config(config); }
+        catch (const std::exception &ex) { throw std::runtime_error{ "Error while loading scene: " + std::string{ ex.what() } }; }
+        return c;
+    }
+    uint32_t material_index(const std::string &name) const
+    {
+        for (size_t i = 0; i < material_names.size(); i++) if (material_names[i] == name) return (uint32_t)i;
+        throw std::out_of_range("key '" + name + "' not found");
+    }
+    // scene.cpp:38-48 + 300-334: each mesh's OBJ, placed; the triangle soup mcrt_upload_scene takes
+    void triangles(std::vector<float> &tri, std::vector<uint32_t> &tri_mesh, std::vector<mcrt_mesh> &recs) const
+    {
+        for (size_t mi = 0; mi < meshes.size(); mi++) {
+            const mesh &m = meshes[mi];
+            std::vector<float> t9;
+            load_obj_triangles(working_dir + m.filename, t9);
+            float pos[3];
+            for (int i = 0; i < 3; i++) pos[i] = m.deltas[(size_t)i] * scaling * scaling + origin[(size_t)i];   // scene.cpp:322-324
+            for (size_t k = 0; k < t9.size(); k++) t9[k] = t9[k] * scaling + pos[k % 3];
+            tri.insert(tri.end(), t9.begin(), t9.end());
+            tri_mesh.insert(tri_mesh.end(), t9.size() / 9, (uint32_t)mi);
+            recs.push_back(mcrt_mesh{ m.material_inside, m.material_outside, m.is_vascular ? 1u : 0u, 0u });
+        }
+    }
+private:
+    static std::array<float, 3> float3(const json &a)
+    {
+        if (!a.is_array()) throw std::domain_error("type must be array");
+        return { (float)a[0], (float)a[1], (float)a[2] };
+    }
+    void parse_config(const json &config)   // scene.cpp:185-247
+    {
+        working_dir = config.contains("workingDirectory") ? (std::string)config.at("workingDirectory") : "";
+        (void)config.at("transducerPosition");
+        origin = float3(config.at("origin"));
+        spacing = float3(config.at("spacing"));
+        starting_material = (std::string)config.at("startingMaterial");
+        scaling = (float)config.at("scaling");
+        const auto &mats = config.at("materials");
+        if (!mats.is_array()) throw std::runtime_error("materials must be an array");
+        for (const auto &m : mats.arr) {
+            const std::string name = m.at("name");
+            material v{ m.at("impedance"), m.at("attenuation"), m.at("mu0"), m.at("mu1"), m.at("sigma"), m.at("specularity"), m.at("shininess"), m.at("thickness") };
+            bool found = false;
+            for (size_t i = 0; i < material_names.size(); i++) if (material_names[i] == name) { materials[i] = v; found = true; }
+            if (!found) { material_names.push_back(name); materials.push_back(v); }
+        }
+        const auto &ms = config.at("meshes");
+        if (!ms.is_array()) throw std::runtime_error("meshes must be an array");
+        for (const auto &m : ms.arr) {
+            // (every field into a local first: an initializer that throws half way through a braced aggregate leaks the fields already built
+            //  under GCC < 12 -- found by the sanitizer run, tests/test_host_sanitize.py)
+            const std::string file = m.at("file");
+            const bool rigid = m.at("rigid"), vascular = m.at("vascular"), outside_normals = m.at("outsideNormals");
+            const std::array<float, 3> deltas = float3(m.at("deltas"));
+            const uint32_t inside = material_index(m.at("material")), outside = material_index(m.at("outsideMaterial"));
+            meshes.push_back(mesh{ file, rigid, vascular, deltas, outside_normals, inside, outside });
+        }
+        (void)material_index(starting_material);
+    }
+};
+
+class scene : public scene_config {
 public:
     // scene(json, transducer&): parse_config + upload (replaces create_empty_world/init/add_rigidbody_from_obj)
     template <size_t N>
     scene(const json &config, transducer<N> &t, std::shared_ptr<device> dev_ = nullptr, unsigned samples = 5, unsigned seed = 0x5EED)
-        : dev(dev_ ? std::move(dev_) : default_device())
+        : scene_config(scene_config::load(config)), dev(dev_ ? std::move(dev_) : default_device())
     {
-        try { parse_config(config); }
-        catch (const std::exception &ex) { throw std::runtime_error{ "Error while loading scene: " + std::string{ ex.what() } }; }
         mcrt_params p; mcrt_default_params(&p);
         p.n_elements = (uint32_t)N; p.n_samples = samples; p.frequency = t.frequency; p.seed = seed;
         check(this->dev->set_params(&p), "mcrt_set_params");
@@ -378,59 +513,13 @@ public:
     std::shared_ptr<device> dev;
     mcrt_params params{};
     uint32_t frame_id = 0;
-    std::vector<std::string> material_names;
-    std::vector<material> materials;
-    std::vector<mesh> meshes;
-    std::string working_dir, starting_material;
-    std::array<float, 3> spacing{}, origin{};
-    float scaling = 1.f;
 
 private:
-    uint32_t material_index(const std::string &name) const
-    {
-        for (size_t i = 0; i < material_names.size(); i++) if (material_names[i] == name) return (uint32_t)i;
-        throw std::out_of_range("key '" + name + "' not found");
-    }
-    void parse_config(const json &config)   // scene.cpp:185-247
-    {
-        working_dir = config.contains("workingDirectory") ? (std::string)config.at("workingDirectory") : "";
-        (void)config.at("transducerPosition");
-        const auto &orig = config.at("origin"); origin = { (float)orig[0], (float)orig[1], (float)orig[2] };
-        const auto &spac = config.at("spacing"); spacing = { (float)spac[0], (float)spac[1], (float)spac[2] };
-        starting_material = (std::string)config.at("startingMaterial");
-        scaling = (float)config.at("scaling");
-        const auto &mats = config.at("materials");
-        if (!mats.is_array()) throw std::runtime_error("materials must be an array");
-        for (const auto &m : mats.arr) {
-            const std::string name = m.at("name");
-            material v{ m.at("impedance"), m.at("attenuation"), m.at("mu0"), m.at("mu1"), m.at("sigma"), m.at("specularity"), m.at("shininess"), m.at("thickness") };
-            bool found = false;
-            for (size_t i = 0; i < material_names.size(); i++) if (material_names[i] == name) { materials[i] = v; found = true; }
-            if (!found) { material_names.push_back(name); materials.push_back(v); }
-        }
-        const auto &ms = config.at("meshes");
-        if (!ms.is_array()) throw std::runtime_error("meshes must be an array");
-        for (const auto &m : ms.arr) {
-            const auto &d = m.at("deltas");
-            meshes.push_back(mesh{ m.at("file"), m.at("rigid"), m.at("vascular"), { (float)d[0], (float)d[1], (float)d[2] }, m.at("outsideNormals"),
-                                   material_index(m.at("material")), material_index(m.at("outsideMaterial")) });
-        }
-        (void)material_index(starting_material);
-    }
     void init()   // scene.cpp:38-48 + 300-334: load each OBJ, place it, hand the triangle soup to the GPU
     {
         std::vector<float> tri; std::vector<uint32_t> tri_mesh; std::vector<mcrt_mesh> recs;
-        for (size_t mi = 0; mi < meshes.size(); mi++) {
-            const mesh &m = meshes[mi];
-            std::vector<float> t9;
-            load_obj_triangles(working_dir + m.filename, t9);
-            float pos[3];
-            for (int i = 0; i < 3; i++) pos[i] = m.deltas[(size_t)i] * scaling * scaling + origin[(size_t)i];   // scene.cpp:322-324
-            for (size_t k = 0; k < t9.size(); k++) t9[k] = t9[k] * scaling + pos[k % 3];
-            tri.insert(tri.end(), t9.begin(), t9.end());
-            tri_mesh.insert(tri_mesh.end(), t9.size() / 9, (uint32_t)mi);
-            recs.push_back(mcrt_mesh{ m.material_inside, m.material_outside, m.is_vascular ? 1u : 0u, 0u });
-        }
+        triangles(tri, tri_mesh, recs);
+        if (materials.empty()) throw std::runtime_error("Error while loading scene: no materials");
         check(dev->upload_scene(tri.data(), tri_mesh.data(), (uint32_t)(tri.size() / 9), recs.data(), (uint32_t)recs.size(),
                                 &materials[0].impedance, (uint32_t)materials.size(), material_index(starting_material), spacing.data()), "mcrt_upload_scene");
     }

@@ -13,22 +13,48 @@ class SceneError(RuntimeError):
     pass
 
 
+def _atof(tok):
+    """(float)atof(token), tiny_obj_loader.cpp:122-128: "nan" / "inf" are values, anything unreadable is 0"""
+    try:
+        return float(tok)
+    except ValueError:
+        return 0.0
+
+
+def _atoi(tok):
+    """atoi of a face corner up to its first '/': optional sign + leading digits, 0 when there are none"""
+    head = tok.split("/")[0]
+    n = 1 if head[:1] in "+-" else 0
+    while n < len(head) and head[n].isdigit():
+        n += 1
+    try:
+        return int(head[:n])
+    except ValueError:
+        return 0
+
+
 def load_obj(path):
-    """-> (V [n,3] float32, F [m,3] int32) in file order; polygons become fans (v0, v[k], v[k+1])."""
+    """-> (V [n,3] float32, F [m,3] int32) in file order; polygons become fans (v0, v[k], v[k+1]).  Indices as the reference's
+    loader fixes them (tiny_obj_loader.cpp:97-109): > 0 counts from one, < 0 from the end, 0 is the first vertex.  The reference then
+    indexes unchecked; a corner outside the vertices read so far is a SceneError here."""
     verts, faces = [], []
-    with open(path, "r") as f:
+    with open(path, "r", errors="replace") as f:
         for line in f:
             t = line.split()
             if not t or t[0].startswith("#"):
                 continue
             if t[0] == "v":
-                verts.append((float(t[1]), float(t[2]), float(t[3])))
+                c = [_atof(x) for x in t[1:4]] + [0.0, 0.0, 0.0]
+                verts.append((c[0], c[1], c[2]))
             elif t[0] == "f":
                 idx = []
                 for tok in t[1:]:
-                    i = int(tok.split("/")[0])
-                    idx.append(i - 1 if i > 0 else len(verts) + i)
+                    i = _atoi(tok)
+                    idx.append(i - 1 if i > 0 else (0 if i == 0 else len(verts) + i))
                 for k in range(1, len(idx) - 1):
+                    for i in (idx[0], idx[k], idx[k + 1]):
+                        if not 0 <= i < len(verts):
+                            raise SceneError("face index out of range in '%s'" % path)
                     faces.append((idx[0], idx[k], idx[k + 1]))
     return np.asarray(verts, np.float32).reshape(-1, 3), np.asarray(faces, np.int32).reshape(-1, 3)
 

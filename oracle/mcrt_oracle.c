@@ -1469,6 +1469,10 @@ void orc_packet_count(const orc_scene *sc, const orc_params *prm, const orc_segm
                       uint32_t *out /*[packets][6]*/, int32_t *tri /*[n]*/, int n_threads)
 {
     const orc_bvh4_child *nodes = (const orc_bvh4_child *)sc->nodes4;
+    if (W == 0 || W > 64 || !nodes) {                     /* the per-ray arrays below hold 64 rays: anything else is a caller's error, reported in the results */
+        for (uint64_t i = 0; i < n; i++) tri[i] = -3;
+        return;
+    }
     const int64_t n_pack = (int64_t)((n + W - 1) / W);
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #pragma omp parallel for schedule(dynamic, 16)
@@ -1488,7 +1492,7 @@ void orc_packet_count(const orc_scene *sc, const orc_params *prm, const orc_segm
             hit_t b1 = best[r]; orc_stats st; memset(&st, 0, sizeof st);
             walk_bvh4(sc, from[r], to[r], &b1, &st); alone[r] = (uint32_t)st.nodes_visited;
         }
-        int32_t stack[256]; int sp = 0; int32_t cur = 0;
+        int32_t stack[256]; int sp = 0; int32_t cur = 0; int overflow = 0;
         uint32_t nn = 0, nl = 0, nt = 0;
         for (;;) {
             if (cur >= 0) {
@@ -1514,7 +1518,7 @@ void orc_packet_count(const orc_scene *sc, const orc_params *prm, const orc_segm
                     int ord[4], c = 0;
                     for (int k = 0; k < 4; k++) if (hitc[k]) ord[c++] = k;
                     for (int i = 1; i < c; i++) { int x = ord[i], j = i - 1; while (j >= 0 && key[ord[j]] > key[x]) { ord[j + 1] = ord[j]; j--; } ord[j + 1] = x; }
-                    for (int i = c - 1; i >= 1; i--) if (sp < 256) stack[sp++] = N[ord[i]].ref;        /* farthest first: the nearest pops first */
+                    for (int i = c - 1; i >= 1; i--) { if (sp < 256) stack[sp++] = N[ord[i]].ref; else overflow = 1; }        /* farthest first: the nearest pops first */
                     cur = N[ord[0]].ref;
                     continue;
                 }
@@ -1532,7 +1536,7 @@ void orc_packet_count(const orc_scene *sc, const orc_params *prm, const orc_segm
             cur = stack[--sp];
         }
         uint32_t sum = 0, mx = 0;
-        for (uint32_t r = 0; r < m; r++) { sum += alone[r]; if (alone[r] > mx) mx = alone[r]; tri[(uint64_t)p * W + r] = best[r].tri; }
+        for (uint32_t r = 0; r < m; r++) { sum += alone[r]; if (alone[r] > mx) mx = alone[r]; tri[(uint64_t)p * W + r] = overflow ? -3 : best[r].tri; }      /* a dropped stack entry would under-count: the packet's results are marked instead */
         uint32_t *o = out + 6 * p;
         o[0] = nn; o[1] = nl; o[2] = nt; o[3] = sum; o[4] = mx; o[5] = m;
     }
