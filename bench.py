@@ -411,6 +411,7 @@ def main():
                                         t_over["shade"][0], t_alone["shade"][0], other.get("shade"), per_frame["queries"] * 212.0 / lpf, clock,
                                         note="algorithmic bytes = 212 B per ray (state in and out 96, march record 48, winning triangle 3 x 16, keys / queue / counts 20)"),
             }
+        roof["salu"] = salu_block(pmc)
         out["roofline"] = roof
         if world == 1 and F > 1 and not args.no_latency_leg:
             # the same workload strictly one frame at a time (each launch carries one frame's rays), for the record
@@ -436,6 +437,27 @@ def main():
             dts = statistics.median(lat)
             out["sweep"] = {"value": E * S * K / dts, "unit": "rays/s", "ms_per_step": dts / K * 1e3, "frames_per_sec": K / dts, "frames_in_flight": F,
                             "what": "the timed region with a different probe pose in every frame of a pass (mcrt_trace_frames_poses)"}
+        if world == 1 and not args.no_latency_leg and pipe.F >= 2:
+            # the STEADY STATE, for the record beside the driver's pass size: whole passes of min(128, frames-in-flight) frames, outside
+            # the timed region like the two legs above -- what a caller who keeps the GPU fed sees per frame (tails of a launch amortised over more rays)
+            P = min(128, pipe.F)
+            pipe.run_steps(6000, P); pipe.sync()               # (work buffers grow to the pass size here, not inside the clock)
+            lat = []
+            for _ in range(5):
+                pipe.sync(); t1 = time.perf_counter()
+                pipe.run_steps(0, P)
+                pipe.drain(); lat.append(time.perf_counter() - t1)
+            pipe.sync()
+            dtp = statistics.median(lat)
+            out["pass%d" % P] = {"value": E * S * P / dtp, "unit": "rays/s", "ms_per_step": dtp / P * 1e3, "frames_per_sec": P / dtp, "frames_in_flight": P, "repeats": len(lat),
+                                 "ms_per_step_min_max": [min(lat) / P * 1e3, max(lat) / P * 1e3],
+                                 "what": "one pass of %d frames per repeat (whole B-mode frames: trace, accumulate, PSF, envelope, scan conversion), median of %d" % (P, len(lat))}
+        if world > 1 and not args.no_cpu_baseline:
+            # N > 1: the oracle on rank 0's OWN shard (seconds), so that a scaling line carries oracle evidence and not only gather_check
+            ctx.set_stream(pipe.s_trace.cuda_stream)
+            ctx.trace_frames(0, pass_sizes[0], pipe.buf[0], e0, e1)
+            torch.cuda.synchronize(); ctx.synchronize()
+            out["parity_check"] = shard_parity(m, sd, tr, ctx, S, R, pipe.buf[0][0].cpu().numpy(), e0, e1)
         if world == 1 and not args.no_cpu_baseline:
             # frame 0 of the timed workload, traced the way the timed region traces it (first pass), before the PSF
             ctx.set_stream(pipe.s_trace.cuda_stream)
@@ -553,6 +575,26 @@ def roofline_from(pmc, k_ms, alg_gbs, alg_bytes):
     return r
 
 
+def salu_block(pmc):
+    """The scalar pipe: a CU's four SIMDs share ONE scalar ALU, which issues at most one instruction per cycle.  Per kernel:
+    SQ_INSTS_SALU per launch over the launch's busy CU cycles (SQ_BUSY_CU_CYCLES, summed over the 256 CUs) = scalar instructions per cycle and CU,
+    i.e. the share of that pipe's issue slots the kernel fills while it runs alone under --pmc; and scalar per vector instruction."""
+    def one(d):
+        if not d or not d.get("salu_instructions_per_launch") or not d.get("busy_cu_cycles_per_launch"):
+            return None
+        per_cu_cycle = d["salu_instructions_per_launch"] / (d["busy_cu_cycles_per_launch"] * 256.0)
+        return {"salu_instructions_per_launch": d["salu_instructions_per_launch"], "busy_cycles_per_cu": d["busy_cu_cycles_per_launch"],
+                "salu_per_cycle_and_cu": per_cu_cycle, "frac_of_scalar_issue": per_cu_cycle / 1.0,
+                "salu_per_valu_instruction": d["salu_instructions_per_launch"] / d["valu_instructions_per_launch"] if d.get("valu_instructions_per_launch") else None}
+    if not pmc:
+        return None
+    o = {"what": "scalar ALU issue: SQ_INSTS_SALU per launch / busy CU cycles (one scalar ALU per CU, one instruction per cycle); kernels run one at a time under --pmc",
+         "peak": 1.0, "unit": "scalar instructions per cycle and CU", "walk": one(pmc)}
+    for fam, d in (pmc.get("other_kernels") or {}).items():
+        o["k_" + fam] = one(d)
+    return o if any(v for k_, v in o.items() if k_ in ("walk", "k_march", "k_shade")) else None
+
+
 def kernel_block(name, what, t_ms, t_alone_ms, pmc_k, alg_bytes, clock, note=None):
     """one of the bounce's other kernels in the walk's terms: duration per launch beside the rest of the pipeline and alone (dilation), its VALU
     issue share of the architectural rate over its own duration, lane-level share, algorithmic and measured bytes"""
@@ -637,7 +679,7 @@ def live_pmc(args):
                 "fetch_size_kib": got["FETCH_SIZE"][0], "write_size_kib": got["WRITE_SIZE"][0],
                 "traffic_bytes_per_launch": (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0,
                 "other_kernels": {fam: {"launches_profiled": o["SQ_INSTS_VALU"][1], "valu_instructions_per_launch": o["SQ_INSTS_VALU"][0],
-                                        "busy_cu_cycles_per_launch": o["SQ_BUSY_CU_CYCLES"][0] / 256.0,
+                                        "busy_cu_cycles_per_launch": o["SQ_BUSY_CU_CYCLES"][0] / 256.0, "salu_instructions_per_launch": o.get("SQ_INSTS_SALU", (None, 0))[0],
                                         "lane_utilisation": o["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * o["SQ_ACTIVE_INST_VALU"][0]) if o["SQ_ACTIVE_INST_VALU"][0] else None,
                                         "tcp_lane_accesses_per_launch": o["TCP_TOTAL_CACHE_ACCESSES_sum"][0],
                                         "traffic_bytes_per_launch": (2.0 * o["FETCH_SIZE"][0] + o["WRITE_SIZE"][0]) * 1024.0}
@@ -736,6 +778,24 @@ def cpu_baseline(m, sd, tr, ctx, S, R, rf0):
             "sample": "%d whole frame(s) of %dx%d rays, same workload, %d OpenMP threads (trace + accumulate, no PSF)" % (frames, E, S, cores),
             "seconds": dt}
     return base, parity
+
+
+def shard_parity(m, sd, tr, ctx, S, R, rf0, e0, e1):
+    """rank 0's shard [e0, e1) of frame 0 against the oracle, bit for bit (the N > 1 line's parity evidence; no timing)"""
+    import numpy as np
+    from oracle import orc
+    cores, _ = usable_cores()
+    nodes, btri, _ = ctx.get_bvh()
+    osc = orc.OracleScene(sd.tri, sd.tri_mesh, sd.meshes, sd.materials, sd.start_mat, sd.spacing, bvh=(nodes, btri))
+    osc.set_bvh4(ctx.get_bvh4()[0])
+    p = orc.default_params(n_elements=tr.n_elements, n_samples=S, n_rows=R)
+    t0 = time.perf_counter()
+    o = osc.trace_frame(p, tr.pos, tr.dir, orc.texture(256), frame_id=0, e_begin=e0, e_end=e1, use_bvh=2, n_threads=cores, want_hits=False, want_ref=False)
+    want = o["rf"]                                               # [R][e1 - e0]
+    got = np.ascontiguousarray(rf0.T)
+    return {"rf_bit_exact": bool(want.shape == got.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))), "frame": 0, "rank": 0, "scan_lines": [int(e0), int(e1)],
+            "paths": int((e1 - e0) * S), "oracle_seconds": time.perf_counter() - t0,
+            "what": "fixed-point RF image of rank 0's scan-line shard of frame 0 (traced in the timed pass size), GPU vs oracle, before the gather and the PSF"}
 
 
 if __name__ == "__main__":

@@ -59,6 +59,8 @@ struct Work {
 struct Knobs {
     uint32_t ksplit_limit = MCRT_KSPLIT_DEFAULT, trace_blocks = 0, trace_blocks_wide = 0, wide_from = 0 /* 0: the kernels' own default */, wide_max_tree_mb = 128, groups = MCRT_GROUPS_DEFAULT, march_streams = MCRT_SIDE_STREAMS_DEFAULT, march_blocks = 0;   // march_blocks 0: launch_march picks
     bool no_overlap = false, no_priority = false, no_fast_div = false, no_lean = false;
+    uint32_t path_groups = MCRT_PATH_GROUPS_DEFAULT;   // ... as this many scan-line groups on their own streams: a group's accumulation runs beside the other groups' last walks
+    uint32_t path_max = MCRT_PATH_MAX_DEFAULT;    // passes of at most this many paths run as ONE launch that carries every path through all of its bounces (k_path: the latency form)
     uint32_t packet_mask = MCRT_PACKET_MASK_DEFAULT, packet_from = MCRT_PACKET_FROM;   // bit b: bounce b is walked by k_trace_packet (one wavefront per packet of 64 queue neighbours), in passes of at least packet_from paths
     uint32_t march_cus = 0;                    // CUs the accumulation's side stream is confined to (0 = no mask); the mask's bit order is the driver's
     bool main_mask = false;                    // with march_cus: the walk / shade chain runs on its own stream confined to the OTHER CUs
@@ -75,6 +77,8 @@ static Knobs read_knobs()
     if (const char *e = tuning_env("MCRT_WIDE_FROM")) { long long v = atoll(e); if (v >= 1 && v <= 0xffffffffll) k.wide_from = (uint32_t)v; }   // rays in a launch from which the walk takes its five-wavefront form (1: always; 4294967295: never)
     if (const char *e = tuning_env("MCRT_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 16) k.groups = (uint32_t)v; }
     if (const char *e = tuning_env("MCRT_PACKET_BOUNCES")) { long v = strtol(e, nullptr, 0); if (v >= 0) k.packet_mask = (uint32_t)v; }
+    if (const char *e = tuning_env("MCRT_PATH_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= 16) k.path_groups = (uint32_t)v; }
+    if (const char *e = tuning_env("MCRT_PATH_MAX")) { long long v = atoll(e); if (v >= 0 && v <= 0xffffffffll) k.path_max = (uint32_t)v; }
     if (const char *e = tuning_env("MCRT_PACKET_FROM")) { long long v = atoll(e); if (v >= 0 && v <= 0xffffffffll) k.packet_from = (uint32_t)v; }
     if (const char *e = tuning_env("MCRT_MARCH_STREAMS")) { int v = atoi(e); if (v >= 1 && v <= MCRT_SIDE_STREAMS) k.march_streams = (uint32_t)v; }
     if (const char *e = tuning_env("MCRT_MARCH_BLOCKS")) { int v = atoi(e); if (v >= 1) k.march_blocks = (uint32_t)v; }
@@ -739,7 +743,8 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne_frame, uint32_t n_frame
     }
     {   // traversal-stack entries beyond the LDS part, one slot per thread of THIS work set's walk launches
         const uint32_t lds_part = mcrt::lane_stack_entries();
-        const uint32_t blocks = std::max(std::max(c->knobs.trace_blocks, c->knobs.trace_blocks_wide), c->n_cu * 5u);      // (the larger of the walk's two forms)
+        uint32_t blocks = std::max(std::max(c->knobs.trace_blocks, c->knobs.trace_blocks_wide), c->n_cu * 5u);      // (the larger of the walk's two forms)
+        blocks = std::max(blocks, (uint32_t)((std::min<size_t>(np, c->knobs.path_max) + 255u) / 256u));                // (... and k_path's one workgroup per 256 paths)
         const size_t need = c->bvh4.max_stack > lds_part ? (size_t)(c->bvh4.max_stack - lds_part) * blocks * 256 : 0;
         if (need > w.ovf_cap) {
             HIP_TRY(hipDeviceSynchronize());
@@ -908,7 +913,25 @@ static int enqueue_frame(mcrt_ctx *c, const std::vector<mcrt::FrameArgs> &args, 
         if (gst[g] != c->stream) HIP_TRY(hipStreamWaitEvent(gst[g], c->ev_start, 0));
         HIP_TRY(mcrt::launch_init(args[g], gst[g]));
     }
-    for (uint32_t b = 0; b < c->p.max_depth; b++)
+    // A pass that cannot fill the GPU runs in its LATENCY form: one launch carries every path through all of its bounces (k_path), one more
+    // accumulates every bounce's segments -- instead of a walk / shade launch pair per bounce, each as long as its slowest wavefront.
+    uint64_t paths = 0;
+    for (uint32_t g = 0; g < groups; g++) paths += (uint64_t)args[g].ne * args[g].S;
+    const bool fused = !c->stats_on && paths <= c->knobs.path_max;
+    for (uint32_t g = 0; g < groups && fused; g++) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        { int rc = timing_events(c, 0, &e0, &e1); if (rc) return rc; }
+        if (e0) HIP_TRY(hipEventRecord(e0, gst[g]));
+        HIP_TRY(mcrt::launch_path(args[g], gst[g]));
+        if (e1) HIP_TRY(hipEventRecord(e1, gst[g]));
+        if (accumulate) {
+            { int rc = timing_events(c, 2, &e0, &e1); if (rc) return rc; }
+            if (e0) HIP_TRY(hipEventRecord(e0, gst[g]));
+            HIP_TRY(mcrt::launch_march(args[g], mcrt::MCRT_ALL_BOUNCES, false, gst[g]));
+            if (e1) HIP_TRY(hipEventRecord(e1, gst[g]));
+        }
+    }
+    for (uint32_t b = 0; b < c->p.max_depth && !fused; b++)
         for (uint32_t g = 0; g < groups; g++) {
             int rc = run_bounce(c, *ws[g], gst[g], args[g], b, accumulate, overlap); if (rc) return rc;
         }
@@ -950,7 +973,9 @@ extern "C" int mcrt_trace_frames(mcrt_ctx *c, uint32_t frame, uint32_t n_frames,
         return set_error(MCRT_ERR_LIMIT, "%u frames x %u scan-lines x %u samples: more than 2^27 paths in one pass", n_frames, e1 - e0, c->p.n_samples);
     const uint32_t lines = (e1 - e0) * n_frames;
     rc = ensure_acc(c, lines); if (rc) return rc;
-    rc = run_frame(c, frame, n_frames, e0, e1, true, frame_groups(c), 0); if (rc) return rc;
+    uint32_t groups = frame_groups(c);
+    if (groups == 1u && !c->stats_on && (uint64_t)lines * c->p.n_samples <= c->knobs.path_max) groups = c->knobs.path_groups;      // the latency form (enqueue_frame)
+    rc = run_frame(c, frame, n_frames, e0, e1, true, groups, 0); if (rc) return rc;
     HIP_TRY(mcrt::launch_finalize(c->d_acc, c->d_flags, rf_dev, lines, c->p.n_rows, c->d_error, c->stream));
     c->acc_clean_ne = lines; c->acc_clean_rows = c->p.n_rows;
     return MCRT_OK;

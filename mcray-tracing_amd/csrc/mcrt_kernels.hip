@@ -1342,6 +1342,167 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
     }
 }
 
+// =============================================================================================================
+// k_path -- the LATENCY form of cast_rays (scene.cpp:50-183), for passes that cannot fill the GPU: ONE launch carries every path through ALL of its
+// bounces.  The reference traces one frame at a time (main.cpp:92-152); at 128 x 1024 paths that is 2048 wavefronts on 1024 SIMDs, and the staged
+// pipeline above spends it on ten dependent walk -> shade launch pairs, each as long as its slowest wavefront plus two launch gaps (round 5: 1.48 ms
+// per frame against 0.32 ms of throughput).  Here a lane OWNS a path: walk (the lane walk's own node and leaf steps), shade_path, next bounce -- no queue, no
+// compaction, no grid-wide dependency; a wavefront goes on to its next bounce as soon as ITS 64 walks are done.  Lanes whose path has died (and lanes that
+// finish a walk early) are what the throughput form would compact away; here the GPU is under-filled anyway, so they HELP: they adopt the bottom stack
+// entries of the lanes still walking (the same hand-over as at the end of a k_trace_lane launch) and report through the owner's closest-hit word, which
+// lives in LDS (the walkers of a ray are lanes of one wavefront).  Bit-exact by the contract's order-independence: the word's minimum is the single walk's
+// answer.  Round 2's fused kernel lost in THROUGHPUT mode (fp64 physics at a quarter of the lanes, 173 registers: DESIGN.md A.4); that argument does not
+// hold where registers are free.  k_march(MCRT_ALL_BOUNCES) accumulates the segments afterwards.
+// =============================================================================================================
+#ifndef MCRT_PATH_WAVES
+#define MCRT_PATH_WAVES 2            // wavefronts per SIMD k_path's registers are budgeted for (one 128 x 1024 frame = 2 per SIMD)
+#endif
+#ifndef MCRT_PATH_ADOPT_STEPS
+#define MCRT_PATH_ADOPT_STEPS 2       // node steps between two hand-overs while idle lanes wait (k_trace_lane: 4; here 1 / 2 / 4 / 8 / 16: 1.12 / 1.09-1.12 / 1.14 / 1.19 / 1.24 ms per frame)
+#endif
+#ifndef MCRT_PATH_LEAF_BATCH
+#define MCRT_PATH_LEAF_BATCH MCRT_LANE_LEAF_BATCH        // lanes parked on a leaf that end the inner-node phase (8 / 20 / 32: 1.20 / 1.14 / 1.19 ms per frame)
+#endif
+#ifndef MCRT_PATH_OWNERS
+#define MCRT_PATH_OWNERS 64          // paths per wavefront: the first MCRT_PATH_OWNERS lanes own one each, the others only ever help
+#endif
+__global__ void __launch_bounds__(256, MCRT_PATH_WAVES) k_path(FrameArgs a)
+{
+    __shared__ int stack[MCRT_LANE_STACK * 256];
+    __shared__ unsigned long long wbest[256];         // closest-hit word of the ray the lane OWNS in this bounce; helpers (lanes of the same wavefront) publish here
+    __shared__ float4 mats_l[2 * MCRT_SHADE_TABLE];
+    __shared__ uint4 meshes_l[MCRT_SHADE_TABLE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t np = a.ne * a.S, pos = (blockIdx.x * 4u + (uint32_t)(tid >> 6)) * (uint32_t)MCRT_PATH_OWNERS + (uint32_t)lane;
+    const bool tables_in_lds = a.n_mat <= (uint32_t)MCRT_SHADE_TABLE && a.n_mesh <= (uint32_t)MCRT_SHADE_TABLE;
+    if (tables_in_lds) {
+        for (uint32_t r = tid; r < 2u * a.n_mat; r += blockDim.x) mats_l[r] = a.mats[r];
+        for (uint32_t r = tid; r < a.n_mesh; r += blockDim.x) meshes_l[r] = a.meshes[r];
+        __syncthreads();
+    }
+    const ShadeTables tb = { a.mats, a.meshes, mats_l, meshes_l, tables_in_lds };
+    const LaneStackT<MCRT_LANE_STACK> S = { stack, a.stack_ovf + ((size_t)blockIdx.x * 256 + tid), (size_t)gridDim.x * 256, tid };
+    // the path of this lane, as k_init left it (queue position -> path id, state of bounce 0)
+    bool alive = lane < MCRT_PATH_OWNERS && pos < np;
+    uint32_t pid = 0; float Ls = 0.0f;
+    PathState ps; ps.from = mk(0, 0, 0); ps.dir = mk(0, 0, 1); ps.intensity = 0.0f; ps.media = 0; ps.outside = OUT_NONE; ps.dist_mm = 0.0;
+    if (alive) {
+        pid = a.queue[pos];
+        const float4 s0 = a.st0[pos], s1 = a.st1[pos], s2 = a.st2[pos];
+        ps.from = mk(s0.x, s0.y, s0.z); Ls = s0.w; ps.dir = mk(s1.x, s1.y, s1.z); ps.media = __float_as_int(s1.w);
+        ps.dist_mm = __hiloint2double(__float_as_int(s2.y), __float_as_int(s2.x)); ps.outside = __float_as_int(s2.z); ps.intensity = s2.w;
+    }
+#define MCRT_ON_INNER(c) __builtin_amdgcn_sicmp((c), -1, 38)
+#define MCRT_ON_LEAF(c) __builtin_amdgcn_uicmp((uint32_t)(c), 0x80000000u, 34)
+#define MCRT_WALKING(c) __builtin_amdgcn_sicmp((c), CUR_IDLE, 33)
+#define MCRT_WORD(bst) (((unsigned long long)__float_as_uint((bst).frac) << 32) | (unsigned long long)(uint32_t)(bst).tri)
+    MCRT_WATCHDOG_DECL()
+    bool abandoned = false;
+    for (uint32_t b = 0; b < a.B && !abandoned; b++) {
+        if (!__any(alive)) break;
+        // ---- the walk: every live lane starts its own ray at the root; the others start as helpers-in-waiting ----
+        f3 f2 = mk(0, 0, 0), to = mk(1, 1, 1), inv = mk(1, 1, 1);
+        float t_lo = 0.0f;
+        Best best; best.frac = 1.0f; best.tri = -1;
+        int sp = 0, sb = 0, cur = CUR_IDLE, owner = tid;      // owner: the lane (index in the workgroup) whose ray this lane is walking
+        bool fresh = true, shared = false, helper = false;
+        unsigned long long poll_old = 0; int poll_owner = -1; bool poll_pending = false;
+        wbest[tid] = MCRT_KEY_MISS;
+        // Bounce 0: every sample path of a scan-line starts as a copy of the same first_ray (scene.cpp:83-101), so ONE lane per scan-line of the wavefront
+        // walks it -- its first -- and the others start as its helpers (k_trace_lane walks one ray per scan-line at bounce 0 for the same reason); each lane
+        // then takes its leader's word.  (64 lanes walking the same ray in lockstep cost a tenth of the launch: 140 of 1480 k cycles per wavefront.)
+        const bool leads = b != 0u || lane == 0 || pos % a.S == 0u;
+        const unsigned long long lead_mask = __ballot(alive && leads);
+        if (alive && leads) {
+            const Ray ry = ray_of(ps.from, ps.dir, Ls, a);
+            f2 = ry.f2; to = ry.to;
+            const f3 d = to - f2;
+            inv = mk(rcp_dir(d.x), rcp_dir(d.y), rcp_dir(d.z));
+            cur = a.n_nodes != 0u ? 0 : CUR_IDLE; fresh = false;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+        for (;;) {
+            { if ((++wd_iter & 4095u) == 0u && wall_clock64() - wd_start > (unsigned long long)MCRT_WATCHDOG_SECONDS * 100000000ull) { if (lane == 0) atomicOr(a.error_flag, 2u); abandoned = true; break; } }
+            // a lane that has finished a walk -- its own ray's or an adopted subtree -- reports to the ray's word and is free to help
+            if (cur == CUR_IDLE && !fresh) {
+                if (best.tri >= 0) atomicMin(&wbest[owner], MCRT_WORD(best));
+                fresh = true; shared = false; helper = false;
+            }
+            if (MCRT_WALKING(cur) == 0ull) break;
+            // ---- idle lanes take over subtrees (see k_trace_lane: the same hand-over, from the first step on) ----
+            {
+                const bool thief = cur == CUR_IDLE && fresh;
+                const bool donor = cur != CUR_IDLE && sp > sb && sb < MCRT_LANE_STACK;
+                const unsigned long long tm = __ballot(thief), dm = __ballot(donor);
+                if (tm != 0ull && dm != 0ull) {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const uint32_t pairs = (uint32_t)min(__popcll(tm), __popcll(dm));
+                    const uint32_t trank = (uint32_t)__popcll(tm & below), drank = (uint32_t)__popcll(dm & below);
+                    const bool take = thief && trank < pairs, give = donor && drank < pairs;
+                    const int src = take ? nth_set_bit(dm, trank) : lane;
+                    const int d_sb = __shfl(sb, src, 64);
+                    const float c0 = __shfl(f2.x, src, 64), c1 = __shfl(f2.y, src, 64), c2 = __shfl(f2.z, src, 64);
+                    const float c3 = __shfl(to.x, src, 64), c4 = __shfl(to.y, src, 64), c5 = __shfl(to.z, src, 64);
+                    const float c6 = __shfl(inv.x, src, 64), c7 = __shfl(inv.y, src, 64), c8 = __shfl(inv.z, src, 64);
+                    const float c9 = __shfl(t_lo, src, 64), c10 = __shfl(best.frac, src, 64);
+                    const int c11 = __shfl(owner, src, 64);
+                    const int c12 = __shfl(best.tri, src, 64), c13 = __shfl((int)helper, src, 64);
+                    if (take) {
+                        cur = stack[d_sb * 256 + (tid & ~63) + src];        // the donor's bottom entry (same wavefront, read before the donor moves on)
+                        f2 = mk(c0, c1, c2); to = mk(c3, c4, c5); inv = mk(c6, c7, c8); t_lo = c9;
+                        best.frac = c10; best.tri = -1; owner = c11;
+                        sp = 0; sb = 0; fresh = false; shared = true;
+                        helper = c12 >= 0 || c13 != 0;
+                    }
+                    if (give) { sb++; shared = true; }
+                }
+            }
+            // ---- phase 1: inner nodes, until enough lanes are parked on a leaf (cut short while idle lanes wait for a subtree) ----
+            const float tcap = fminf(1.0f, best.frac);
+            const int thieves_wait = __builtin_amdgcn_readfirstlane(__any(cur == CUR_IDLE && fresh) ? 1 : 0);
+            int steps_left = MCRT_PATH_ADOPT_STEPS;
+            const f3 rc = ray_c(f2, inv);
+            const LaneRay lr = { rc.x, rc.y, rc.z, inv.x, inv.y, inv.z, inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f };
+            for (;;) {
+                const unsigned long long inner = MCRT_ON_INNER(cur);
+                if (inner == 0ull) break;
+                if (popc_mask(MCRT_ON_LEAF(cur)) >= (uint32_t)MCRT_PATH_LEAF_BATCH) break;
+                if (thieves_wait && --steps_left < 0) break;
+                if (cur >= 0) lane_node_step(a, S, lr, t_lo, tcap, cur, sp, sb);
+            }
+            // ---- phase 2: the parked leaves ----
+            if ((uint32_t)cur > 0x80000000u) lane_leaf_test(a, S, f2, to, inv, rc, t_lo, helper, best, cur, sp, sb);
+            // ---- walkers of one ray meet in its word: publish the find, take the smallest word back one round later ----
+            if (poll_pending) {
+                poll_pending = false;
+                const unsigned long long mine = MCRT_WORD(best);      // (no find: id 0xffffffff)
+                if (poll_owner == owner && cur != CUR_IDLE && poll_old < mine) {
+                    best.frac = __uint_as_float((uint32_t)(poll_old >> 32)); best.tri = (int)(uint32_t)poll_old; helper = false;
+                }
+            }
+            if (shared && cur != CUR_IDLE) {
+                const unsigned long long word = (best.tri >= 0) ? MCRT_WORD(best) : ~0ull;
+                poll_old = atomicMin(&wbest[owner], word); poll_owner = owner; poll_pending = true;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (abandoned) break;
+        // ---- the interface: thickness draw, travel, hit_boundary, the segment's records (k_shade's own code) ----
+        if (alive) {
+            const int leader = 63 - __clzll((long long)(lead_mask & ((2ull << lane) - 1ull)));        // (bounce 0: the nearest leading lane at or below this one; later: the lane itself)
+            const unsigned long long key = wbest[(tid & ~63) + leader];
+            const Ray ry = ray_of(ps.from, ps.dir, Ls, a);            // the segment the walk tested (same expressions, same bits)
+            bool reflected = false; unsigned long long st_seg = 0, st_hits = 0;
+            alive = shade_path<false>(a, tb, b, pid, ps, ry.f2, ry.to, key, reflected, st_seg, st_hits);
+            if (alive) Ls = ray_len(ps.intensity, tb.mat(2 * ps.media).y, a);
+        }
+    }
+#undef MCRT_ON_INNER
+#undef MCRT_ON_LEAF
+#undef MCRT_WALKING
+#undef MCRT_WORD
+}
+
 // ---- RF accumulation (main.cpp:112-140) of the segments produced in bounce b.  A workgroup owns a range of the sample
 // slots of ONE scan-line ("line" = frame * ne_frame + scan-line), so its fixed-point bins live in LDS and are flushed once
 // with global integer atomics.  Inside it every wavefront runs its slots as a task pool: a group of G lanes (template parameter: 2 or 4) per
@@ -1840,6 +2001,14 @@ hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
     const dim3 grid((np + 255u) / 256u), blk(256);
     if (stats) hipLaunchKernelGGL((k_shade<true>), grid, blk, 0, st, a, b);
     else hipLaunchKernelGGL((k_shade<false>), grid, blk, 0, st, a, b);
+    return hipGetLastError();
+}
+
+// every bounce of every path in one launch (k_path): the latency form, for passes of at most path_max paths (mcrt_api.cpp)
+hipError_t launch_path(const FrameArgs &a, hipStream_t st)
+{
+    const uint32_t np = a.ne * a.S;
+    hipLaunchKernelGGL(k_path, dim3((np + 4u * MCRT_PATH_OWNERS - 1u) / (4u * MCRT_PATH_OWNERS)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -628,8 +628,12 @@ def test_randomised_configurations(mcrt, orc, case, monkeypatch, tex256):
     textures of several sizes, TIR sanitising on and off, frequency, seed, frames in flight -- hits and RF bit for bit"""
     rng = np.random.default_rng(1000 + case)
     # every fourth case without cutting the rays of small bounces into pieces, one with two scan-line groups on two streams (the library reads its knobs at mcrt_create)
-    for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_PACKET_BOUNCES", "MCRT_PACKET_FROM"):
+    for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_PACKET_BOUNCES", "MCRT_PACKET_FROM", "MCRT_PATH_MAX"):
         monkeypatch.delenv(k, raising=False)
+    if case % 2 == 1 or case == 6:
+        # these small passes would all take the LATENCY form (k_path: one launch for every bounce); every other case keeps the staged pipeline
+        # (walk / shade / accumulate per bounce, queues, compaction), which is what the knobs below act on
+        monkeypatch.setenv("MCRT_PATH_MAX", "0")
     if case % 4 == 3:
         monkeypatch.setenv("MCRT_KSPLIT_LIMIT", "0")
     if case == 6:
@@ -784,6 +788,27 @@ def test_two_ranks_gather_equals_single_process():
     assert out["roofline"]["frac"] is not None and out["roofline"]["derived"] is True and 0.0 < out["roofline"]["frac"] < 1.0
 
 
+def test_eight_ranks_weak_and_ragged_strong():
+    """What the driver's SCALE step runs at 2, 4 and 8 GPUs, at its widest, on this box's one GPU: bench.py with EIGHT ranks in fresh child
+    processes (gloo carries the collectives: RCCL refuses eight ranks on one device), weak scaling (8 x 16 scan-lines) and strong scaling over a
+    ragged split (100 scan-lines = four ranks of 13 and four of 12).  ranks_seen == 8, the gathered whole B-mode frames equal one process's bit
+    for bit, and the N > 1 line carries the oracle's word on rank 0's own shard (`parity_check`), not only `gather_check`."""
+    small = ["--workload", "sphere", "--rays", "64", "--steps", "4", "--warmup", "2", "--frames-in-flight", "2",
+             "--no-latency-leg", "--no-pmc", "--same-gpu", "--check-gather", "--min-time", "0.05", "--backend", "gloo"]
+    r, out = _run_bench(small + ["--scanlines", "16"], nproc=8, timeout=900)
+    assert r is not None and r.returncode == 0 and out is not None, "" if r is None else _why((r.stderr or "")[-6000:])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["scaling"] == "weak" and out["config"]["scan_lines_total"] == 128
+    assert out["gather_check"]["equal"] and out["gather_check"]["ranks"] == 8 and out["gather_check"]["nonzero_bmode"] > 1000
+    assert [p["rank"] for p in out["per_rank"]] == list(range(8)) and [p["scan_lines"] for p in out["per_rank"]] == [[16 * k, 16 * k + 16] for k in range(8)]
+    assert out["parity_check"]["rf_bit_exact"] is True and out["parity_check"]["scan_lines"] == [0, 16] and out["parity_check"]["rank"] == 0
+    assert "cpu_baseline" not in out                                  # (the timed CPU leg stays an N = 1 matter)
+    r, out = _run_bench(small + ["--scanlines-total", "100"], nproc=8, timeout=900)
+    assert r is not None and r.returncode == 0 and out is not None, "" if r is None else _why((r.stderr or "")[-6000:])
+    assert out["ranks_seen"] == 8 and out["scaling"] == "strong" and out["config"]["scan_lines_total"] == 100 and out["gather_check"]["equal"]
+    assert [p["scan_lines"][1] - p["scan_lines"][0] for p in out["per_rank"]] == [13, 13, 13, 13, 12, 12, 12, 12]
+    assert out["parity_check"]["rf_bit_exact"] is True and out["parity_check"]["scan_lines"] == [0, 13]
+
+
 def test_rccl_carries_the_collectives_of_the_pass():
     """What a one-GPU box can show of the RCCL leg: a process group over the `nccl` backend (= RCCL on ROCm) with its one rank on this
     GPU runs every collective bench.py's N > 1 path issues -- the gather-to-root probe, the gather of a pass's [F][E/N][R] block on a side
@@ -881,14 +906,17 @@ def test_schedules_do_not_change_anything(mcrt, orc, tex256, monkeypatch):
     sd = mcrt.scene_io.build_scene(cfg, meshes)
     E, S, frame = 24, 160, 11
     got = {}
-    variants = (("default", {}), ("packets_every_bounce", {"MCRT_PACKET_BOUNCES": "0xfffe", "MCRT_PACKET_FROM": "0"}), ("no_packets", {"MCRT_PACKET_BOUNCES": "0"}),
+    # ("default" at this size is the LATENCY form -- k_path, every bounce in one launch; the other variants switch it off: they are schedules of the staged pipeline)
+    staged = {"MCRT_PATH_MAX": "0"}
+    variants = (("default", {}), ("staged", {}), ("packets_every_bounce", {"MCRT_PACKET_BOUNCES": "0xfffe", "MCRT_PACKET_FROM": "0"}), ("no_packets", {"MCRT_PACKET_BOUNCES": "0"}),
                 ("two_groups", {"MCRT_GROUPS": "2"}), ("three_groups_no_split", {"MCRT_GROUPS": "3", "MCRT_KSPLIT_LIMIT": "0"}),
                 ("masked", {"MCRT_MARCH_CUS": "64", "MCRT_MAIN_MASK": "1"}), ("march_masked", {"MCRT_MARCH_CUS": "96"}), ("no_overlap", {"MCRT_NO_OVERLAP": "1"}),
-                ("wide_walk", {"MCRT_WIDE_FROM": "1"}), ("wide_walk_two_groups_no_split", {"MCRT_WIDE_FROM": "1", "MCRT_GROUPS": "2", "MCRT_KSPLIT_LIMIT": "0"}))
+                ("wide_walk", {"MCRT_WIDE_FROM": "1"}), ("wide_walk_two_groups_no_split", {"MCRT_WIDE_FROM": "1", "MCRT_GROUPS": "2", "MCRT_KSPLIT_LIMIT": "0"}),
+                ("latency_form_masked", {"MCRT_MARCH_CUS": "64", "MCRT_MAIN_MASK": "1", "MCRT_PATH_MAX": "1000000"}))
     for name, env in variants:
-        for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP", "MCRT_WIDE_FROM", "MCRT_PACKET_BOUNCES", "MCRT_PACKET_FROM"):
+        for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP", "MCRT_WIDE_FROM", "MCRT_PACKET_BOUNCES", "MCRT_PACKET_FROM", "MCRT_PATH_MAX"):
             monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
+        for k, v in (env if name == "default" else dict(staged, **env)).items():
             monkeypatch.setenv(k, v)                               # (the library reads its knobs once, at mcrt_create)
         tr, sim = _sim(mcrt, cfg, sd, E, S, texture=tex256)
         hits, segs, cnt = sim.ctx.trace_frame_debug(frame, sim.rf_dev, want_segs=True)
@@ -904,7 +932,7 @@ def test_schedules_do_not_change_anything(mcrt, orc, tex256, monkeypatch):
         nodes4 = sim.ctx.get_bvh4()[0]
         sim.close()
         got[name] = (hits, segs.tobytes(), cnt, rf, st, batch[1].T.copy(), nodes4)
-    for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP", "MCRT_WIDE_FROM", "MCRT_PACKET_BOUNCES", "MCRT_PACKET_FROM"):
+    for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP", "MCRT_WIDE_FROM", "MCRT_PACKET_BOUNCES", "MCRT_PACKET_FROM", "MCRT_PATH_MAX"):
         monkeypatch.delenv(k, raising=False)
     a = got["default"]
     for name in [v[0] for v in variants[1:]]:
@@ -945,8 +973,11 @@ def test_deep_tree_overflow_stacks_of_two_groups(mcrt, orc, tex256, monkeypatch)
     sd.tri = np.ascontiguousarray(tri); sd.tri_mesh = (np.arange(n) % len(sd.meshes)).astype(np.uint32)
     E, S = 16, 96
     out = {}
-    for groups in ("1", "2", "2w", "1p"):
+    for groups in ("1", "2", "2w", "1p", "1f"):
         monkeypatch.setenv("MCRT_GROUPS", groups[0])
+        monkeypatch.setenv("MCRT_PATH_MAX", "1000000" if groups == "1f" else "0")      # "1f": the latency form (k_path), whose lanes stack into the same overflow array
+        if groups == "1f":
+            monkeypatch.delenv("MCRT_PACKET_BOUNCES", raising=False); monkeypatch.delenv("MCRT_PACKET_FROM", raising=False)
         if groups == "2w":
             monkeypatch.setenv("MCRT_WIDE_FROM", "1")
         if groups == "1p":          # every bounce a wavefront per ray packet: the packet's ONE 64-entry stack register against a 51-entry worst case
@@ -962,8 +993,9 @@ def test_deep_tree_overflow_stacks_of_two_groups(mcrt, orc, tex256, monkeypatch)
             hits, _, _ = sim.ctx.trace_frame_debug(5, sim.rf_dev)
             nodes4 = sim.ctx.get_bvh4()[0]; _, btri, _ = sim.ctx.get_bvh()
         sim.close()
-    for k in ("MCRT_GROUPS", "MCRT_WIDE_FROM", "MCRT_PACKET_BOUNCES", "MCRT_PACKET_FROM"):
+    for k in ("MCRT_GROUPS", "MCRT_WIDE_FROM", "MCRT_PACKET_BOUNCES", "MCRT_PACKET_FROM", "MCRT_PATH_MAX"):
         monkeypatch.delenv(k, raising=False)
+    assert np.array_equal(out["1"].view(np.uint32), out["1f"].view(np.uint32))
     assert np.array_equal(out["1"].view(np.uint32), out["2"].view(np.uint32))
     assert np.array_equal(out["1"].view(np.uint32), out["2w"].view(np.uint32))
     assert np.array_equal(out["1"].view(np.uint32), out["1p"].view(np.uint32))
