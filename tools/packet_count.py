@@ -20,6 +20,7 @@ order = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 pure = len(sys.argv) > 4 and sys.argv[4] == "pure"       # packets cut from PURE bundles (the queue sorted by reflect / refract history: what a sorting compaction would give)
 wgkey = len(sys.argv) > 4 and sys.argv[4] == "wgkey"     # 256-ray blocks grouped by (triangle hit last, decision): largest group first (what a workgroup-local grouping in k_shade would give)
 stray = len(sys.argv) > 4 and sys.argv[4] == "stray"     # 256-ray blocks ordered: rays that hit their wavefront's dominant triangle (reflected, then refracted), then the strays
+segdec = len(sys.argv) > 4 and sys.argv[4] == "segdec"   # round 6: the WHOLE (scan-line, frame) segment partitioned by its rays' reflect / refract decisions so far (no triangle ids): what a segmented partition after k_shade would give
 blk3 = len(sys.argv) > 4 and sys.argv[4] == "blk3"       # k_shade's 256-ray blocks sorted by the class of the last three reflect / refract decisions (a counting sort inside the workgroup)
 dec = None
 E, W = 128, 64
@@ -52,7 +53,9 @@ for b in range(1, p.max_depth):
     key = (key * np.uint64(0x9E3779B97F4A7C15) + (hits[:, :, b - 1].astype(np.int64).astype(np.uint64) * np.uint64(2) + side + np.uint64(1))) & np.uint64(0xFFFFFFFFFFFFFFFF)
     d_now = np.zeros((E, S), np.uint64); d_now[e_idx, s_idx] = refl.astype(np.uint64)
     dec = d_now if dec is None else (((dec << np.uint64(1)) | d_now) & np.uint64(7))
+    dec_all = d_now if b == 1 else ((dec_all << np.uint64(1)) | d_now)
     if pure: order_idx = np.lexsort((s_idx, key[e_idx, s_idx], e_idx))
+    elif segdec: order_idx = np.lexsort((s_idx, dec_all[e_idx, s_idx], e_idx))
     elif wgkey:
         pos = e_idx * S + s_idx; b256 = pos // 256
         k2 = prev.astype(np.int64) * 2 + refl.astype(np.int64)
@@ -89,7 +92,7 @@ for b in range(1, p.max_depth):
          "other_packets_solo_nodes_per_ray": float(out[~is_pure, 3].sum() / max(out[~is_pure, 5].sum(), 1)) if (~is_pure).any() else None}
     rows.append(r); sys.stderr.write(json.dumps(r) + "\n")
 tot_pack = sum(r["packet_nodes_mean"] * r["packets"] for r in rows); tot_solo = sum(r["solo_nodes_per_ray"] * r["rays"] for r in rows)
-print(json.dumps({"queue": "sorted into pure bundles (scan-line, history)" if pure else "256-ray blocks sorted by the last three decisions" if blk3 else "as k_shade's compaction leaves it (reflected first inside a 256-ray block)", "workload": workload, "scan_lines": E, "rays": S, "packet": W, "order": "first hitting ray" if order else "smallest t_near of the packet", "seconds": round(time.time() - t0, 1),
+print(json.dumps({"queue": "sorted into pure bundles (scan-line, history)" if pure else "every scan-line's rays partitioned by their reflect / refract decisions so far (no triangle ids)" if segdec else "256-ray blocks sorted by the last three decisions" if blk3 else "as k_shade's compaction leaves it (reflected first inside a 256-ray block)", "workload": workload, "scan_lines": E, "rays": S, "packet": W, "order": "first hitting ray" if order else "smallest t_near of the packet", "seconds": round(time.time() - t0, 1),
                   "per_bounce": rows,
                   "bounces_ge1": {"packet_node_visits_per_ray": tot_pack / sum(r["rays"] for r in rows), "solo_node_visits_per_ray": tot_solo / sum(r["rays"] for r in rows),
                                   "wave_level_node_steps_packet_over_lane_walk_at_full_lanes": tot_pack * 64 / tot_solo}}, indent=1))
