@@ -49,7 +49,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMD = 1024           # 256 CUs x 4 SIMD-32
-PMC_ROUND = "round5" if os.path.exists(os.path.join(ROOT, "profiles", "round5", "pmc_bench.json")) else "round4"      # the committed single-GPU passes N > 1 runs fall back to
+PMC_ROUND = next((r for r in ("round6", "round5", "round4") if os.path.exists(os.path.join(ROOT, "profiles", r, "pmc_bench.json"))), "round4")      # the newest committed single-GPU passes: what N > 1 runs fall back to
 MIN_SPLIT_PASS = 48     # N > 1: a timed region is cut into two passes (gather + post of the first hidden behind the second) only if each has this many frames
 TRACE_KERNELS = ("k_trace_lane<false", "k_trace_lane_wide", "k_trace_packet")   # the walk of the timed build, pooled: the lane walk's four- and five-wavefront forms (large launches take the second) and bounce 1's ray packets
 KERNEL_FAMILIES = {"walk": TRACE_KERNELS, "march": ("k_march<false",), "shade": ("k_shade<false",)}
