@@ -744,7 +744,7 @@ static int ensure_work(mcrt_ctx *c, Work &w, uint32_t ne_frame, uint32_t n_frame
     {   // traversal-stack entries beyond the LDS part, one slot per thread of THIS work set's walk launches
         const uint32_t lds_part = mcrt::lane_stack_entries();
         uint32_t blocks = std::max(std::max(c->knobs.trace_blocks, c->knobs.trace_blocks_wide), c->n_cu * 5u);      // (the larger of the walk's two forms)
-        blocks = std::max(blocks, (uint32_t)((std::min<size_t>(np, c->knobs.path_max) + 255u) / 256u));                // (... and k_path's one workgroup per 256 paths)
+        if (np <= c->knobs.path_max) blocks = std::max(blocks, mcrt::path_blocks(np));                                   // (... and k_path's grid, when this pass takes the latency form)
         const size_t need = c->bvh4.max_stack > lds_part ? (size_t)(c->bvh4.max_stack - lds_part) * blocks * 256 : 0;
         if (need > w.ovf_cap) {
             HIP_TRY(hipDeviceSynchronize());

@@ -18,7 +18,7 @@
 #define MCRT_PACKET_MASK_DEFAULT 2u   // bounces (bit b) walked a wavefront per ray packet (k_trace_packet): bounce 1 -- every pass size from two frames up and every BASELINE
                                       // configuration gains 0.3-6 % (profiles/round5/exp_packet.txt); bounce 2 is a wash, later bounces lose (packet_count_*.json)
 #define MCRT_PACKET_FROM 262144u      // ... in passes of at least this many paths (one 128 x 1024 frame at a time keeps the lane walk: its launches are cut into pieces, 1.624 vs 1.634 ms)
-#define MCRT_PATH_MAX_DEFAULT 262144u  // passes of at most this many paths take the latency form (k_path: one launch for all bounces): two 128 x 1024 frames (1.14 vs 1.62 ms per frame at one, 0.96 vs 1.13 at two)
+#define MCRT_PATH_MAX_DEFAULT 524288u  // passes of at most this many paths take the latency form (k_path: one launch for all bounces): four 128 x 1024 frames (ms per frame at 1 / 2 / 3 / 4 frames: 0.95 / 0.82 / 0.77 / 0.73 against the staged 1.62 / 1.12 / 0.91 / 0.79)
 #define MCRT_PATH_GROUPS_DEFAULT 2u     // ... traced as this many scan-line groups on their own streams (a group's k_march runs beside the other groups' slowest wavefronts)
 #define MCRT_MAX_ROWS 2048
 #define MCRT_MAX_BOUNCES 16

@@ -54,6 +54,7 @@ hipError_t launch_nodes_walk_decode(const uint4 *walk, uint32_t n_nodes, float4 
 uint32_t lane_stack_entries();
 uint32_t lane_wide_from();
 hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
+uint32_t path_blocks(size_t np);                                  // workgroups of a k_path launch over np paths (sizes the overflow stacks)
 hipError_t launch_path(const FrameArgs &a, hipStream_t st);      // k_path: every bounce of every path in one launch (the latency form)
 hipError_t launch_march(const FrameArgs &a, uint32_t b, bool stats, hipStream_t st);
 hipError_t launch_finalize(long long *acc, uint32_t *flags, float *rf, uint32_t ne, uint32_t R, const uint32_t *error_flag, hipStream_t st);

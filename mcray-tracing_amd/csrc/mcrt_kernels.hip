@@ -1355,16 +1355,17 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
 // hold where registers are free.  k_march(MCRT_ALL_BOUNCES) accumulates the segments afterwards.
 // =============================================================================================================
 #ifndef MCRT_PATH_WAVES
-#define MCRT_PATH_WAVES 2            // wavefronts per SIMD k_path's registers are budgeted for (one 128 x 1024 frame = 2 per SIMD)
+#define MCRT_PATH_WAVES 4            // wavefronts per SIMD k_path's registers are budgeted for (109 registers without machine LICM, see the Makefile)
 #endif
 #ifndef MCRT_PATH_ADOPT_STEPS
-#define MCRT_PATH_ADOPT_STEPS 2       // node steps between two hand-overs while idle lanes wait (k_trace_lane: 4; here 1 / 2 / 4 / 8 / 16: 1.12 / 1.09-1.12 / 1.14 / 1.19 / 1.24 ms per frame)
+#define MCRT_PATH_ADOPT_STEPS 1       // node steps between two hand-overs while idle lanes wait (k_trace_lane: 4; here, at 32 owners per wavefront, 1 / 2 / 3: 0.946 / 0.953 / 0.980 ms per frame)
 #endif
 #ifndef MCRT_PATH_LEAF_BATCH
 #define MCRT_PATH_LEAF_BATCH MCRT_LANE_LEAF_BATCH        // lanes parked on a leaf that end the inner-node phase (8 / 20 / 32: 1.20 / 1.14 / 1.19 ms per frame)
 #endif
 #ifndef MCRT_PATH_OWNERS
-#define MCRT_PATH_OWNERS 64          // paths per wavefront: the first MCRT_PATH_OWNERS lanes own one each, the others only ever help
+#define MCRT_PATH_OWNERS 32          // paths per wavefront: the first MCRT_PATH_OWNERS lanes own one each, the others only ever help -- one 128 x 1024 frame is then 4096
+                                     // wavefronts = four per SIMD, each walk shared by twice the lanes (64 owners at two per SIMD: 0.88 ms per launch; 32 at four: 0.70)
 #endif
 __global__ void __launch_bounds__(256, MCRT_PATH_WAVES) k_path(FrameArgs a)
 {
@@ -2005,10 +2006,10 @@ hipError_t launch_shade(const FrameArgs &a, uint32_t b, bool stats, hipStream_t 
 }
 
 // every bounce of every path in one launch (k_path): the latency form, for passes of at most path_max paths (mcrt_api.cpp)
+uint32_t path_blocks(size_t np) { return (uint32_t)((np + 4u * MCRT_PATH_OWNERS - 1u) / (4u * MCRT_PATH_OWNERS)); }      // workgroups of a k_path launch over np paths
 hipError_t launch_path(const FrameArgs &a, hipStream_t st)
 {
-    const uint32_t np = a.ne * a.S;
-    hipLaunchKernelGGL(k_path, dim3((np + 4u * MCRT_PATH_OWNERS - 1u) / (4u * MCRT_PATH_OWNERS)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_path, dim3(path_blocks((size_t)a.ne * a.S)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
