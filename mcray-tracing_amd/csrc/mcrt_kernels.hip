@@ -921,20 +921,27 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
 // in the refill, hand-over and reporting code outside the node and leaf loops.  Sensitivity builds (profiles/round4/exp_sensitivity.txt) had shown the
 // walk at the knee of its two pipes with four wavefronts to hide latency behind; the fifth is worth 3-4 % of a 128-frame pass (0.330 against
 // 0.342 ms per frame; 1.8 % at 96 frames, 1.4 % at 48, 0.5 % at 32), costs a 20-frame pass 1 % and one frame at a time 6 % -- so launch_trace
-// takes the wide form from MCRT_LANE_WIDE_FROM queued rays (32 frames of the headline workload) upwards, for trees the caches hold (mcrt_api.cpp: fill_args).  (Its stack is sized at the launch: with a static LDS array the compiler caps the kernel's occupancy
+// took the wide form from 4 Mi queued rays (32 frames of the headline workload) upwards through round 5.  Round 6 (kernels built without machine LICM: the
+// wide form spills 20 bytes per lane instead of 48, and the small passes that the narrow form was kept for run as k_path): the wide form wins at EVERY staged
+// pass size -- 5 / 6 / 8 / 12 / 20 frames: 0.678 / 0.614 / 0.512 / 0.426 / 0.359 against 0.699 / 0.628 / 0.530 / 0.446 / 0.381 ms per frame -- so it is the
+// default from the first ray (MCRT_LANE_WIDE_FROM), for trees the caches hold (mcrt_api.cpp: fill_args); the narrow form stays for larger trees, CU-masked
+// streams and the counting build.  (Its stack is sized at the launch: with a static LDS array the compiler caps the kernel's occupancy
 // by LDS and hands the registers back.)
 #ifndef MCRT_LANE_WIDE_STACK
 #define MCRT_LANE_WIDE_STACK 24          // (28: 0.332 against 0.3295 ms per frame; deeper walks go on in the overflow array, as in the other form)
 #endif
 #ifndef MCRT_LANE_WIDE_FROM
-#define MCRT_LANE_WIDE_FROM 4194304u
+#define MCRT_LANE_WIDE_FROM 1u
 #endif
 template <bool STATS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(MCRT_LANE_VGPRS))) k_trace_lane(FrameArgs a, uint32_t b)
 {
     trace_lane_body<STATS, MCRT_LANE_STACK, false>(a, b);
 }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6), amdgpu_num_vgpr(80))) k_trace_lane_wide(FrameArgs a, uint32_t b)
+#ifndef MCRT_LANE_WIDE_WAVES
+#define MCRT_LANE_WIDE_WAVES 6           // wavefronts per SIMD k_trace_lane_wide's registers are budgeted for: five of its own + one of k_march (512 / 6 -> 80 registers)
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCRT_LANE_WIDE_WAVES, MCRT_LANE_WIDE_WAVES))) k_trace_lane_wide(FrameArgs a, uint32_t b)
 {
     trace_lane_body<false, MCRT_LANE_WIDE_STACK, true>(a, b);
 }

@@ -912,6 +912,7 @@ def test_schedules_do_not_change_anything(mcrt, orc, tex256, monkeypatch):
                 ("two_groups", {"MCRT_GROUPS": "2"}), ("three_groups_no_split", {"MCRT_GROUPS": "3", "MCRT_KSPLIT_LIMIT": "0"}),
                 ("masked", {"MCRT_MARCH_CUS": "64", "MCRT_MAIN_MASK": "1"}), ("march_masked", {"MCRT_MARCH_CUS": "96"}), ("no_overlap", {"MCRT_NO_OVERLAP": "1"}),
                 ("wide_walk", {"MCRT_WIDE_FROM": "1"}), ("wide_walk_two_groups_no_split", {"MCRT_WIDE_FROM": "1", "MCRT_GROUPS": "2", "MCRT_KSPLIT_LIMIT": "0"}),
+                ("narrow_walk", {"MCRT_WIDE_FROM": "4294967295"}), ("narrow_walk_two_groups", {"MCRT_WIDE_FROM": "4294967295", "MCRT_GROUPS": "2"}),      # (round 6: the five-wavefront form is the default from the first ray)
                 ("latency_form_masked", {"MCRT_MARCH_CUS": "64", "MCRT_MAIN_MASK": "1", "MCRT_PATH_MAX": "1000000"}))
     for name, env in variants:
         for k in ("MCRT_KSPLIT_LIMIT", "MCRT_GROUPS", "MCRT_MARCH_CUS", "MCRT_MAIN_MASK", "MCRT_NO_OVERLAP", "MCRT_WIDE_FROM", "MCRT_PACKET_BOUNCES", "MCRT_PACKET_FROM", "MCRT_PATH_MAX"):
