@@ -124,12 +124,11 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 | `baseline_configs.txt` | the five BASELINE.json configurations on one GPU (tools/configs.sh) |
 | `bench_random16m.json` | `python bench.py --workload random16m`: the STREAMING regime (16 M triangles, 2 GB of BVH past the Infinity Cache) |
 | `group_bench.json` | `tools/group_bench.py 0,0`: whole B-mode frames through `mcrt_group_*` (two ranks sharing the GPU) against one context |
-| `seed_count_random1m.json`, `seed_count_liver.json` | `tools/seed_count.py` (CPU): node visits with no seed / the query's own answer / the bundle leader's answer as the initial closest-hit bound (-11 %%, not built) |
-| `packet_count_random1m.json`, `packet_count_random1m_pure.json` | `tools/packet_count.py` (CPU): nodes a 64-ray packet visits against its rays' solo walks, per bounce, for the queue as it is and sorted into pure bundles |
-| `exp_packet.txt` | `k_trace_packet` (one wavefront per ray packet): every version measured, PMC of the kept one, which pass sizes and BASELINE configurations take it |
-| `exp_tail.txt`, `stamps_pass20_tail_histograms.txt`, `stamps_pass20_ilv4.txt` | the tail of the driver's 20-frame pass: per-wavefront histograms (`mcrt_debug_tail_histograms`), its cause, four ways out built and measured |
-| `exp_line_order.txt` | heavy scan-lines first: counted (`tools/tail_predict.py`), modelled (`tools/tail_sim.py`), measured with the archived hook — no gain |
-| `exp_walk_share.txt`, `frame_timeline_no_overlap.txt`, `frame_timeline_pass20.txt` | the wide walk at 3 / 4 / 5 / 6 wavefronts per SIMD against the pass; every launch of a 128-frame pass one after the other: the pass is bound by the sum of its kernels' work; the driver's 20-frame pass launch by launch (`k_march`'s stream is busy for 7.0 of its 7.6 ms) |
+| `bench_driver_cmd_k_path.json`, `bench_driver_cmd_wide.json` | the driver's command at two milestones of the round: with `k_path` (one frame at a time 1.48 -> 1.11 ms), and with the kernels built without machine LICM + the five-wavefront walk from the first ray (0.386 -> 0.3595 ms per frame, one frame at a time 0.915 ms) |
+| `march_layout_count_random1m.json`, `exp_march_layout.txt` | `tools/march_layout_count.py` (CPU): 128-byte lines and 4-KiB regions `k_march`'s gathers touch for six device layouts of the 256^3 texture; the layouts built and measured (all slower: recorded loss) |
+| `packet_count_random1m_segdec.json`, `exp_packet_sorted.txt` | `tools/packet_count.py ... segdec` (CPU): packets over scan-lines partitioned by their rays' decisions; why sorted queues for bounces 2-3 were not built |
+| `exp_path.txt`, `pmc_k_path.txt`, `frame_timeline_one_frame.txt` | the latency form `k_path`: every step measured, its counters (`tools/pmc_path.sh`), the launches of one frame |
+| `frame_timeline_pass20.txt` | the driver's 20-frame pass launch by launch |
 
 ## What the kernels do (per launch = one bounce of a @FIF@-frame pass)
 
@@ -165,7 +164,7 @@ bytes, %.1f GB per launch, flow at %.1f TB/s from the caches).
     "the walk %.3f / %.3f ms per launch" % ((dk.get("k_trace_lane") or {}).get("ms_per_launch_overlapped") or 0, (dk.get("k_trace_lane") or {}).get("ms_per_launch_alone") or 0))
 txt = txt.replace("@FIF@", str(FIF)).replace("@RND@", rnd)
 open(os.path.join(dst, "README.md"), "w").write(txt)
-for extra in ("bench_random16m.json", "group_bench.json"):
+for extra in ("bench_random16m.json", "group_bench.json", "frame_timeline_pass20.txt", "pmc_k_path.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(dst, extra))
 print(txt)
