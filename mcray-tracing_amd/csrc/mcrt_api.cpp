@@ -918,18 +918,19 @@ static int enqueue_frame(mcrt_ctx *c, const std::vector<mcrt::FrameArgs> &args, 
     uint64_t paths = 0;
     for (uint32_t g = 0; g < groups; g++) paths += (uint64_t)args[g].ne * args[g].S;
     const bool fused = !c->stats_on && paths <= c->knobs.path_max;
-    for (uint32_t g = 0; g < groups && fused; g++) {
+    for (uint32_t g = 0; g < groups && fused; g++) {          // (every group's k_path first, then the accumulations: the second group must not wait for the host to enqueue the first's k_march)
         hipEvent_t e0 = nullptr, e1 = nullptr;
         { int rc = timing_events(c, 0, &e0, &e1); if (rc) return rc; }
         if (e0) HIP_TRY(hipEventRecord(e0, gst[g]));
         HIP_TRY(mcrt::launch_path(args[g], gst[g]));
         if (e1) HIP_TRY(hipEventRecord(e1, gst[g]));
-        if (accumulate) {
-            { int rc = timing_events(c, 2, &e0, &e1); if (rc) return rc; }
-            if (e0) HIP_TRY(hipEventRecord(e0, gst[g]));
-            HIP_TRY(mcrt::launch_march(args[g], mcrt::MCRT_ALL_BOUNCES, false, gst[g]));
-            if (e1) HIP_TRY(hipEventRecord(e1, gst[g]));
-        }
+    }
+    for (uint32_t g = 0; g < groups && fused && accumulate; g++) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        { int rc = timing_events(c, 2, &e0, &e1); if (rc) return rc; }
+        if (e0) HIP_TRY(hipEventRecord(e0, gst[g]));
+        HIP_TRY(mcrt::launch_march(args[g], mcrt::MCRT_ALL_BOUNCES, false, gst[g]));
+        if (e1) HIP_TRY(hipEventRecord(e1, gst[g]));
     }
     for (uint32_t b = 0; b < c->p.max_depth && !fused; b++)
         for (uint32_t g = 0; g < groups; g++) {
