@@ -51,7 +51,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMD = 1024           # 256 CUs x 4 SIMD-32
 PMC_ROUND = next((r for r in ("round6", "round5", "round4") if os.path.exists(os.path.join(ROOT, "profiles", r, "pmc_bench.json"))), "round4")      # the newest committed single-GPU passes: what N > 1 runs fall back to
 MIN_SPLIT_PASS = 48     # N > 1: a timed region is cut into two passes (gather + post of the first hidden behind the second) only if each has this many frames
-TRACE_KERNELS = ("k_trace_lane<false", "k_trace_lane_wide", "k_trace_packet")   # the walk of the timed build, pooled: the lane walk's four- and five-wavefront forms (large launches take the second) and bounce 1's ray packets
+TRACE_KERNELS = ("k_trace_lane<false", "k_trace_lane_wide", "k_trace_packet")   # the walk of the timed build, pooled: the lane walk's five-wavefront form (k_trace_lane_wide: the default since round 6) and its four-wavefront form (large trees, CU-masked streams) and bounce 1's ray packets
 KERNEL_FAMILIES = {"walk": TRACE_KERNELS, "march": ("k_march<false",), "shade": ("k_shade<false",)}
 ARCH_IPC = 0.5          # MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles on the SIMD-32 -> 0.5 instructions per cycle and SIMD
 
@@ -365,7 +365,7 @@ def main():
         if pmc is None:
             pmc = committed_pmc(args, pass_sizes, per_frame["queries"] / launches_per_frame)
         roof = roofline_from(pmc, k_ms, alg_gbs, alg_bytes)
-        roof.update({"kernel": "the walk, one launch per bounce, pooled: k_trace_lane<false> / k_trace_lane_wide (a lane per ray; launches of >= 4 Mi rays take the five-wavefront form) and k_trace_packet (bounce 1 of passes of >= 262144 paths: a wavefront per ray packet)", "kernel_ms": k_ms, "launches": k_n,
+        roof.update({"kernel": "the walk, one launch per bounce, pooled: k_trace_lane_wide (a lane per ray, five wavefronts per SIMD: every launch since round 6; k_trace_lane<false>, the four-wavefront form, for trees past half the Infinity Cache) and k_trace_packet (bounce 1 of passes of >= 262144 paths: a wavefront per ray packet)", "kernel_ms": k_ms, "launches": k_n,
                      "launches_per_frame": launches_per_frame, "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps_cache_served": alg_gbs, "node_bytes": node_bytes,
                      "trace_bytes_per_frame": trace_bytes_frame, "other_stage_bytes_per_frame": other_bytes_frame, "per_frame": per_frame})
         if world == 1 and not args.no_latency_leg:
@@ -537,7 +537,7 @@ def roofline_from(pmc, k_ms, alg_gbs, alg_bytes):
         # the OTHER roof of the walk: the CU's vector memory pipe.  Cost model (round 4, fetch_roof_same under --pmc): every access the
         # counter counts costs at least `cost` cycles of its CU's pipe, whatever the sharing pattern; the launch cannot be shorter than its accesses
         # x cost / (256 CUs x clock).  The accesses are counted on the walk's FOUR-wavefront form (what the walk needs); where the timed launches ran
-        # in the five-wavefront form (>= 4 Mi rays: its refill code spills, coalesced scratch accesses the counter counts per lane) the as-run count
+        # in the five-wavefront form (every launch since round 6: its refill code spills, coalesced scratch accesses the counter counts per lane) the as-run count
         # is reported beside it and the pair (needed accesses, as-run duration) is labelled as mixed.
         cost, src = tcp_access_cost()
         need, as_run = pmc["tcp_lane_accesses_per_launch"], pmc.get("tcp_lane_accesses_per_launch_as_run")
@@ -645,7 +645,7 @@ def live_pmc(args):
         for name, ctrs in (("sq", ["SQ_INSTS_VALU", "SQ_BUSY_CU_CYCLES", "SQ_WAVES", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"]),
                            ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("tcp", ["TCP_TOTAL_CACHE_ACCESSES_sum"]), ("tcp_all", ["TCP_TOTAL_CACHE_ACCESSES_sum"])):
             d = os.path.join(tmp, name)
-            # (the walk's ACCESSES are counted on its four-wavefront form: the five-wavefront form, which large launches take, adds the spill
+            # (the walk's ACCESSES are counted on its four-wavefront form: the five-wavefront form, which the timed launches take, adds the spill
             #  traffic of its refill code -- coalesced 4-byte scratch accesses that the counter counts per lane but the pipe serves a wavefront
             #  at a time, so the floor price per counted access does not apply to them; "tcp_all" counts that form as it runs)
             env_pass = dict(env, MCRT_TUNING="1", MCRT_WIDE_FROM="4294967295") if name == "tcp" else env
