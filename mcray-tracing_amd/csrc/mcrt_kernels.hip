@@ -279,6 +279,22 @@ MCRT_DEV uint32_t vox_cell_lean256(f3 p, const FrameArgs &a)
     const uint32_t yz = __builtin_amdgcn_perm(vox_q(p.y, a), vox_q(p.z, a), 0x0c0c0400u);      // { z.b0, y.b0, 0, 0 }
     return __builtin_amdgcn_perm(vox_q(p.x, a), yz, 0x0c040100u);                                // { z.b0, y.b0, x.b0, 0 }
 }
+// The same with the reciprocal and the resolution held in VECTOR registers.  gfx950 issues v_mul_f32 / v_fma_f32 / v_add_f32 in 2 cycles per wavefront when every register
+// operand is a vector register, and in 4 as soon as one is a SCALAR register (profiles/round6/valu_classes.json: the same for v_add_u32, v_and_b32 ...; min / max / compare /
+// convert / shift / packed / f64 / fma_mix instructions take 4 either way).  The three instructions of a quotient read the wave-uniform constants: as scalar operands -- what the
+// compiler picks by itself -- the 36 of an iteration of k_march cost twice what they need to.  (vgpr(): an empty asm the compiler cannot see through.)
+MCRT_DEV float vgpr(float s) { float v = s; asm volatile("" : "+v"(v)); return v; }
+MCRT_DEV uint32_t vox_q_v(float x, float rcp_v, float res_v)
+{
+    const float q0 = x * rcp_v;
+    const float r = fmaf(-q0, res_v, x);
+    return (uint32_t)(int)fmaf(r, rcp_v, q0);
+}
+MCRT_DEV uint32_t vox_cell_lean256_v(f3 p, float rcp_v, float res_v)
+{
+    const uint32_t yz = __builtin_amdgcn_perm(vox_q_v(p.y, rcp_v, res_v), vox_q_v(p.z, rcp_v, res_v), 0x0c0c0400u);
+    return __builtin_amdgcn_perm(vox_q_v(p.x, rcp_v, res_v), yz, 0x0c040100u);
+}
 MCRT_DEV float abs_sum(f3 p) { return (fabsf(p.x) + fabsf(p.y)) + fabsf(p.z); }   // >= every |coordinate|; NaN/inf propagate
 
 // one echo into the scan-line's fixed-point LDS bins (2^-40 units; integer adds commute, so the image does not depend
@@ -1598,6 +1614,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
     // the other (seg_b = the one in progress, seg_n = how many the path has) before it takes the next slot
     const bool all_b = b == MCRT_ALL_BOUNCES;
     uint32_t seg_b = all_b ? 0u : b, seg_n = 0; size_t seg_pid = 0;
+    const float rcp_v = vgpr(a.tex_rcp), res_v = vgpr(a.tex_res);      // (vector-register copies: see vox_cell_lean256_v)
 #define MCRT_LOAD_SEGMENT() { \
         const float4 *mr = a.mrec + 3 * ((size_t)seg_b * a.ne * a.S + seg_pid); \
         const float4 g0 = mr[0], g1 = mr[1], g2 = mr[2]; \
@@ -1703,7 +1720,7 @@ __global__ void __launch_bounds__(256, MCRT_MARCH_WAVES) k_march(FrameArgs a, ui
             float2 vox[H];
             if (reach < a.lean_bound) {
 #pragma unroll
-                for (int h = 0; h < H; h++) vox[h] = a.tex[FAST ? vox_cell_lean256(myp[h], a) : vox_cell_lean(myp[h], a)];
+                for (int h = 0; h < H; h++) vox[h] = a.tex[FAST ? vox_cell_lean256_v(myp[h], rcp_v, res_v) : vox_cell_lean(myp[h], a)];
             } else {
 #pragma unroll
                 for (int h = 0; h < H; h++) vox[h] = myv[h] ? a.tex[vox_cell(myp[h], a)] : make_float2(0.0f, 0.0f);
