@@ -851,7 +851,7 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
                 const uint32_t pairs = (uint32_t)min(__popcll(tm), __popcll(dm));
                 const uint32_t trank = (uint32_t)__popcll(tm & below), drank = (uint32_t)__popcll(dm & below);
                 const bool take = thief && trank < pairs, give = donor && drank < pairs;
-                const int src = take ? nth_set_bit(dm, trank) : lane;
+                const int src = take ? nth_set_bit(dm, trank) : lane;       // (k_path posts the donors' lanes in LDS instead: worth 4 % there, nothing here -- the hand-over only runs in a launch's tail)
                 const int d_sb = __shfl(sb, src, 64);
                 const float c0 = __shfl(f2.x, src, 64), c1 = __shfl(f2.y, src, 64), c2 = __shfl(f2.z, src, 64);
                 const float c3 = __shfl(to.x, src, 64), c4 = __shfl(to.y, src, 64), c5 = __shfl(to.z, src, 64);
@@ -1394,6 +1394,7 @@ __global__ void __launch_bounds__(256, MCRT_PATH_WAVES) k_path(FrameArgs a)
 {
     __shared__ int stack[MCRT_LANE_STACK * 256];
     __shared__ unsigned long long wbest[256];         // closest-hit word of the ray the lane OWNS in this bounce; helpers (lanes of the same wavefront) publish here
+    __shared__ unsigned char donor_of[256];           // hand-over: the k-th donor of a wavefront posts its lane here, the k-th idle lane reads it (instead of a 6-round search of the donors' ballot)
     __shared__ float4 mats_l[2 * MCRT_SHADE_TABLE];
     __shared__ uint4 meshes_l[MCRT_SHADE_TABLE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1463,17 +1464,19 @@ __global__ void __launch_bounds__(256, MCRT_PATH_WAVES) k_path(FrameArgs a)
                     const uint32_t pairs = (uint32_t)min(__popcll(tm), __popcll(dm));
                     const uint32_t trank = (uint32_t)__popcll(tm & below), drank = (uint32_t)__popcll(dm & below);
                     const bool take = thief && trank < pairs, give = donor && drank < pairs;
-                    const int src = take ? nth_set_bit(dm, trank) : lane;
+                    if (give) donor_of[(tid & ~63) + (int)drank] = (unsigned char)lane;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    const int src = take ? (int)donor_of[(tid & ~63) + (int)trank] : lane;
                     const int d_sb = __shfl(sb, src, 64);
                     const float c0 = __shfl(f2.x, src, 64), c1 = __shfl(f2.y, src, 64), c2 = __shfl(f2.z, src, 64);
                     const float c3 = __shfl(to.x, src, 64), c4 = __shfl(to.y, src, 64), c5 = __shfl(to.z, src, 64);
                     const float c6 = __shfl(inv.x, src, 64), c7 = __shfl(inv.y, src, 64), c8 = __shfl(inv.z, src, 64);
-                    const float c9 = __shfl(t_lo, src, 64), c10 = __shfl(best.frac, src, 64);
+                    const float c10 = __shfl(best.frac, src, 64);
                     const int c11 = __shfl(owner, src, 64);
                     const int c12 = __shfl(best.tri, src, 64), c13 = __shfl((int)helper, src, 64);
                     if (take) {
                         cur = stack[d_sb * 256 + (tid & ~63) + src];        // the donor's bottom entry (same wavefront, read before the donor moves on)
-                        f2 = mk(c0, c1, c2); to = mk(c3, c4, c5); inv = mk(c6, c7, c8); t_lo = c9;
+                        f2 = mk(c0, c1, c2); to = mk(c3, c4, c5); inv = mk(c6, c7, c8);
                         best.frac = c10; best.tri = -1; owner = c11;
                         sp = 0; sb = 0; fresh = false; shared = true;
                         helper = c12 >= 0 || c13 != 0;
