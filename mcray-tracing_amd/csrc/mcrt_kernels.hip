@@ -1386,6 +1386,10 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
 #ifndef MCRT_PATH_LEAF_BATCH
 #define MCRT_PATH_LEAF_BATCH MCRT_LANE_LEAF_BATCH        // lanes parked on a leaf that end the inner-node phase (8 / 20 / 32: 1.20 / 1.14 / 1.19 ms per frame)
 #endif
+#ifndef MCRT_PATH_LEAF_GATE
+#define MCRT_PATH_LEAF_GATE 16       // the triangle tests of an iteration wait until this many lanes are parked on a leaf (or no lane has an inner node left): none / 4 / 8 / 16: 0.913 / 0.916 / 0.907 / 0.900 ms per frame
+#endif
+static_assert(MCRT_PATH_LEAF_GATE <= MCRT_PATH_LEAF_BATCH, "k_path: with more parked lanes than MCRT_PATH_LEAF_BATCH the inner-node phase stops stepping, so the leaf phase must have started by then");
 #ifndef MCRT_PATH_OWNERS
 #define MCRT_PATH_OWNERS 32          // paths per wavefront: the first MCRT_PATH_OWNERS lanes own one each, the others only ever help -- one 128 x 1024 frame is then 4096
                                      // wavefronts = four per SIMD, each walk shared by twice the lanes (64 owners at two per SIMD: 0.88 ms per launch; 32 at four: 0.70)
@@ -1498,6 +1502,9 @@ __global__ void __launch_bounds__(256, MCRT_PATH_WAVES) k_path(FrameArgs a)
                 if (cur >= 0) lane_node_step(a, S, lr, t_lo, tcap, cur, sp, sb);
             }
             // ---- phase 2: the parked leaves ----
+            // (the triangle tests wait until MCRT_PATH_LEAF_GATE lanes are parked on a leaf, or no lane has an inner node left: with a hand-over every node step the leaf
+            //  phase -- the whole wavefront executes it -- would otherwise run in nearly every iteration for a lane or two)
+            if (popc_mask(MCRT_ON_LEAF(cur)) >= (uint32_t)MCRT_PATH_LEAF_GATE || MCRT_ON_INNER(cur) == 0ull)
             if ((uint32_t)cur > 0x80000000u) lane_leaf_test(a, S, f2, to, inv, rc, t_lo, helper, best, cur, sp, sb);
             // ---- walkers of one ray meet in its word: publish the find, take the smallest word back one round later ----
             if (poll_pending) {

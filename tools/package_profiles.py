@@ -124,7 +124,7 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 | `baseline_configs.txt` | the five BASELINE.json configurations on one GPU (tools/configs.sh) |
 | `bench_random16m.json` | `python bench.py --workload random16m`: the STREAMING regime (16 M triangles, 2 GB of BVH past the Infinity Cache) |
 | `group_bench.json` | `tools/group_bench.py 0,0`: whole B-mode frames through `mcrt_group_*` (two ranks sharing the GPU) against one context |
-| `bench_driver_cmd_k_path.json`, `bench_driver_cmd_wide.json` | the driver's command at two milestones of the round: with `k_path` (one frame at a time 1.48 -> 1.11 ms), and with the kernels built without machine LICM + the five-wavefront walk from the first ray (0.386 -> 0.3595 ms per frame, one frame at a time 0.915 ms) |
+| `bench_driver_cmd_k_path.json`, `bench_driver_cmd_wide.json`, `bench_driver_cmd_final.json` | the driver's command at three milestones of the round (the last: one frame at a time 0.872 ms): with `k_path` (one frame at a time 1.48 -> 1.11 ms), and with the kernels built without machine LICM + the five-wavefront walk from the first ray (0.386 -> 0.3595 ms per frame, one frame at a time 0.915 ms) |
 | `march_layout_count_random1m.json`, `exp_march_layout.txt` | `tools/march_layout_count.py` (CPU): 128-byte lines and 4-KiB regions `k_march`'s gathers touch for six device layouts of the 256^3 texture; the layouts built and measured (all slower: recorded loss) |
 | `packet_count_random1m_segdec.json`, `exp_packet_sorted.txt` | `tools/packet_count.py ... segdec` (CPU): packets over scan-lines partitioned by their rays' decisions; why sorted queues for bounces 2-3 were not built |
 | `exp_path.txt`, `pmc_k_path.txt`, `frame_timeline_one_frame.txt` | the latency form `k_path`: every step measured, its counters (`tools/pmc_path.sh`), the launches of one frame |
