@@ -18,7 +18,7 @@
 #define MCRT_PACKET_MASK_DEFAULT 2u   // bounces (bit b) walked a wavefront per ray packet (k_trace_packet): bounce 1 -- every pass size from two frames up and every BASELINE
                                       // configuration gains 0.3-6 % (profiles/round5/exp_packet.txt); bounce 2 is a wash, later bounces lose (packet_count_*.json)
 #define MCRT_PACKET_FROM 262144u      // ... in passes of at least this many paths (one 128 x 1024 frame at a time keeps the lane walk: its launches are cut into pieces, 1.624 vs 1.634 ms)
-#define MCRT_PATH_MAX_DEFAULT 524288u  // passes of at most this many paths take the latency form (k_path: one launch for all bounces): four 128 x 1024 frames (ms per frame at 1 / 2 / 3 / 4 frames: 0.95 / 0.82 / 0.77 / 0.73 against the staged 1.62 / 1.12 / 0.91 / 0.79)
+#define MCRT_PATH_MAX_DEFAULT 655360u  // passes of at most this many paths take the latency form (k_path: one launch for all bounces): five 128 x 1024 frames (ms per frame at 1 / 2 / 3 / 4 / 5 / 6 frames: 0.87 / 0.77 / 0.72 / 0.69 / 0.67 / 0.65 against the staged 1.62 / 1.12 / 0.88 / 0.76 / 0.68 / 0.60)
 #define MCRT_PATH_GROUPS_DEFAULT 2u     // ... traced as this many scan-line groups on their own streams (a group's k_march runs beside the other groups' slowest wavefronts)
 #define MCRT_MAX_ROWS 2048
 #define MCRT_MAX_BOUNCES 16
