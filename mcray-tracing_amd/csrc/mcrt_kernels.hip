@@ -567,7 +567,12 @@ template <int STACK> struct LaneStackT { int *lds; int *ovf; size_t ovf_stride; 
 constexpr int CUR_IDLE = (int)0x80000000;      // walk state: cur >= 0 inner node, cur < 0 ~(leaf descriptor), CUR_IDLE = no walk in progress
 template <class LS> MCRT_DEV void lane_pop(const LS &S, int &cur, int &sp, int sb)
 {
-    if (sp > sb) { sp--; cur = (sp < LS::depth) ? S.lds[sp * 256 + S.tid] : S.ovf[(size_t)(sp - LS::depth) * S.ovf_stride]; }
+    if (sp > sb) {
+        sp--;
+        // (the overflow part is asked for the whole wavefront first: the general form alone computes the 64-bit overflow address in every popping lane and reads through a flat load)
+        if (__builtin_expect(__any(sp >= LS::depth), 0)) cur = (sp < LS::depth) ? S.lds[sp * 256 + S.tid] : S.ovf[(size_t)(sp - LS::depth) * S.ovf_stride];
+        else cur = S.lds[sp * 256 + S.tid];
+    }
     else cur = CUR_IDLE;
 }
 template <class LS> MCRT_DEV void lane_push(const LS &S, int &sp, int v)
@@ -623,7 +628,8 @@ template <class LS> MCRT_DEV void lane_node_compute(const LS &S, const LaneRay &
     asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));      // (the child references are fetched WITH the boxes, not after the tests in a second round trip:
                                                                      //  with the references only for nodes that have a hit child 0.440 vs 0.429 ms per frame, round 3)
     if (kmin == 0xffffffffu) { lane_pop(S, cur, sp, sb); return; }
-    const bool p0 = h0 && k0 != kmin, p1 = h1 && k1 != kmin, p2 = h2 && k2 != kmin, p3 = h3 && k3 != kmin;
+    const bool e0 = k0 == kmin, e1 = k1 == kmin, e2 = k2 == kmin, e3 = k3 == kmin;
+    const bool p0 = h0 && !e0, p1 = h1 && !e1, p2 = h2 && !e2, p3 = h3 && !e3;
     if (__builtin_expect(__any(sp + 4 > LS::depth), 0)) {       // (some lane may leave the LDS part: the general form)
         if (p0) lane_push(S, sp, r0);
         if (p1) lane_push(S, sp, r1);
@@ -640,8 +646,7 @@ template <class LS> MCRT_DEV void lane_node_compute(const LS &S, const LaneRay &
         top[s3] = r3;
         sp += (s3 >> 8) + (p3 ? 1 : 0);
     }
-    const uint32_t jn = kmin & 3u;
-    cur = jn == 0u ? r0 : jn == 1u ? r1 : jn == 2u ? r2 : r3;
+    cur = e0 ? r0 : e1 ? r1 : e2 ? r2 : r3;      // (on the comparisons the pushes made already)
 }
 
 // one leaf: the contract's triangle test (btTriangleRaycastCallback::processTriangle behind the padded-bounds rule) on each of its
