@@ -624,9 +624,11 @@ template <class LS> MCRT_DEV void lane_node_compute(const LS &S, const LaneRay &
     const uint32_t k0 = h0 ? ((__float_as_uint(tn0) & ~3u) | 0u) : 0xffffffffu, k1 = h1 ? ((__float_as_uint(tn1) & ~3u) | 1u) : 0xffffffffu;
     const uint32_t k2 = h2 ? ((__float_as_uint(tn2) & ~3u) | 2u) : 0xffffffffu, k3 = h3 ? ((__float_as_uint(tn3) & ~3u) | 3u) : 0xffffffffu;
     const uint32_t kmin = min(min(k0, k1), min(k2, k3));
-    int r0 = (int)RF.x, r1 = (int)RF.y, r2 = (int)RF.z, r3 = (int)RF.w;
-    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));      // (the child references are fetched WITH the boxes, not after the tests in a second round trip:
+    typedef int vi4 __attribute__((ext_vector_type(4)));
+    vi4 RV = { (int)RF.x, (int)RF.y, (int)RF.z, (int)RF.w };
+    asm volatile("" : "+v"(RV));                                     // (the child references are fetched WITH the boxes, not after the tests in a second round trip:
                                                                      //  with the references only for nodes that have a hit child 0.440 vs 0.429 ms per frame, round 3)
+    const int r0 = RV.x, r1 = RV.y, r2 = RV.z, r3 = RV.w;
     if (kmin == 0xffffffffu) { lane_pop(S, cur, sp, sb); return; }
     const bool e0 = k0 == kmin, e1 = k1 == kmin, e2 = k2 == kmin, e3 = k3 == kmin;
     const bool p0 = h0 && !e0, p1 = h1 && !e1, p2 = h2 && !e2, p3 = h3 && !e3;
@@ -660,8 +662,10 @@ template <class LS> MCRT_DEV uint32_t lane_leaf_test(const FrameArgs &a, const L
         const float4 *T = (const float4 *)((const char *)a.tris + (first + k) * (uint32_t)(16 * MCRT_TRI_PIECES));
         // the record's pieces are fetched TOGETHER, not stage by stage behind the early exits: a leaf phase then costs one
         // memory round trip (the pieces of a rejected triangle are wasted loads; staged: 0.349 against 0.343 ms per frame, round 4)
-        float4 V0 = T[0], V1 = T[1], V2 = T[2];
-        asm volatile("" : "+v"(V0.x), "+v"(V0.y), "+v"(V0.z), "+v"(V0.w), "+v"(V1.x), "+v"(V1.y), "+v"(V1.z), "+v"(V2.x), "+v"(V2.y), "+v"(V2.z), "+v"(V2.w));
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        vf4 W0 = ((const vf4 *)T)[0], W1 = ((const vf4 *)T)[1], W2 = ((const vf4 *)T)[2];
+        asm volatile("" : "+v"(W0), "+v"(W1), "+v"(W2));      // (pinned as three register tuples: pinned word by word the compiler copied seven of them out of the tuples first)
+        const float4 V0 = make_float4(W0.x, W0.y, W0.z, W0.w), V1 = make_float4(W1.x, W1.y, W1.z, W1.w), V2 = make_float4(W2.x, W2.y, W2.z, W2.w);
         const float4 P = tri_plane(xyz(V0), xyz(V1), xyz(V2));
         const f3 nrm = xyz(P);
         const float da = dot(nrm, f2) - P.w;
@@ -880,14 +884,14 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
         const float tcap = fminf(1.0f, best.frac);               // best only changes in phase 2
         // (then phase 1 is cut short: see MCRT_LANE_ADOPT_STEPS; held as scalars -- as a per-lane condition it made the whole loop a divergent one)
         const int thieves_wait = __builtin_amdgcn_readfirstlane((!STATS && queue_empty && __any(cur == CUR_IDLE && fresh)) ? 1 : 0);
-        int steps_left = MCRT_LANE_ADOPT_STEPS;
+        int steps_left = thieves_wait ? MCRT_LANE_ADOPT_STEPS : 0x7fffffff;      // (one counter, no second condition in the loop)
         const f3 rc = ray_c(f2, inv);
         const LaneRay lr = { rc.x, rc.y, rc.z, inv.x, inv.y, inv.z, inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f };
         for (;;) {
             const unsigned long long inner = MCRT_ON_INNER(cur);
             if (inner == 0ull) break;
             if (popc_mask(MCRT_ON_LEAF(cur)) >= (uint32_t)MCRT_LANE_LEAF_BATCH) break;     // (as 32-bit scalars: a 64-bit comparison is a vector instruction)
-            if (thieves_wait && --steps_left < 0) break;
+            if (--steps_left < 0) break;
             if (cur >= 0) {
                 if (STATS) st_nodes++;
                 lane_node_step(a, S, lr, t_lo, tcap, cur, sp, sb);
@@ -1496,14 +1500,14 @@ __global__ void __launch_bounds__(256, MCRT_PATH_WAVES) k_path(FrameArgs a)
             // ---- phase 1: inner nodes, until enough lanes are parked on a leaf (cut short while idle lanes wait for a subtree) ----
             const float tcap = fminf(1.0f, best.frac);
             const int thieves_wait = __builtin_amdgcn_readfirstlane(__any(cur == CUR_IDLE && fresh) ? 1 : 0);
-            int steps_left = MCRT_PATH_ADOPT_STEPS;
+            int steps_left = thieves_wait ? MCRT_PATH_ADOPT_STEPS : 0x7fffffff;
             const f3 rc = ray_c(f2, inv);
             const LaneRay lr = { rc.x, rc.y, rc.z, inv.x, inv.y, inv.z, inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f };
             for (;;) {
                 const unsigned long long inner = MCRT_ON_INNER(cur);
                 if (inner == 0ull) break;
                 if (popc_mask(MCRT_ON_LEAF(cur)) >= (uint32_t)MCRT_PATH_LEAF_BATCH) break;
-                if (thieves_wait && --steps_left < 0) break;
+                if (--steps_left < 0) break;
                 if (cur >= 0) lane_node_step(a, S, lr, t_lo, tcap, cur, sp, sb);
             }
             // ---- phase 2: the parked leaves ----
