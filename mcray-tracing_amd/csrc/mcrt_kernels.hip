@@ -713,6 +713,11 @@ MCRT_DEV int nth_set_bit(unsigned long long m, uint32_t r)
     return base;
 }
 
+// x = taken ? nx : x, in place (the hand-over of a subtree replaces a lane's ray state: trace_lane_body)
+MCRT_DEV void take_if(float &x, float nx, unsigned long long m) { asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(nx), "s"(m)); }
+MCRT_DEV void take_if(int &x, int nx, unsigned long long m) { asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(nx), "s"(m)); }
+MCRT_DEV void take_if(uint32_t &x, uint32_t nx, unsigned long long m) { asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(nx), "s"(m)); }
+
 template <bool STATS, int STACK, bool DYN>
 MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
 {
@@ -839,8 +844,8 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
                 } else exhausted = true;
             }
         }
-        if (MCRT_WALKING(cur) == 0ull) { if (!__any(!exhausted)) break; else continue; }
-
+        // (This block stands BEFORE the test below for a reason of code generation only -- without walking lanes there are no donors --: behind it the compiler
+        //  kept a second copy of the ray's state and moved 16 registers over at the top of every round and back at its end; here it needs 73 registers, not 80.)
         // ---- the END of a launch (and one frame at a time, where a bounce has fewer rays than the GPU has lanes): the queue is
         // empty, lanes run out of rays while a few long walks go on.  Idle lanes then TAKE OVER SUBTREES: the k-th idle lane adopts
         // the bottom stack entry (the farthest, usually largest pending subtree) of the k-th lane that has one, with a copy of its
@@ -851,7 +856,7 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
         // Measured and not kept: the same hand-over BETWEEN wavefronts through tickets and entries in global memory
         // (the heaviest wavefront's walks are chains with little to give away: its 230-odd node steps stayed, the pushes' round
         // trips were added); one ray per four lanes at the start of a small launch; rays dealt out across the wavefronts.
-        if (!STATS && queue_empty) {
+        if (!STATS && __builtin_amdgcn_readfirstlane((int)queue_empty)) {      // (a SCALAR branch: as a lane condition the compiler copied the whole ray state, 16 registers, at the top of every round)
             const bool thief = cur == CUR_IDLE && fresh;
             const bool donor = cur != CUR_IDLE && sp > sb && sb < STACK;
             const unsigned long long tm = __ballot(thief), dm = __ballot(donor);
@@ -868,17 +873,28 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
                 const float c9 = __shfl(t_lo, src, 64), c10 = __shfl(best.frac, src, 64);
                 const uint32_t c11 = (uint32_t)__shfl((int)ray_id, src, 64);
                 const int c12 = __shfl(best.tri, src, 64), c13 = __shfl((int)helper, src, 64);
-                if (take) {
-                    cur = stack[d_sb * 256 + (tid & ~63) + src];        // the donor's bottom entry (same wavefront, read before the donor moves on)
-                    f2 = mk(c0, c1, c2); to = mk(c3, c4, c5); inv = mk(c6, c7, c8); t_lo = c9;
-                    best.frac = c10; best.tri = -1; ray_id = c11;
-                    sp = 0; sb = 0; fresh = false; shared = true;
-                    helper = c12 >= 0 || c13 != 0;                       // (an owner without a find so far passes on the ray's own bound, which stays exclusive;
+                // (the state is replaced IN PLACE, one select per register on the takers' mask: written as assignments under `if (take)` the compiler kept
+                //  a second copy of the ray's state for the branch and moved 16 registers over at the top of EVERY round of the walk, and back at its end)
+                const unsigned long long tk = __ballot(take);
+                const int got = stack[take ? d_sb * 256 + (tid & ~63) + src : tid];      // the donor's bottom entry (same wavefront, read before the donor moves on)
+                take_if(cur, got, tk);
+                take_if(f2.x, c0, tk); take_if(f2.y, c1, tk); take_if(f2.z, c2, tk);
+                take_if(to.x, c3, tk); take_if(to.y, c4, tk); take_if(to.z, c5, tk);
+                take_if(inv.x, c6, tk); take_if(inv.y, c7, tk); take_if(inv.z, c8, tk);
+                take_if(t_lo, c9, tk); take_if(best.frac, c10, tk); take_if(best.tri, -1, tk); take_if(ray_id, c11, tk);
+                take_if(sp, 0, tk); take_if(sb, 0, tk);
+                fresh = fresh && !take;
+                helper = take ? (c12 >= 0 || c13 != 0) : helper;         // (an owner without a find so far passes on the ray's own bound, which stays exclusive;
                                                                          // a lane that is itself a helper passes its owner's fraction on)
-                }
-                if (give) { sb++; shared = true; }
+                sb += give ? 1 : 0;
+                shared = shared || take || give;
             }
         }
+
+        // (ONE way round the loop: with a second back edge from here -- `continue` -- the compiler kept two copies of the ray's state, one across the
+        //  refill and one across the walk, and moved 16 registers over at the top of every round and back at its end)
+        if (MCRT_WALKING(cur) == 0ull) { if (!__any(!exhausted)) break; }
+        else {
 
         // ---- phase 1: inner nodes, until enough lanes are parked on a leaf ----
         const float tcap = fminf(1.0f, best.frac);               // best only changes in phase 2
@@ -921,6 +937,7 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
                 const unsigned long long word = (best.tri >= 0) ? (((unsigned long long)__float_as_uint(best.frac) << 32) | (unsigned long long)(uint32_t)best.tri) : ~0ull;
                 poll_old = atomicMin(MCRT_KEYP(ray_id), word); poll_ray = ray_id; poll_pending = true;
             }
+        }
         }
     }
 #undef MCRT_SUB_LO
