@@ -640,13 +640,16 @@ template <class LS> MCRT_DEV void lane_node_compute(const LS &S, const LaneRay &
     } else {
         // four UNCONDITIONAL stores instead of four branches: a reference that is not kept is overwritten by the next one (its
         // offset does not advance), and the last lands above the new top of the stack (inside the lane's column: sp + 3 < 32)
-        int *top = &S.lds[sp * 256 + S.tid];
-        const int s1 = p0 ? 256 : 0, s2 = s1 + (p1 ? 256 : 0), s3 = s2 + (p2 ? 256 : 0);
-        top[0] = r0;
-        top[s1] = r1;
-        top[s2] = r2;
-        top[s3] = r3;
-        sp += (s3 >> 8) + (p3 ? 1 : 0);
+        // (offsets as 0 / 1 counts shifted into the address -- v_lshl_add_u32 with inline constants --: with 0 / 256 the step also paid for the literal and for a shift of the sum)
+        char *top = (char *)&S.lds[sp * 256 + S.tid];
+        int c0 = p0 ? 1 : 0, c1 = p1 ? 1 : 0, c2 = p2 ? 1 : 0, c3 = p3 ? 1 : 0;
+        asm("" : "+v"(c0), "+v"(c1), "+v"(c2));      // (opaque: seen through, every shifted count becomes a second select on a literal)
+        char *t1 = top + (c0 << 10), *t2 = t1 + (c1 << 10), *t3 = t2 + (c2 << 10);
+        *(int *)top = r0;
+        *(int *)t1 = r1;
+        *(int *)t2 = r2;
+        *(int *)t3 = r3;
+        sp += c0 + c1 + c2 + c3;
     }
     cur = e0 ? r0 : e1 ? r1 : e2 ? r2 : r3;      // (on the comparisons the pushes made already)
 }
