@@ -971,7 +971,9 @@ MCRT_DEV void trace_lane_body(const FrameArgs &a, const uint32_t b)
 // pass size -- 5 / 6 / 8 / 12 / 20 frames: 0.678 / 0.614 / 0.512 / 0.426 / 0.359 against 0.699 / 0.628 / 0.530 / 0.446 / 0.381 ms per frame -- so it is the
 // default from the first ray (MCRT_LANE_WIDE_FROM), for trees the caches hold (mcrt_api.cpp: fill_args); the narrow form stays for larger trees, CU-masked
 // streams and the counting build.  (Its stack is sized at the launch: with a static LDS array the compiler caps the kernel's occupancy
-// by LDS and hands the registers back.)
+// by LDS and hands the registers back.)  Late round 6: with the hand-over in front of the walking test (trace_lane_body) the body needs 67 registers and no scratch in
+// either form; a SIXTH walk wavefront per SIMD then fits (MCRT_LANE_WIDE_WAVES 7, 1536 workgroups): 0.345-0.348 against 0.340 ms on the 20-frame pass, 0.295-0.298
+// against 0.300 at 128 frames -- five stay.
 #ifndef MCRT_LANE_WIDE_STACK
 #define MCRT_LANE_WIDE_STACK 24          // (28: 0.332 against 0.3295 ms per frame; deeper walks go on in the overflow array, as in the other form)
 #endif
