@@ -29,6 +29,16 @@ MCRT_DEV uint64_t d2u(double x) { return (uint64_t)__double_as_longlong(x); }
 MCRT_DEV double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
 MCRT_DEV double dinf() { return u2d(0x7ff0000000000000ull); }
 
+// fma(a, b, k) with the CONSTANT k read from a scalar register pair: one vector instruction (v_fma_f64) and two scalar moves per Horner step.
+// Written as fma(a, b, literal) the compiler materialises the literal in a vector register pair and accumulates into it (2 x v_mov_b32 +
+// v_fmac_f64): every third vector instruction of the physics was such a move.  Same operation, same bits.
+MCRT_DEV double fma_k(double a, double b, double k)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+
 MCRT_DEV double det_log(double x)
 {
     if (x != x) return x;
@@ -45,16 +55,16 @@ MCRT_DEV double det_log(double x)
     double s = f / (2.0 + f);
     double z = s * s;
     double p = 2.0 / 23.0;
-    p = fma(p, z, 2.0 / 21.0);
-    p = fma(p, z, 2.0 / 19.0);
-    p = fma(p, z, 2.0 / 17.0);
-    p = fma(p, z, 2.0 / 15.0);
-    p = fma(p, z, 2.0 / 13.0);
-    p = fma(p, z, 2.0 / 11.0);
-    p = fma(p, z, 2.0 / 9.0);
-    p = fma(p, z, 2.0 / 7.0);
-    p = fma(p, z, 2.0 / 5.0);
-    p = fma(p, z, 2.0 / 3.0);
+    p = fma_k(p, z, 2.0 / 21.0);
+    p = fma_k(p, z, 2.0 / 19.0);
+    p = fma_k(p, z, 2.0 / 17.0);
+    p = fma_k(p, z, 2.0 / 15.0);
+    p = fma_k(p, z, 2.0 / 13.0);
+    p = fma_k(p, z, 2.0 / 11.0);
+    p = fma_k(p, z, 2.0 / 9.0);
+    p = fma_k(p, z, 2.0 / 7.0);
+    p = fma_k(p, z, 2.0 / 5.0);
+    p = fma_k(p, z, 2.0 / 3.0);
     p = p * z;
     double r = fma(s, p, 2.0 * s);
     double kd = (double)k;
@@ -70,19 +80,19 @@ MCRT_DEV double det_exp(double x)
     double r = fma(-kd, LN2_HI, x);
     r = fma(-kd, LN2_LO, r);
     double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
+    p = fma_k(p, r, 1.0 / 479001600.0);
+    p = fma_k(p, r, 1.0 / 39916800.0);
+    p = fma_k(p, r, 1.0 / 3628800.0);
+    p = fma_k(p, r, 1.0 / 362880.0);
+    p = fma_k(p, r, 1.0 / 40320.0);
+    p = fma_k(p, r, 1.0 / 5040.0);
+    p = fma_k(p, r, 1.0 / 720.0);
+    p = fma_k(p, r, 1.0 / 120.0);
+    p = fma_k(p, r, 1.0 / 24.0);
+    p = fma_k(p, r, 1.0 / 6.0);
+    p = fma_k(p, r, 0.5);
+    p = fma_k(p, r, 1.0);
+    p = fma_k(p, r, 1.0);
     int k = (int)kd;
     int k1 = k / 2, k2 = k - k1;
     double s1 = u2d((uint64_t)(k1 + 1023) << 52);
@@ -97,24 +107,24 @@ MCRT_DEV void det_sincos(double a, double &sn, double &cs)
     r = fma(-kd, PIO2_LO, r);
     double z = r * r;
     double s = 1.0 / 355687428096000.0;
-    s = fma(s, z, -1.0 / 1307674368000.0);
-    s = fma(s, z, 1.0 / 6227020800.0);
-    s = fma(s, z, -1.0 / 39916800.0);
-    s = fma(s, z, 1.0 / 362880.0);
-    s = fma(s, z, -1.0 / 5040.0);
-    s = fma(s, z, 1.0 / 120.0);
-    s = fma(s, z, -1.0 / 6.0);
+    s = fma_k(s, z, -1.0 / 1307674368000.0);
+    s = fma_k(s, z, 1.0 / 6227020800.0);
+    s = fma_k(s, z, -1.0 / 39916800.0);
+    s = fma_k(s, z, 1.0 / 362880.0);
+    s = fma_k(s, z, -1.0 / 5040.0);
+    s = fma_k(s, z, 1.0 / 120.0);
+    s = fma_k(s, z, -1.0 / 6.0);
     double sr = fma(r * z, s, r);
     double c = -1.0 / 6402373705728000.0;
-    c = fma(c, z, 1.0 / 20922789888000.0);
-    c = fma(c, z, -1.0 / 87178291200.0);
-    c = fma(c, z, 1.0 / 479001600.0);
-    c = fma(c, z, -1.0 / 3628800.0);
-    c = fma(c, z, 1.0 / 40320.0);
-    c = fma(c, z, -1.0 / 720.0);
-    c = fma(c, z, 1.0 / 24.0);
-    c = fma(c, z, -0.5);
-    double cr = fma(z, c, 1.0);
+    c = fma_k(c, z, 1.0 / 20922789888000.0);
+    c = fma_k(c, z, -1.0 / 87178291200.0);
+    c = fma_k(c, z, 1.0 / 479001600.0);
+    c = fma_k(c, z, -1.0 / 3628800.0);
+    c = fma_k(c, z, 1.0 / 40320.0);
+    c = fma_k(c, z, -1.0 / 720.0);
+    c = fma_k(c, z, 1.0 / 24.0);
+    c = fma_k(c, z, -0.5);
+    double cr = fma_k(z, c, 1.0);
     long long q = (long long)kd & 3;
     if (q == 0) { sn = sr; cs = cr; }
     else if (q == 1) { sn = cr; cs = -sr; }
