@@ -107,6 +107,7 @@ struct mcrt_ctx {
     uint4 *d_nodes_walk = nullptr; uint32_t nodes_walk_cap = 0;   // the walk's child-transposed half-float nodes
     uint4 *d_meshes = nullptr;
     uint32_t *d_tri_slot = nullptr;
+    float4 *d_tris_id = nullptr; uint32_t tris_id_cap = 0;      // the triangle records in id order (refresh_soa)
     uint32_t n_mesh = 0, n_mat = 0, start_mat = 0, n_cu = 256;
     int builder = MCRT_BVH_HOST_SAH; bool host_bvh_stale = false;   // device-built tree: host copies are downloaded on demand
     std::vector<uint32_t> tri_mesh;   // per-triangle mesh index of the uploaded scene (for mcrt_update_triangles)
@@ -317,6 +318,12 @@ static int refresh_soa(mcrt_ctx *c)
         c->nodes_walk_cap = c->bvh4.n_nodes;
     }
     HIP_TRY(mcrt::launch_nodes_walk(c->d_nodes, c->bvh4.n_nodes, c->d_nodes_walk, c->stream));
+    if (c->tris_id_cap != c->bvh.n_tri) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(c->d_tris_id); c->d_tris_id = nullptr; c->tris_id_cap = 0;
+        if (c->bvh.n_tri) { HIP_TRY(hipMalloc(&c->d_tris_id, 16 * (size_t)MCRT_TRI_PIECES * c->bvh.n_tri)); c->tris_id_cap = c->bvh.n_tri; }
+    }
+    HIP_TRY(mcrt::launch_tris_by_id((const float4 *)c->d_tris, c->bvh.n_tri, c->d_tris_id, c->stream));
     if (!c->ev_scene) HIP_TRY(hipEventCreateWithFlags(&c->ev_scene, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c->ev_scene, c->stream));
     c->scene_stream = c->stream; c->scene_pending = true;
@@ -326,6 +333,7 @@ static int refresh_soa(mcrt_ctx *c)
 static void free_scene(mcrt_ctx *c)
 {
     free(c->walked_nodes); c->walked_nodes = nullptr; c->walked_stale = true;
+    hipFree(c->d_tris_id); c->d_tris_id = nullptr; c->tris_id_cap = 0;
     hipFree(c->d_nodes_walk); c->d_nodes_walk = nullptr; c->nodes_walk_cap = 0;
     hipFree(c->d_nodes); hipFree(c->d_tris); hipFree(c->d_mats); hipFree(c->d_meshes); hipFree(c->d_tri_slot); c->d_tri_slot = nullptr;
     c->d_nodes = c->d_tris = c->d_mats = nullptr; c->d_meshes = nullptr;
@@ -781,7 +789,7 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     a.acc = c->d_acc; a.flags = c->d_flags;                 // the frame block [n_frames][acc_ne][R]; this group owns columns e0-acc_e0 ...
     a.acc_stride = acc_ne; a.acc_off = e0 - acc_e0;
     a.st0 = w.d_st0; a.st1 = w.d_st1; a.st2 = w.d_st2; a.queue = w.d_q;
-    a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.counts = w.d_counts; a.cursors = w.d_cursors; a.segs = w.d_segs; a.hits = w.d_hits; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
+    a.key0 = w.d_key0; a.key1 = w.d_key1; a.tri_slot = c->d_tri_slot; a.tris_id = c->d_tris_id; a.counts = w.d_counts; a.cursors = w.d_cursors; a.segs = w.d_segs; a.hits = w.d_hits; a.mrec = w.d_mrec; a.mtab = c->d_mtab; a.seg_count = w.d_seg_count;
     a.stats = c->d_stats; a.error_flag = c->d_error; a.stamps = c->d_stats + 8;
     a.n_mat = c->n_mat; a.n_mesh = c->n_mesh; a.n_nodes = c->bvh4.n_nodes; a.S = c->p.n_samples; a.B = c->p.max_depth; a.R = c->p.n_rows;
     a.e_begin = e0; a.ne_frame = e1 - e0; a.ne = (e1 - e0) * n_frames;   // n_frames consecutive frame ids traced as one pass

@@ -12,6 +12,7 @@ struct FrameArgs {
     const uint4 *nodes_walk;   // [n_nodes][4]  the walk's 64-byte nodes: child-transposed half-float boxes (rounded outwards) + refs
     int *stack_ovf;            // [max_stack - MCRT_LANE_STACK][trace_blocks * 256] traversal-stack entries beyond the LDS part (this work set's own)
     const float4 *tris;        // [T][3]         48-B triangle records, leaf order: v0|id, v1|mesh, v2|edge tolerance
+    const float4 *tris_id;     // [T][3]         the same records in TRIANGLE-ID order (k_shade looks the winning triangle up by its id: one dependent load less than through tri_slot)
     const uint4 *meshes;       // [n_mesh]      mat_inside, mat_outside, vascular, -
     const float4 *mats;        // [n_mat][2]    imp, att, mu0, mu1 | sigma, spec, shine, thick
     const float2 *tex;         // [n^3]         texture_noise, scattering_probability
@@ -65,6 +66,7 @@ hipError_t launch_blocks_to_frames(const float *blocks, float *frames, uint32_t 
 hipError_t launch_transpose(const float *in, float *out, uint32_t E, uint32_t R, hipStream_t st);
 hipError_t launch_math_probe(int op, const double *x, const double *y, double *out, uint32_t n, hipStream_t st);
 hipError_t launch_verify_div(float res, float rcp, unsigned long long *bad, hipStream_t st);
+hipError_t launch_tris_by_id(const float4 *tris, uint32_t n_tri, float4 *out, hipStream_t st);   // leaf-order records -> id order (record i goes to slot id(i))
 hipError_t launch_expand_tris(const float4 *in48, uint32_t n_tri, float4 *out, hipStream_t st);   // (v0|id, v1|mesh, v2|-) -> the walk's records (v2.w = the edge tolerance)
 hipError_t launch_material_table(const float4 *mats, uint32_t n_mat, float axial_res_f, float freq, float4 *mtab, hipStream_t st);
 hipError_t launch_philox_probe(const uint32_t c[4], const uint32_t k[2], uint32_t *out, hipStream_t st);

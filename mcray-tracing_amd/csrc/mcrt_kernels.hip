@@ -91,6 +91,17 @@ struct Best { float frac; int tri; };
 // Rounds 1-3 stored plane AND padded bounds (96 bytes, six pieces per triangle tested), round 4 tried the plane as a fourth piece.  The walk is bound by
 // the cache accesses it makes: what a few register instructions rebuild -- with the contract's own expressions, so bit for bit -- is not
 // fetched.
+// the walk's leaf-order triangle records once more in triangle-id order, for k_shade (refresh_soa: after every build, update and refit)
+__global__ void k_tris_by_id(const float4 *tris, uint32_t n_tri, float4 *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tri) return;
+    const float4 r0 = tris[MCRT_TRI_PIECES * (size_t)i], r1 = tris[MCRT_TRI_PIECES * (size_t)i + 1], r2 = tris[MCRT_TRI_PIECES * (size_t)i + 2];
+    const uint32_t id = __float_as_uint(r0.w);
+    if (id >= n_tri) return;
+    out[MCRT_TRI_PIECES * (size_t)id] = r0; out[MCRT_TRI_PIECES * (size_t)id + 1] = r1; out[MCRT_TRI_PIECES * (size_t)id + 2] = r2;
+}
+
 __global__ void k_expand_tris(const float4 *in, uint32_t n_tri, float4 *out)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1182,7 +1193,7 @@ MCRT_DEV bool shade_path(const FrameArgs &a, const ShadeTables &tb, uint32_t b, 
         Hit best; best.frac = __uint_as_float((uint32_t)(key >> 32)); best.tri = (int)(uint32_t)key; best.da = 0.0f; best.mesh = 0; best.n = mk(0, 0, 0);
         if (best.tri >= 0) {
             // plane normal, mesh and the origin-side value of the winning triangle, as the walk's test evaluated them
-            const float4 *T = a.tris + MCRT_TRI_PIECES * (size_t)a.tri_slot[best.tri];
+            const float4 *T = a.tris_id + MCRT_TRI_PIECES * (size_t)best.tri;      // (the id-ordered copy: through tri_slot the fetch was a chain of two dependent random reads)
             const float4 t2 = T[1];                                     // (v1, mesh)
             const float4 P = tri_plane(xyz(T[0]), xyz(t2), xyz(T[2]));
             best.n = xyz(P);
@@ -2162,6 +2173,13 @@ hipError_t launch_math_probe(int op, const double *x, const double *y, double *o
 hipError_t launch_verify_div(float res, float rcp, unsigned long long *bad, hipStream_t st)
 {
     hipLaunchKernelGGL(k_verify_div, dim3(256 * 16), dim3(256), 0, st, res, rcp, bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_tris_by_id(const float4 *tris, uint32_t n_tri, float4 *out, hipStream_t st)
+{
+    if (n_tri == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tris_by_id, dim3((n_tri + 255u) / 256u), dim3(256), 0, st, tris, n_tri, out);
     return hipGetLastError();
 }
 
