@@ -378,6 +378,7 @@ MCRT_DEV Ray ray_of(f3 from, f3 dir, float Ls, const FrameArgs &a)
     return r;
 }
 
+#define MCRT_STATE0_AT(pos, S) ((pos) - (pos) % (S))      /* queue position of the bounce-0 state of the path queued at pos: its scan-line's first sample (k_init) */
 __global__ void __launch_bounds__(256) k_init(FrameArgs a)
 {
     const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;          // this thread fills queue position `pos`
@@ -397,9 +398,14 @@ __global__ void __launch_bounds__(256) k_init(FrameArgs a)
     const f3 from = mk(a.el_pos[3 * pe], a.el_pos[3 * pe + 1], a.el_pos[3 * pe + 2]);
     const f3 dir = mk(a.el_dir[3 * pe], a.el_dir[3 * pe + 1], a.el_dir[3 * pe + 2]);
     const float intensity = a.I0 / (float)a.S;
-    a.st0[pos] = make_float4(from.x, from.y, from.z, ray_len(intensity, a.mats[2 * a.start_mat].y, a));   // origin | length factor of the ray (ray_of)
-    a.st1[pos] = make_float4(dir.x, dir.y, dir.z, __int_as_float((int)a.start_mat));
-    a.st2[pos] = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), intensity);  // distance_traveled (double) | outside | intensity
+    // Every sample path of a scan-line starts as a copy of the same first_ray (scene.cpp:83-101): the state of bounce 0 is written ONCE per queued
+    // (scan-line, frame), at its first sample's position -- where the walk reads it (ray_stride) and where k_shade / k_path look it up for all S samples
+    // (MCRT_STATE0_AT) -- instead of S times (48 B x 2.6 M paths per 20-frame pass written here and read back by k_shade).
+    if (sample == 0u) {
+        a.st0[pos] = make_float4(from.x, from.y, from.z, ray_len(intensity, a.mats[2 * a.start_mat].y, a));   // origin | length factor of the ray (ray_of)
+        a.st1[pos] = make_float4(dir.x, dir.y, dir.z, __int_as_float((int)a.start_mat));
+        a.st2[pos] = make_float4(0.0f, 0.0f, __int_as_float(OUT_NONE), intensity);  // distance_traveled (double) | outside | intensity
+    }
     a.queue[pos] = pid;                                  // queue of bounce 0 (buffer 0 of two)
     a.seg_count[pid] = 0u;
     if (pos < a.ne) a.key0[pos] = MCRT_KEY_MISS;          // bounce 0: one closest-hit word per queued (scan-line, frame)
@@ -1354,7 +1360,7 @@ __global__ void __launch_bounds__(256, MCRT_SHADE_WAVES) k_shade(FrameArgs a, ui
     if (valid) {
         pid = q_in[i];
         // path state lives in queue order (ping-pong halves by bounce parity), so a wavefront reads and writes it coalesced
-        const size_t sin = (size_t)(b & 1u) * a.ne * a.S + i;
+        const size_t sin = (size_t)(b & 1u) * a.ne * a.S + (b == 0u ? MCRT_STATE0_AT(i, a.S) : i);
         const float4 s0 = a.st0[sin], s1 = a.st1[sin], s2 = a.st2[sin];
         ps.from = mk(s0.x, s0.y, s0.z); ps.intensity = s2.w;
         ps.dir = mk(s1.x, s1.y, s1.z); ps.media = __float_as_int(s1.w);
@@ -1459,7 +1465,8 @@ __global__ void __launch_bounds__(256, MCRT_PATH_WAVES) k_path(FrameArgs a)
     PathState ps; ps.from = mk(0, 0, 0); ps.dir = mk(0, 0, 1); ps.intensity = 0.0f; ps.media = 0; ps.outside = OUT_NONE; ps.dist_mm = 0.0;
     if (alive) {
         pid = a.queue[pos];
-        const float4 s0 = a.st0[pos], s1 = a.st1[pos], s2 = a.st2[pos];
+        const uint32_t p0 = MCRT_STATE0_AT(pos, a.S);
+        const float4 s0 = a.st0[p0], s1 = a.st1[p0], s2 = a.st2[p0];
         ps.from = mk(s0.x, s0.y, s0.z); Ls = s0.w; ps.dir = mk(s1.x, s1.y, s1.z); ps.media = __float_as_int(s1.w);
         ps.dist_mm = __hiloint2double(__float_as_int(s2.y), __float_as_int(s2.x)); ps.outside = __float_as_int(s2.z); ps.intensity = s2.w;
     }
