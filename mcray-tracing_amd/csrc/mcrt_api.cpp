@@ -43,7 +43,7 @@ static Consts derive_consts(const mcrt_params &p)
 // several, to trace the scan-lines of a pass as independent groups on separate streams (MCRT_GROUPS, a tuning knob: one group
 // measured best).
 struct Work {
-    hipStream_t stream = nullptr, side[MCRT_SIDE_STREAMS] = {};   // k_march of bounce b runs on side[b % n] (n = 1 unless MCRT_MARCH_STREAMS says otherwise)
+    hipStream_t stream = nullptr, side[MCRT_SIDE_STREAMS] = {};   // k_march of bounce b runs on side[b % n] (n = 1, or 2 in large passes: side_streams)
     hipEvent_t ev_bounce[MCRT_MAX_BOUNCES] = {}, ev_join[MCRT_SIDE_STREAMS] = {}, ev_done = nullptr;
     float4 *d_st0 = nullptr, *d_st1 = nullptr, *d_st2 = nullptr;
     unsigned long long *d_key0 = nullptr, *d_key1 = nullptr;
@@ -833,7 +833,11 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
     c->last_lean_bound = a.lean_bound; c->last_march_rows = a.march_rows;
 }
 
-static uint32_t side_streams(const mcrt_ctx *c) { return c->knobs.march_streams; }
+static uint32_t side_streams(const mcrt_ctx *c, const mcrt::FrameArgs &a)
+{
+    if (c->knobs.march_streams) return c->knobs.march_streams;
+    return (uint64_t)a.ne * a.S >= (uint64_t)MCRT_SIDE_STREAMS_TWO_FROM ? 2u : 1u;
+}
 
 static int timing_events(mcrt_ctx *c, int kind, hipEvent_t *e0, hipEvent_t *e1);
 
@@ -856,7 +860,7 @@ static int run_bounce(mcrt_ctx *c, Work &w, hipStream_t st, const mcrt::FrameArg
     if (accumulate && overlap) {   // the segments of bounce b are final: accumulate them beside the next bounce's walk
         HIP_TRY(hipEventRecord(w.ev_bounce[b], st));
         hipStream_t side;
-        { int rc = side_stream(c, w, b % side_streams(c), &side); if (rc) return rc; }
+        { int rc = side_stream(c, w, b % side_streams(c, a), &side); if (rc) return rc; }
         HIP_TRY(hipStreamWaitEvent(side, w.ev_bounce[b], 0));
         { int rc = timing_events(c, 2, &e0, &e1); if (rc) return rc; }
         if (e0) HIP_TRY(hipEventRecord(e0, side));
@@ -946,7 +950,7 @@ static int enqueue_frame(mcrt_ctx *c, const std::vector<mcrt::FrameArgs> &args, 
         }
     for (uint32_t g = 0; g < groups; g++) {
         if (accumulate && overlap) {
-            for (uint32_t i = 0; i < side_streams(c); i++) {
+            for (uint32_t i = 0; i < side_streams(c, args[g]); i++) {
                 if (!ws[g]->side[i]) continue;
                 HIP_TRY(hipEventRecord(ws[g]->ev_join[i], ws[g]->side[i]));
                 HIP_TRY(hipStreamWaitEvent(gst[g], ws[g]->ev_join[i], 0));

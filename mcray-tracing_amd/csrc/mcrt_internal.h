@@ -10,7 +10,10 @@
 #endif
 #define MCRT_GROUPS_DEFAULT 1        // independent scan-line groups a frame is traced as (their kernels overlap)
 #define MCRT_SIDE_STREAMS 4         // streams k_march launches rotate over
-#define MCRT_SIDE_STREAMS_DEFAULT 1
+#define MCRT_SIDE_STREAMS_DEFAULT 0       // 0: by the size of the pass -- one side stream, two from MCRT_SIDE_STREAMS_TWO_FROM paths
+#define MCRT_SIDE_STREAMS_TWO_FROM 5242880u   // (40 frames of 128 x 1024 paths.  One box, ms per B-mode frame with one / two side streams: 20 frames 0.338 / 0.350, 32: 0.311 / 0.314, 48: 0.306 / 0.298,
+                                              //  64: 0.300 / 0.291, 96: 0.298 / 0.282, 128: 0.295 / 0.283 (three: 0.287; at 20 frames 0.446).  In a large pass the accumulations, stretched threefold beside the
+                                              //  walks, are the longer chain: two of them side by side shorten it; in a small pass the second one takes the walk's tail away.)
 #define MCRT_LBVH_LEAF 1             // device builder: triangles per leaf (1..4); measured best at 1, like the SAH builder's own leaves
 #define MCRT_XCDS 8                   // XCDs of the MI355X = sub-queues of a bounce's ray queue (see k_trace)
 #define MCRT_CURSOR_STRIDE 64         // uint32 between two queue cursors: 256 B, so they sit in different L2 lines / channels
