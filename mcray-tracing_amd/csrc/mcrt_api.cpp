@@ -836,7 +836,9 @@ static void fill_args(mcrt_ctx *c, const Work &w, mcrt::FrameArgs &a, uint32_t f
 static uint32_t side_streams(const mcrt_ctx *c, const mcrt::FrameArgs &a)
 {
     if (c->knobs.march_streams) return c->knobs.march_streams;
-    return (uint64_t)a.ne * a.S >= (uint64_t)MCRT_SIDE_STREAMS_TWO_FROM ? 2u : 1u;
+    // (two only where the walk runs from the caches -- the five-wavefront form's own criterion, fill_args --: on the 16 M-triangle streaming scene the walks are the longer chain and a
+    //  second accumulation beside them costs 1.5 %: 0.607 against 0.598 ms per frame)
+    return (a.trace_blocks_wide != 0u && (uint64_t)a.ne * a.S >= (uint64_t)MCRT_SIDE_STREAMS_TWO_FROM) ? 2u : 1u;
 }
 
 static int timing_events(mcrt_ctx *c, int kind, hipEvent_t *e0, hipEvent_t *e1);
