@@ -130,7 +130,7 @@ box and packaged by `tools/package_profiles.py`, which also wrote this file from
 | `exp_path.txt`, `pmc_k_path.txt`, `frame_timeline_one_frame.txt` | the latency form `k_path`: every step measured, its counters (`tools/pmc_path.sh`), the launches of one frame |
 | `frame_timeline_pass20.txt` | the driver's 20-frame pass launch by launch |
 | `exp_valu_classes.txt`, `valu_classes.json`, `vgpr_bank.json`, `cndmask_cost.json`, `issue_pairs.json` | what a wave64 instruction costs gfx950 to issue: by class and operand kind, in mixed streams, and what followed from it (the build flags, `k_march`'s constants, the walk's plane picks as logic / `v_bitop3`: measured, not kept) |
-| `soak_final.txt` | `tools/soak.py` on the round's final binary: 650 857 frames in passes of 1 / 3 / 20 / 128, every repeat identical to the first |
+| `soak_final.txt` | `tools/soak.py` on the round's final binary: 1 123 638 frames in passes of 1 / 3 / 20 / 128, every repeat identical to the first |
 
 ## What the kernels do (per launch = one bounce of a @FIF@-frame pass)
 
